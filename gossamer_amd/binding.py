@@ -1,0 +1,193 @@
+"""ctypes binding of libgossgpu.so (the C ABI declared in include/goss_gpu.h).
+
+This module is plumbing only: it loads the in-tree shared library, declares the entry
+points and wraps them in a small context class.  There is no fallback of any kind: if the
+library is missing, or no gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgossgpu.so")
+
+MODE_KMER_SET = 0
+MODE_GRAPH = 1
+
+# every symbol include/goss_gpu.h declares
+SYMBOLS = [
+    "goss_gpu_strerror", "goss_gpu_last_error", "goss_gpu_abi_version", "goss_gpu_create",
+    "goss_gpu_destroy", "goss_gpu_push_bases_host", "goss_gpu_push_bases_device",
+    "goss_gpu_finish", "goss_gpu_result", "goss_gpu_result_copy", "goss_gpu_emit",
+    "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
+    "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
+    "goss_gpu_synth_reads", "goss_synth_reads_host",
+]
+
+
+class GossGpuError(RuntimeError):
+    def __init__(self, status, text, detail=""):
+        super().__init__("%s (status %d)%s" % (text, status, (": " + detail) if detail else ""))
+        self.status = status
+
+
+class Counts(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("keys", C.c_uint64), ("distinct", C.c_uint64),
+                ("key_words", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("extract_ms", C.c_float), ("sort_ms", C.c_float), ("reduce_ms", C.c_float),
+                ("emit_ms", C.c_float), ("total_ms", C.c_float),
+                ("extract_launches", C.c_uint32), ("sort_launches", C.c_uint32),
+                ("reduce_launches", C.c_uint32), ("emit_launches", C.c_uint32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libgossgpu.so; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GossGpuError(-2, "libgossgpu.so is not built", LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.goss_gpu_strerror.restype = C.c_char_p
+    L.goss_gpu_strerror.argtypes = [C.c_int]
+    L.goss_gpu_last_error.restype = C.c_char_p
+    L.goss_gpu_last_error.argtypes = [C.c_void_p]
+    L.goss_gpu_abi_version.restype = C.c_uint32
+    L.goss_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_void_p]
+    L.goss_gpu_destroy.argtypes = [C.c_void_p]
+    L.goss_gpu_destroy.restype = None
+    L.goss_gpu_push_bases_host.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.goss_gpu_push_bases_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.goss_gpu_finish.argtypes = [C.c_void_p, C.POINTER(Counts)]
+    L.goss_gpu_result.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.goss_gpu_result_copy.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.goss_gpu_emit.argtypes = [C.c_void_p]
+    L.goss_gpu_file_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.goss_gpu_file_info.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.goss_gpu_file_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.goss_gpu_emit_sparse_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                             C.c_uint64, C.c_uint64, C.c_uint64]
+    L.goss_gpu_timing_get.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.goss_gpu_timing_reset.argtypes = [C.c_void_p]
+    L.goss_gpu_synth_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.goss_synth_reads_host.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
+    _lib = L
+    return L
+
+
+def synth_reads_host(nreads, read_len, genome_len, seed=1, first_read=0):
+    """The synthetic read generator on the host: bytes of nreads*(read_len+1)."""
+    L = load()
+    buf = C.create_string_buffer(nreads * (read_len + 1))
+    rc = L.goss_synth_reads_host(buf, nreads, read_len, genome_len, seed, first_read)
+    if rc:
+        raise GossGpuError(rc, L.goss_gpu_strerror(rc).decode())
+    return buf.raw
+
+
+class Context:
+    """One counting context on one GPU (include/goss_gpu.h)."""
+
+    def __init__(self, k, mode=MODE_KMER_SET, device=0, hbm_budget=0, stream=None):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.goss_gpu_create(C.byref(self._h), device, k, mode, hbm_budget, stream)
+        if rc:
+            self._h = None
+            raise GossGpuError(rc, self._L.goss_gpu_strerror(rc).decode())
+        self.k = k
+        self.mode = mode
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.goss_gpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise GossGpuError(rc, self._L.goss_gpu_strerror(rc).decode(),
+                               self._L.goss_gpu_last_error(self._h).decode())
+
+    def push_host(self, data):
+        if isinstance(data, str):
+            data = data.encode()
+        self._check(self._L.goss_gpu_push_bases_host(self._h, data, len(data)))
+
+    def push_device(self, ptr, nbytes):
+        self._check(self._L.goss_gpu_push_bases_device(self._h, C.c_void_p(ptr), nbytes))
+
+    def finish(self):
+        c = Counts()
+        self._check(self._L.goss_gpu_finish(self._h, C.byref(c)))
+        self.counts = c
+        return c
+
+    def result_ptrs(self):
+        k, v, m = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self._L.goss_gpu_result(self._h, C.byref(k), C.byref(v), C.byref(m)))
+        return k.value, v.value, m.value
+
+    def result(self):
+        """(keys as python ints, counts) copied to the host."""
+        import numpy as np
+        m = self.counts.distinct
+        w = self.counts.key_words
+        keys = np.zeros(max(1, m * w), dtype=np.uint64)
+        cnts = np.zeros(max(1, m), dtype=np.uint32)
+        self._check(self._L.goss_gpu_result_copy(self._h, 0, m, keys.ctypes.data_as(C.c_void_p), cnts.ctypes.data_as(C.c_void_p)))
+        keys = keys[: m * w]
+        cnts = cnts[:m]
+        if w == 1:
+            ks = [int(x) for x in keys]
+        else:
+            ks = [int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64) for i in range(m)]
+        return ks, cnts
+
+    def emit(self):
+        self._check(self._L.goss_gpu_emit(self._h))
+        return self.files()
+
+    def emit_sparse_array(self, dev_ptr, key_words, n, N, M, N_end=None):
+        if N_end is None:
+            N_end = N
+        mask = (1 << 64) - 1
+        self._check(self._L.goss_gpu_emit_sparse_array(self._h, C.c_void_p(dev_ptr), key_words, n, N & mask, N >> 64, M,
+                                                       N_end & mask, N_end >> 64))
+        return self.files()
+
+    def files(self):
+        n = C.c_uint32()
+        self._check(self._L.goss_gpu_file_count(self._h, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(256)
+            size = C.c_uint64()
+            self._check(self._L.goss_gpu_file_info(self._h, i, name, 256, C.byref(size)))
+            buf = C.create_string_buffer(max(1, size.value))
+            self._check(self._L.goss_gpu_file_read(self._h, i, 0, buf, size.value))
+            out[name.value.decode()] = buf.raw[: size.value]
+        return out
+
+    def timing(self, reset=False):
+        t = Timing()
+        self._check(self._L.goss_gpu_timing_get(self._h, C.byref(t)))
+        if reset:
+            self._check(self._L.goss_gpu_timing_reset(self._h))
+        return t
+
+    def synth_reads(self, dev_ptr, nreads, read_len, genome_len, seed=1, first_read=0):
+        self._check(self._L.goss_gpu_synth_reads(self._h, C.c_void_p(dev_ptr), nreads, read_len, genome_len, seed, first_read))

@@ -1,0 +1,989 @@
+// goss_gpu.hip -- implementation of the C ABI in include/goss_gpu.h on top of the HIP
+// kernels in goss_kernels.hpp.  gfx950 only; no CPU fallback: every entry point that needs
+// the device fails with GOSS_ERR_NO_DEVICE / GOSS_ERR_HIP when it is not usable.
+#include "../../include/goss_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "goss_kernels.hpp"
+
+using namespace goss;
+
+namespace {
+
+constexpr uint32_t kAbiVersion = 1;
+
+struct HipError { hipError_t e; const char* what; };
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) throw HipError{_e, #expr};                      \
+    } while (0)
+
+struct StatusError { int status; std::string msg; };
+
+// Two-ended bump arena over one hipMalloc: permanent blocks grow from the bottom, temporary
+// blocks from the top (released by mark).
+struct Arena {
+    uint8_t* base = nullptr;
+    uint64_t size = 0;
+    uint64_t lo = 0;        // permanent top
+    uint64_t hi = 0;        // temporary bottom (offset from base)
+
+    void* perm(uint64_t bytes)
+    {
+        uint64_t a = (lo + 255) & ~255ULL;
+        if (a + bytes > hi) throw StatusError{GOSS_ERR_OOM, "HBM budget exceeded (permanent)"};
+        lo = a + bytes;
+        return base + a;
+    }
+    void* temp(uint64_t bytes)
+    {
+        if (bytes + 256 > hi) throw StatusError{GOSS_ERR_OOM, "HBM budget exceeded (temporary)"};
+        uint64_t a = (hi - bytes) & ~255ULL;
+        if (a < lo) throw StatusError{GOSS_ERR_OOM, "HBM budget exceeded (temporary)"};
+        hi = a;
+        return base + a;
+    }
+    uint64_t mark() const { return hi; }
+    void release(uint64_t m) { hi = m; }
+    uint64_t avail() const { return hi > lo ? hi - lo : 0; }
+};
+
+struct OutFile {
+    std::string suffix;
+    uint64_t size = 0;
+    const uint8_t* dev = nullptr;      // device-resident image, or
+    std::vector<uint8_t> host;         // host-built bytes
+};
+
+struct Run { void* keys; uint32_t* counts; uint64_t m; };
+
+struct PhaseEvents { hipEvent_t a, b; int phase; };
+
+}  // namespace
+
+struct goss_gpu_ctx {
+    int device = 0;
+    uint32_t k = 0, len = 0;
+    int mode = 0;
+    int words = 1;
+    uint64_t budget = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    Arena arena;
+    std::vector<Run> runs;
+    uint64_t windows = 0, keys_total = 0;
+    bool finished = false, emitted = false;
+    void* res_keys = nullptr;
+    uint32_t* res_counts = nullptr;
+    uint64_t M = 0;
+    std::vector<OutFile> files;
+    ExtractCounters* d_ctr = nullptr;     // device counters
+    uint32_t* d_flags = nullptr;          // device error flags [0]=count overflow [1]=ef overflow
+    void* h_pinned = nullptr;             // pinned scratch (>= 64 bytes)
+    std::vector<PhaseEvents> events;
+    std::vector<hipEvent_t> event_pool;
+    goss_gpu_timing timing{};
+};
+
+namespace {
+
+enum { PH_EXTRACT = 0, PH_SORT = 1, PH_REDUCE = 2, PH_EMIT = 3 };
+
+struct PhaseTimer {
+    goss_gpu_ctx* c;
+    PhaseEvents pe;
+    PhaseTimer(goss_gpu_ctx* ctx, int phase) : c(ctx)
+    {
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(&e));
+            return e;
+        };
+        pe.a = get(); pe.b = get(); pe.phase = phase;
+        HIP_TRY(hipEventRecord(pe.a, c->stream));
+    }
+    void stop()
+    {
+        HIP_TRY(hipEventRecord(pe.b, c->stream));
+        c->events.push_back(pe);
+    }
+};
+
+void resolve_timing(goss_gpu_ctx* c)
+{
+    for (auto& pe : c->events)
+    {
+        HIP_TRY(hipEventSynchronize(pe.b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, pe.a, pe.b));
+        switch (pe.phase)
+        {
+            case PH_EXTRACT: c->timing.extract_ms += ms; c->timing.extract_launches++; break;
+            case PH_SORT: c->timing.sort_ms += ms; c->timing.sort_launches++; break;
+            case PH_REDUCE: c->timing.reduce_ms += ms; c->timing.reduce_launches++; break;
+            default: c->timing.emit_ms += ms; c->timing.emit_launches++; break;
+        }
+        c->timing.total_ms += ms;
+        c->event_pool.push_back(pe.a);
+        c->event_pool.push_back(pe.b);
+    }
+    c->events.clear();
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t per_block)
+{
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g == 0) g = 1;
+    if (g > 0x7FFFFFFFULL) throw StatusError{GOSS_ERR_INVALID_ARG, "launch grid too large"};
+    return (uint32_t)g;
+}
+
+void ensure_arena(goss_gpu_ctx* c)
+{
+    if (c->arena.base) return;
+    uint64_t budget = c->budget;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (budget == 0) budget = (uint64_t)((double)free_b * 0.8);
+    if (budget > free_b) throw StatusError{GOSS_ERR_OOM, "hbm_budget larger than free device memory"};
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, budget);
+    if (e != hipSuccess) throw StatusError{GOSS_ERR_OOM, std::string("hipMalloc(budget) failed: ") + hipGetErrorString(e)};
+    c->arena.base = (uint8_t*)p;
+    c->arena.size = budget;
+    c->arena.lo = 0;
+    c->arena.hi = budget;
+    c->budget = budget;
+}
+
+// ---- device-wide exclusive scan (in place) -------------------------------------------
+void exclusive_scan_u64(goss_gpu_ctx* c, uint64_t* a, uint64_t n)
+{
+    if (n == 0) return;
+    uint64_t nchunks = (n + kScanChunk - 1) / kScanChunk;
+    if (nchunks == 1)
+    {
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(kTB), 0, c->stream, a, n, (const uint64_t*)nullptr);
+        return;
+    }
+    uint64_t mark = c->arena.mark();
+    uint64_t* partial = (uint64_t*)c->arena.temp(nchunks * 8);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(grid_for(n, kScanChunk)), dim3(kTB), 0, c->stream, (const uint64_t*)a, n, partial);
+    exclusive_scan_u64(c, partial, nchunks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(grid_for(n, kScanChunk)), dim3(kTB), 0, c->stream, a, n, (const uint64_t*)partial);
+    // the stream orders the kernels; the scratch can be reused by later launches on the
+    // same stream once released
+    c->arena.release(mark);
+}
+
+// ---- LSD radix sort -------------------------------------------------------------------
+// Sorts n keys on digits [0, ndigits).  Returns true if the result is in (kb, vb).
+template <class K, bool HAS_VAL>
+bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint64_t n, uint32_t ndigits)
+{
+    if (n < 2) return false;
+    constexpr int tile = SortCfg<K>::kTile;
+    const uint64_t ntiles = (n + tile - 1) / tile;
+    uint64_t mark = c->arena.mark();
+    uint64_t* table = (uint64_t*)c->arena.temp(256ULL * ntiles * 8);
+    bool in_b = false;
+    for (uint32_t d = 0; d < ndigits; ++d)
+    {
+        K* src = in_b ? kb : ka; K* dst = in_b ? ka : kb;
+        uint32_t* vs = in_b ? vb : va; uint32_t* vd = in_b ? va : vb;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                           (const K*)src, n, d, ntiles, table);
+        exclusive_scan_u64(c, table, 256ULL * ntiles);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                           (const K*)src, (const uint32_t*)vs, dst, vd, n, d, ntiles, (const uint64_t*)table);
+        in_b = !in_b;
+    }
+    c->arena.release(mark);
+    return in_b;
+}
+
+// ---- run compaction ---------------------------------------------------------------------
+// keys sorted (n).  Produces a permanent Run (distinct keys + u32 counts).  If vals != null
+// the counts are sums of vals over each run, else run lengths.  `scratch_keys` is a buffer
+// of >= n keys that may be clobbered (the free half of the sort ping-pong).
+template <class K>
+Run reduce_runs(goss_gpu_ctx* c, const K* keys, const uint32_t* vals, uint64_t n, K* scratch_keys)
+{
+    Run r{nullptr, nullptr, 0};
+    if (n == 0) return r;
+    uint64_t mark = c->arena.mark();
+    const uint64_t ntiles = (n + kRedTile - 1) / kRedTile;
+    uint64_t* tile_counts = (uint64_t*)c->arena.temp((ntiles + 1) * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_count_kernel<K>), dim3(grid_for(n, kRedTile)), dim3(kTB), 0, c->stream,
+                       keys, n, tile_counts);
+    // total = last offset + last count: append a zero element and scan ntiles+1 entries
+    HIP_TRY(hipMemsetAsync(tile_counts + ntiles, 0, 8, c->stream));
+    exclusive_scan_u64(c, tile_counts, ntiles + 1);
+    uint64_t* h = (uint64_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, tile_counts + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t m = h[0];
+    uint64_t* starts = (uint64_t*)c->arena.temp(m * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_write_kernel<K>), dim3(grid_for(n, kRedTile)), dim3(kTB), 0, c->stream,
+                       keys, n, (const uint64_t*)tile_counts, scratch_keys, starts);
+    // permanent storage
+    r.m = m;
+    r.keys = c->arena.perm(m * sizeof(K));
+    r.counts = (uint32_t*)c->arena.perm(m * 4);
+    HIP_TRY(hipMemcpyAsync(r.keys, scratch_keys, m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+    if (vals)
+        hipLaunchKernelGGL(run_sums_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                           (const uint64_t*)starts, m, n, vals, r.counts, c->d_flags);
+    else
+        hipLaunchKernelGGL(run_lengths_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                           (const uint64_t*)starts, m, n, r.counts, c->d_flags);
+    HIP_TRY(hipStreamSynchronize(c->stream));   // temporaries are released below
+    c->arena.release(mark);
+    return r;
+}
+
+template <class K, int MODE, int P>
+void launch_extract(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out)
+{
+    constexpr int T = kTB * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_kernel<K, MODE, P>), dim3(grid_for(nstarts, T)), dim3(kTB), 0, c->stream,
+                       aligned, mis, nstarts, navail, c->len, out, c->d_ctr);
+}
+
+template <class K>
+void extract_dispatch(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out);
+template <>
+void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
+{
+    if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key1, 0, 16>(c, aligned, mis, nstarts, navail, out);
+    else launch_extract<Key1, 1, 8>(c, aligned, mis, nstarts, navail, out);
+}
+template <>
+void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
+{
+    if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key2, 0, 8>(c, aligned, mis, nstarts, navail, out);
+    else launch_extract<Key2, 1, 4>(c, aligned, mis, nstarts, navail, out);
+}
+
+inline uint32_t key_digits(const goss_gpu_ctx* c) { return (2 * c->len + 7) / 8; }
+
+// Process window starts [0, nstarts) of a device-resident byte string (navail readable bytes,
+// navail >= nstarts): extract -> sort -> reduce -> append a run.
+template <class K>
+void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail)
+{
+    const uint32_t S = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
+    const uint64_t cap = nstarts * S;              // upper bound on keys
+    uint64_t mark = c->arena.mark();
+    K* ka = (K*)c->arena.temp(cap * sizeof(K));
+    K* kb = (K*)c->arena.temp(cap * sizeof(K));
+    HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
+    uintptr_t addr = (uintptr_t)d_bases;
+    uint32_t mis = (uint32_t)(addr & 15u);
+    const uint8_t* aligned = (const uint8_t*)(addr - mis);
+    {
+        PhaseTimer t(c, PH_EXTRACT);
+        extract_dispatch<K>(c, aligned, mis, nstarts, navail, ka);
+        t.stop();
+    }
+    ExtractCounters* h = (ExtractCounters*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, c->d_ctr, sizeof(ExtractCounters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t n = h->keys_out;
+    c->windows += h->windows;
+    c->keys_total += n;
+    if (n)
+    {
+        bool in_b;
+        {
+            PhaseTimer t(c, PH_SORT);
+            in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
+            t.stop();
+        }
+        PhaseTimer t(c, PH_REDUCE);
+        Run r = reduce_runs<K>(c, in_b ? kb : ka, nullptr, n, in_b ? ka : kb);
+        t.stop();
+        c->runs.push_back(r);
+    }
+    c->arena.release(mark);
+}
+
+// Merge all runs into one (concatenate, sort pairs, sum equal keys).
+template <class K>
+void merge_runs(goss_gpu_ctx* c)
+{
+    if (c->runs.size() <= 1) return;
+    uint64_t total = 0;
+    for (auto& r : c->runs) total += r.m;
+    uint64_t mark = c->arena.mark();
+    K* ka = (K*)c->arena.temp(total * sizeof(K));
+    K* kb = (K*)c->arena.temp(total * sizeof(K));
+    uint32_t* va = (uint32_t*)c->arena.temp(total * 4);
+    uint32_t* vb = (uint32_t*)c->arena.temp(total * 4);
+    uint64_t off = 0;
+    for (auto& r : c->runs)
+    {
+        HIP_TRY(hipMemcpyAsync(ka + off, r.keys, r.m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(va + off, r.counts, r.m * 4, hipMemcpyDeviceToDevice, c->stream));
+        off += r.m;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the old runs' permanent storage is dead now: rewind the permanent end to the first run
+    c->arena.lo = (uint64_t)((uint8_t*)c->runs.front().keys - c->arena.base);
+    c->runs.clear();
+    bool in_b;
+    {
+        PhaseTimer t(c, PH_SORT);
+        in_b = radix_sort<K, true>(c, ka, kb, va, vb, total, key_digits(c));
+        t.stop();
+    }
+    PhaseTimer t(c, PH_REDUCE);
+    Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb);
+    t.stop();
+    c->runs.push_back(r);
+    c->arena.release(mark);
+}
+
+// Largest number of window starts one chunk may cover with the memory currently free.
+uint64_t chunk_capacity(goss_gpu_ctx* c)
+{
+    const uint64_t ksz = c->words * 8;
+    const uint32_t S = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
+    // per key: two key buffers + histogram table + worst-case output (keys, counts, starts)
+    const double per_key = 2.0 * ksz + 1.2 + (ksz + 12.0);
+    uint64_t avail = c->arena.avail();
+    uint64_t keys = (uint64_t)((double)avail * 0.9 / per_key);
+    uint64_t starts = keys / S;
+    starts &= ~4095ULL;
+    return starts;
+}
+
+template <class K>
+void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
+{
+    if (nbytes < c->len) return;
+    ensure_arena(c);
+    const uint64_t nstarts_total = nbytes - c->len + 1;
+    uint64_t done = 0;
+    while (done < nstarts_total)
+    {
+        uint64_t capn = chunk_capacity(c);
+        if (capn < 4096)
+        {
+            // try to make room by merging what we have
+            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c); }
+            if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
+        }
+        uint64_t ns = std::min(capn, nstarts_total - done);
+        uint64_t navail = std::min(nbytes - done, ns + c->len - 1);
+        process_chunk<K>(c, d + done, ns, navail);
+        done += ns;
+        // keep the accumulated runs from eating the budget
+        uint64_t run_bytes = 0;
+        for (auto& r : c->runs) run_bytes += r.m * (c->words * 8 + 4);
+        if (c->runs.size() > 1 && run_bytes > c->arena.size / 4) merge_runs<K>(c);
+    }
+}
+
+// ---- on-disk arrays ---------------------------------------------------------------------
+
+struct IaCol { std::string suffix; uint32_t bytes; uint32_t shift; };
+
+// IntegerArray::builder column layout (IntegerArray.cc:259-357, StackedArray.hh:152-178).
+bool ia_layout(uint32_t bits, const std::string& prefix, uint32_t shift, std::vector<IaCol>& out)
+{
+    uint32_t ub = 0, lb = 0;
+    switch (bits)
+    {
+        case 8: case 16: case 32: case 64: out.push_back({prefix, bits / 8, shift}); return true;
+        case 24: ub = 8; lb = 16; break;
+        case 40: ub = 8; lb = 32; break;
+        case 48: ub = 16; lb = 32; break;
+        case 56: ub = 8; lb = 48; break;
+        case 72: ub = 8; lb = 64; break;
+        case 80: ub = 16; lb = 64; break;
+        case 88: ub = 8; lb = 80; break;
+        case 96: ub = 32; lb = 64; break;
+        case 104: ub = 8; lb = 96; break;
+        case 112: ub = 16; lb = 96; break;
+        case 120: ub = 24; lb = 96; break;
+        case 128: ub = 64; lb = 64; break;
+        default: return false;
+    }
+    return ia_layout(ub, prefix + ".upr", shift + lb, out) && ia_layout(lb, prefix + ".lwr", shift, out);
+}
+
+// SparseArray::Builder::d (SparseArray.cc:47-72).
+uint64_t sparse_d(uint64_t n_lo, uint64_t n_hi, uint64_t M)
+{
+    double scale = 18446744073709551616.0;
+    double n = (double)n_hi * scale + (double)n_lo;
+    double m = (double)M;
+    double d0 = std::log2(n / ((1 + m) * 1.4426950408889634));
+    uint64_t d = (uint64_t)std::ceil(d0);
+    if (d < 8) d = 8; else if (d > 128) d = 128;
+    return d;
+}
+
+struct DsHeader {
+    uint64_t version, flags, indexArrayOffset, rankArrayOffset;
+    uint64_t logBlockSize, blockSize, logSampleRate, sampleRate;
+    uint64_t numBlocks, indexSize, smallBlocks, smallBlocksSize;
+    uint64_t intermediateBlocks, intermediateBlocksSize, largeBlocks, largeBlocksSize;
+};
+static_assert(sizeof(DsHeader) == 128, "DenseSelect header is 128 bytes");
+
+// DenseSelect file image over the virtual position sequence (DenseArray.cc:446-694).
+template <class K>
+void emit_dense_select(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, int invert, uint64_t count,
+                       const std::string& suffix)
+{
+    const uint64_t nblocks = (count + 8191) >> 13;
+    DsHeader h{};
+    h.version = 2012092701ULL;
+    h.flags = invert ? 1 : 0;
+    h.logBlockSize = 13; h.blockSize = 8192; h.logSampleRate = 6; h.sampleRate = 64;
+    std::vector<uint32_t> btype(nblocks);
+    std::vector<uint64_t> bbytes(nblocks), boff(nblocks);
+    uint64_t mark = c->arena.mark();
+    uint32_t* d_btype = nullptr; uint64_t* d_bbytes = nullptr; uint64_t* d_brank = nullptr; uint64_t* d_boff = nullptr;
+    if (nblocks)
+    {
+        d_btype = (uint32_t*)c->arena.temp(nblocks * 4);
+        d_bbytes = (uint64_t*)c->arena.temp(nblocks * 8);
+        d_brank = (uint64_t*)c->arena.temp(nblocks * 8);
+        d_boff = (uint64_t*)c->arena.temp(nblocks * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_classify_kernel<K>), dim3(grid_for(nblocks, 64)), dim3(64), 0, c->stream,
+                           keys, m, D, invert, count, nblocks, d_btype, d_bbytes, d_brank);
+        HIP_TRY(hipMemcpyAsync(btype.data(), d_btype, nblocks * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(bbytes.data(), d_bbytes, nblocks * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    uint64_t pos = 4096;
+    for (uint64_t b = 0; b < nblocks; ++b)
+    {
+        boff[b] = pos;
+        uint64_t cnt = std::min<uint64_t>(8192, count - (b << 13));
+        switch (btype[b])
+        {
+            case kDsSmall: h.smallBlocks++; h.smallBlocksSize += 256; break;
+            case kDsIntermediate: h.intermediateBlocks++; h.intermediateBlocksSize += bbytes[b]; break;
+            case kDsSpill32: h.largeBlocks++; h.largeBlocksSize += cnt * 4; break;
+            default: h.largeBlocks++; h.largeBlocksSize += cnt * 8; break;
+        }
+        pos += bbytes[b];
+    }
+    h.numBlocks = nblocks;
+    pos = (pos + 15) & ~15ULL;
+    h.indexArrayOffset = pos;
+    h.rankArrayOffset = pos + nblocks * 8;
+    h.indexSize = nblocks * 16;
+    const uint64_t size = pos + nblocks * 16;
+    uint8_t* image = (uint8_t*)c->arena.perm(size);
+    HIP_TRY(hipMemsetAsync(image, 0, size, c->stream));
+    HIP_TRY(hipMemcpyAsync(image, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    if (nblocks)
+    {
+        HIP_TRY(hipMemcpyAsync(d_boff, boff.data(), nblocks * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_fill_kernel<K>), dim3((uint32_t)nblocks), dim3(128), 0, c->stream,
+                           keys, m, D, invert, count, (const uint32_t*)d_btype, (const uint64_t*)d_boff,
+                           (const uint64_t*)d_brank, image, (uint64_t*)(image + h.indexArrayOffset));
+        HIP_TRY(hipMemcpyAsync(image + h.rankArrayOffset, d_brank, nblocks * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));    // host vectors / header go out of scope
+    c->arena.release(mark);
+    OutFile f; f.suffix = suffix; f.size = size; f.dev = image;
+    c->files.push_back(std::move(f));
+}
+
+struct SaHeader { uint64_t version, D, quantizedD, mask_lo, mask_hi, size_lo, size_hi, count; };
+static_assert(sizeof(SaHeader) == 64, "SparseArray header is 64 bytes");
+
+// SparseArray at suffix `base` (SparseArray::Builder ctor + push_back* + end).
+template <class K>
+void emit_sparse_array(goss_gpu_ctx* c, const K* keys, uint64_t m, uint64_t N_lo, uint64_t N_hi, uint64_t Mest,
+                       uint64_t Nend_lo, uint64_t Nend_hi, const std::string& base)
+{
+    const uint32_t D = (uint32_t)sparse_d(N_lo, N_hi, Mest);
+    const uint32_t qD = 8 * ((D + 7) / 8);
+    // nd = Nend >> D must fit 64 bits (SparseArray.cc:79-86)
+    uint64_t nd;
+    if (D >= 128) nd = 0;
+    else if (D >= 64) nd = Nend_hi >> (D - 64);
+    else
+    {
+        if (D > 0 && (Nend_hi >> D) != 0) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
+        nd = D == 0 ? Nend_lo : ((Nend_lo >> D) | (Nend_hi << (64 - D)));
+        if (D == 0 && Nend_hi) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
+    }
+    // every key's high part must fit too (SparseArray.hh:91-95)
+    HIP_TRY(hipMemsetAsync(c->d_flags + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_check_kernel<K>), dim3(1), dim3(64), 0, c->stream, keys, m, D, c->d_flags + 1);
+
+    // header
+    SaHeader h{};
+    h.version = 2012030501ULL; h.D = D; h.quantizedD = qD;
+    if (D >= 128) { h.mask_lo = ~0ULL; h.mask_hi = ~0ULL; }
+    else if (D >= 64) { h.mask_lo = ~0ULL; h.mask_hi = D == 64 ? 0 : ((1ULL << (D - 64)) - 1); }
+    else { h.mask_lo = (1ULL << D) - 1; h.mask_hi = 0; }
+    h.size_lo = Nend_lo; h.size_hi = Nend_hi; h.count = m;
+    {
+        OutFile f; f.suffix = base + ".header"; f.size = sizeof h;
+        f.host.assign((uint8_t*)&h, (uint8_t*)&h + sizeof h);
+        c->files.push_back(std::move(f));
+    }
+    // high bits
+    {
+        const uint64_t nwords = (nd + m + 3) / 64 + 1;
+        uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
+                           keys, m, D, nwords, words);
+        OutFile f; f.suffix = base + ".high-bits"; f.size = nwords * 8; f.dev = (const uint8_t*)words;
+        c->files.push_back(std::move(f));
+    }
+    // d0 (zeros, inverted sense) and d1 (ones)
+    emit_dense_select<K>(c, keys, m, D, 1, nd + 2, base + "-d0");
+    emit_dense_select<K>(c, keys, m, D, 0, m, base + "-d1");
+    // low bits columns
+    {
+        std::vector<IaCol> cols;
+        if (!ia_layout(qD, "", 0, cols)) throw StatusError{GOSS_ERR_INVALID_ARG, "IntegerArray::builder: unsupported integer width"};
+        EfColumns ec{};
+        ec.n = (uint32_t)cols.size();
+        for (size_t i = 0; i < cols.size(); ++i)
+        {
+            uint8_t* dst = (uint8_t*)c->arena.perm(std::max<uint64_t>(m * cols[i].bytes, 8));
+            ec.c[i] = EfColumn{dst, cols[i].bytes, cols[i].shift};
+            OutFile f; f.suffix = base + ".low-bits" + cols[i].suffix; f.size = m * cols[i].bytes; f.dev = dst;
+            c->files.push_back(std::move(f));
+        }
+        if (m)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_low_bits_kernel<K>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                               keys, m, D, ec);
+    }
+    uint32_t* hf = (uint32_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hf, c->d_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hf[0]) throw StatusError{GOSS_ERR_TOO_LARGE, "SparseArray::push_back: high bits do not fit 64 bits"};
+}
+
+void add_host_file(goss_gpu_ctx* c, const std::string& suffix, const void* p, size_t n)
+{
+    OutFile f; f.suffix = suffix; f.size = n;
+    f.host.assign((const uint8_t*)p, (const uint8_t*)p + n);
+    c->files.push_back(std::move(f));
+}
+
+// VariableByteArray + counts histogram (VariableByteArray.hh:76-118, Graph.cc:115-134).
+void emit_counts(goss_gpu_ctx* c, const uint32_t* counts, uint64_t m, const std::string& out_counts, const std::string& out_hist)
+{
+    uint64_t mark = c->arena.mark();
+    uint8_t* ord0 = (uint8_t*)c->arena.perm(std::max<uint64_t>(m, 8));
+    uint64_t n1 = 0, n2 = 0;
+    Key1* pos1 = nullptr; uint8_t* ord1 = nullptr; Key1* pos2 = nullptr; uint16_t* ord2 = nullptr;
+    uint64_t* h = (uint64_t*)c->h_pinned;
+    if (m)
+    {
+        uint64_t* slot = (uint64_t*)c->arena.temp((m + 1) * 8);
+        hipLaunchKernelGGL(vba_ord0_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, ord0, slot);
+        HIP_TRY(hipMemsetAsync(slot + m, 0, 8, c->stream));
+        exclusive_scan_u64(c, slot, m + 1);
+        HIP_TRY(hipMemcpyAsync(h, slot + m, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        n1 = h[0];
+        pos1 = (Key1*)c->arena.perm(std::max<uint64_t>(n1 * 8, 8));
+        ord1 = (uint8_t*)c->arena.perm(std::max<uint64_t>(n1, 8));
+        if (n1)
+        {
+            uint32_t* hi16 = (uint32_t*)c->arena.temp(n1 * 4);
+            uint64_t* slot2 = (uint64_t*)c->arena.temp((n1 + 1) * 8);
+            hipLaunchKernelGGL(vba_ord1_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m,
+                               (const uint64_t*)slot, n1, (uint64_t*)pos1, ord1, hi16);
+            hipLaunchKernelGGL(vba_flag2_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, c->stream, (const uint32_t*)hi16, n1, slot2);
+            HIP_TRY(hipMemsetAsync(slot2 + n1, 0, 8, c->stream));
+            exclusive_scan_u64(c, slot2, n1 + 1);
+            HIP_TRY(hipMemcpyAsync(h, slot2 + n1, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            n2 = h[0];
+            pos2 = (Key1*)c->arena.perm(std::max<uint64_t>(n2 * 8, 8));
+            ord2 = (uint16_t*)c->arena.perm(std::max<uint64_t>(n2 * 2, 8));
+            if (n2)
+                hipLaunchKernelGGL(vba_ord2_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, c->stream, (const uint32_t*)hi16, n1,
+                                   (const uint64_t*)slot2, (uint64_t*)pos2, ord2);
+        }
+    }
+    if (!pos1) pos1 = (Key1*)c->arena.perm(8);
+    if (!pos2) pos2 = (Key1*)c->arena.perm(8);
+    if (!ord1) ord1 = (uint8_t*)c->arena.perm(8);
+    if (!ord2) ord2 = (uint16_t*)c->arena.perm(8);
+    { OutFile f; f.suffix = out_counts + ".ord0"; f.size = m; f.dev = ord0; c->files.push_back(std::move(f)); }
+    const uint64_t mest = (uint64_t)((double)m * 0.001);
+    emit_sparse_array<Key1>(c, pos1, n1, m, 0, mest, m, 0, out_counts + ".ord1p");
+    { OutFile f; f.suffix = out_counts + ".ord1"; f.size = n1; f.dev = ord1; c->files.push_back(std::move(f)); }
+    emit_sparse_array<Key1>(c, pos2, n2, m, 0, mest, n1, 0, out_counts + ".ord2p");
+    { OutFile f; f.suffix = out_counts + ".ord2"; f.size = n2 * 2; f.dev = (const uint8_t*)ord2; c->files.push_back(std::move(f)); }
+
+    // histogram of counts: sort the counts as keys, run-length them, format on the host
+    std::string text;
+    if (m)
+    {
+        Key1* ka = (Key1*)c->arena.temp(m * 8);
+        Key1* kb = (Key1*)c->arena.temp(m * 8);
+        hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, ka);
+        bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, m, 4);
+        const Key1* sorted = in_b ? kb : ka;
+        Key1* distinct = in_b ? ka : kb;
+        const uint64_t ntiles = (m + kRedTile - 1) / kRedTile;
+        uint64_t* tile_counts = (uint64_t*)c->arena.temp((ntiles + 1) * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_count_kernel<Key1>), dim3(grid_for(m, kRedTile)), dim3(kTB), 0, c->stream,
+                           sorted, m, tile_counts);
+        HIP_TRY(hipMemsetAsync(tile_counts + ntiles, 0, 8, c->stream));
+        exclusive_scan_u64(c, tile_counts, ntiles + 1);
+        HIP_TRY(hipMemcpyAsync(h, tile_counts + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint64_t nd = h[0];
+        uint64_t* starts = (uint64_t*)c->arena.temp(nd * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_write_kernel<Key1>), dim3(grid_for(m, kRedTile)), dim3(kTB), 0, c->stream,
+                           sorted, m, (const uint64_t*)tile_counts, distinct, starts);
+        std::vector<uint64_t> hv(nd), hs(nd);
+        HIP_TRY(hipMemcpyAsync(hv.data(), distinct, nd * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hs.data(), starts, nd * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        char line[64];
+        for (uint64_t i = 0; i < nd; ++i)
+        {
+            uint64_t e = i + 1 < nd ? hs[i + 1] : m;
+            int l = snprintf(line, sizeof line, "%llu\t%llu\n", (unsigned long long)hv[i], (unsigned long long)(e - hs[i]));
+            text.append(line, (size_t)l);
+        }
+    }
+    add_host_file(c, out_hist, text.data(), text.size());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+}
+
+template <class K>
+void emit_object(goss_gpu_ctx* c)
+{
+    const K* keys = (const K*)c->res_keys;
+    const uint64_t m = c->M;
+    PhaseTimer t(c, PH_EMIT);
+    if (c->mode == GOSS_MODE_KMER_SET)
+    {
+        // N = 4^K (KmerSet.hh:84,72)
+        uint32_t bits = 2 * c->k;
+        uint64_t nlo = bits < 64 ? (1ULL << bits) : 0, nhi = bits >= 64 ? (1ULL << (bits - 64)) : 0;
+        emit_sparse_array<K>(c, keys, m, nlo, nhi, m, nlo, nhi, ".kmers");
+        uint64_t hdr[3] = {2011101701ULL, c->k, m};
+        add_host_file(c, ".header", hdr, sizeof hdr);
+    }
+    else
+    {
+        uint64_t hdr[3] = {2011101014ULL, c->k, 0};
+        add_host_file(c, ".header", hdr, sizeof hdr);
+        uint32_t bits = 2 * c->k + 2;
+        uint64_t nlo = bits < 64 ? (1ULL << bits) : 0, nhi = bits >= 64 ? (1ULL << (bits - 64)) : 0;
+        emit_sparse_array<K>(c, keys, m, nlo, nhi, m, nlo, nhi, "-edges");
+        emit_counts(c, c->res_counts, m, "-counts", "-counts-hist.txt");
+    }
+    t.stop();
+}
+
+template <class F>
+int guarded(goss_gpu_ctx* c, F&& f)
+{
+    try
+    {
+        if (c) HIP_TRY(hipSetDevice(c->device));
+        f();
+        return GOSS_OK;
+    }
+    catch (const HipError& e)
+    {
+        if (c) c->last_error = std::string(e.what) + ": " + hipGetErrorString(e.e);
+        return GOSS_ERR_HIP;
+    }
+    catch (const StatusError& e)
+    {
+        if (c) c->last_error = e.msg;
+        return e.status;
+    }
+    catch (const std::bad_alloc&)
+    {
+        if (c) c->last_error = "host allocation failed";
+        return GOSS_ERR_OOM;
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+
+extern "C" {
+
+const char* goss_gpu_strerror(int status)
+{
+    switch (status)
+    {
+        case GOSS_OK: return "ok";
+        case GOSS_ERR_INVALID_ARG: return "invalid argument";
+        case GOSS_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+        case GOSS_ERR_OOM: return "out of memory (HBM budget)";
+        case GOSS_ERR_HIP: return "HIP runtime error";
+        case GOSS_ERR_STATE: return "call out of order";
+        case GOSS_ERR_K_RANGE: return "unable to build a graph with that k";
+        case GOSS_ERR_COUNT_OVERFLOW: return "a key count does not fit 32 bits";
+        case GOSS_ERR_TOO_LARGE: return "SparseArray high bits do not fit 64 bits";
+        default: return "unknown status";
+    }
+}
+
+const char* goss_gpu_last_error(const goss_gpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+uint32_t goss_gpu_abi_version(void) { return kAbiVersion; }
+
+int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64_t hbm_budget, void* stream)
+{
+    if (!out) return GOSS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (mode != GOSS_MODE_KMER_SET && mode != GOSS_MODE_GRAPH) return GOSS_ERR_INVALID_ARG;
+    if (k == 0) return GOSS_ERR_K_RANGE;
+    if (mode == GOSS_MODE_KMER_SET && k > 63) return GOSS_ERR_K_RANGE;   // KmerSet::MaxK
+    if (mode == GOSS_MODE_GRAPH && k > 62) return GOSS_ERR_K_RANGE;      // Graph::MaxK
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return GOSS_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GOSS_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GOSS_ERR_NO_DEVICE;
+    goss_gpu_ctx* c = new (std::nothrow) goss_gpu_ctx();
+    if (!c) return GOSS_ERR_OOM;
+    c->device = device; c->k = k; c->mode = mode;
+    c->len = mode == GOSS_MODE_GRAPH ? k + 1 : k;
+    c->words = (2 * c->len <= 62) ? 1 : 2;
+    c->budget = hbm_budget;
+    int rc = guarded(c, [&]() {
+        if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+        else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        HIP_TRY(hipMalloc((void**)&c->d_ctr, sizeof(ExtractCounters)));
+        HIP_TRY(hipMalloc((void**)&c->d_flags, 16));
+        HIP_TRY(hipMemsetAsync(c->d_flags, 0, 16, c->stream));
+        HIP_TRY(hipHostMalloc(&c->h_pinned, 256, hipHostMallocDefault));
+    });
+    if (rc != GOSS_OK) { goss_gpu_destroy(c); return rc == GOSS_ERR_HIP ? GOSS_ERR_NO_DEVICE : rc; }
+    *out = c;
+    return GOSS_OK;
+}
+
+void goss_gpu_destroy(goss_gpu_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& pe : c->events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes)
+{
+    if (!c || (!d_bases && nbytes)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        if (c->words == 1) push_device<Key1>(c, (const uint8_t*)d_bases, nbytes);
+        else push_device<Key2>(c, (const uint8_t*)d_bases, nbytes);
+    });
+}
+
+int goss_gpu_push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes)
+{
+    if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        if (nbytes < c->len) return;
+        ensure_arena(c);
+        // stage the bytes in HBM in pieces of at most 1/8 of the free arena; pieces overlap
+        // by len-1 bytes so that no window is lost at a cut
+        uint64_t done = 0;
+        const uint64_t nstarts_total = nbytes - c->len + 1;
+        while (done < nstarts_total)
+        {
+            uint64_t piece = std::max<uint64_t>(c->arena.avail() / 8, 1 << 20);
+            piece &= ~4095ULL;
+            uint64_t ns = std::min(piece, nstarts_total - done);
+            uint64_t nb = ns + c->len - 1;
+            uint64_t mark = c->arena.mark();
+            uint8_t* d = (uint8_t*)c->arena.temp(nb + 16);
+            HIP_TRY(hipMemcpyAsync(d, bases + done, nb, hipMemcpyHostToDevice, c->stream));
+            if (c->words == 1) push_device<Key1>(c, d, nb); else push_device<Key2>(c, d, nb);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->arena.release(mark);
+            done += ns;
+        }
+    });
+}
+
+int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "finish called twice"; return GOSS_ERR_STATE; }
+    int rc = guarded(c, [&]() {
+        ensure_arena(c);
+        if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
+        if (!c->runs.empty()) { c->res_keys = c->runs[0].keys; c->res_counts = c->runs[0].counts; c->M = c->runs[0].m; }
+        else { c->res_keys = c->arena.perm(16); c->res_counts = (uint32_t*)c->arena.perm(16); c->M = 0; }
+        uint32_t* hf = (uint32_t*)c->h_pinned;
+        HIP_TRY(hipMemcpyAsync(hf, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hf[0]) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "a key occurred 2^32 times or more"};
+        c->finished = true;
+    });
+    if (rc == GOSS_OK && out)
+    {
+        out->windows = c->windows; out->keys = c->keys_total; out->distinct = c->M;
+        out->key_words = (uint32_t)c->words; out->reserved = 0;
+    }
+    return rc;
+}
+
+int goss_gpu_result(goss_gpu_ctx* c, const void** d_keys, const uint32_t** d_counts, uint64_t* distinct)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished) { c->last_error = "result before finish"; return GOSS_ERR_STATE; }
+    if (d_keys) *d_keys = c->res_keys;
+    if (d_counts) *d_counts = c->res_counts;
+    if (distinct) *distinct = c->M;
+    return GOSS_OK;
+}
+
+int goss_gpu_result_copy(goss_gpu_ctx* c, uint64_t first, uint64_t n, uint64_t* h_keys, uint32_t* h_counts)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished) { c->last_error = "result before finish"; return GOSS_ERR_STATE; }
+    if (first > c->M || n > c->M - first) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() {
+        const uint64_t ksz = c->words * 8;
+        if (h_keys && n) HIP_TRY(hipMemcpyAsync(h_keys, (const uint8_t*)c->res_keys + first * ksz, n * ksz, hipMemcpyDeviceToHost, c->stream));
+        if (h_counts && n) HIP_TRY(hipMemcpyAsync(h_counts, c->res_counts + first, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
+int goss_gpu_emit(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished || c->emitted) { c->last_error = "emit needs exactly one finish before it"; return GOSS_ERR_STATE; }
+    int rc = guarded(c, [&]() {
+        c->files.clear();
+        if (c->words == 1) emit_object<Key1>(c); else emit_object<Key2>(c);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+    if (rc == GOSS_OK) c->emitted = true;
+    return rc;
+}
+
+int goss_gpu_emit_sparse_array(goss_gpu_ctx* c, const void* d_positions, uint32_t key_words, uint64_t n,
+                               uint64_t N_lo, uint64_t N_hi, uint64_t M, uint64_t Nend_lo, uint64_t Nend_hi)
+{
+    if (!c || (key_words != 1 && key_words != 2) || (!d_positions && n)) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        c->files.clear();
+        PhaseTimer t(c, PH_EMIT);
+        // private copy so the caller's buffer need not outlive the call
+        const uint64_t ksz = key_words * 8;
+        void* keys = c->arena.perm(std::max<uint64_t>(n * ksz, 16));
+        if (n) HIP_TRY(hipMemcpyAsync(keys, d_positions, n * ksz, hipMemcpyDeviceToDevice, c->stream));
+        if (key_words == 1) emit_sparse_array<Key1>(c, (const Key1*)keys, n, N_lo, N_hi, M, Nend_lo, Nend_hi, "");
+        else emit_sparse_array<Key2>(c, (const Key2*)keys, n, N_lo, N_hi, M, Nend_lo, Nend_hi, "");
+        t.stop();
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
+int goss_gpu_file_count(goss_gpu_ctx* c, uint32_t* n)
+{
+    if (!c || !n) return GOSS_ERR_INVALID_ARG;
+    *n = (uint32_t)c->files.size();
+    return GOSS_OK;
+}
+
+int goss_gpu_file_info(goss_gpu_ctx* c, uint32_t i, char* suffix, size_t cap, uint64_t* size)
+{
+    if (!c || i >= c->files.size()) return GOSS_ERR_INVALID_ARG;
+    if (suffix && cap) { std::snprintf(suffix, cap, "%s", c->files[i].suffix.c_str()); }
+    if (size) *size = c->files[i].size;
+    return GOSS_OK;
+}
+
+int goss_gpu_file_read(goss_gpu_ctx* c, uint32_t i, uint64_t offset, void* dst, uint64_t n)
+{
+    if (!c || i >= c->files.size() || (!dst && n)) return GOSS_ERR_INVALID_ARG;
+    const OutFile& f = c->files[i];
+    if (offset > f.size || n > f.size - offset) return GOSS_ERR_INVALID_ARG;
+    if (n == 0) return GOSS_OK;
+    if (!f.dev) { std::memcpy(dst, f.host.data() + offset, n); return GOSS_OK; }
+    return guarded(c, [&]() {
+        HIP_TRY(hipMemcpyAsync(dst, f.dev + offset, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
+int goss_gpu_timing_get(goss_gpu_ctx* c, goss_gpu_timing* out)
+{
+    if (!c || !out) return GOSS_ERR_INVALID_ARG;
+    int rc = guarded(c, [&]() { resolve_timing(c); });
+    *out = c->timing;
+    return rc;
+}
+
+int goss_gpu_timing_reset(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    int rc = guarded(c, [&]() { resolve_timing(c); });
+    c->timing = goss_gpu_timing{};
+    return rc;
+}
+
+int goss_gpu_synth_reads(goss_gpu_ctx* c, void* d_out, uint64_t nreads, uint32_t read_len, uint64_t genome_len,
+                         uint64_t seed, uint64_t first_read)
+{
+    if (!c || !d_out || read_len == 0 || genome_len < read_len) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() {
+        hipLaunchKernelGGL(synth_reads_kernel, dim3(256 * 8), dim3(256), 0, c->stream, (uint8_t*)d_out, nreads, read_len,
+                           genome_len, seed, first_read);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
+int goss_synth_reads_host(char* out, uint64_t nreads, uint32_t read_len, uint64_t genome_len, uint64_t seed,
+                          uint64_t first_read)
+{
+    if (!out || read_len == 0 || genome_len < read_len) return GOSS_ERR_INVALID_ARG;
+    const uint64_t stride = read_len + 1;
+    for (uint64_t r = 0; r < nreads; ++r)
+        for (uint32_t j = 0; j <= read_len; ++j)
+            out[r * stride + j] = synth_read_byte(seed, genome_len, read_len, first_read + r, j);
+    return GOSS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,801 @@
+// goss_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X): key extraction,
+// LSD radix sort, run compaction, Elias-Fano (SparseArray) + DenseSelect image build.
+// All integer / byte work, HBM-bound; no MFMA by design.
+//
+// Wave size is 64 everywhere; workgroups are 256 threads (4 waves, one per SIMD).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "goss_key.hpp"
+
+namespace goss {
+
+constexpr int kTB = 256;           // threads per workgroup
+constexpr int kWaves = kTB / 64;
+
+// --------------------------------------------------------------------------------------
+// wave / block primitives
+// --------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        T o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across the 256-thread block; `sh` holds kWaves+1
+// elements of scratch.  Returns the exclusive prefix; *total = block sum.
+template <class T>
+__device__ __forceinline__ T block_excl_scan(T v, T* sh, T* total)
+{
+    T inc = wave_incl_scan(v);
+    if (lane_id() == 63) sh[wave_id()] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+    {
+        T s = sh[w];
+        if ((int)wave_id() > w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// --------------------------------------------------------------------------------------
+// device-wide exclusive scan of a u64 array (in place): reduce / scan partials / apply
+// --------------------------------------------------------------------------------------
+
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kTB * kScanItems;
+
+__global__ __launch_bounds__(kTB) void scan_reduce_kernel(const uint64_t* __restrict__ a, uint64_t n,
+                                                          uint64_t* __restrict__ partial)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) s += a[i];
+    }
+    uint64_t tot;
+    block_excl_scan<uint64_t>(s, sh, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// Exclusive scan of one chunk, adding partial[blockIdx] (already exclusive-scanned) as offset.
+__global__ __launch_bounds__(kTB) void scan_apply_kernel(uint64_t* __restrict__ a, uint64_t n,
+                                                         const uint64_t* __restrict__ partial)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + j;
+        v[j] = i < n ? a[i] : 0;
+        s += v[j];
+    }
+    uint64_t tot;
+    uint64_t off = block_excl_scan<uint64_t>(s, sh, &tot) + (partial ? partial[blockIdx.x] : 0);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + j;
+        if (i < n) a[i] = off;
+        off += v[j];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K2: rolling / canonical k-mer extraction straight from ASCII bases
+// --------------------------------------------------------------------------------------
+//
+// One workgroup handles a tile of T = 256*P window starts.  Phase A loads T+80 bytes with
+// 16-byte vector loads and writes one code byte (0..3, 4 = not a base) per position to LDS.
+// Phase B1: every thread derives the validity mask of its P windows; block scan gives the
+// compacted slot of each thread.  Phase B2: threads roll the forward and reverse-complement
+// key together, hash both (FNV-1a, in registers) for valid windows only and store the
+// canonical key (or both strands) into an LDS staging buffer at the compacted slot.
+// Phase C: one atomicAdd per tile reserves dense output space; staged keys are written with
+// fully coalesced stores.
+//
+// MODE 0: canonical key per window.  MODE 1: forward key and its reverse complement.
+
+struct ExtractCounters {
+    unsigned long long keys_out;   // dense output cursor (keys)
+    unsigned long long windows;    // valid windows
+};
+
+template <class K> struct KeyOps;
+template <> struct KeyOps<Key1> {
+    static __device__ __forceinline__ Key1 zero() { return Key1{0}; }
+    static __device__ __forceinline__ void push(Key1& f, Key1& r, uint32_t c, uint64_t mask_lo, uint64_t, uint32_t topshift)
+    {
+        f.lo = ((f.lo << 2) | c) & mask_lo;
+        r.lo = (r.lo >> 2) | ((uint64_t)(3u - c) << topshift);
+    }
+};
+template <> struct KeyOps<Key2> {
+    static __device__ __forceinline__ Key2 zero() { return Key2{0, 0}; }
+    static __device__ __forceinline__ void push(Key2& f, Key2& r, uint32_t c, uint64_t mask_lo, uint64_t mask_hi, uint32_t topshift)
+    {
+        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+        f.lo = ((f.lo << 2) | c) & mask_lo;
+        r.lo = (r.lo >> 2) | (r.hi << 62);
+        r.hi >>= 2;
+        uint64_t cc = (uint64_t)(3u - c);
+        if (topshift >= 64) r.hi |= cc << (topshift - 64);
+        else r.lo |= cc << topshift;
+    }
+};
+
+template <class K, int MODE, int P>
+__global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                      uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                      K* __restrict__ out, ExtractCounters* __restrict__ ctr)
+{
+    constexpr int T = kTB * P;
+    constexpr int NVEC = T / 16 + 5;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t code[NVEC * 16];
+    __shared__ K stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+
+    const uint64_t tile_base = (uint64_t)blockIdx.x * T;   // first window start of the tile
+    const uint32_t tid = threadIdx.x;
+
+    // ---- phase A: ASCII -> code bytes -------------------------------------------------
+    // LDS index a corresponds to byte (tile_base + a) of the aligned stream, i.e. window
+    // position (tile_base + a - mis).  Bytes whose position is >= navail are invalid.
+    for (uint32_t v = tid; v < NVEC; v += kTB)
+    {
+        uint64_t byte0 = tile_base + (uint64_t)v * 16;            // aligned-stream offset
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        // positions byte0-mis .. byte0-mis+15 ; fully in range?
+        if (byte0 + 16 <= navail + mis)
+        {
+            uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        else if (byte0 < navail + mis)
+        {
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            // SWAR over 4 bytes: lower-case, 2-bit code, validity.
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            // nz(v): 0x80 in every byte of v that is non-zero
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            // bad byte -> code 4
+            uint32_t badm = (bad >> 7) * 0xFFu;      // 0xFF in bad bytes
+            o[i] = (x & ~badm) | ((bad >> 5) & 0x04040404u);
+        }
+        *reinterpret_cast<uint4*>(&code[v * 16]) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+
+    // ---- phase B1: validity of this thread's P windows --------------------------------
+    const uint32_t q0 = tid * P + mis;               // LDS index of the first base of window 0
+    const uint64_t p0 = tile_base + (uint64_t)tid * P;   // global window start
+    uint32_t vmask = 0;
+    {
+        uint32_t run = 0;
+        const uint32_t steps = P + len - 1;
+        for (uint32_t j = 0; j < steps; ++j)
+        {
+            uint32_t c = code[q0 + j];
+            run = c < 4 ? run + 1 : 0;
+            if (j + 1 >= len && run >= len) vmask |= 1u << (j + 1 - len);
+        }
+        // windows starting at or beyond nstarts do not belong to this launch
+        if (p0 + P > nstarts)
+        {
+            uint32_t keep = p0 >= nstarts ? 0u : (uint32_t)(nstarts - p0);
+            vmask &= keep >= 32 ? 0xFFFFFFFFu : ((1u << keep) - 1u);
+        }
+    }
+    uint32_t cnt = __popc(vmask);
+    uint32_t tile_cnt;
+    uint32_t slot = block_excl_scan<uint32_t>(cnt, sh_scan, &tile_cnt);
+
+    // ---- phase B2: roll keys, canonicalise valid windows ------------------------------
+    if (cnt)
+    {
+        const uint32_t bits = 2 * len;
+        uint64_t mask_lo, mask_hi;
+        if (bits >= 128) { mask_lo = ~0ULL; mask_hi = ~0ULL; }
+        else if (bits >= 64) { mask_lo = ~0ULL; mask_hi = bits == 64 ? 0 : ((1ULL << (bits - 64)) - 1); }
+        else { mask_lo = (1ULL << bits) - 1; mask_hi = 0; }
+        const uint32_t topshift = bits - 2;
+        K f = KeyOps<K>::zero(), r = KeyOps<K>::zero();
+        const uint32_t steps = P + len - 1;
+        uint32_t s = slot * S;
+        for (uint32_t j = 0; j < steps; ++j)
+        {
+            uint32_t c = code[q0 + j] & 3u;
+            KeyOps<K>::push(f, r, c, mask_lo, mask_hi, topshift);
+            if (j + 1 >= len && ((vmask >> (j + 1 - len)) & 1u))
+            {
+                if (MODE == 0) stage[s++] = canonical(f, r);
+                else { stage[s++] = f; stage[s++] = r; }
+            }
+        }
+    }
+    if (tid == 0)
+    {
+        unsigned long long b = 0;
+        if (tile_cnt)
+        {
+            b = atomicAdd(&ctr->keys_out, (unsigned long long)tile_cnt * S);
+            atomicAdd(&ctr->windows, (unsigned long long)tile_cnt);
+        }
+        sh_base = b;
+    }
+    __syncthreads();
+
+    // ---- phase C: coalesced dense store -----------------------------------------------
+    const uint64_t ob = sh_base;
+    const uint32_t total = tile_cnt * S;
+    for (uint32_t i = tid; i < total; i += kTB) out[ob + i] = stage[i];
+}
+
+// --------------------------------------------------------------------------------------
+// K4: LSD radix sort, 8-bit digits: per-tile histogram, scan (above), stable scatter
+// --------------------------------------------------------------------------------------
+
+template <class K> struct SortCfg {
+    static constexpr int kItems = sizeof(K) == 8 ? 16 : 8;     // keys per thread
+    static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
+};
+
+// table layout: table[digit * ntiles + tile]
+template <class K>
+__global__ __launch_bounds__(kTB) void radix_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t digit,
+                                                         uint64_t ntiles, uint64_t* __restrict__ table)
+{
+    constexpr int kSortItems = SortCfg<K>::kItems;
+    constexpr int kSortTile = SortCfg<K>::kTile;
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+#pragma unroll 4
+    for (int j = 0; j < kSortItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) atomicAdd(&hist[key_digit(keys[i], digit)], 1u);
+    }
+    __syncthreads();
+    table[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Peers of this lane = lanes of the wave whose (valid) item has the same 8-bit digit.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+    {
+        bool bit = (d >> b) & 1u;
+        uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+template <class K, bool HAS_VAL>
+__global__ __launch_bounds__(kTB) void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint64_t n, uint32_t digit, uint64_t ntiles,
+                                                            const uint64_t* __restrict__ table)
+{
+    constexpr int kSortItems = SortCfg<K>::kItems;
+    constexpr int kSortTile = SortCfg<K>::kTile;
+    __shared__ uint32_t wave_hist[kWaves][256];
+    __shared__ uint32_t digit_start[256];
+    __shared__ uint64_t global_base[256];
+    __shared__ K stage[kSortTile];
+    __shared__ uint32_t vstage[HAS_VAL ? kSortTile : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t tile_base = (uint64_t)blockIdx.x * kSortTile;
+    const uint32_t tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
+
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
+    __syncthreads();
+
+    K key[kSortItems];
+    uint32_t val[HAS_VAL ? kSortItems : 1];
+    uint16_t rank[kSortItems];
+    const uint32_t wbase = w * 64 * kSortItems;
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        bool valid = li < tile_n;
+        if (valid)
+        {
+            key[r] = keys_in[tile_base + li];
+            if (HAS_VAL) val[r] = vals_in[tile_base + li];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        bool valid = li < tile_n;
+        uint32_t d = valid ? key_digit(key[r], digit) : 0u;
+        uint64_t peers = match_digit(d, valid);
+        uint32_t before = __popcll(peers & lt_mask);
+        uint32_t base = 0;
+        volatile uint32_t* wh = wave_hist[w];
+        if (valid) base = wh[d];
+        // all reads of this round happen before the leader's update (same wave, in order)
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) wh[d] = base + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = (uint16_t)(base + before);
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over waves, tile totals, exclusive scan over digits
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i)
+        {
+            uint32_t c = wave_hist[i][tid];
+            wave_hist[i][tid] = tot;
+            tot += c;
+        }
+        uint32_t tile_total;
+        uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
+        digit_start[tid] = start;
+        global_base[tid] = table[(uint64_t)tid * ntiles + blockIdx.x] - start;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n)
+        {
+            uint32_t d = key_digit(key[r], digit);
+            uint32_t pos = digit_start[d] + wave_hist[w][d] + rank[r];
+            stage[pos] = key[r];
+            if (HAS_VAL) vstage[pos] = val[r];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = tid; i < tile_n; i += kTB)
+    {
+        K k = stage[i];
+        uint64_t o = global_base[key_digit(k, digit)] + i;
+        keys_out[o] = k;
+        if (HAS_VAL) vals_out[o] = vstage[i];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K5: run compaction (merge equal adjacent keys)
+// --------------------------------------------------------------------------------------
+
+constexpr int kRedItems = 16;
+constexpr int kRedTile = kTB * kRedItems;
+
+template <class K>
+__global__ __launch_bounds__(kTB) void heads_count_kernel(const K* __restrict__ keys, uint64_t n,
+                                                          uint64_t* __restrict__ tile_counts)
+{
+    __shared__ uint32_t sh[kWaves + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * kRedTile;
+    uint32_t c = 0;
+#pragma unroll 4
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    }
+    uint32_t tot;
+    block_excl_scan<uint32_t>(c, sh, &tot);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+// Writes distinct keys and the index at which each run starts.  tile_offsets = exclusive
+// scan of tile_counts.  Row j of the tile is the 256 consecutive keys base + j*256 + tid
+// (coalesced); output order is (row, wave, lane) = index order.
+template <class K>
+__global__ __launch_bounds__(kTB) void heads_write_kernel(const K* __restrict__ keys, uint64_t n,
+                                                          const uint64_t* __restrict__ tile_offsets,
+                                                          K* __restrict__ out_keys, uint64_t* __restrict__ starts)
+{
+    __shared__ uint32_t cnt[kRedItems * kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kRedTile;
+    const uint32_t lane = lane_id(), w = wave_id();
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+    K key[kRedItems];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        bool head = false;
+        if (i < n)
+        {
+            key[j] = keys[i];
+            head = (i == 0) || (key[j] != keys[i - 1]);
+        }
+        if (head) flags |= 1u << j;
+        uint64_t bal = __ballot(head);
+        if (lane == 0) cnt[j * kWaves + w] = __popcll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+    {
+        uint32_t c = cnt[threadIdx.x];
+        uint32_t inc = wave_incl_scan(c);
+        cnt[threadIdx.x] = inc - c;
+    }
+    __syncthreads();
+    const uint64_t tile_off = tile_offsets[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        bool head = (flags >> j) & 1u;
+        uint64_t bal = __ballot(head);
+        if (head)
+        {
+            uint64_t o = tile_off + cnt[j * kWaves + w] + __popcll(bal & lt_mask);
+            out_keys[o] = key[j];
+            starts[o] = base + (uint64_t)j * kTB + threadIdx.x;
+        }
+    }
+}
+
+// counts[j] = starts[j+1] - starts[j] (run length), last run ends at n.
+__global__ void run_lengths_kernel(const uint64_t* __restrict__ starts, uint64_t m, uint64_t n,
+                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ overflow)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    uint64_t e = j + 1 < m ? starts[j + 1] : n;
+    uint64_t c = e - starts[j];
+    if (c > 0xFFFFFFFFULL) { atomicOr(overflow, 1u); c = 0xFFFFFFFFULL; }
+    counts[j] = (uint32_t)c;
+}
+
+// weighted form: counts[j] = sum of vals over the run (runs are short: <= number of merged
+// sorted runs), used when merging (key,count) runs.
+__global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m, uint64_t n,
+                                const uint32_t* __restrict__ vals, uint32_t* __restrict__ counts,
+                                uint32_t* __restrict__ overflow)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    uint64_t e = j + 1 < m ? starts[j + 1] : n;
+    uint64_t s = 0;
+    for (uint64_t i = starts[j]; i < e; ++i) s += vals[i];
+    if (s > 0xFFFFFFFFULL) { atomicOr(overflow, 1u); s = 0xFFFFFFFFULL; }
+    counts[j] = (uint32_t)s;
+}
+
+// --------------------------------------------------------------------------------------
+// K7: Elias-Fano split (SparseArray::Builder::push_back, SparseArray.hh:87-118)
+// --------------------------------------------------------------------------------------
+
+struct EfColumn { uint8_t* dst; uint32_t bytes; uint32_t shift; };
+struct EfColumns { EfColumn c[4]; uint32_t n; };
+
+// bits [shift, shift+64) of (key & (2^D - 1))
+template <class K>
+__device__ __forceinline__ uint64_t masked_bits(const K& k, uint32_t D, uint32_t shift)
+{
+    uint64_t lo = key_lo_word(k), hi = key_hi_word(k);
+    if (D < 64) { lo &= (1ULL << D) - 1; hi = 0; }
+    else if (D < 128) { hi &= D == 64 ? 0 : ((1ULL << (D - 64)) - 1); }
+    if (shift == 0) return lo;
+    if (shift < 64) return (lo >> shift) | (hi << (64 - shift));
+    return shift >= 128 ? 0 : (hi >> (shift - 64));
+}
+
+template <class K>
+__global__ void ef_low_bits_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, EfColumns cols)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    K k = keys[i];
+    for (uint32_t c = 0; c < cols.n; ++c)
+    {
+        uint64_t v = masked_bits(k, D, cols.c[c].shift);
+        uint8_t* p = cols.c[c].dst + i * cols.c[c].bytes;
+        switch (cols.c[c].bytes)
+        {
+            case 1: *p = (uint8_t)v; break;
+            case 2: *reinterpret_cast<uint16_t*>(p) = (uint16_t)v; break;
+            case 4: *reinterpret_cast<uint32_t*>(p) = (uint32_t)v; break;
+            default: *reinterpret_cast<uint64_t*>(p) = v; break;
+        }
+    }
+}
+
+// high part of key i: (key >> D) as u64 (D >= 128 -> 0)
+template <class K>
+__device__ __forceinline__ uint64_t ef_hi(const K* keys, uint64_t i, uint32_t D)
+{
+    return D >= 128 ? 0 : key_shr64(keys[i], D);
+}
+
+template <class K>
+__global__ void ef_check_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, uint32_t* __restrict__ err)
+{
+    // the largest key decides whether every high part fits 64 bits
+    if (blockIdx.x == 0 && threadIdx.x == 0 && m)
+    {
+        if (D < 128 && key_shr_overflows(keys[m - 1], D)) atomicOr(err, 1u);
+    }
+}
+
+// One thread per 64-bit word of the high-bits bitmap.  Position of one i is
+// h_i = (key_i >> D) + i, strictly increasing, so the ones of word w are found by a binary
+// search for the first h_i >= 64w and a short forward walk.
+template <class K>
+__global__ void ef_high_bits_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D,
+                                    uint64_t nwords, uint64_t* __restrict__ words)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const uint64_t lo_pos = w * 64;
+    uint64_t a = 0, b = m;
+    while (a < b)
+    {
+        uint64_t mid = a + ((b - a) >> 1);
+        if (ef_hi(keys, mid, D) + mid < lo_pos) a = mid + 1; else b = mid;
+    }
+    uint64_t bits = 0;
+    for (uint64_t i = a; i < m; ++i)
+    {
+        uint64_t h = ef_hi(keys, i, D) + i;
+        if (h >= lo_pos + 64) break;
+        bits |= 1ULL << (h - lo_pos);
+    }
+    words[w] = bits;
+}
+
+// --------------------------------------------------------------------------------------
+// K8: DenseSelect image (DenseSelect::Builder, DenseArray.cc:446-694)
+// --------------------------------------------------------------------------------------
+//
+// The indexed positions are never materialised: for sense 1 (ones) position i is h_i; for
+// sense 0 (zeros) the j-th zero sits at j + #{i : (key_i >> D) <= j}.
+
+template <class K>
+__device__ __forceinline__ uint64_t ds_pos(const K* keys, uint64_t m, uint32_t D, int invert, uint64_t idx)
+{
+    if (!invert) return ef_hi(keys, idx, D) + idx;
+    uint64_t a = 0, b = m;                  // upper_bound of idx among the high parts
+    while (a < b)
+    {
+        uint64_t mid = a + ((b - a) >> 1);
+        if (ef_hi(keys, mid, D) <= idx) a = mid + 1; else b = mid;
+    }
+    return idx + a;
+}
+
+enum : uint32_t { kDsSmall = 0, kDsSpill64 = 1, kDsSpill32 = 2, kDsSpill16 = 3, kDsSpill8 = 4, kDsIntermediate = 5 };
+
+// Pass 1: one thread per block of 8192 indexed positions: block type and byte size (already
+// padded to 8).  count = number of indexed positions.
+template <class K>
+__global__ void ds_classify_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, int invert,
+                                   uint64_t count, uint64_t nblocks,
+                                   uint32_t* __restrict__ btype, uint64_t* __restrict__ bbytes,
+                                   uint64_t* __restrict__ brank)
+{
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint64_t first = b << 13;
+    uint64_t cnt = count - first < 8192 ? count - first : 8192;
+    uint64_t pp = ds_pos(keys, m, D, invert, first);
+    uint64_t p = ds_pos(keys, m, D, invert, first + cnt - 1);
+    uint64_t span = p - pp;
+    uint32_t t;
+    uint64_t bytes;
+    if (span >= (1ULL << 24) || cnt < 8192)
+    {
+        if (span < (1ULL << 32)) { t = kDsSpill32; bytes = cnt * 4; }
+        else { t = kDsSpill64; bytes = cnt * 8; }
+    }
+    else if (span >= (1ULL << 16))
+    {
+        t = kDsIntermediate;
+        bytes = 128 * 6;
+        for (uint32_t s = 0; s < 128; ++s)
+        {
+            uint64_t r = ds_pos(keys, m, D, invert, first + s * 64 + 63) - ds_pos(keys, m, D, invert, first + s * 64);
+            if (r <= 128) {}
+            else if (r < 256) bytes += 64;
+            else if (r < 65536) bytes += 128;
+            else bytes += 256;
+        }
+    }
+    else { t = kDsSmall; bytes = 256; }
+    btype[b] = t;
+    bbytes[b] = (bytes + 7) & ~7ULL;
+    brank[b] = pp;
+}
+
+// Pass 2: one workgroup of 128 threads per block writes the block body at boff[b] and the
+// master index entry.  The image was zero-filled, so alignment padding is already there.
+template <class K>
+__global__ __launch_bounds__(128) void ds_fill_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, int invert,
+                                                      uint64_t count, const uint32_t* __restrict__ btype,
+                                                      const uint64_t* __restrict__ boff, const uint64_t* __restrict__ brank,
+                                                      uint8_t* __restrict__ image, uint64_t* __restrict__ index)
+{
+    __shared__ uint32_t sh_sub[128];
+    const uint64_t b = blockIdx.x;
+    const uint32_t s = threadIdx.x;
+    const uint64_t first = b << 13;
+    const uint64_t cnt = count - first < 8192 ? count - first : 8192;
+    const uint32_t t = btype[b];
+    const uint64_t off = boff[b];
+    const uint64_t pp = brank[b];
+    uint8_t* blk = image + off;
+    if (s == 0) index[b] = off | t;
+    if (t == kDsSmall)
+    {
+        uint16_t v = (uint16_t)(ds_pos(keys, m, D, invert, first + (uint64_t)s * 64) - pp);
+        reinterpret_cast<uint16_t*>(blk)[s] = v;
+    }
+    else if (t == kDsSpill32)
+    {
+        for (uint64_t i = s; i < cnt; i += 128)
+            reinterpret_cast<uint32_t*>(blk)[i] = (uint32_t)(ds_pos(keys, m, D, invert, first + i) - pp);
+    }
+    else if (t == kDsSpill64)
+    {
+        for (uint64_t i = s; i < cnt; i += 128)
+            reinterpret_cast<uint64_t*>(blk)[i] = ds_pos(keys, m, D, invert, first + i);
+    }
+    else
+    {
+        // intermediate: 128 x u32 sample offsets, 128 x u16 internal pointers, sub-blocks
+        uint64_t p0 = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64);
+        uint64_t p1 = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64 + 63);
+        uint64_t r = p1 - p0;
+        reinterpret_cast<uint32_t*>(blk)[s] = (uint32_t)(p0 - pp);
+        uint32_t sz = r <= 128 ? 0u : r < 256 ? 64u : r < 65536 ? 128u : 256u;
+        uint32_t ty = r <= 128 ? 0u : r < 256 ? kDsSpill8 : r < 65536 ? kDsSpill16 : kDsSpill32;
+        sh_sub[s] = sz;
+        __syncthreads();
+        uint32_t base = 768;
+        for (uint32_t i = 0; i < s; ++i) base += sh_sub[i];
+        uint16_t ip = sz ? (uint16_t)(base | ty) : (uint16_t)0;
+        reinterpret_cast<uint16_t*>(blk + 512)[s] = ip;
+        if (sz)
+        {
+            for (uint32_t j = 0; j < 64; ++j)
+            {
+                uint64_t d = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64 + j) - p0;
+                if (ty == kDsSpill8) blk[base + j] = (uint8_t)d;
+                else if (ty == kDsSpill16) reinterpret_cast<uint16_t*>(blk + base)[j] = (uint16_t)d;
+                else reinterpret_cast<uint32_t*>(blk + base)[j] = (uint32_t)d;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K9: counts -> VariableByteArray pieces (VariableByteArray.hh:81-103)
+// --------------------------------------------------------------------------------------
+
+__global__ void vba_ord0_kernel(const uint32_t* __restrict__ counts, uint64_t m, uint8_t* __restrict__ ord0,
+                                uint64_t* __restrict__ flag1)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t c = counts[i];
+    ord0[i] = (uint8_t)(c & 0xFF);
+    flag1[i] = (c >> 8) ? 1 : 0;
+}
+
+// after an exclusive scan of flag1 -> slot: gather the items with count > 255
+__global__ void vba_ord1_kernel(const uint32_t* __restrict__ counts, uint64_t m, const uint64_t* __restrict__ slot,
+                                uint64_t n1, uint64_t* __restrict__ pos1, uint8_t* __restrict__ ord1,
+                                uint32_t* __restrict__ hi16)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t c = counts[i];
+    if (c >> 8)
+    {
+        uint64_t s = slot[i];
+        (void)n1;
+        pos1[s] = i;
+        ord1[s] = (uint8_t)((c >> 8) & 0xFF);
+        hi16[s] = c >> 16;
+    }
+}
+
+__global__ void vba_flag2_kernel(const uint32_t* __restrict__ hi16, uint64_t n1, uint64_t* __restrict__ flag2)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    flag2[i] = hi16[i] ? 1 : 0;
+}
+
+__global__ void vba_ord2_kernel(const uint32_t* __restrict__ hi16, uint64_t n1, const uint64_t* __restrict__ slot,
+                                uint64_t* __restrict__ pos2, uint16_t* __restrict__ ord2)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    uint32_t h = hi16[i];
+    if (h)
+    {
+        uint64_t s = slot[i];
+        pos2[s] = i;
+        ord2[s] = (uint16_t)h;
+    }
+}
+
+__global__ void widen_counts_kernel(const uint32_t* __restrict__ counts, uint64_t m, Key1* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i].lo = counts[i];
+}
+
+// --------------------------------------------------------------------------------------
+// synthetic reads
+// --------------------------------------------------------------------------------------
+
+__global__ void synth_reads_kernel(uint8_t* __restrict__ out, uint64_t nreads, uint32_t read_len,
+                                   uint64_t genome_len, uint64_t seed, uint64_t first_read)
+{
+    const uint64_t stride = read_len + 1;
+    uint64_t total = nreads * stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t r = i / stride;
+        uint32_t j = (uint32_t)(i - r * stride);
+        out[i] = (uint8_t)synth_read_byte(seed, genome_len, read_len, first_read + r, j);
+    }
+}
+
+}  // namespace goss

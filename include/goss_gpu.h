@@ -1,0 +1,165 @@
+/*
+ * goss_gpu.h -- C ABI of libgossgpu.so: the MI355X (gfx950) implementation of gossamer's
+ * k-mer counting / de Bruijn edge-set construction hot path.
+ *
+ * The reference (data61/gossamer) has no FFI; this is the seam a maintainer would bind from
+ * GossCmdBuildKmerSet / GossCmdBuildGraph.  Each entry point names the
+ * reference code whose role it takes over (paths relative to the reference's src/).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (GOSS_OK) or a
+ * negative goss_status; no exceptions cross the boundary; one host thread per context;
+ * the library fails loudly (GOSS_ERR_NO_DEVICE) when no gfx950 device is usable -- there is
+ * no CPU fallback behind this ABI.
+ */
+#ifndef GOSS_GPU_H
+#define GOSS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct goss_gpu_ctx goss_gpu_ctx;
+
+typedef enum {
+    GOSS_OK               = 0,
+    GOSS_ERR_INVALID_ARG  = -1,
+    GOSS_ERR_NO_DEVICE    = -2,   /* no HIP device / not gfx950 / runtime failure at create */
+    GOSS_ERR_OOM          = -3,   /* HBM budget exceeded */
+    GOSS_ERR_HIP          = -4,   /* a HIP call failed; see goss_gpu_last_error */
+    GOSS_ERR_STATE        = -5,   /* call out of order (e.g. push after finish) */
+    GOSS_ERR_K_RANGE      = -6,   /* "unable to build a graph with k=<K>" (KmerSet.hh:89-95, Graph.cc:152-158) */
+    GOSS_ERR_COUNT_OVERFLOW = -7, /* a key occurred >= 2^32 times */
+    GOSS_ERR_TOO_LARGE    = -8    /* high-bits value does not fit 64 bits (SparseArray.hh:91-95) */
+} goss_status;
+
+/* mode: which reference command's key stream is produced. */
+enum {
+    GOSS_MODE_KMER_SET = 0,  /* canonical k-mers: KmerizingAdapter + position_type::normalize
+                                (KmerizingAdapter.hh:20-86, RankSelect.hh:126-140) */
+    GOSS_MODE_GRAPH    = 1   /* every (k+1)-mer and its reverse complement, un-normalised:
+                                ReverseComplementAdapter (ReverseComplementAdapter.hh:20-93) */
+};
+
+/* Human readable text for a status code. */
+const char* goss_gpu_strerror(int status);
+
+/* Detail of the last failure on this context (HIP error string etc.). */
+const char* goss_gpu_last_error(const goss_gpu_ctx* ctx);
+
+/* ABI version (bumped on incompatible change). */
+uint32_t goss_gpu_abi_version(void);
+
+/*
+ * Create a counting context on HIP device `device`.
+ * Takes over: BackyardHash h(S, 2K, N) + the consumer threads
+ * (GossCmdBuildKmerSet.tcc:226-233, GossCmdBuildGraph.cc:315-322).
+ *   k           the command's -k (KmerSet: 1..63, Graph: 1..62; Graph keys are (k+1)-mers)
+ *   mode        GOSS_MODE_*
+ *   hbm_budget  bytes of HBM the context may use for keys/sort workspace (0 = 80% of free)
+ *   stream      a hipStream_t to run on, or NULL for a stream owned by the context
+ */
+int goss_gpu_create(goss_gpu_ctx** ctx, int device, uint32_t k, int mode,
+                    uint64_t hbm_budget, void* stream);
+
+void goss_gpu_destroy(goss_gpu_ctx* ctx);
+
+/*
+ * Feed read bases.  `bases` is a byte string in which A/C/G/T (either case) are bases and
+ * ANY other byte ends the current run of k-windows -- the caller separates reads with one
+ * such byte (the host parsers emit '\n').  Windows never span two push calls.
+ * Takes over: GossRead::Iterator / GossReadBaseString::{firstKmer,nextKmer,getBase,getEdge}
+ * (GossRead.hh:57-114, GossReadBaseString.hh:52-188) and the insert loop
+ * (GossCmdBuildKmerSet.tcc:246-256 + BackyardHash::insert BackyardHash.cc:115-242).
+ * _host: bytes in host memory (pinned memory makes the copy asynchronous);
+ * _device: bytes already resident in HBM on the context's device (not modified).
+ */
+int goss_gpu_push_bases_host(goss_gpu_ctx* ctx, const char* bases, uint64_t nbytes);
+int goss_gpu_push_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes);
+
+typedef struct {
+    uint64_t windows;    /* valid k-windows seen (kmer-set: k-mers; graph: rho-mer windows) */
+    uint64_t keys;       /* keys inserted (= windows, or 2*windows in graph mode) */
+    uint64_t distinct;   /* M: distinct keys */
+    uint32_t key_words;  /* 1: keys are u64; 2: keys are {lo,hi} u64 pairs */
+    uint32_t reserved;
+} goss_gpu_counts;
+
+/*
+ * Sort + merge equal keys, summing counts.
+ * Takes over: BackyardHash::sort + BlendedSort (BackyardHash.cc:244-271, BlendedSort.hh:58-167)
+ * and the run-summing walk of flush() (GossCmdBuildKmerSet.tcc:183-202,
+ * GossCmdBuildGraph.cc:238-257).  After this call no more bases may be pushed.
+ */
+int goss_gpu_finish(goss_gpu_ctx* ctx, goss_gpu_counts* out);
+
+/* Device-resident result: sorted distinct keys (key_words u64 per key) and u32 counts.
+ * Valid until destroy.  Either pointer may be NULL. */
+int goss_gpu_result(goss_gpu_ctx* ctx, const void** d_keys, const uint32_t** d_counts,
+                    uint64_t* distinct);
+
+/* Copy a slice [first, first+n) of the result to host memory (keys: n*key_words u64). */
+int goss_gpu_result_copy(goss_gpu_ctx* ctx, uint64_t first, uint64_t n,
+                         uint64_t* h_keys, uint32_t* h_counts);
+
+/*
+ * Build every on-disk array of the output object on the device.
+ * kmer-set: KmerSet::Builder (KmerSet.hh:64-103) = SparseArray at "<out>.kmers".
+ * graph:    Graph::Builder (Graph.hh:101-127, Graph.cc:115-167) = SparseArray "<out>-edges",
+ *           VariableByteArray "<out>-counts", "<out>-counts-hist.txt".
+ * Covers SparseArray::Builder (SparseArray.hh:87-118, SparseArray.cc:47-131),
+ * WordyBitVector::Builder (WordyBitVector.hh:54-134), DenseSelect::Builder
+ * (DenseArray.cc:446-694), IntegerArray::builder (IntegerArray.cc:259-357) and
+ * VariableByteArray::Builder (VariableByteArray.hh:76-118).
+ * The SparseArray estimate M is the exact distinct count (single-pass reference result).
+ */
+int goss_gpu_emit(goss_gpu_ctx* ctx);
+
+/* The emitted object as a list of files: name suffix (appended to the -O prefix), size. */
+int goss_gpu_file_count(goss_gpu_ctx* ctx, uint32_t* n);
+int goss_gpu_file_info(goss_gpu_ctx* ctx, uint32_t i, char* suffix, size_t suffix_cap,
+                       uint64_t* size);
+/* Copy bytes [offset, offset+n) of file i into host memory. */
+int goss_gpu_file_read(goss_gpu_ctx* ctx, uint32_t i, uint64_t offset, void* dst, uint64_t n);
+
+/*
+ * Stand-alone SparseArray build from caller-supplied sorted positions on the device
+ * (SparseArray::Builder(base, fac, N, M) + push_back* + end(N_end)).  Positions are
+ * key_words u64 each, strictly increasing.  N is given as {lo,hi}.  Produces the files
+ * ".header", ".high-bits", "-d0", "-d1", ".low-bits*" retrievable through goss_gpu_file_*.
+ */
+int goss_gpu_emit_sparse_array(goss_gpu_ctx* ctx, const void* d_positions, uint32_t key_words,
+                               uint64_t n, uint64_t N_lo, uint64_t N_hi, uint64_t M,
+                               uint64_t Nend_lo, uint64_t Nend_hi);
+
+/* Timing of the phases of the last push/finish/emit on this context, in milliseconds
+ * measured with HIP events on the context's stream (for bench.py's roofline block). */
+typedef struct {
+    float extract_ms;    /* key extraction kernels */
+    float sort_ms;       /* radix sort passes */
+    float reduce_ms;     /* run compaction */
+    float emit_ms;       /* on-disk array build */
+    float total_ms;
+    uint32_t extract_launches, sort_launches, reduce_launches, emit_launches;
+} goss_gpu_timing;
+int goss_gpu_timing_get(goss_gpu_ctx* ctx, goss_gpu_timing* out);
+int goss_gpu_timing_reset(goss_gpu_ctx* ctx);
+
+/*
+ * Deterministic synthetic read generator: fills d_out (device) with
+ * nreads reads of read_len bases sampled from an i.i.d. uniform genome of genome_len bases,
+ * each followed by '\n'; strand flipped with p = 1/2; one 'N' in every 97th read.
+ * Bytes written = nreads * (read_len + 1).  The same generator exists on the host
+ * (goss_synth_reads_host) so CPU and GPU runs see identical input.
+ */
+int goss_gpu_synth_reads(goss_gpu_ctx* ctx, void* d_out, uint64_t nreads, uint32_t read_len,
+                         uint64_t genome_len, uint64_t seed, uint64_t first_read);
+int goss_synth_reads_host(char* out, uint64_t nreads, uint32_t read_len,
+                          uint64_t genome_len, uint64_t seed, uint64_t first_read);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOSS_GPU_H */
