@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- M canonical k-mers/s counted (k=25, 150 bp reads) on N MI355X GPUs.
+
+A "step" is one pass of the hot path over the whole synthetic read set that is already
+resident in HBM: 2-bit/rolling canonical k-mer extraction -> radix sort -> run compaction ->
+SparseArray (Elias-Fano + DenseSelect) images of the KmerSet, all on the device.  For N > 1
+every rank counts its own 100 M reads (weak scaling), the sorted key space is range-partitioned
+with one RCCL all-to-all(v), and rank 0 assembles and emits the object.
+
+Prints ONE JSON line on rank 0 (contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_window(k, read_len, key_bytes=8, keys_per_window=1):
+    """packed read traffic + one write and one read of each key."""
+    return read_len / (read_len - k + 1) * 3.0 / 8.0 + 2.0 * key_bytes * keys_per_window
+
+
+def cpu_baseline(k, read_len, genome_len, seed, sample_reads):
+    """The CPU oracle (oracle/, a restatement of the reference algorithm: kind "port") timed
+    on a bounded sample of the same synthetic workload, one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gossamer_amd as g
+    import oracle_lib as o
+    reads = g.synth_reads_host(sample_reads, read_len, genome_len, seed=seed)
+    o.lib()
+    t0 = time.perf_counter()
+    files, nwin = o.build_kmer_set([(o.LINE, "reads", reads)], k)
+    dt = time.perf_counter() - t0
+    return {"value": nwin / dt / 1e6, "unit": "M k-mers/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic set (%d k-mers) through oracle go_build_kmer_set "
+                      "(parse + canonicalise + sort + KmerSet emit, in memory), %.1f s" % (sample_reads, nwin, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", type=int, default=100_000_000, help="genome length per GPU's worth of reads")
+    ap.add_argument("-k", type=int, default=25)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gossamer_amd as g
+    from gossamer_amd import dist as gdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    k, L = args.k, args.read_len
+    nreads = args.reads
+    genome_len = args.genome * world
+    nbytes = nreads * (L + 1)
+
+    # ---- synthetic input, generated on the device (untimed) ------------------------------
+    bases = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * 0.94)
+    ctx = g.Context(k, g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
+    ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)
+    torch.cuda.synchronize(device)
+
+    def step():
+        if world == 1:
+            ctx.reset()
+            ctx.push_device(bases.data_ptr(), nbytes)
+            c = ctx.finish()
+            ctx.emit_device()
+            return c.windows, c.distinct
+        r = gdist.count_distributed(ctx, bases.data_ptr(), nbytes, 2 * k, device)
+        return r["windows"], r["M"]
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    windows = distinct = 0
+    for _ in range(args.steps):
+        w, distinct = step()
+        windows += w
+    barrier()
+    dt = time.perf_counter() - t0
+    tim = ctx.timing().as_dict()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        wt = torch.tensor([windows], dtype=torch.int64, device=device)
+        dist.all_reduce(wt, op=dist.ReduceOp.SUM)
+        windows = int(wt.item())
+
+    if rank == 0:
+        value = windows / dt / 1e6
+        b_per_window = algorithmic_bytes_per_window(k, L)
+        # dominant kernel class by device time over the timed region
+        dom = max(tim, key=lambda n: tim[n]["ms"] if n != "emit" else -1.0)
+        d = tim[dom]
+        per_launch_units = d["units"] / max(1, d["launches"])
+        avg_ms = d["ms"] / max(1, d["launches"])
+        # algorithmic bytes of one launch: the key traffic term of section 8(d) (one write and
+        # one read of every key = 2*W bytes per key) for the sort kernels; the full per-window
+        # figure for the extraction kernel
+        per_unit = b_per_window if dom == "extract" else 16.0
+        achieved = per_unit * per_launch_units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        dev_ms = sum(v["ms"] for n, v in tim.items() if n != "emit") + tim["emit"]["ms"]
+        out = {
+            "metric": "M k-mers/s (canonical, counted) at k=%d, %d bp reads" % (k, L),
+            "value": value,
+            "unit": "M k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "k=%d, %d x %d bp synthetic reads per GPU (genome %d bp, seed %d), in-HBM "
+                                   "sort-count, KmerSet SparseArray emitted" % (k, nreads, L, genome_len, args.seed),
+                       "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
+                       "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
+            "roofline": {"bound": "hbm", "kernel": {"extract": "extract_kernel", "hist": "radix_hist_kernel",
+                                                    "scan": "scan_*_kernel", "scatter": "radix_scatter_kernel",
+                                                    "reduce": "heads_*_kernel"}.get(dom, dom),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "launch_avg_ms": avg_ms, "launches": d["launches"], "units_per_launch": per_launch_units,
+                         "algorithmic_bytes_per_unit": per_unit,
+                         "pipeline": {"algorithmic_bytes_per_kmer": b_per_window,
+                                      "achieved": b_per_window * (windows / world) / (dt) / 1e9,
+                                      "frac": b_per_window * (windows / world) / dt / 1e9 / HBM_PEAK_GBS},
+                         "device_ms_per_step": {n: v["ms"] / args.steps for n, v in tim.items()},
+                         "device_ms_total_per_step": dev_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ SYMBOLS = [
     "goss_gpu_finish", "goss_gpu_result", "goss_gpu_result_copy", "goss_gpu_emit",
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
-    "goss_gpu_synth_reads", "goss_synth_reads_host",
+    "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device",
 ]
 
 
@@ -35,11 +35,17 @@ class Counts(C.Structure):
                 ("key_words", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+T_EXTRACT, T_HIST, T_SCAN, T_SCATTER, T_REDUCE, T_EMIT, T_CLASSES = 0, 1, 2, 3, 4, 5, 8
+T_NAMES = ["extract", "hist", "scan", "scatter", "reduce", "emit"]
+
+
 class Timing(C.Structure):
-    _fields_ = [("extract_ms", C.c_float), ("sort_ms", C.c_float), ("reduce_ms", C.c_float),
-                ("emit_ms", C.c_float), ("total_ms", C.c_float),
-                ("extract_launches", C.c_uint32), ("sort_launches", C.c_uint32),
-                ("reduce_launches", C.c_uint32), ("emit_launches", C.c_uint32)]
+    _fields_ = [("ms", C.c_float * T_CLASSES), ("launches", C.c_uint32 * T_CLASSES),
+                ("units", C.c_uint64 * T_CLASSES)]
+
+    def as_dict(self):
+        return {n: {"ms": self.ms[i], "launches": self.launches[i], "units": self.units[i]}
+                for i, n in enumerate(T_NAMES)}
 
 
 _lib = None
@@ -52,6 +58,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GossGpuError(-2, "libgossgpu.so is not built", LIB_PATH)
+    try:
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing it
+        # first makes libgossgpu.so bind to that same runtime (same SONAME) instead of
+        # bringing /opt/rocm's copy in beside it, which leaves torch without a GPU.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.goss_gpu_strerror.restype = C.c_char_p
     L.goss_gpu_strerror.argtypes = [C.c_int]
@@ -74,6 +87,8 @@ def load():
                                              C.c_uint64, C.c_uint64, C.c_uint64]
     L.goss_gpu_timing_get.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.goss_gpu_timing_reset.argtypes = [C.c_void_p]
+    L.goss_gpu_reset.argtypes = [C.c_void_p]
+    L.goss_gpu_push_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.goss_gpu_synth_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.goss_synth_reads_host.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
     _lib = L
@@ -130,6 +145,12 @@ class Context:
     def push_device(self, ptr, nbytes):
         self._check(self._L.goss_gpu_push_bases_device(self._h, C.c_void_p(ptr), nbytes))
 
+    def push_run(self, keys_ptr, counts_ptr, m):
+        self._check(self._L.goss_gpu_push_run_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
+
+    def reset(self):
+        self._check(self._L.goss_gpu_reset(self._h))
+
     def finish(self):
         c = Counts()
         self._check(self._L.goss_gpu_finish(self._h, C.byref(c)))
@@ -157,8 +178,12 @@ class Context:
             ks = [int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64) for i in range(m)]
         return ks, cnts
 
-    def emit(self):
+    def emit_device(self):
+        """Build the on-disk arrays in HBM without copying them to the host."""
         self._check(self._L.goss_gpu_emit(self._h))
+
+    def emit(self):
+        self.emit_device()
         return self.files()
 
     def emit_sparse_array(self, dev_ptr, key_words, n, N, M, N_end=None):

@@ -68,7 +68,7 @@ struct OutFile {
 
 struct Run { void* keys; uint32_t* counts; uint64_t m; };
 
-struct PhaseEvents { hipEvent_t a, b; int phase; };
+struct PhaseEvents { hipEvent_t a, b; int phase; uint64_t units; };
 
 }  // namespace
 
@@ -99,13 +99,13 @@ struct goss_gpu_ctx {
 
 namespace {
 
-enum { PH_EXTRACT = 0, PH_SORT = 1, PH_REDUCE = 2, PH_EMIT = 3 };
-
+// HIP-event timer around the launches of one kernel class (GOSS_T_*).
 struct PhaseTimer {
     goss_gpu_ctx* c;
     PhaseEvents pe;
-    PhaseTimer(goss_gpu_ctx* ctx, int phase) : c(ctx)
+    PhaseTimer(goss_gpu_ctx* ctx, int phase, uint64_t units = 0) : c(ctx)
     {
+        pe.units = units;
         auto get = [&]() {
             hipEvent_t e;
             if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
@@ -129,14 +129,9 @@ void resolve_timing(goss_gpu_ctx* c)
         HIP_TRY(hipEventSynchronize(pe.b));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, pe.a, pe.b));
-        switch (pe.phase)
-        {
-            case PH_EXTRACT: c->timing.extract_ms += ms; c->timing.extract_launches++; break;
-            case PH_SORT: c->timing.sort_ms += ms; c->timing.sort_launches++; break;
-            case PH_REDUCE: c->timing.reduce_ms += ms; c->timing.reduce_launches++; break;
-            default: c->timing.emit_ms += ms; c->timing.emit_launches++; break;
-        }
-        c->timing.total_ms += ms;
+        c->timing.ms[pe.phase] += ms;
+        c->timing.launches[pe.phase] += 1;
+        c->timing.units[pe.phase] += pe.units;
         c->event_pool.push_back(pe.a);
         c->event_pool.push_back(pe.b);
     }
@@ -204,11 +199,23 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
     {
         K* src = in_b ? kb : ka; K* dst = in_b ? ka : kb;
         uint32_t* vs = in_b ? vb : va; uint32_t* vd = in_b ? va : vb;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
-                           (const K*)src, n, d, ntiles, table);
-        exclusive_scan_u64(c, table, 256ULL * ntiles);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
-                           (const K*)src, (const uint32_t*)vs, dst, vd, n, d, ntiles, (const uint64_t*)table);
+        {
+            PhaseTimer t(c, GOSS_T_HIST, n);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                               (const K*)src, n, d, ntiles, table);
+            t.stop();
+        }
+        {
+            PhaseTimer t(c, GOSS_T_SCAN, 256ULL * ntiles);
+            exclusive_scan_u64(c, table, 256ULL * ntiles);
+            t.stop();
+        }
+        {
+            PhaseTimer t(c, GOSS_T_SCATTER, n);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                               (const K*)src, (const uint32_t*)vs, dst, vd, n, d, ntiles, (const uint64_t*)table);
+            t.stop();
+        }
         in_b = !in_b;
     }
     c->arena.release(mark);
@@ -295,7 +302,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     uint32_t mis = (uint32_t)(addr & 15u);
     const uint8_t* aligned = (const uint8_t*)(addr - mis);
     {
-        PhaseTimer t(c, PH_EXTRACT);
+        PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         extract_dispatch<K>(c, aligned, mis, nstarts, navail, ka);
         t.stop();
     }
@@ -307,13 +314,8 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     c->keys_total += n;
     if (n)
     {
-        bool in_b;
-        {
-            PhaseTimer t(c, PH_SORT);
-            in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
-            t.stop();
-        }
-        PhaseTimer t(c, PH_REDUCE);
+        bool in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
+        PhaseTimer t(c, GOSS_T_REDUCE, n);
         Run r = reduce_runs<K>(c, in_b ? kb : ka, nullptr, n, in_b ? ka : kb);
         t.stop();
         c->runs.push_back(r);
@@ -344,13 +346,8 @@ void merge_runs(goss_gpu_ctx* c)
     // the old runs' permanent storage is dead now: rewind the permanent end to the first run
     c->arena.lo = (uint64_t)((uint8_t*)c->runs.front().keys - c->arena.base);
     c->runs.clear();
-    bool in_b;
-    {
-        PhaseTimer t(c, PH_SORT);
-        in_b = radix_sort<K, true>(c, ka, kb, va, vb, total, key_digits(c));
-        t.stop();
-    }
-    PhaseTimer t(c, PH_REDUCE);
+    bool in_b = radix_sort<K, true>(c, ka, kb, va, vb, total, key_digits(c));
+    PhaseTimer t(c, GOSS_T_REDUCE, total);
     Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb);
     t.stop();
     c->runs.push_back(r);
@@ -680,7 +677,7 @@ void emit_object(goss_gpu_ctx* c)
 {
     const K* keys = (const K*)c->res_keys;
     const uint64_t m = c->M;
-    PhaseTimer t(c, PH_EMIT);
+    PhaseTimer t(c, GOSS_T_EMIT, m);
     if (c->mode == GOSS_MODE_KMER_SET)
     {
         // N = 4^K (KmerSet.hh:84,72)
@@ -908,7 +905,7 @@ int goss_gpu_emit_sparse_array(goss_gpu_ctx* c, const void* d_positions, uint32_
     return guarded(c, [&]() {
         ensure_arena(c);
         c->files.clear();
-        PhaseTimer t(c, PH_EMIT);
+        PhaseTimer t(c, GOSS_T_EMIT, n);
         // private copy so the caller's buffer need not outlive the call
         const uint64_t ksz = key_words * 8;
         void* keys = c->arena.perm(std::max<uint64_t>(n * ksz, 16));
@@ -962,6 +959,43 @@ int goss_gpu_timing_reset(goss_gpu_ctx* c)
     int rc = guarded(c, [&]() { resolve_timing(c); });
     c->timing = goss_gpu_timing{};
     return rc;
+}
+
+int goss_gpu_reset(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->runs.clear();
+        c->files.clear();
+        c->windows = c->keys_total = 0;
+        c->finished = c->emitted = false;
+        c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;
+        c->arena.lo = 0; c->arena.hi = c->arena.size;
+        HIP_TRY(hipMemsetAsync(c->d_flags, 0, 16, c->stream));
+    });
+}
+
+int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t* d_counts, uint64_t m)
+{
+    if (!c || (m && (!d_keys || !d_counts))) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (m == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        const uint64_t ksz = c->words * 8;
+        Run r{nullptr, nullptr, m};
+        r.keys = c->arena.perm(m * ksz);
+        r.counts = (uint32_t*)c->arena.perm(m * 4);
+        HIP_TRY(hipMemcpyAsync(r.keys, d_keys, m * ksz, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(r.counts, d_counts, m * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->runs.push_back(r);
+        uint64_t sum = 0;
+        // keys_total keeps meaning "keys inserted": a run stands for the sum of its counts,
+        // which the caller accounts for; windows are not known here.
+        (void)sum;
+    });
 }
 
 int goss_gpu_synth_reads(goss_gpu_ctx* c, void* d_out, uint64_t nreads, uint32_t read_len, uint64_t genome_len,

@@ -1,0 +1,138 @@
+"""Multi-GPU counting: range-partition the sorted key space over the ranks of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Each
+rank counts its own share of the reads, then ONE exchange step moves every (key,count) pair
+to the rank that owns the key's range -- an all-to-all(v) in which each rank sends 1/P of its
+distinct keys to each peer, so all xGMI links carry traffic at once -- and the owner merges
+what it received.  An all-gather of the per-range distinct counts gives the global M (which
+fixes the Elias-Fano split D) and each range's rank offset.  There is no ring all-reduce of
+bulk data anywhere.  The reference has no distributed path; this module
+is new design, constrained only by having to produce the reference's single-pass result.
+
+The functions below work on torch tensors and a process group only, so the same code runs
+under gloo on CPU (tests, world_size 2) and under RCCL on GPUs (bench.py).  Keys are one
+64-bit word (2*len <= 62 bits), carried in int64 tensors: their sign bit is never set, so
+signed comparisons order them correctly.
+"""
+import torch
+import torch.distributed as dist
+
+
+def uniform_splitters(key_bits, parts, dtype=torch.int64, device="cpu"):
+    """parts-1 interior splitters cutting [0, 2^key_bits) into equal ranges.  Hash-chosen
+    canonical k-mers of an i.i.d. genome are uniform on the top bits;
+    sampled splitters can replace this for skewed data without changing anything else."""
+    total = 1 << key_bits
+    return torch.tensor([(total * p) // parts for p in range(1, parts)], dtype=dtype, device=device)
+
+
+def split_sizes(sorted_keys, splitters):
+    """How many of this rank's sorted distinct keys fall in each range."""
+    if splitters.numel() == 0:
+        return [int(sorted_keys.numel())]
+    cuts = torch.searchsorted(sorted_keys, splitters, right=False).tolist()
+    edges = [0] + cuts + [int(sorted_keys.numel())]
+    return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
+
+
+def exchange_runs(keys, counts, splitters, group=None):
+    """all-to-all(v): send range p of (keys, counts) to rank p.
+    Returns (recv_keys, recv_counts, recv_sizes): the concatenation of one sorted run per
+    source rank, and the run lengths."""
+    world = dist.get_world_size(group)
+    send = split_sizes(keys, splitters)
+    assert len(send) == world
+    send_t = torch.tensor(send, dtype=torch.int64, device=keys.device)
+    recv_t = torch.empty(world, dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(recv_t, send_t, group=group)
+    recv = [int(x) for x in recv_t.tolist()]
+    rk = torch.empty(sum(recv), dtype=keys.dtype, device=keys.device)
+    rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
+    dist.all_to_all_single(rk, keys, recv, send, group=group)
+    dist.all_to_all_single(rc, counts, recv, send, group=group)
+    return rk, rc, recv
+
+
+def gather_counts(m_local, device, group=None):
+    """all-gather of the per-range distinct counts -> (list M_p, global M, this rank's offset)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([m_local], dtype=torch.int64, device=device)
+    allm = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(allm, mine, group=group)
+    ms = [int(x.item()) for x in allm]
+    return ms, sum(ms), sum(ms[:rank])
+
+
+def gather_ranges_to_root(keys, counts, ms, group=None):
+    """Concatenate every rank's range on rank 0 (ranges are disjoint and ordered by rank, so
+    the concatenation is the globally sorted distinct key set)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    send = [int(keys.numel())] + [0] * (world - 1)
+    recv = ms if rank == 0 else [0] * world
+    rk = torch.empty(sum(recv), dtype=keys.dtype, device=keys.device)
+    rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
+    dist.all_to_all_single(rk, keys, recv, send, group=group)
+    dist.all_to_all_single(rc, counts, recv, send, group=group)
+    return rk, rc
+
+
+class DevArray:
+    """Zero-copy torch view of device memory owned by libgossgpu.so."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_view(ptr, n, dtype, device):
+    typestr = {torch.int64: "<i8", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(DevArray(ptr, n, typestr), device=device)
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True):
+    """The whole multi-GPU job for one-word keys on an already created Context:
+    local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
+    Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
+    world = dist.get_world_size(group)
+    ctx.reset()
+    ctx.push_device(bases_ptr, nbytes)
+    c = ctx.finish()
+    if c.key_words != 1:
+        raise NotImplementedError("multi-GPU exchange is implemented for one-word keys (2*len <= 62)")
+    windows = c.windows
+    kp, cp, m = ctx.result_ptrs()
+    keys = device_view(kp, m, torch.int64, device)
+    counts = device_view(cp, m, torch.int32, device)
+    splitters = uniform_splitters(key_bits, world, device=device)
+    rk, rc, recv = exchange_runs(keys, counts, splitters, group)
+    _sync(device)          # the library runs on its own stream: finish the collectives first
+    # merge the received runs: they replace the local result
+    ctx.reset()
+    off = 0
+    for n in recv:
+        if n:
+            ctx.push_run(rk.data_ptr() + off * 8, rc.data_ptr() + off * 4, n)
+        off += n
+    c2 = ctx.finish()
+    ms, M, _ = gather_counts(c2.distinct, device, group)
+    out = {"windows": windows, "M": M, "m_range": c2.distinct}
+    if emit_on_root:
+        kp, cp, m = ctx.result_ptrs()
+        keys = device_view(kp, m, torch.int64, device).clone()
+        counts = device_view(cp, m, torch.int32, device).clone()
+        ak, ac = gather_ranges_to_root(keys, counts, ms, group)
+        _sync(device)
+        if dist.get_rank(group) == 0:
+            ctx.reset()
+            ctx.push_run(ak.data_ptr(), ac.data_ptr(), M)
+            ctx.finish()
+            ctx.emit_device()
+    return out

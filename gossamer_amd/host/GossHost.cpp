@@ -1,0 +1,685 @@
+// GossHost.cpp -- see GossHost.hpp.  Host C++ only: all device work goes through the C ABI of
+// libgossgpu.so; there is no CPU counting path in this program.
+#include "GossHost.hpp"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cerrno>
+#include <cmath>
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+
+#include "../../include/goss_gpu.h"
+
+namespace gosshost {
+
+// --------------------------------------------------------------------------------------
+// InFile
+// --------------------------------------------------------------------------------------
+
+static bool endsWith(const std::string& s, const char* suf)
+{
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+InFile::InFile(const std::string& name) : mName(name)
+{
+    if (name == "-") { mStdin = true; mFd = 0; return; }
+    if (endsWith(name, ".bz2"))
+        throw Error::General("bzip2 input is not supported by this build: '" + name + "'\n");
+    if (endsWith(name, ".gz"))
+    {
+        mGz = gzopen(name.c_str(), "rb");
+        if (!mGz) throw Error::Errno(name, errno ? errno : ENOENT);
+        gzbuffer((gzFile)mGz, 1 << 20);
+        return;
+    }
+    mFd = ::open(name.c_str(), O_RDONLY);
+    if (mFd < 0) throw Error::Errno(name, errno);
+}
+
+InFile::~InFile()
+{
+    if (mGz) gzclose((gzFile)mGz);
+    else if (mFd > 0) ::close(mFd);
+}
+
+size_t InFile::read(char* dst, size_t cap)
+{
+    if (mGz)
+    {
+        int n = gzread((gzFile)mGz, dst, (unsigned)std::min<size_t>(cap, 1u << 30));
+        if (n < 0) throw Error::Errno(mName, EIO);
+        return (size_t)n;
+    }
+    size_t got = 0;
+    while (got < cap)
+    {
+        ssize_t n = ::read(mFd, dst + got, cap - got);
+        if (n < 0) { if (errno == EINTR) continue; throw Error::Errno(mName, errno); }
+        if (n == 0) break;
+        got += (size_t)n;
+        if (mStdin) break;
+    }
+    return got;
+}
+
+bool InFile::readable(const std::string& name)
+{
+    if (name == "-") return true;
+    struct stat st;
+    if (::stat(name.c_str(), &st) != 0 || S_ISDIR(st.st_mode)) return false;
+    return ::access(name.c_str(), R_OK) == 0;
+}
+
+// --------------------------------------------------------------------------------------
+// LineReader
+// --------------------------------------------------------------------------------------
+
+LineReader::LineReader(const std::string& name, size_t bufBytes) : mFile(name), mBuf(bufBytes)
+{
+    // PlainLineSource ctor: if (good) getline  (LineSource.cc:40-48)
+    getline();
+}
+
+bool LineReader::refill()
+{
+    if (mEof) return false;
+    if (mBeg > 0 && mBeg < mEnd) memmove(mBuf.data(), mBuf.data() + mBeg, mEnd - mBeg);
+    mEnd -= mBeg; mBeg = 0;
+    if (mEnd == mBuf.size()) mBuf.resize(mBuf.size() * 2);
+    size_t n = mFile.read(mBuf.data() + mEnd, mBuf.size() - mEnd);
+    if (n == 0) { mEof = true; return false; }
+    mEnd += n;
+    return true;
+}
+
+void LineReader::getline()
+{
+    mLine = mBuf.data() + mBeg; mLen = 0;
+    if (!mGood) return;
+    size_t scanned = 0;
+    for (;;)
+    {
+        const char* p = mBuf.data() + mBeg;
+        const char* nl = (const char*)memchr(p + scanned, '\n', mEnd - mBeg - scanned);
+        if (nl)
+        {
+            mLine = p; mLen = (size_t)(nl - p);
+            mBeg += mLen + 1;
+            return;
+        }
+        scanned = mEnd - mBeg;
+        if (!refill())
+        {
+            // end of file: whatever is left is the last line; the stream is no longer good
+            mLine = mBuf.data() + mBeg; mLen = mEnd - mBeg;
+            mBeg = mEnd;
+            mGood = false;
+            return;
+        }
+    }
+}
+
+void LineReader::next() { getline(); }
+
+// --------------------------------------------------------------------------------------
+// parsers
+// --------------------------------------------------------------------------------------
+
+static std::string num(uint64_t v) { return std::to_string(v); }
+
+// FastqParser::next (FastqParser.hh:78-176); getLine strips one trailing '\r' (:62-75).
+uint64_t parseFastq(const std::string& name, const ReadSink& sink)
+{
+    LineReader src(name);
+    uint64_t lineNum = 1, reads = 0;
+    std::string label, seq;
+    auto cur = [&](const char*& l, size_t& n) {
+        l = src.line(); n = src.len();
+        if (n > 0 && l[n - 1] == '\r') --n;
+    };
+    for (;;)
+    {
+        if (!src.valid()) break;
+        const char* l; size_t n;
+        cur(l, n);
+        if (!(n > 0 && l[0] == '@'))
+            throw Error::Parse(name, "expected '@' at beginning of line " + num(lineNum));
+        label.assign(l + 1, n - 1);
+        seq.clear();
+        for (;;)
+        {
+            src.next(); ++lineNum;
+            if (!src.valid())
+                throw Error::Parse(name, "expected sequence data or quality header at line " + num(lineNum));
+            cur(l, n);
+            if (n > 0 && (l[0] == '@' || l[0] == '+')) break;
+            seq.append(l, n);
+        }
+        if (!(n > 0 && l[0] == '+'))
+            throw Error::Parse(name, "expected '+' at beginning of line " + num(lineNum));
+        if (n > 1 && !(n - 1 == label.size() && memcmp(l + 1, label.data(), n - 1) == 0))
+            throw Error::Parse(name, "quality title does not match sequence title at line " + num(lineNum));
+        size_t qual = 0;
+        for (;;)
+        {
+            src.next(); ++lineNum;
+            if (!src.valid()) break;
+            cur(l, n);
+            if (n > 0 && (l[0] == '@' || l[0] == '+'))
+            {
+                // '@' may start a quality line: only a record boundary once enough quality
+                // has been seen
+                if (qual >= seq.size()) break;
+            }
+            qual += n;
+        }
+        if (seq.size() != qual)
+            throw Error::Parse(name, "length mistmatch between sequence and quality data just before line " + num(lineNum));
+        ++reads;
+        sink(seq.data(), seq.size());
+    }
+    return reads;
+}
+
+// FastaParser::next (FastaParser.hh:51-87); no '\r' stripping; line numbers start at 0.
+uint64_t parseFasta(const std::string& name, const ReadSink& sink)
+{
+    LineReader src(name);
+    uint64_t lineNum = 0, reads = 0;
+    std::string seq;
+    for (;;)
+    {
+        if (!src.valid()) break;
+        if (!(src.len() > 0 && src.line()[0] == '>'))
+            throw Error::Parse(name, "expected '>' at beginning of line " + num(lineNum));
+        seq.clear();
+        for (;;)
+        {
+            src.next(); ++lineNum;
+            if (!src.valid()) break;
+            if (src.len() > 0 && src.line()[0] == '>') break;
+            seq.append(src.line(), src.len());
+        }
+        ++reads;
+        sink(seq.data(), seq.size());
+    }
+    return reads;
+}
+
+// LineParser::next (LineParser.hh:71-82): every line is a read.
+uint64_t parseLines(const std::string& name, const ReadSink& sink)
+{
+    LineReader src(name);
+    uint64_t reads = 0;
+    while (src.valid())
+    {
+        ++reads;
+        sink(src.line(), src.len());
+        src.next();
+    }
+    return reads;
+}
+
+// --------------------------------------------------------------------------------------
+// the build commands
+// --------------------------------------------------------------------------------------
+
+namespace {
+
+struct GpuCtx {
+    goss_gpu_ctx* h = nullptr;
+    ~GpuCtx() { if (h) goss_gpu_destroy(h); }
+    void check(int rc, const char* what)
+    {
+        if (rc == GOSS_OK) return;
+        std::string msg = std::string(what) + ": " + goss_gpu_strerror(rc);
+        const char* d = h ? goss_gpu_last_error(h) : "";
+        if (d && *d) msg += std::string(" (") + d + ")";
+        throw Error::General(msg + "\n");
+    }
+};
+
+void writeFile(const std::string& path, const std::string& objName, GpuCtx& g, uint32_t idx, uint64_t size)
+{
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) throw Error::Write(objName);
+    const uint64_t piece = 64u << 20;
+    std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
+    for (uint64_t off = 0; off < size; off += piece)
+    {
+        uint64_t n = std::min(piece, size - off);
+        g.check(goss_gpu_file_read(g.h, idx, off, buf.data(), n), "reading device file");
+        if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { fclose(fp); throw Error::Write(objName); }
+    }
+    if (fclose(fp) != 0) throw Error::Write(objName);
+}
+
+void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string& out, const strings& fastas,
+              const strings& fastqs, const strings& lines, BuildStats& stats)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = cxt.log;
+    const uint64_t maxK = mode == GOSS_MODE_GRAPH ? 62 : 63;
+    if (K > maxK || K == 0)
+        throw Error::General("unable to build a graph with k=" + num(K));      // KmerSet.hh:89-95, Graph.cc:152-158
+
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, cxt.hbmBudget, nullptr), "creating the GPU context");
+
+    std::vector<char> batch;
+    batch.reserve(cxt.batchBytes + (1u << 20));
+    uint64_t reads = 0;
+    auto flush = [&]() {
+        if (batch.empty()) return;
+        g.check(goss_gpu_push_bases_host(g.h, batch.data(), batch.size()), "counting k-mers");
+        batch.clear();
+    };
+    uint64_t progress = 0;
+    ReadSink sink = [&](const char* seq, size_t len) {
+        batch.insert(batch.end(), seq, seq + len);
+        batch.push_back('\n');
+        if (batch.size() >= cxt.batchBytes) flush();
+        if (++progress % 100000 == 0) log(info, num(progress) + " reads");   // UnboundedProgressMonitor
+    };
+    // same order as the reference: line, fasta, fastq (GossCmdBuildKmerSet.cc:118-141)
+    for (auto& f : lines) { log(info, "parsing sequences from " + f); reads += parseLines(f, sink); }
+    for (auto& f : fastas) { log(info, "parsing sequences from " + f); reads += parseFasta(f, sink); }
+    for (auto& f : fastqs) { log(info, "parsing sequences from " + f); reads += parseFastq(f, sink); }
+    if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
+    flush();
+
+    log(info, "sorting the hashtable...");
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "sorting");
+    log(info, "sorting done.");
+    log(info, "writing out graph.");
+    g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
+    uint32_t nfiles = 0;
+    g.check(goss_gpu_file_count(g.h, &nfiles), "listing output files");
+    for (uint32_t i = 0; i < nfiles; ++i)
+    {
+        char suffix[256]; uint64_t size = 0;
+        g.check(goss_gpu_file_info(g.h, i, suffix, sizeof suffix, &size), "listing output files");
+        writeFile(out + suffix, out, g, i, size);
+    }
+    stats.reads = reads; stats.windows = counts.windows; stats.keys = counts.keys; stats.distinct = counts.distinct;
+    stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::ostringstream os;
+    os << "total build time: " << stats.seconds << "s";
+    log(info, os.str());
+    os.str("");
+    os << "k-mer windows: " << counts.windows << ", keys: " << counts.keys << ", distinct: " << counts.distinct;
+    log(info, os.str());
+}
+
+}  // namespace
+
+void GossCmdBuildKmerSet::operator()(const GossCmdContext& pCxt)
+{
+    runBuild(pCxt, mK, GOSS_MODE_KMER_SET, mKmerSetName, mFastaNames, mFastqNames, mLineNames, mStats);
+}
+
+void GossCmdBuildGraph::operator()(const GossCmdContext& pCxt)
+{
+    runBuild(pCxt, mK, GOSS_MODE_GRAPH, mGraphName, mFastaNames, mFastqNames, mLineNames, mStats);
+}
+
+// --------------------------------------------------------------------------------------
+// command line (App.cc:176-417, GossApp.cc:145-202, GossOptionChecker.hh)
+// --------------------------------------------------------------------------------------
+
+namespace {
+
+enum OptKind { kFlag, kU64, kString, kStrings };
+struct OptDef { const char* lng; const char* sht; OptKind kind; const char* help; };
+
+const OptDef kGlobal[] = {
+    {"debug", "D", kStrings, "enable particular debugging output"},
+    {"help", "h", kFlag, "show a help message"},
+    {"log-file", "l", kString, "place to write messages"},
+    {"tmp-dir", "", kStrings, "a directory to use for temporary files (default /tmp)"},
+    {"num-threads", "T", kU64, "maximum number of worker threads to use, where possible"},
+    {"verbose", "v", kFlag, "show progress messages"},
+    {"version", "V", kFlag, "show the software version"},
+};
+const OptDef kCommon[] = {
+    {"buffer-size", "B", kU64, "maximum size (in GB) for in-memory buffers (default: 2)"},
+    {"fasta-in", "I", kStrings, "input file in FASTA format"},
+    {"fastas-in", "F", kStrings, "input file containing filenames in FASTA format"},
+    {"fastq-in", "i", kStrings, "input file in FASTQ format"},
+    {"fastqs-in", "f", kStrings, "input file containing filenames in FASTQ format"},
+    {"line-in", "", kStrings, "input file with one sequence per line"},
+    {"graph-out", "O", kString, "name of the output graph object"},
+    {"kmer-size", "k", kU64, "kmer size to use"},
+};
+const OptDef kKmerSetSpecific[] = {
+    {"log-hash-slots", "S", kU64, "log2 of the number of hash slots to use (default 24)"},
+};
+// not in the reference: where and how much HBM to use
+const OptDef kGpuSpecific[] = {
+    {"device", "", kU64, "HIP device ordinal (default 0)"},
+    {"hbm-budget", "", kU64, "HBM budget in GB for keys and sort workspace (default: 80% of free HBM)"},
+};
+
+struct Parsed {
+    std::map<std::string, std::vector<std::string>> vals;
+    size_t count(const std::string& k) const { auto i = vals.find(k); return i == vals.end() ? 0 : i->second.size(); }
+    const std::string& str(const std::string& k) const { return vals.at(k).back(); }
+    const std::vector<std::string>& strs(const std::string& k) const { return vals.at(k); }
+};
+
+struct OptTable {
+    std::vector<OptDef> defs;
+    const OptDef* findLong(const std::string& n, bool& ambiguous) const
+    {
+        ambiguous = false;
+        const OptDef* hit = nullptr;
+        for (auto& d : defs) if (n == d.lng) return &d;
+        for (auto& d : defs)                      // unique-prefix guessing, as program_options does
+            if (strncmp(d.lng, n.c_str(), n.size()) == 0) { if (hit) { ambiguous = true; return nullptr; } hit = &d; }
+        return hit;
+    }
+    const OptDef* findShort(char c) const
+    {
+        for (auto& d : defs) if (d.sht[0] == c && d.sht[0]) return &d;
+        return nullptr;
+    }
+    std::string describe() const
+    {
+        std::ostringstream os;
+        for (auto& d : defs)
+        {
+            std::string l = "  ";
+            if (d.sht[0]) l += std::string("-") + d.sht + " [ --" + d.lng + " ]"; else l += std::string("--") + d.lng;
+            if (d.kind != kFlag) l += " arg";
+            if (l.size() < 40) l.resize(40, ' '); else l += " ";
+            os << l << d.help << "\n";
+        }
+        return os.str();
+    }
+};
+
+uint64_t toU64(const std::string& opt, const std::string& v)
+{
+    if (v.empty() || v[0] == '-') throw Error::Usage("the argument ('" + v + "') for option '--" + opt + "' is invalid\n");
+    char* end = nullptr;
+    errno = 0;
+    unsigned long long x = strtoull(v.c_str(), &end, 10);
+    if (errno || *end) throw Error::Usage("the argument ('" + v + "') for option '--" + opt + "' is invalid\n");
+    return x;
+}
+
+// Parses argv[first..] against the table; unknown tokens are collected like
+// command_line_parser(...).allow_unregistered() + the check at App.cc:255-262.
+void parseArgs(int argc, char** argv, int first, const OptTable& t, Parsed& out, std::string& badMsg)
+{
+    for (int i = first; i < argc; ++i)
+    {
+        std::string tok = argv[i];
+        const OptDef* d = nullptr;
+        std::string inlineVal; bool hasInline = false;
+        if (tok.size() > 2 && tok[0] == '-' && tok[1] == '-')
+        {
+            std::string name = tok.substr(2);
+            size_t eq = name.find('=');
+            if (eq != std::string::npos) { inlineVal = name.substr(eq + 1); name = name.substr(0, eq); hasInline = true; }
+            bool amb;
+            d = t.findLong(name, amb);
+        }
+        else if (tok.size() >= 2 && tok[0] == '-' && tok[1] != '-')
+        {
+            d = t.findShort(tok[1]);
+            if (d && tok.size() > 2)
+            {
+                if (d->kind == kFlag) d = nullptr;      // grouped flags are not used by goss
+                else { inlineVal = tok.substr(2); hasInline = true; }
+            }
+        }
+        if (!d)
+        {
+            badMsg += "unknown option '" + tok + "'\n";
+            continue;
+        }
+        if (d->kind == kFlag)
+        {
+            out.vals[d->lng].push_back("1");
+            continue;
+        }
+        std::string v;
+        if (hasInline) v = inlineVal;
+        else if (i + 1 < argc) v = argv[++i];
+        else throw Error::Usage(std::string("the required argument for option '--") + d->lng + "' is missing\n");
+        if (d->kind == kU64) toU64(d->lng, v);
+        out.vals[d->lng].push_back(v);
+    }
+}
+
+// GossOptionChecker: accumulates error text, decides usage vs general error.
+struct Checker {
+    const Parsed& o;
+    std::string errors;
+    bool suggestUsage = false;
+    bool mandatoryU64(const std::string& n, uint64_t& v, uint64_t maxv)
+    {
+        if (!o.count(n)) { errors += "mandatory option " + n + " was not given.\n"; suggestUsage = true; return false; }
+        v = toU64(n, o.str(n));
+        if (v > maxv)
+        {
+            errors += "The given value of the option " + n + " was invalid.\n";
+            errors += "\tvalue " + num(v) + " is out of range.\n\tthe maximum allowed value is " + num(maxv) + ".\n";
+            suggestUsage = true;
+            return false;
+        }
+        return true;
+    }
+    bool optionalU64(const std::string& n, uint64_t& v)
+    {
+        if (!o.count(n)) return false;
+        v = toU64(n, o.str(n));
+        return true;
+    }
+    // FileCreateCheck(fac, true): "<name>.test" must be creatable (GossOptionChecker.hh:80-122)
+    bool mandatoryOut(const std::string& n, std::string& v)
+    {
+        if (!o.count(n)) { errors += "mandatory option " + n + " was not given.\n"; suggestUsage = true; return false; }
+        v = o.str(n);
+        std::string probe = v + ".test";
+        FILE* fp = fopen(probe.c_str(), "wb");
+        if (!fp)
+        {
+            errors += "The given value of the option " + n + " was invalid.\n";
+            errors += "\tcannot create filenames with prefix '" + v + "'\n";
+            return false;
+        }
+        fclose(fp);
+        ::remove(probe.c_str());
+        return true;
+    }
+    // FileReadCheck (GossOptionChecker.hh:125-156)
+    void repeatingIn(const std::string& n, strings& vals)
+    {
+        if (!o.count(n)) return;
+        vals = o.strs(n);
+        for (auto& f : vals)
+            if (!InFile::readable(f))
+            {
+                errors += "The given value of the option " + n + " was invalid.\n";
+                errors += "\tcannot open file '" + f + "' for reading\n";
+            }
+    }
+    // expandFilenames (GossOptionChecker.hh:405-430): one name per '\n'-terminated line
+    void expand(const std::string& n, strings& names)
+    {
+        if (!o.count(n)) return;
+        for (auto& lf : o.strs(n))
+        {
+            InFile in(lf);
+            std::string all; char buf[65536]; size_t got;
+            while ((got = in.read(buf, sizeof buf)) > 0) all.append(buf, got);
+            size_t b = 0;
+            for (;;)
+            {
+                size_t e = all.find('\n', b);
+                if (e == std::string::npos) break;      // a last line without '\n' is dropped
+                names.push_back(all.substr(b, e - b));
+                b = e + 1;
+            }
+        }
+    }
+    void throwIfNecessary()
+    {
+        if (errors.empty()) return;
+        if (suggestUsage) throw Error::Usage(errors);
+        throw Error::General(errors);
+    }
+};
+
+const char* kVersion = "1.3.0-mi355x";
+
+void printHelp(const std::string& cmdName, const OptTable* t)
+{
+    std::cerr << "goss <command> [options]\n\ncommands implemented by this build:\n"
+              << "  build-graph      create a new graph\n"
+              << "  build-kmer-set   create a new graph\n"
+              << "  help             print a summary of all the commands.\n";
+    if (t)
+    {
+        std::cerr << "\n" << cmdName << "\n" << t->describe() << std::endl;
+    }
+}
+
+}  // namespace
+
+int gossMain(int argc, char* argv[])
+{
+    std::string cmdName;
+    try
+    {
+        for (int i = 1; i < argc; ++i)
+            if (!strcmp(argv[i], "--version")) { std::cout << "goss version " << kVersion << std::endl; return 0; }
+
+        int argsToSkip = 0;
+        if (argc < 2) cmdName = "help";
+        else if (argc == 2 && (!strcmp(argv[1], "--help") || !strcmp(argv[1], "-h"))) cmdName = "help";
+        else { cmdName = argv[1]; if (argv[1][0] != '-') argsToSkip = 1; }
+
+        const bool isKmerSet = cmdName == "build-kmer-set", isGraph = cmdName == "build-graph";
+        if (!isKmerSet && !isGraph)
+        {
+            if (cmdName != "help") std::cerr << "unknown command '" << cmdName << "'" << std::endl;
+            printHelp(cmdName, nullptr);
+            return 0;
+        }
+
+        OptTable t;
+        for (auto& d : kGlobal) t.defs.push_back(d);
+        for (auto& d : kCommon) t.defs.push_back(d);
+        if (isKmerSet) for (auto& d : kKmerSetSpecific) t.defs.push_back(d);
+        for (auto& d : kGpuSpecific) t.defs.push_back(d);
+
+        Parsed opts;
+        std::string bad;
+        parseArgs(argc, argv, 1 + argsToSkip, t, opts, bad);
+        if (!bad.empty())
+        {
+            if (opts.count("help")) { std::cerr << bad; printHelp(cmdName, &t); return 1; }
+            throw Error::Usage(bad);
+        }
+
+        // logging (App.cc:291-301)
+        Severity sev = opts.count("verbose") ? info : warning;
+        std::unique_ptr<Logger> logger;
+        if (opts.count("log-file"))
+        {
+            FILE* fp = fopen(opts.str("log-file").c_str(), "w");
+            if (!fp) throw Error::Errno(opts.str("log-file"), errno);
+            logger.reset(new Logger(fp, sev, true));
+        }
+        else logger.reset(new Logger(stderr, sev));
+        if (opts.count("debug"))
+            for (auto& d : opts.strs("debug")) (*logger)(warning, "unknown debug: " + d);
+
+        // the factory (GossCmdBuildKmerSet.cc:151-198, GossCmdBuildGraph.cc:428-476)
+        Checker chk{opts};
+        uint64_t K = 0;
+        chk.mandatoryU64("kmer-size", K, isGraph ? 62 : 63);
+        uint64_t B = 2;
+        chk.optionalU64("buffer-size", B);
+        if (isGraph && B > 24)
+        {
+            (*logger)(warning, "Unsupported --buffer-size " + num(B) + ", truncating to 24.");
+            B = 24;
+        }
+        // BackyardHash::maxSlotBits(B << 30) = floor(log2((B<<30)/22)) (BackyardHash.hh:414-418)
+        uint64_t S = 0;
+        { uint64_t slots = (uint64_t)((double)(B << 30) / (1.5 * 4 + 16)); S = (uint64_t)std::log2((double)slots); }
+        if (isKmerSet) chk.optionalU64("log-hash-slots", S);
+        uint64_t N = (uint64_t)((double)(B << 30) / (1.5 * 4 + 16));
+        uint64_t T = 4;
+        chk.optionalU64("num-threads", T);
+        std::string outName;
+        chk.mandatoryOut("graph-out", outName);
+        strings fastas, fastqs, lines;
+        chk.repeatingIn("fasta-in", fastas);
+        chk.expand("fastas-in", fastas);
+        chk.repeatingIn("fastq-in", fastqs);
+        chk.expand("fastqs-in", fastqs);
+        chk.repeatingIn("line-in", lines);
+        if (opts.count("help")) { printHelp(cmdName, &t); return 1; }
+        chk.throwIfNecessary();
+
+        GossCmdContext cxt{*logger, cmdName};
+        uint64_t dev = 0, budgetGb = 0;
+        if (chk.optionalU64("device", dev)) cxt.device = (int)dev;
+        if (chk.optionalU64("hbm-budget", budgetGb)) cxt.hbmBudget = budgetGb << 30;
+        try
+        {
+            if (isKmerSet) { GossCmdBuildKmerSet cmd(K, S, N, T, outName, fastas, fastqs, lines); cmd(cxt); }
+            else { GossCmdBuildGraph cmd(K, S, N, T, outName, fastas, fastqs, lines); cmd(cxt); }
+        }
+        catch (Error& e) { e.cmd = cmdName; throw; }
+    }
+    catch (const Error& e)
+    {
+        // the printing order of App.cc:328-417
+        if (!e.cmd.empty()) std::cerr << "error performing " << e.cmd << ":" << std::endl;
+        if (!e.parse.empty()) std::cerr << "\t'" << e.file << "': " << e.parse << std::endl;
+        if (!e.write_name.empty()) std::cerr << "\tcannot write to '" << e.write_name << "'" << std::endl;
+        if (!e.general.empty()) std::cerr << e.general;
+        if (e.err_no)
+        {
+            std::cerr << "\t";
+            if (!e.file.empty()) std::cerr << "'" << e.file << "': ";
+            std::cerr << strerror(e.err_no) << std::endl;
+        }
+        if (!e.usage.empty())
+        {
+            std::cerr << e.usage;
+            std::cerr << "use\n\tgoss " << cmdName << " -h\nfor more usage information." << std::endl;
+        }
+        return 1;
+    }
+    catch (std::exception& e)
+    {
+        std::cerr << "caught unexpected exception: " << e.what() << std::endl;
+        return 1;
+    }
+    catch (...)
+    {
+        std::cerr << "caught unknown exception" << std::endl;
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace gosshost

@@ -134,18 +134,43 @@ int goss_gpu_emit_sparse_array(goss_gpu_ctx* ctx, const void* d_positions, uint3
                                uint64_t n, uint64_t N_lo, uint64_t N_hi, uint64_t M,
                                uint64_t Nend_lo, uint64_t Nend_hi);
 
-/* Timing of the phases of the last push/finish/emit on this context, in milliseconds
- * measured with HIP events on the context's stream (for bench.py's roofline block). */
+/* Device time per kernel class on this context since the last reset, measured with HIP events
+ * recorded on the context's stream around every launch (for bench.py's roofline block).
+ * units[] = items processed by the launches of that class (keys for the sort kernels,
+ * window starts for extraction, distinct keys for emit). */
+enum {
+    GOSS_T_EXTRACT = 0,   /* extract_kernel */
+    GOSS_T_HIST    = 1,   /* radix_hist_kernel */
+    GOSS_T_SCAN    = 2,   /* scan_reduce/scan_apply over the digit tables */
+    GOSS_T_SCATTER = 3,   /* radix_scatter_kernel */
+    GOSS_T_REDUCE  = 4,   /* heads_count/heads_write/run_lengths */
+    GOSS_T_EMIT    = 5,   /* Elias-Fano / DenseSelect / VariableByteArray image build */
+    GOSS_T_CLASSES = 8
+};
 typedef struct {
-    float extract_ms;    /* key extraction kernels */
-    float sort_ms;       /* radix sort passes */
-    float reduce_ms;     /* run compaction */
-    float emit_ms;       /* on-disk array build */
-    float total_ms;
-    uint32_t extract_launches, sort_launches, reduce_launches, emit_launches;
+    float    ms[GOSS_T_CLASSES];
+    uint32_t launches[GOSS_T_CLASSES];
+    uint64_t units[GOSS_T_CLASSES];
 } goss_gpu_timing;
 int goss_gpu_timing_get(goss_gpu_ctx* ctx, goss_gpu_timing* out);
 int goss_gpu_timing_reset(goss_gpu_ctx* ctx);
+
+/*
+ * Forget everything counted so far but keep the HBM arena, the stream and (k, mode):
+ * the context can then be used for a new build.  Role of BackyardHash::clear()
+ * (GossCmdBuildKmerSet.tcc:288).
+ */
+int goss_gpu_reset(goss_gpu_ctx* ctx);
+
+/*
+ * Feed an already counted run: m distinct keys (key_words u64 each, strictly increasing)
+ * with their u32 counts, both resident in HBM.  Runs are merged with everything else at
+ * finish (equal keys summed).  Used to combine partial results -- per-GPU ranges after the
+ * all-to-all exchange, or previously built objects (the role AsyncMerge::merge plays for the
+ * reference's spill runs, AsyncMerge.tcc:174-324).
+ */
+int goss_gpu_push_run_device(goss_gpu_ctx* ctx, const void* d_keys, const uint32_t* d_counts,
+                             uint64_t m);
 
 /*
  * Deterministic synthetic read generator: fills d_out (device) with
