@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgossgpu.so")
+LIB_PATH = os.environ.get("GOSS_GPU_LIB") or os.path.join(_PKG, "libgossgpu.so")
 
 MODE_KMER_SET = 0
 MODE_GRAPH = 1
@@ -20,7 +20,7 @@ SYMBOLS = [
     "goss_gpu_finish", "goss_gpu_result", "goss_gpu_result_copy", "goss_gpu_emit",
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
-    "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device",
+    "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
     L.goss_gpu_timing_get.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.goss_gpu_timing_reset.argtypes = [C.c_void_p]
     L.goss_gpu_reset.argtypes = [C.c_void_p]
+    L.goss_gpu_set_path.argtypes = [C.c_void_p, C.c_int]
     L.goss_gpu_push_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.goss_gpu_synth_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.goss_synth_reads_host.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -147,6 +148,10 @@ class Context:
 
     def push_run(self, keys_ptr, counts_ptr, m):
         self._check(self._L.goss_gpu_push_run_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
+
+    def set_path(self, path):
+        """0: segment hash path with LSD fallback (default); 1: LSD radix sort only."""
+        self._check(self._L.goss_gpu_set_path(self._h, path))
 
     def reset(self):
         self._check(self._L.goss_gpu_reset(self._h))

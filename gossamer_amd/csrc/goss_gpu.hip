@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -77,6 +78,10 @@ struct goss_gpu_ctx {
     uint32_t k = 0, len = 0;
     int mode = 0;
     int words = 1;
+    int path = 0;                       // 0 auto, 1 LSD sort only
+    bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
+    bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
+    uint32_t lookback_failures = 0;
     uint64_t budget = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -185,39 +190,111 @@ void exclusive_scan_u64(goss_gpu_ctx* c, uint64_t* a, uint64_t n)
 }
 
 // ---- LSD radix sort -------------------------------------------------------------------
-// Sorts n keys on digits [0, ndigits).  Returns true if the result is in (kb, vb).
+// Stable passes on the 8-bit digits at bit first_shift, first_shift+8, ... (ndigits of them).
+// Returns true if the result is in (kb, vb).
+//
+// One pass with per-tile histogram table: histogram kernel, device scan, stable scatter.
 template <class K, bool HAS_VAL>
-bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint64_t n, uint32_t ndigits)
+void radix_pass_table(goss_gpu_ctx* c, const K* src, const uint32_t* vs, K* dst, uint32_t* vd, uint64_t n, uint32_t d,
+                      uint64_t ntiles, uint64_t* table)
+{
+    constexpr int tile = SortCfg<K>::kTile;
+    {
+        PhaseTimer t(c, GOSS_T_HIST, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                           src, n, d, ntiles, table);
+        t.stop();
+    }
+    {
+        PhaseTimer t(c, GOSS_T_SCAN, 256ULL * ntiles);
+        exclusive_scan_u64(c, table, 256ULL * ntiles);
+        t.stop();
+    }
+    {
+        PhaseTimer t(c, GOSS_T_SCATTER, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+                           src, vs, dst, vd, n, d, ntiles, (const uint64_t*)table);
+        t.stop();
+    }
+}
+
+template <class K, bool HAS_VAL>
+bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint64_t n, uint32_t ndigits,
+                uint32_t first_shift = 0)
 {
     if (n < 2) return false;
     constexpr int tile = SortCfg<K>::kTile;
     const uint64_t ntiles = (n + tile - 1) / tile;
     uint64_t mark = c->arena.mark();
-    uint64_t* table = (uint64_t*)c->arena.temp(256ULL * ntiles * 8);
     bool in_b = false;
-    for (uint32_t d = 0; d < ndigits; ++d)
+    // the per-tile table (classic passes) and the look-back status words share one buffer
+    uint64_t* table = (uint64_t*)c->arena.temp(256ULL * ntiles * 8);
+    unsigned long long* status = (unsigned long long*)table;
+    unsigned long long* hist = nullptr;
+    LookbackCtl* ctl = nullptr;
+    LookbackCtl* hctl = (LookbackCtl*)((uint8_t*)c->h_pinned + 128);
+    bool lookback = c->lookback && ndigits <= 16;
+    if (lookback)
     {
-        K* src = in_b ? kb : ka; K* dst = in_b ? ka : kb;
-        uint32_t* vs = in_b ? vb : va; uint32_t* vd = in_b ? va : vb;
+        // single-pass form: all digit histograms in one read of the keys, then one look-back
+        // scatter per digit
+        hist = (unsigned long long*)c->arena.temp(ndigits * 256 * 8);
+        ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
+        HIP_TRY(hipMemsetAsync(hist, 0, ndigits * 256 * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
         {
             PhaseTimer t(c, GOSS_T_HIST, n);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
-                               (const K*)src, n, d, ntiles, table);
+            uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + kTB - 1) / kTB);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<K>), dim3(grid), dim3(kTB), 0, c->stream,
+                               (const K*)ka, n, first_shift, ndigits, hist);
             t.stop();
         }
         {
-            PhaseTimer t(c, GOSS_T_SCAN, 256ULL * ntiles);
-            exclusive_scan_u64(c, table, 256ULL * ntiles);
+            PhaseTimer t(c, GOSS_T_SCAN, ndigits * 256);
+            hipLaunchKernelGGL(scan_rows256_kernel, dim3(ndigits), dim3(kTB), 0, c->stream, hist);
             t.stop();
         }
+    }
+    for (uint32_t di = 0; di < ndigits; ++di)
+    {
+        const uint32_t d = first_shift + 8 * di;       // bit offset of this pass's digit
+        K* src = in_b ? kb : ka; K* dst = in_b ? ka : kb;
+        uint32_t* vs = in_b ? vb : va; uint32_t* vd = in_b ? va : vb;
+        bool done = false;
+        if (lookback)
         {
-            PhaseTimer t(c, GOSS_T_SCATTER, n);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
-                               (const K*)src, (const uint32_t*)vs, dst, vd, n, d, ntiles, (const uint64_t*)table);
-            t.stop();
+            HIP_TRY(hipMemsetAsync(status, 0, ntiles * 256 * 8, c->stream));
+            {
+                PhaseTimer t(c, GOSS_T_SCATTER, n);
+                if (c->ordered_tiles)
+                {
+                    HIP_TRY(hipMemsetAsync(&ctl->ticket, 0, 4, c->stream));
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, true>), dim3(grid_for(n, tile)), dim3(kTB), 0,
+                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d,
+                                       (const unsigned long long*)(hist + di * 256), status, ctl);
+                }
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, false>), dim3(grid_for(n, tile)), dim3(kTB), 0,
+                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d,
+                                       (const unsigned long long*)(hist + di * 256), status, ctl);
+                t.stop();
+            }
+            // the source buffer is still intact: a chain that gave up is redone below
+            HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (hctl->error)
+            {
+                std::fprintf(stderr, "libgossgpu: radix look-back chain gave up; redoing the pass with histogram tables\n");
+                c->lookback_failures++;
+                if (!c->ordered_tiles) c->ordered_tiles = true;     // next passes take tickets
+                HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
+            }
+            else done = true;
         }
+        if (!done) radix_pass_table<K, HAS_VAL>(c, src, vs, dst, vd, n, d, ntiles, table);
         in_b = !in_b;
     }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena.release(mark);
     return in_b;
 }
@@ -287,6 +364,66 @@ void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
 
 inline uint32_t key_digits(const goss_gpu_ctx* c) { return (2 * c->len + 7) / 8; }
 
+// ---- fast path: 16-bit partition + per-segment LDS hash table ---------------------------
+template <class K> bool use_segment_path(const goss_gpu_ctx*) { return false; }
+template <> bool use_segment_path<Key1>(const goss_gpu_ctx* c)
+{
+    if (c->path == 1) return false;                   // LSD only
+    return 2 * c->len >= 24;                          // enough key bits below the 16 partition bits
+}
+
+// Partition ka on its top 16 bits (result back in ka), count every segment in LDS.
+// Returns false (and leaves the keys, permuted, in ka) if some segment holds too many
+// distinct keys for the LDS table: the caller then runs the full LSD sort.
+template <class K>
+bool segment_count(goss_gpu_ctx*, K*, K*, uint64_t, Run*) { return false; }
+template <>
+bool segment_count<Key1>(goss_gpu_ctx* c, Key1* ka, Key1* kb, uint64_t n, Run* out)
+{
+    const uint32_t keybits = 2 * c->len;
+    const uint32_t shift = keybits - kSegBits;
+    uint64_t mark = c->arena.mark();
+    bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, n, 2, shift);
+    // two passes: the data is back in ka
+    if (in_b) throw StatusError{GOSS_ERR_INVALID_ARG, "internal: partition parity"};
+    PhaseTimer t(c, GOSS_T_REDUCE, n);
+    uint64_t* seg_off = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
+    uint64_t* seg_pos = (uint64_t*)c->arena.temp(kSegCount * 8);
+    uint64_t* seg_cnt = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
+    uint64_t* seg_dst = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
+    SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
+    const uint64_t stage_cap = std::min<uint64_t>(n, (uint64_t)kSegCount * kSegLimit);
+    uint32_t* stage_counts = (uint32_t*)c->arena.temp(stage_cap * 4);
+    Key1* stage_keys = kb;                             // free half of the ping-pong
+    HIP_TRY(hipMemsetAsync(so, 0, sizeof(SegOut), c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<Key1>), dim3(kSegCount / 256 + 1), dim3(256), 0, c->stream,
+                       (const Key1*)ka, n, shift, seg_off);
+    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(kSegCount), dim3(kTB), 0, c->stream,
+                       (const Key1*)ka, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+    SegOut* h = (SegOut*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h->overflow)
+    {
+        t.stop();
+        c->arena.release(mark);
+        return false;
+    }
+    const uint64_t m = h->cursor;
+    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, kSegCount * 8, hipMemcpyDeviceToDevice, c->stream));
+    exclusive_scan_u64(c, seg_dst, kSegCount);
+    out->m = m;
+    out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(Key1));
+    out->counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
+    hipLaunchKernelGGL(seg_gather_kernel, dim3(kSegCount), dim3(kTB), 0, c->stream,
+                       (const Key1*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
+                       (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (Key1*)out->keys, out->counts);
+    t.stop();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+    return true;
+}
+
 // Process window starts [0, nstarts) of a device-resident byte string (navail readable bytes,
 // navail >= nstarts): extract -> sort -> reduce -> append a run.
 template <class K>
@@ -314,10 +451,17 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     c->keys_total += n;
     if (n)
     {
-        bool in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
-        PhaseTimer t(c, GOSS_T_REDUCE, n);
-        Run r = reduce_runs<K>(c, in_b ? kb : ka, nullptr, n, in_b ? ka : kb);
-        t.stop();
+        Run r{nullptr, nullptr, 0};
+        bool done = false;
+        if (use_segment_path<K>(c))
+            done = segment_count<K>(c, ka, kb, n, &r);     // ka keeps all keys either way
+        if (!done)
+        {
+            bool in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
+            PhaseTimer t(c, GOSS_T_REDUCE, n);
+            r = reduce_runs<K>(c, in_b ? kb : ka, nullptr, n, in_b ? ka : kb);
+            t.stop();
+        }
         c->runs.push_back(r);
     }
     c->arena.release(mark);
@@ -773,6 +917,8 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     c->len = mode == GOSS_MODE_GRAPH ? k + 1 : k;
     c->words = (2 * c->len <= 62) ? 1 : 2;
     c->budget = hbm_budget;
+    { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
+    { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
     int rc = guarded(c, [&]() {
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -959,6 +1105,13 @@ int goss_gpu_timing_reset(goss_gpu_ctx* c)
     int rc = guarded(c, [&]() { resolve_timing(c); });
     c->timing = goss_gpu_timing{};
     return rc;
+}
+
+int goss_gpu_set_path(goss_gpu_ctx* c, int path)
+{
+    if (!c || path < 0 || path > 1) return GOSS_ERR_INVALID_ARG;
+    c->path = path;
+    return GOSS_OK;
 }
 
 int goss_gpu_reset(goss_gpu_ctx* c)

@@ -274,8 +274,14 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 // K4: LSD radix sort, 8-bit digits: per-tile histogram, scan (above), stable scatter
 // --------------------------------------------------------------------------------------
 
+#ifndef GOSS_SORT_ITEMS1
+#define GOSS_SORT_ITEMS1 16
+#endif
+#ifndef GOSS_LB_BATCH
+#define GOSS_LB_BATCH 1
+#endif
 template <class K> struct SortCfg {
-    static constexpr int kItems = sizeof(K) == 8 ? 16 : 8;     // keys per thread
+    static constexpr int kItems = sizeof(K) == 8 ? GOSS_SORT_ITEMS1 : 8;     // keys per thread
     static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
 };
 
@@ -414,6 +420,207 @@ __global__ __launch_bounds__(kTB) void radix_scatter_kernel(const K* __restrict_
 }
 
 // --------------------------------------------------------------------------------------
+// K4 single-pass form: global digit histograms once, then a scatter whose tile offsets come
+// from a chained scan with decoupled look-back (no per-tile histogram table, no second read
+// of the keys).
+// --------------------------------------------------------------------------------------
+
+// hist[p * 256 + d] += number of keys whose digit at bit (first_shift + 8p) is d, for
+// p < npass (npass <= 16).  Persistent grid: every workgroup accumulates in LDS over many
+// tiles and flushes once.
+template <class K>
+__global__ __launch_bounds__(kTB) void global_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t first_shift,
+                                                          uint32_t npass, unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t lh[16 * 256];
+    for (uint32_t i = threadIdx.x; i < npass * 256; i += kTB) lh[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kTB;
+    uint32_t since_flush = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x; i < n; i += stride)
+    {
+        K k = keys[i];
+        for (uint32_t p = 0; p < npass; ++p) atomicAdd(&lh[p * 256 + key_digit(k, first_shift + 8 * p)], 1u);
+        // a 32-bit LDS bin cannot overflow before 2^32 keys have gone through this workgroup
+        (void)since_flush;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < npass * 256; i += kTB)
+        if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+// In-place exclusive scan of each 256-entry row (one workgroup per row).
+__global__ __launch_bounds__(kTB) void scan_rows256_kernel(unsigned long long* __restrict__ hist)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t v = hist[blockIdx.x * 256 + threadIdx.x];
+    uint64_t tot;
+    uint64_t ex = block_excl_scan<uint64_t>(v, sh, &tot);
+    hist[blockIdx.x * 256 + threadIdx.x] = ex;
+}
+
+struct LookbackCtl {
+    uint32_t ticket;       // next tile number
+    uint32_t error;        // a look-back spin gave up (never expected)
+};
+
+constexpr uint64_t kLbFlagAgg = 1ULL << 62;      // tile's own count is published
+constexpr uint64_t kLbFlagPrefix = 2ULL << 62;   // inclusive prefix up to this tile is published
+constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
+
+template <class K, bool HAS_VAL, bool ORDERED>
+__global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                             uint64_t n, uint32_t digit,
+                                                             const unsigned long long* __restrict__ bucket_base,
+                                                             unsigned long long* __restrict__ status,
+                                                             LookbackCtl* __restrict__ ctl)
+{
+    constexpr int kSortItems = SortCfg<K>::kItems;
+    constexpr int kSortTile = SortCfg<K>::kTile;
+    __shared__ uint32_t wave_hist[kWaves][256];
+    __shared__ uint32_t digit_start[256];
+    __shared__ uint64_t global_base[256];
+    __shared__ K stage[kSortTile];
+    __shared__ uint32_t vstage[HAS_VAL ? kSortTile : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ uint32_t sh_tile;
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    // Tile number.  ORDERED: a ticket (one returning atomic per tile: every lower-numbered tile
+    // has then started, so the chain cannot stall, but a single word serves only ~88 M
+    // tickets/s chip-wide).  Otherwise blockIdx.x: the dispatcher starts workgroups in
+    // blockIdx order in practice; HIP does not promise it, so the look-back spin is bounded and
+    // a give-up makes the host redo the pass with the histogram-table kernels.
+    if (ORDERED) { if (tid == 0) sh_tile = atomicAdd(&ctl->ticket, 1u); }
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
+    __syncthreads();
+    const uint32_t tile = ORDERED ? sh_tile : blockIdx.x;
+    const uint64_t tile_base = (uint64_t)tile * kSortTile;
+    const uint32_t tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
+
+    K key[kSortItems];
+    uint32_t val[HAS_VAL ? kSortItems : 1];
+    uint16_t rank[kSortItems];
+    const uint32_t wbase = w * 64 * kSortItems;
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n)
+        {
+            key[r] = keys_in[tile_base + li];
+            if (HAS_VAL) val[r] = vals_in[tile_base + li];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        bool valid = li < tile_n;
+        uint32_t d = valid ? key_digit(key[r], digit) : 0u;
+        uint64_t peers = match_digit(d, valid);
+        uint32_t before = __popcll(peers & lt_mask);
+        uint32_t base = 0;
+        volatile uint32_t* wh = wave_hist[w];
+        if (valid) base = wh[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) wh[d] = base + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = (uint16_t)(base + before);
+    }
+    __syncthreads();
+
+    {
+        // thread tid owns digit tid
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i)
+        {
+            uint32_t c = wave_hist[i][tid];
+            wave_hist[i][tid] = tot;
+            tot += c;
+        }
+        unsigned long long* mine = status + (uint64_t)tile * 256 + tid;
+        uint64_t excl = 0;
+        if (tile == 0)
+        {
+            __hip_atomic_store(mine, kLbFlagPrefix | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+        {
+            __hip_atomic_store(mine, kLbFlagAgg | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Walk back over the predecessors kLbBatch tiles at a time: the loads of one batch
+            // are independent, so a deep walk costs one memory latency per batch instead of
+            // one per tile.
+            constexpr int kLbBatch = GOSS_LB_BATCH;
+            int64_t t = (int64_t)tile - 1;
+            uint32_t spins = 0;
+            bool found = false;
+            while (!found)
+            {
+                unsigned long long v[kLbBatch];
+#pragma unroll
+                for (int j = 0; j < kLbBatch; ++j)
+                {
+                    int64_t tj = t - j;
+                    v[j] = tj >= 0 ? __hip_atomic_load(status + (uint64_t)tj * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : kLbFlagPrefix;       // before tile 0: an empty prefix
+                }
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < kLbBatch; ++j)
+                {
+                    if (found || used != j) continue;     // stopped at an unpublished tile
+                    uint64_t f = v[j] & ~kLbValueMask;
+                    if (f == 0) continue;
+                    excl += v[j] & kLbValueMask;
+                    used = j + 1;
+                    if (f == kLbFlagPrefix) found = true;
+                }
+                t -= used;
+                if (!found && used < kLbBatch)
+                {
+                    if (++spins > (1u << 20)) { atomicOr(&ctl->error, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __hip_atomic_store(mine, kLbFlagPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t tile_total;
+        uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
+        digit_start[tid] = start;
+        global_base[tid] = bucket_base[tid] + excl - start;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n)
+        {
+            uint32_t d = key_digit(key[r], digit);
+            uint32_t pos = digit_start[d] + wave_hist[w][d] + rank[r];
+            stage[pos] = key[r];
+            if (HAS_VAL) vstage[pos] = val[r];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = tid; i < tile_n; i += kTB)
+    {
+        K k = stage[i];
+        uint64_t o = global_base[key_digit(k, digit)] + i;
+        keys_out[o] = k;
+        if (HAS_VAL) vals_out[o] = vstage[i];
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // K5: run compaction (merge equal adjacent keys)
 // --------------------------------------------------------------------------------------
 
@@ -514,6 +721,166 @@ __global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m,
     for (uint64_t i = starts[j]; i < e; ++i) s += vals[i];
     if (s > 0xFFFFFFFFULL) { atomicOr(overflow, 1u); s = 0xFFFFFFFFULL; }
     counts[j] = (uint32_t)s;
+}
+
+// --------------------------------------------------------------------------------------
+// K3/K5 fast path: per-segment counting in an LDS hash table
+// --------------------------------------------------------------------------------------
+//
+// After two partition passes on the top 16 key bits the keys of one segment (equal top 16
+// bits) are contiguous.  One workgroup streams a segment through an open-addressing table
+// held in LDS (64-bit CAS on the key, 32-bit add on the count), then sorts the table with a
+// bitonic network and appends (key,count) pairs to a staging area; segment order is restored
+// by a gather.  This replaces the remaining radix passes whenever a segment has at most
+// kSegLimit distinct keys -- the high-coverage regime of read sets.  A segment that exceeds
+// the limit raises a flag and the caller falls back to the full LSD sort.
+
+constexpr int kSegBits = 16;
+constexpr int kSegCount = 1 << kSegBits;
+constexpr int kSegSlots = 4096;
+constexpr int kSegLimit = 3072;
+
+// seg_off[s] = first index whose top-16-bit value is >= s (s = 0..65536).
+template <class K>
+__global__ void seg_bounds_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift, uint64_t* __restrict__ seg_off)
+{
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > kSegCount) return;
+    uint64_t a = 0, b = n;
+    while (a < b)
+    {
+        uint64_t mid = a + ((b - a) >> 1);
+        if (key_shr64(keys[mid], shift) < (uint64_t)s) a = mid + 1; else b = mid;
+    }
+    seg_off[s] = a;
+}
+
+struct SegOut {
+    unsigned long long cursor;     // staging cursor (entries)
+    uint32_t overflow;             // some segment had more than kSegLimit distinct keys
+    uint32_t count_overflow;
+};
+
+__global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                              SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                              uint64_t* __restrict__ seg_cnt,
+                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+{
+    __shared__ unsigned long long tab[kSegSlots];
+    __shared__ uint32_t cnt[kSegSlots];
+    __shared__ uint32_t ndist;
+    __shared__ uint32_t ovf;
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_off[s + 1];
+    if (b == e)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    constexpr unsigned long long kEmpty = ~0ULL;
+    for (uint32_t i = tid; i < kSegSlots; i += kTB) { tab[i] = kEmpty; cnt[i] = 0; }
+    if (tid == 0) { ndist = 0; ovf = 0; }
+    __syncthreads();
+
+    volatile uint32_t* vovf = &ovf;
+    // kSegUnroll independent coalesced loads are issued before the first insert so that
+    // enough bytes are in flight per CU to cover the HBM latency
+    constexpr int kSegUnroll = 8;
+    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kSegUnroll)
+    {
+        unsigned long long kv[kSegUnroll];
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            uint64_t i = i0 + (uint64_t)u * kTB + tid;
+            kv[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+        }
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            const unsigned long long key = kv[u];
+            if (key == kEmpty) continue;
+            uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - 12));
+            volatile unsigned long long* vtab = tab;
+            for (;;)
+            {
+                // a plain read settles the common case (key already present) without a CAS
+                unsigned long long cur = vtab[slot];
+                if (cur == kEmpty)
+                {
+                    cur = atomicCAS(&tab[slot], kEmpty, key);
+                    if (cur == kEmpty)
+                    {
+                        uint32_t nd = atomicAdd(&ndist, 1u);
+                        if (nd + 1 > kSegLimit) *vovf = 1;
+                        cur = key;
+                    }
+                }
+                if (cur == key) { atomicAdd(&cnt[slot], 1u); break; }
+                slot = (slot + 1) & (kSegSlots - 1);
+                if (*vovf) break;
+            }
+        }
+        if (*vovf) break;
+    }
+    __syncthreads();
+    if (ovf)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+
+    // bitonic sort of the 4096 (key,count) slots by key; empty slots (all ones) sort last
+    for (uint32_t k2 = 2; k2 <= kSegSlots; k2 <<= 1)
+    {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+        {
+            for (uint32_t t = tid; t < kSegSlots / 2; t += kTB)
+            {
+                uint32_t i = 2 * t - (t & (j - 1));       // element with bit j clear
+                uint32_t p = i + j;
+                bool up = (i & k2) == 0;
+                unsigned long long a = tab[i], c = tab[p];
+                if ((a > c) == up)
+                {
+                    tab[i] = c; tab[p] = a;
+                    uint32_t ca = cnt[i]; cnt[i] = cnt[p]; cnt[p] = ca;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t d = ndist;
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    for (uint32_t i = tid; i < d; i += kTB)
+    {
+        stage_keys[ob + i].lo = tab[i];
+        stage_counts[ob + i] = cnt[i];
+    }
+}
+
+// Restore segment order: out[seg_dst[s] + i] = stage[seg_pos[s] + i].
+__global__ __launch_bounds__(kTB) void seg_gather_kernel(const Key1* __restrict__ stage_keys, const uint32_t* __restrict__ stage_counts,
+                                                         const uint64_t* __restrict__ seg_pos, const uint64_t* __restrict__ seg_dst,
+                                                         const uint64_t* __restrict__ seg_cnt_unscanned,
+                                                         Key1* __restrict__ out_keys, uint32_t* __restrict__ out_counts)
+{
+    const uint32_t s = blockIdx.x;
+    const uint64_t d = seg_cnt_unscanned[s];
+    const uint64_t src = seg_pos[s], dst = seg_dst[s];
+    for (uint64_t i = threadIdx.x; i < d; i += kTB)
+    {
+        out_keys[dst + i] = stage_keys[src + i];
+        out_counts[dst + i] = stage_counts[src + i];
+    }
 }
 
 // --------------------------------------------------------------------------------------

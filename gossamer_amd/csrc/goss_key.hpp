@@ -38,13 +38,6 @@ GK_HD bool operator==(const Key2& a, const Key2& b) { return a.lo == b.lo && a.h
 GK_HD bool operator!=(const Key2& a, const Key2& b) { return a.lo != b.lo || a.hi != b.hi; }
 GK_HD bool operator<(const Key2& a, const Key2& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 
-// 8-bit digit d (0 = least significant byte) of a key.
-GK_HD uint32_t key_digit(const Key1& k, uint32_t d) { return (uint32_t)(k.lo >> (8 * d)) & 0xFFu; }
-GK_HD uint32_t key_digit(const Key2& k, uint32_t d)
-{
-    return d < 8 ? (uint32_t)(k.lo >> (8 * d)) & 0xFFu : (uint32_t)(k.hi >> (8 * (d - 8))) & 0xFFu;
-}
-
 // key >> s, returning the low 64 bits (s < 128).
 GK_HD uint64_t key_shr64(const Key1& k, uint32_t s) { return s >= 64 ? 0 : (k.lo >> s); }
 GK_HD uint64_t key_shr64(const Key2& k, uint32_t s)
@@ -53,6 +46,10 @@ GK_HD uint64_t key_shr64(const Key2& k, uint32_t s)
     if (s < 64) return (k.lo >> s) | (k.hi << (64 - s));
     return s >= 128 ? 0 : (k.hi >> (s - 64));
 }
+// 8-bit digit of a key starting at bit `shift` (any alignment).
+GK_HD uint32_t key_digit(const Key1& k, uint32_t shift) { return (uint32_t)key_shr64(k, shift) & 0xFFu; }
+GK_HD uint32_t key_digit(const Key2& k, uint32_t shift) { return (uint32_t)key_shr64(k, shift) & 0xFFu; }
+
 // true if (key >> s) does not fit 64 bits
 GK_HD bool key_shr_overflows(const Key1&, uint32_t) { return false; }
 GK_HD bool key_shr_overflows(const Key2& k, uint32_t s) { return s < 64 && (k.hi >> s) != 0; }

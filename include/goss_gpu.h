@@ -163,6 +163,14 @@ int goss_gpu_timing_reset(goss_gpu_ctx* ctx);
 int goss_gpu_reset(goss_gpu_ctx* ctx);
 
 /*
+ * Counting strategy.  0 (default): partition on the top 16 key bits, then count every segment
+ * in an LDS hash table, falling back to the full LSD radix sort when a segment holds too many
+ * distinct keys.  1: always the full LSD radix sort + run compaction.  The result is the same;
+ * BackyardHash's layout never reaches disk either.
+ */
+int goss_gpu_set_path(goss_gpu_ctx* ctx, int path);
+
+/*
  * Feed an already counted run: m distinct keys (key_words u64 each, strictly increasing)
  * with their u32 counts, both resident in HBM.  Runs are merged with everything else at
  * finish (equal keys summed).  Used to combine partial results -- per-GPU ranges after the

@@ -36,8 +36,9 @@ def oracle_counts(oracle, reads, length, mode):
     return ks, [d[k] for k in ks], nwin
 
 
-def gpu_counts(reads, k, mode, budget=256 * MB, pushes=1):
+def gpu_counts(reads, k, mode, budget=256 * MB, pushes=1, path=0):
     with g.Context(k, mode, hbm_budget=budget) as ctx:
+        ctx.set_path(path)
         per = (len(reads) + pushes - 1) // pushes
         for i in range(0, len(reads), per):
             ctx.push_host("\n".join(reads[i:i + per]) + "\n")
@@ -52,12 +53,13 @@ def test_keys_and_counts_match_oracle(oracle, k, mode):
     reads = make_reads(rng, 300, (max(5, k - 3), 160), 3000, lower=True)
     length = k + 1 if mode == 1 else k
     ek, ec, nwin = oracle_counts(oracle, reads, length, mode)
-    ks, cs, c = gpu_counts(reads, k, mode)
-    assert c.windows == nwin
-    assert c.keys == nwin * (2 if mode else 1)
-    assert c.distinct == len(ek)
-    assert ks == ek
-    assert cs == ec
+    for path in (0, 1):          # segment-hash path (with its fallback) and LSD-only path
+        ks, cs, c = gpu_counts(reads, k, mode, path=path)
+        assert c.windows == nwin
+        assert c.keys == nwin * (2 if mode else 1)
+        assert c.distinct == len(ek)
+        assert ks == ek
+        assert cs == ec
 
 
 def test_high_coverage_counts(oracle):
@@ -67,6 +69,19 @@ def test_high_coverage_counts(oracle):
     ks, cs, c = gpu_counts(reads, 25, 0)
     assert (ks, cs) == (ek, ec)
     assert max(cs) > 255
+
+
+def test_segment_overflow_falls_back(oracle):
+    """More distinct keys in one top-16-bit segment than the LDS table holds: the library must
+    fall back to the full sort and still give the oracle's answer."""
+    rng = random.Random(21)
+    prefix = "ACGTACGT"
+    reads = [prefix + "".join(rng.choice("ACGT") for _ in range(17)) for _ in range(6000)]
+    reads += make_reads(rng, 200, 150, 3000)
+    ek, ec, nwin = oracle_counts(oracle, reads, 25, 1)
+    ks, cs, c = gpu_counts(reads, 24, 1)
+    assert c.windows == nwin
+    assert (ks, cs) == (ek, ec)
 
 
 def test_multi_push_and_small_budget_merge(oracle):
