@@ -574,6 +574,37 @@ int gossMain(int argc, char* argv[])
         else { cmdName = argv[1]; if (argv[1][0] != '-') argsToSkip = 1; }
 
         const bool isKmerSet = cmdName == "build-kmer-set", isGraph = cmdName == "build-graph";
+        if (cmdName == "dump-bases")
+        {
+            // diagnostic: print exactly the byte stream the build commands hand to the device
+            // (each read's bases followed by '\n'), inputs in the order line, fasta, fastq
+            OptTable t;
+            for (auto& d : kGlobal) t.defs.push_back(d);
+            for (auto& d : kCommon) t.defs.push_back(d);
+            Parsed opts; std::string bad;
+            parseArgs(argc, argv, 2, t, opts, bad);
+            if (!bad.empty()) throw Error::Usage(bad);
+            uint64_t reads = 0;
+            ReadSink sink = [&](const char* seq, size_t len) { fwrite(seq, 1, len, stdout); fputc('\n', stdout); };
+            strings fastas, fastqs, lines;
+            Checker chk{opts};
+            chk.repeatingIn("fasta-in", fastas);
+            chk.expand("fastas-in", fastas);
+            chk.repeatingIn("fastq-in", fastqs);
+            chk.expand("fastqs-in", fastqs);
+            chk.repeatingIn("line-in", lines);
+            chk.throwIfNecessary();
+            try
+            {
+                for (auto& f : lines) reads += parseLines(f, sink);
+                for (auto& f : fastas) reads += parseFasta(f, sink);
+                for (auto& f : fastqs) reads += parseFastq(f, sink);
+            }
+            catch (Error& e) { e.cmd = cmdName; throw; }
+            fflush(stdout);
+            if (reads == 0) { Error e = Error::General("No valid reads."); e.cmd = cmdName; throw e; }
+            return 0;
+        }
         if (!isKmerSet && !isGraph)
         {
             if (cmdName != "help") std::cerr << "unknown command '" << cmdName << "'" << std::endl;

@@ -239,3 +239,43 @@ def test_synth_generator_matches_host():
         ctx.synth_reads(buf.data_ptr(), n, L, G, seed=1, first_read=5)
     assert bytes(buf.cpu().numpy().tobytes()) == host
     assert host.count(b"N") == len([r for r in range(5, 5 + n) if r % 97 == 96])
+
+
+def test_goss_cli_end_to_end(oracle, tmp_path):
+    """The goss executable: FASTQ (+ .gz) / FASTA / line inputs -> files on disk, byte for byte
+    what the oracle's restatement of GossCmdBuildKmerSet / GossCmdBuildGraph writes."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    goss = os.path.join(root, "gossamer_amd", "goss")
+    rng = random.Random(77)
+    reads = make_reads(rng, 600, (30, 150), 8000, lower=True)
+    fq = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads[:300]))
+    fa = "".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(reads[300:500]))
+    ln = "\n".join(reads[500:]) + "\n"
+    (tmp_path / "a.fq").write_text(fq)
+    with gzip.open(tmp_path / "a.fq.gz", "wb") as f:
+        f.write(fq.encode())
+    (tmp_path / "b.fa").write_text(fa)
+    (tmp_path / "c.txt").write_text(ln)
+    inputs = [(oracle.LINE, "c.txt", ln), (oracle.FASTA, "b.fa", fa), (oracle.FASTQ, "a.fq", fq)]
+    for cmd, k, obuild, base, fqname in (("build-kmer-set", 25, oracle.build_kmer_set, "ks", "a.fq"),
+                                         ("build-graph", 27, oracle.build_graph, "gr", "a.fq.gz"),
+                                         ("build-graph", 55, oracle.build_graph, "g55", "a.fq")):
+        exp, nwin = obuild(inputs, k, out=base)
+        out = tmp_path / base
+        p = subprocess.run([goss, cmd, "-k", str(k), "-i", str(tmp_path / fqname), "-I", str(tmp_path / "b.fa"),
+                            "--line-in", str(tmp_path / "c.txt"), "-O", str(out), "--hbm-budget", "1", "-v"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"total build time" in p.stderr
+        got = {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
+        assert sorted(got) == sorted(exp)
+        for name in exp:
+            assert got[name] == exp[name], name
+    # an input without reads is an error, like the reference's KmerizingAdapter
+    (tmp_path / "empty.fq").write_text("")
+    p = subprocess.run([goss, "build-kmer-set", "-k", "25", "-i", str(tmp_path / "empty.fq"), "-O", str(tmp_path / "e"), "--hbm-budget", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 1 and p.stderr.decode() == "error performing build-kmer-set:\nNo valid reads."

@@ -1,0 +1,184 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/goss_gpu.h
+declares (no compute calls without a GPU), the host C++ parsers frame records like the
+reference's, and the goss command line reproduces the reference's error behaviour."""
+import gzip
+import os
+import random
+import re
+import subprocess
+
+import pytest
+
+import gossamer_amd as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOSS = os.path.join(ROOT, "gossamer_amd", "goss")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(g.binding.LIB_PATH) and os.path.exists(GOSS)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gossamer_amd", "csrc"), "all"])
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "goss_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(goss_(?:gpu_)?[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = g.load()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(names) == sorted(g.SYMBOLS)
+    assert L.goss_gpu_abi_version() == 1
+    assert L.goss_gpu_strerror(0) == b"ok"
+    assert b"gfx950" in L.goss_gpu_strerror(-2)
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(g.GossGpuError) as e:
+        g.Context(25)
+    assert e.value.status == -2          # GOSS_ERR_NO_DEVICE: there is no CPU fallback
+
+
+def test_k_range_is_checked_before_the_device():
+    L = g.load()
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.goss_gpu_create(C.byref(h), 0, 64, 0, 0, None) == -6     # KmerSet::MaxK = 63
+    assert L.goss_gpu_create(C.byref(h), 0, 63, 1, 0, None) == -6     # Graph::MaxK = 62
+    assert L.goss_gpu_create(C.byref(h), 0, 0, 0, 0, None) == -6
+    assert L.goss_gpu_create(C.byref(h), 0, 25, 7, 0, None) == -1
+
+
+def test_synth_generator_is_deterministic_and_well_formed():
+    a = g.synth_reads_host(500, 150, 100000, seed=1)
+    b = g.synth_reads_host(500, 150, 100000, seed=1)
+    assert a == b and len(a) == 500 * 151
+    lines = a.split(b"\n")
+    assert lines[-1] == b"" and all(len(x) == 150 for x in lines[:-1])
+    assert set(a) <= set(b"ACGTN\n")
+    assert sum(x.count(b"N") for x in lines) == len([r for r in range(500) if r % 97 == 96])
+    # a slice of the stream equals the stream generated from that read on
+    assert g.synth_reads_host(100, 150, 100000, seed=1, first_read=400) == a[400 * 151:]
+    assert g.synth_reads_host(500, 150, 100000, seed=2) != a
+
+
+def run_goss(*args, stdin=None):
+    p = subprocess.run([GOSS] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, input=stdin, timeout=120)
+    return p.returncode, p.stdout, p.stderr.decode()
+
+
+def test_cli_usage_errors_match_reference_text(tmp_path):
+    """App.cc:176-417 + GossOptionChecker.hh."""
+    out = str(tmp_path / "x")
+    rc, _, err = run_goss("build-kmer-set", "-O", out, "--bogus")
+    assert rc == 1 and err == "unknown option '--bogus'\nuse\n\tgoss build-kmer-set -h\nfor more usage information.\n"
+    rc, _, err = run_goss("build-kmer-set", "-O", out)
+    assert rc == 1 and err.startswith("mandatory option kmer-size was not given.\nuse\n\tgoss build-kmer-set -h\n")
+    rc, _, err = run_goss("build-kmer-set", "-k", "64", "-O", out)
+    assert rc == 1 and "The given value of the option kmer-size was invalid.\n\tvalue 64 is out of range.\n\tthe maximum allowed value is 63.\n" in err
+    rc, _, err = run_goss("build-graph", "-k", "63", "-O", out)
+    assert rc == 1 and "the maximum allowed value is 62." in err
+    rc, _, err = run_goss("build-kmer-set", "-k", "25")
+    assert rc == 1 and "mandatory option graph-out was not given." in err
+    rc, _, err = run_goss("build-kmer-set", "-k", "25", "-O", out, "-i", str(tmp_path / "missing.fq"))
+    assert rc == 1 and "\tcannot open file '%s' for reading\n" % (tmp_path / "missing.fq") in err
+    assert "for more usage information" not in err              # not a usage error
+    rc, _, err = run_goss("build-kmer-set", "-k", "25", "-O", "/nonexistent-dir/x")
+    assert rc == 1 and "\tcannot create filenames with prefix '/nonexistent-dir/x'\n" in err
+    rc, _, err = run_goss("frobnicate")
+    assert rc == 0 and err.startswith("unknown command 'frobnicate'\n")
+    rc, out_b, _ = run_goss("--version")
+    assert rc == 0 and out_b.startswith(b"goss version ")
+    rc, _, err = run_goss("build-graph", "-h")
+    assert rc == 1 and "--kmer-size" in err and "--log-hash-slots" not in err     # -S is build-kmer-set only
+    rc, _, err = run_goss("build-kmer-set", "-h")
+    assert "--log-hash-slots" in err
+
+
+def _bases(oracle, payload_lines, k):
+    return oracle.collect([(oracle.LINE, "l", payload_lines)], k, 0)
+
+
+def test_host_parsers_frame_like_the_reference(tmp_path, oracle):
+    """The byte stream the host hands to the device (one read per line) must produce the same
+    k-mers, in the same order, as the reference's parsers (restated in the oracle) do."""
+    rng = random.Random(2)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTNacgt") for _ in range(n))
+
+    fq_records = []
+    for i in range(300):
+        s = seq(rng.randint(0, 120))
+        q = "".join(rng.choice("I@+#5") for _ in range(len(s)))
+        if i % 7 == 0 and len(s) > 20:       # wrapped record, '@'/'+' may start a quality line
+            cut = rng.randint(1, len(s) - 1)
+            fq_records.append("@r%d\n%s\n%s\n+r%d\n%s\n%s\n" % (i, s[:cut], s[cut:], i, q[:cut], q[cut:]))
+        elif i % 11 == 0:
+            fq_records.append("@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, s, q))
+        else:
+            fq_records.append("@r%d\n%s\n+\n%s\n" % (i, s, q))
+    fq = "".join(fq_records)
+    # a quality string may not *start* with '@'/'+' once it is complete; keep the generator honest
+    fa = "".join(">s%d desc\n%s\n%s\n" % (i, seq(rng.randint(0, 70)), seq(rng.randint(0, 70))) for i in range(100)) + ">last\nACGTACGTAC"
+    ln = "\n".join(seq(rng.randint(0, 90)) for _ in range(100))     # no trailing newline
+    (tmp_path / "a.fq").write_text(fq)
+    (tmp_path / "b.fa").write_text(fa)
+    (tmp_path / "c.txt").write_text(ln)
+    with gzip.open(tmp_path / "a.fq.gz", "wb") as f:
+        f.write(fq.encode())
+    for k in (5, 21):
+        try:
+            exp = oracle.collect([(oracle.LINE, "c", ln), (oracle.FASTA, "b", fa), (oracle.FASTQ, "a", fq)], k, 0)
+        except oracle.OracleError as e:
+            pytest.fail("generator produced an invalid file: %s" % e)
+        for fqname in ("a.fq", "a.fq.gz"):
+            rc, out, err = run_goss("dump-bases", "-i", str(tmp_path / fqname), "-I", str(tmp_path / "b.fa"),
+                                    "--line-in", str(tmp_path / "c.txt"))
+            assert rc == 0, err
+            got = oracle.collect([(oracle.LINE, "dump", out)], k, 0)
+            assert got[0] == exp[0] and got[2] == exp[2]
+            assert got[1] == exp[1]             # same number of reads
+
+
+def test_host_parser_errors_match_reference_text(tmp_path):
+    """FastqParser.hh:89-174 / FastaParser.hh:62-68 messages, formatted as App.cc:357-363."""
+    cases = [
+        ("a.fq", "ACGT\n", "-i", "expected '@' at beginning of line 1"),
+        ("b.fq", "@r\nACGT\n", "-i", "expected sequence data or quality header at line 3"),
+        ("c.fq", "@r\nACGT\n@x\n", "-i", "expected '+' at beginning of line 3"),
+        ("d.fq", "@r\nACGT\n+q\nIIII\n", "-i", "quality title does not match sequence title at line 3"),
+        ("e.fq", "@r\nACGT\n+\nII\n", "-i", "length mistmatch between sequence and quality data just before line 5"),
+        ("f.fa", "ACGT\n", "-I", "expected '>' at beginning of line 0"),
+    ]
+    for name, text, flag, msg in cases:
+        p = tmp_path / name
+        p.write_text(text)
+        rc, _, err = run_goss("dump-bases", flag, str(p))
+        assert rc == 1
+        assert err == "error performing dump-bases:\n\t'%s': %s\n" % (p, msg), err
+    p = tmp_path / "empty.fq"
+    p.write_text("")
+    rc, _, err = run_goss("dump-bases", "-i", str(p))
+    assert rc == 1 and err == "error performing dump-bases:\nNo valid reads."
+
+
+def test_fastqs_in_list_expansion(tmp_path, oracle):
+    """GossOptionChecker::expandFilenames (GossOptionChecker.hh:405-430): one file name per
+    newline-terminated line -- checked through the error path (no GPU needed)."""
+    (tmp_path / "one.fq").write_text("@a\nACGTA\n+\nIIIII\n")
+    (tmp_path / "two.fq").write_text("@b\nTTTTT\n+\nIIIII\n")
+    (tmp_path / "three.fq").write_text("@c\nGGGGG\n+\nIIIII\n")
+    # the last name has no terminating newline: the reference drops it
+    (tmp_path / "list.txt").write_text("%s\n%s\n%s" % (tmp_path / "one.fq", tmp_path / "two.fq", tmp_path / "three.fq"))
+    rc, out, err = run_goss("dump-bases", "-f", str(tmp_path / "list.txt"))
+    assert rc == 0 and out == b"ACGTA\nTTTTT\n", err
