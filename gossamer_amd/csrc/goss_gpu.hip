@@ -198,10 +198,10 @@ template <class K, bool HAS_VAL>
 void radix_pass_table(goss_gpu_ctx* c, const K* src, const uint32_t* vs, K* dst, uint32_t* vd, uint64_t n, uint32_t d,
                       uint64_t ntiles, uint64_t* table)
 {
-    constexpr int tile = SortCfg<K>::kTile;
+    constexpr int tile = SortCfg<K, HAS_VAL>::kTile;
     {
         PhaseTimer t(c, GOSS_T_HIST, n);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<K, HAS_VAL>), dim3(grid_for(n, tile)), dim3(kTB), 0, c->stream,
                            src, n, d, ntiles, table);
         t.stop();
     }
@@ -223,7 +223,7 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
                 uint32_t first_shift = 0)
 {
     if (n < 2) return false;
-    constexpr int tile = SortCfg<K>::kTile;
+    constexpr int tile = SortCfg<K, HAS_VAL>::kTile;
     const uint64_t ntiles = (n + tile - 1) / tile;
     uint64_t mark = c->arena.mark();
     bool in_b = false;
@@ -447,8 +447,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     HIP_TRY(hipMemcpyAsync(h, c->d_ctr, sizeof(ExtractCounters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t n = h->keys_out;
-    c->windows += h->windows;
-    c->keys_total += n;
+    const uint64_t nwin = h->windows;
     if (n)
     {
         Run r{nullptr, nullptr, 0};
@@ -464,6 +463,8 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
         }
         c->runs.push_back(r);
     }
+    c->windows += nwin;           // only once the chunk has succeeded (it may be retried)
+    c->keys_total += n;
     c->arena.release(mark);
 }
 
@@ -499,14 +500,28 @@ void merge_runs(goss_gpu_ctx* c)
 }
 
 // Largest number of window starts one chunk may cover with the memory currently free.
-uint64_t chunk_capacity(goss_gpu_ctx* c)
+// optimistic: size the chunk for the segment-hash path (two key buffers + look-back status;
+// its output is bounded by kSegCount * kSegLimit entries).  If a chunk then needs the full
+// sort with a large output and runs out of memory, push_device halves it and retries.
+uint64_t chunk_capacity(goss_gpu_ctx* c, bool optimistic)
 {
     const uint64_t ksz = c->words * 8;
     const uint32_t S = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
-    // per key: two key buffers + histogram table + worst-case output (keys, counts, starts)
-    const double per_key = 2.0 * ksz + 1.2 + (ksz + 12.0);
     uint64_t avail = c->arena.avail();
-    uint64_t keys = (uint64_t)((double)avail * 0.9 / per_key);
+    double per_key;
+    if (optimistic)
+    {
+        const uint64_t fixed = (uint64_t)kSegCount * kSegLimit * (ksz + 4 + 4) + (64u << 20);
+        if (avail <= fixed) return 0;
+        avail -= fixed;
+        per_key = 2.0 * ksz + 0.6;
+    }
+    else
+    {
+        // per key: two key buffers + histogram table + worst-case output (keys, counts, starts)
+        per_key = 2.0 * ksz + 1.2 + (ksz + 12.0);
+    }
+    uint64_t keys = (uint64_t)((double)avail * 0.95 / per_key);
     uint64_t starts = keys / S;
     starts &= ~4095ULL;
     return starts;
@@ -519,18 +534,37 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
     ensure_arena(c);
     const uint64_t nstarts_total = nbytes - c->len + 1;
     uint64_t done = 0;
+    uint64_t limit = 0;                 // chunk size cap after an out-of-memory retry
     while (done < nstarts_total)
     {
-        uint64_t capn = chunk_capacity(c);
+        const bool optimistic = use_segment_path<K>(c);
+        uint64_t capn = chunk_capacity(c, optimistic);
+        if (capn < 4096) capn = chunk_capacity(c, false);
         if (capn < 4096)
         {
             // try to make room by merging what we have
-            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c); }
+            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c, false); }
             if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
         }
+        if (limit && capn > limit) capn = limit;
         uint64_t ns = std::min(capn, nstarts_total - done);
         uint64_t navail = std::min(nbytes - done, ns + c->len - 1);
-        process_chunk<K>(c, d + done, ns, navail);
+        const uint64_t lo0 = c->arena.lo, hi0 = c->arena.hi;
+        const size_t runs0 = c->runs.size();
+        try
+        {
+            process_chunk<K>(c, d + done, ns, navail);
+        }
+        catch (const StatusError& e)
+        {
+            if (e.status != GOSS_ERR_OOM || ns <= 8192) throw;
+            // undo the partial chunk and retry it in halves
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->arena.lo = lo0; c->arena.hi = hi0;
+            c->runs.resize(runs0);
+            limit = (ns / 2) & ~4095ULL;
+            continue;
+        }
         done += ns;
         // keep the accumulated runs from eating the budget
         uint64_t run_bytes = 0;

@@ -275,23 +275,23 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 // --------------------------------------------------------------------------------------
 
 #ifndef GOSS_SORT_ITEMS1
-#define GOSS_SORT_ITEMS1 16
+#define GOSS_SORT_ITEMS1 32
 #endif
 #ifndef GOSS_LB_BATCH
 #define GOSS_LB_BATCH 1
 #endif
-template <class K> struct SortCfg {
-    static constexpr int kItems = sizeof(K) == 8 ? GOSS_SORT_ITEMS1 : 8;     // keys per thread
+template <class K, bool HAS_VAL = false> struct SortCfg {
+    static constexpr int kItems = sizeof(K) == 8 ? (HAS_VAL ? 16 : GOSS_SORT_ITEMS1) : 8;   // keys per thread
     static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
 };
 
 // table layout: table[digit * ntiles + tile]
-template <class K>
+template <class K, bool HAS_VAL>
 __global__ __launch_bounds__(kTB) void radix_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t digit,
                                                          uint64_t ntiles, uint64_t* __restrict__ table)
 {
-    constexpr int kSortItems = SortCfg<K>::kItems;
-    constexpr int kSortTile = SortCfg<K>::kTile;
+    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
+    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(kTB) void radix_scatter_kernel(const K* __restrict_
                                                             uint64_t n, uint32_t digit, uint64_t ntiles,
                                                             const uint64_t* __restrict__ table)
 {
-    constexpr int kSortItems = SortCfg<K>::kItems;
-    constexpr int kSortTile = SortCfg<K>::kTile;
+    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
+    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
     __shared__ uint32_t wave_hist[kWaves][256];
     __shared__ uint32_t digit_start[256];
     __shared__ uint64_t global_base[256];
@@ -476,8 +476,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
                                                              unsigned long long* __restrict__ status,
                                                              LookbackCtl* __restrict__ ctl)
 {
-    constexpr int kSortItems = SortCfg<K>::kItems;
-    constexpr int kSortTile = SortCfg<K>::kTile;
+    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
+    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
     __shared__ uint32_t wave_hist[kWaves][256];
     __shared__ uint32_t digit_start[256];
     __shared__ uint64_t global_base[256];
@@ -787,22 +787,47 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     // kSegUnroll independent coalesced loads are issued before the first insert so that
     // enough bytes are in flight per CU to cover the HBM latency
     constexpr int kSegUnroll = 8;
+    unsigned long long nxt[kSegUnroll];
+#pragma unroll
+    for (int u = 0; u < kSegUnroll; ++u)
+    {
+        uint64_t i = b + (uint64_t)u * kTB + tid;
+        nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+    }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kSegUnroll)
     {
         unsigned long long kv[kSegUnroll];
 #pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u) kv[u] = nxt[u];
+        // software pipeline: the next batch's loads are in flight while this one is inserted
+#pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
-            uint64_t i = i0 + (uint64_t)u * kTB + tid;
-            kv[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+            uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * kTB + tid;
+            nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+        }
+        // fast path: probe the home slot of all keys of the batch at once (independent LDS
+        // reads); a key that is already there only needs its count bumped
+        volatile unsigned long long* vtab = tab;
+        uint32_t slots[kSegUnroll];
+        unsigned long long seen[kSegUnroll];
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            slots[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - 12));
+            seen[u] = vtab[slots[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            if (kv[u] != kEmpty && seen[u] == kv[u]) { atomicAdd(&cnt[slots[u]], 1u); kv[u] = kEmpty; }
         }
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
             const unsigned long long key = kv[u];
             if (key == kEmpty) continue;
-            uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - 12));
-            volatile unsigned long long* vtab = tab;
+            uint32_t slot = slots[u];
             for (;;)
             {
                 // a plain read settles the common case (key already present) without a CAS
