@@ -270,12 +270,12 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
                 {
                     HIP_TRY(hipMemsetAsync(&ctl->ticket, 0, 4, c->stream));
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, true>), dim3(grid_for(n, tile)), dim3(kTB), 0,
-                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d,
+                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d, first_shift,
                                        (const unsigned long long*)(hist + di * 256), status, ctl);
                 }
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, false>), dim3(grid_for(n, tile)), dim3(kTB), 0,
-                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d,
+                                       c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d, first_shift,
                                        (const unsigned long long*)(hist + di * 256), status, ctl);
                 t.stop();
             }

@@ -471,7 +471,7 @@ constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
 template <class K, bool HAS_VAL, bool ORDERED>
 __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                             uint64_t n, uint32_t digit,
+                                                             uint64_t n, uint32_t digit, uint32_t sorted_lo,
                                                              const unsigned long long* __restrict__ bucket_base,
                                                              unsigned long long* __restrict__ status,
                                                              LookbackCtl* __restrict__ ctl)
@@ -516,21 +516,56 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
             if (HAS_VAL) val[r] = vals_in[tile_base + li];
         }
     }
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r)
+    // Does this tile need a STABLE rank?  Stability only matters when the tile holds keys
+    // that differ in the bits the previous passes sorted (bits [sorted_lo, digit)): a tile whose
+    // keys all share them -- almost every tile of the second partition pass -- may be ranked in
+    // any order, which costs one LDS atomic per key instead of eight ballots.
+    bool stable = false;
+    if (digit > sorted_lo)
     {
-        uint32_t li = wbase + r * 64 + lane;
-        bool valid = li < tile_n;
-        uint32_t d = valid ? key_digit(key[r], digit) : 0u;
-        uint64_t peers = match_digit(d, valid);
-        uint32_t before = __popcll(peers & lt_mask);
-        uint32_t base = 0;
-        volatile uint32_t* wh = wave_hist[w];
-        if (valid) base = wh[d];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && before == 0) wh[d] = base + __popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        rank[r] = (uint16_t)(base + before);
+        const uint32_t nb = digit - sorted_lo;
+        if (nb > 56) stable = true;
+        else
+        {
+            const uint64_t fmask = (1ULL << nb) - 1;
+            const uint64_t first = key_shr64(keys_in[tile_base], sorted_lo) & fmask;
+            uint64_t diff = 0;
+#pragma unroll
+            for (int r = 0; r < kSortItems; ++r)
+            {
+                uint32_t li = wbase + r * 64 + lane;
+                if (li < tile_n) diff |= (key_shr64(key[r], sorted_lo) & fmask) ^ first;
+            }
+            stable = __syncthreads_or(diff != 0);
+        }
+    }
+    if (stable)
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+        {
+            uint32_t li = wbase + r * 64 + lane;
+            bool valid = li < tile_n;
+            uint32_t d = valid ? key_digit(key[r], digit) : 0u;
+            uint64_t peers = match_digit(d, valid);
+            uint32_t before = __popcll(peers & lt_mask);
+            uint32_t base = 0;
+            volatile uint32_t* wh = wave_hist[w];
+            if (valid) base = wh[d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && before == 0) wh[d] = base + __popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = (uint16_t)(base + before);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+        {
+            uint32_t li = wbase + r * 64 + lane;
+            if (li < tile_n) rank[r] = (uint16_t)atomicAdd(&wave_hist[0][key_digit(key[r], digit)], 1u);
+        }
     }
     __syncthreads();
 
@@ -541,7 +576,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         for (int i = 0; i < kWaves; ++i)
         {
             uint32_t c = wave_hist[i][tid];
-            wave_hist[i][tid] = tot;
+            wave_hist[i][tid] = stable ? tot : 0u;     // unstable ranks are tile-wide already
             tot += c;
         }
         unsigned long long* mine = status + (uint64_t)tile * 256 + tid;

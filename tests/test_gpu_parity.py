@@ -279,3 +279,52 @@ def test_goss_cli_end_to_end(oracle, tmp_path):
     p = subprocess.run([goss, "build-kmer-set", "-k", "25", "-i", str(tmp_path / "empty.fq"), "-O", str(tmp_path / "e"), "--hbm-budget", "1"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 1 and p.stderr.decode() == "error performing build-kmer-set:\nNo valid reads."
+
+
+def test_medium_scale_files_vs_oracle(oracle):
+    """300,000 synthetic 150 bp reads (37.7 M k-mers, ~30x coverage of a 1.5 Mbp genome): large
+    enough that the partition passes run thousands of tiles (unstable fast ranking, look-back
+    chain, LDS hash segments) yet small enough for the oracle."""
+    reads = g.synth_reads_host(300000, 150, 1500000, seed=3)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
+    exp = _suffix_map(exp, "ks")
+    for path in (0, 1):
+        with g.Context(25, g.MODE_KMER_SET, hbm_budget=8 << 30) as ctx:
+            ctx.set_path(path)
+            ctx.push_host(reads)
+            c = ctx.finish()
+            got = ctx.emit()
+        assert c.windows == nwin
+        assert sorted(got) == sorted(exp)
+        for name in exp:
+            assert got[name] == exp[name], (path, name)
+
+
+def test_large_scale_properties():
+    """8 M reads (1.0 G k-mers) generated on the device: the segment-hash path and the LSD-only
+    path must agree exactly; counts must add up to the number of windows; keys must be strictly
+    increasing (size-independent properties at a size the oracle cannot reach)."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 8_000_000, 150, 8_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for path in (0, 1):
+        ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=40 << 30)
+        if path == 0:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=5)
+        ctx.set_path(path)
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        kp, cp, m = ctx.result_ptrs()
+        keys = gd.device_view(kp, m, torch.int64, "cuda").clone()
+        counts = gd.device_view(cp, m, torch.int32, "cuda").clone()
+        assert m == c.distinct and c.keys == c.windows
+        assert int(counts.to(torch.int64).sum().item()) == c.windows
+        assert bool((keys[1:] > keys[:-1]).all().item())
+        res.append((keys, counts, c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # windows = reads * 126 minus the windows an 'N' removes
+    assert res[0][2] <= n * (L - 25 + 1) and res[0][2] > n * (L - 25 + 1) * 0.99
