@@ -574,6 +574,36 @@ int gossMain(int argc, char* argv[])
         else { cmdName = argv[1]; if (argv[1][0] != '-') argsToSkip = 1; }
 
         const bool isKmerSet = cmdName == "build-kmer-set", isGraph = cmdName == "build-graph";
+        if (cmdName == "synth-reads")
+        {
+            // goss synth-reads <nreads> <read_len> <genome_len> <seed> <out.fq>: the bench's
+            // deterministic synthetic read set as 4-line FASTQ
+            if (argc != 7) throw Error::Usage("usage: goss synth-reads <nreads> <read-len> <genome-len> <seed> <out.fq>\n");
+            uint64_t n = toU64("nreads", argv[2]), L = toU64("read-len", argv[3]), G = toU64("genome-len", argv[4]);
+            uint64_t seed = toU64("seed", argv[5]);
+            FILE* fp = fopen(argv[6], "wb");
+            if (!fp) throw Error::Errno(argv[6], errno);
+            const uint64_t per = 65536;
+            std::vector<char> bases(per * (L + 1));
+            std::string out;
+            std::string qual(L, 'I');
+            for (uint64_t r0 = 0; r0 < n; r0 += per)
+            {
+                uint64_t m = std::min(per, n - r0);
+                if (goss_synth_reads_host(bases.data(), m, (uint32_t)L, G, seed, r0) != GOSS_OK)
+                    throw Error::General("synth-reads: invalid arguments\n");
+                out.clear();
+                for (uint64_t i = 0; i < m; ++i)
+                {
+                    out += "@r"; out += std::to_string(r0 + i); out += '\n';
+                    out.append(bases.data() + i * (L + 1), L + 1);
+                    out += "+\n"; out += qual; out += '\n';
+                }
+                if (fwrite(out.data(), 1, out.size(), fp) != out.size()) { fclose(fp); throw Error::Write(argv[6]); }
+            }
+            fclose(fp);
+            return 0;
+        }
         if (cmdName == "dump-bases")
         {
             // diagnostic: print exactly the byte stream the build commands hand to the device

@@ -1,0 +1,10 @@
+#!/bin/bash
+# End-to-end wall-clock of the goss CLI (FASTQ on disk -> KmerSet files on disk), PCIe included.
+N=${1:-20000000}
+D=/tmp/goss_e2e; mkdir -p $D
+./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
+ls -la $D/reads.fq
+/usr/bin/time -v ./gossamer_amd/goss build-kmer-set -k 25 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
+tail -25 $D/log.txt | grep -E "total build|windows|Elapsed|Maximum resident"
+ls -la $D | head -12
+rm -rf $D
