@@ -4,7 +4,9 @@ N=${1:-20000000}
 D=/tmp/goss_e2e; mkdir -p $D
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 ls -la $D/reads.fq
-/usr/bin/time -v ./gossamer_amd/goss build-kmer-set -k 25 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
-tail -25 $D/log.txt | grep -E "total build|windows|Elapsed|Maximum resident"
+cat $D/reads.fq > /dev/null      # page cache warm: measure parsing + PCIe + GPU, not the disk
+TIMEFORMAT="wall %R s  user %U s  sys %S s"
+time ./gossamer_amd/goss build-kmer-set -k 25 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
+tail -4 $D/log.txt
 ls -la $D | head -12
 rm -rf $D
