@@ -82,6 +82,7 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     uint64_t budget = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -349,11 +350,24 @@ void launch_extract(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint6
 
 template <class K>
 void extract_dispatch(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out);
+template <int MODE, int P, int G>
+void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
+{
+    constexpr int T = kTB * P * G;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G>), dim3(grid_for(nstarts, T)), dim3(kTB), 0, c->stream,
+                       aligned, mis, nstarts, navail, c->len, out, c->d_ctr);
+}
 template <>
 void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
-    if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key1, 0, 16>(c, aligned, mis, nstarts, navail, out);
-    else launch_extract<Key1, 1, 8>(c, aligned, mis, nstarts, navail, out);
+    if (c->extract_v1)
+    {
+        if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key1, 0, 16>(c, aligned, mis, nstarts, navail, out);
+        else launch_extract<Key1, 1, 8>(c, aligned, mis, nstarts, navail, out);
+        return;
+    }
+    if (c->mode == GOSS_MODE_KMER_SET) launch_extract1<0, 16, 8>(c, aligned, mis, nstarts, navail, out);
+    else launch_extract1<1, 8, 8>(c, aligned, mis, nstarts, navail, out);
 }
 template <>
 void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
@@ -447,7 +461,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     HIP_TRY(hipMemcpyAsync(h, c->d_ctr, sizeof(ExtractCounters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t n = h->keys_out;
-    const uint64_t nwin = h->windows;
+    const uint64_t nwin = n / S;              // S keys per valid window
     if (n)
     {
         Run r{nullptr, nullptr, 0};
@@ -953,6 +967,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     c->budget = hbm_budget;
     { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
+    { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     int rc = guarded(c, [&]() {
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }

@@ -271,6 +271,161 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 }
 
 // --------------------------------------------------------------------------------------
+// K2, one-word keys: windows cut out of packed registers
+// --------------------------------------------------------------------------------------
+//
+// Same contract as extract_kernel<Key1,...>.  Phase A packs every 16 loaded bytes into a
+// 32-bit word of 2-bit codes (base j at bits 2j) and a 16-bit mask of non-bases.  A thread then
+// holds the 128 code bits + 64 mask bits that cover its P windows in registers: the window
+// starting at base i is the field E_i = bits [2i, 2i+2len), its reverse complement is simply
+// ~E_i (complement of every 2-bit code; little-endian packing already reverses the order), its
+// forward value is rolled, and it is valid iff the mask bits [i, i+len) are all zero.  No LDS
+// access and no per-base loop remains in the window loop.
+
+template <int MODE, int P, int G>
+__global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                       uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                       Key1* __restrict__ out, ExtractCounters* __restrict__ ctr)
+{
+    // A workgroup owns G consecutive sub-tiles of T = 256*P window starts and reserves the
+    // output space of all of them with ONE atomicAdd: a single cursor word serves only ~88 M
+    // returning atomics per second chip-wide, which bounded the one-reservation-per-tile form.
+    constexpr int T = kTB * P;
+    constexpr int NVEC = G * T / 16 + 4;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    static_assert(P <= 16, "window mask is 16 bits");
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key1 stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+
+    const uint64_t tile_base = (uint64_t)blockIdx.x * (G * T);
+    const uint32_t tid = threadIdx.x;
+
+    // ---- phase A: ASCII -> packed 2-bit codes + non-base mask, all G sub-tiles -------------
+    for (uint32_t v = tid; v < NVEC; v += kTB)
+    {
+        uint64_t byte0 = tile_base + (uint64_t)v * 16;
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        if (byte0 + 16 <= navail + mis)
+        {
+            uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        else if (byte0 < navail + mis)
+        {
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+        }
+        uint32_t codes = 0, bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            // four code bytes -> 8 bits, four bad flags -> 4 bits
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+        pk[v] = codes;
+        iv[v] = bads;
+    }
+    __syncthreads();
+
+    const uint32_t bits = 2 * len;
+    const uint64_t kmask = (1ULL << bits) - 1;               // len <= 31
+    const uint64_t lmask = (1ULL << len) - 1;
+
+    // ---- phase B: validity masks and compacted slots of every sub-tile ---------------------
+    uint32_t vmask[G], slot[G], sub_cnt[G];
+    uint32_t total = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+        const uint32_t q0 = (g * kTB + tid) * P + mis;
+        const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+        const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+        uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+        const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+        {
+            bool ok = ((inv >> i) & lmask) == 0 && (p0 + i < nstarts);
+            m |= ok ? (1u << i) : 0u;
+        }
+        vmask[g] = m;
+        uint32_t tc;
+        slot[g] = block_excl_scan<uint32_t>(__popc(m), sh_scan, &tc);
+        sub_cnt[g] = tc;
+        total += tc;
+    }
+    if (tid == 0)
+    {
+        unsigned long long b = 0;
+        if (total) b = atomicAdd(&ctr->keys_out, (unsigned long long)total * S);
+        sh_base = b;
+    }
+    __syncthreads();
+    uint64_t ob = sh_base;
+
+    // ---- phase C: per sub-tile, cut the windows out of registers, stage, store --------------
+#pragma unroll 1
+    for (int g = 0; g < G; ++g)
+    {
+        const uint32_t vm = vmask[g];
+        if (vm)
+        {
+            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
+            uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+            const uint32_t s2 = 2 * sh;
+            const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            const uint64_t bhi = hi >> s2;
+            uint32_t s = slot[g] * S;
+            // forward value of window 0: base-4 reversal of its field
+            uint64_t f = rev64(blo & kmask) >> (64 - bits);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                // field of window i: bits [2i, 2i + 2len) of the 128-bit buffer
+                uint64_t e = i ? ((blo >> (2 * i)) | (bhi << (64 - 2 * i))) : blo;
+                e &= kmask;
+                if (i)
+                {
+                    uint32_t pos = 2 * (i + len - 1);      // new last base of the window
+                    uint64_t nb = (pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                    f = ((f << 2) | nb) & kmask;
+                }
+                if ((vm >> i) & 1u)
+                {
+                    Key1 fk{f}, rk{(~e) & kmask};
+                    if (MODE == 0) stage[s++] = canonical(fk, rk);
+                    else { stage[s++] = fk; stage[s++] = rk; }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nk = sub_cnt[g] * S;
+        for (uint32_t i = tid; i < nk; i += kTB) out[ob + i] = stage[i];
+        ob += nk;
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // K4: LSD radix sort, 8-bit digits: per-tile histogram, scan (above), stable scatter
 // --------------------------------------------------------------------------------------
 
