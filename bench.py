@@ -26,6 +26,18 @@ def algorithmic_bytes_per_window(k, read_len, key_bytes=8, keys_per_window=1):
     return read_len / (read_len - k + 1) * 3.0 / 8.0 + 2.0 * key_bytes * keys_per_window
 
 
+def measured_traffic(kernel_class):
+    """HBM bytes per unit of the dominant kernel from the PMC passes committed under profiles/
+    ((2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md HBM section), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return t.get(kernel_class)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(k, read_len, genome_len, seed, sample_reads):
     """The CPU oracle (oracle/, a restatement of the reference algorithm: kind "port") timed
     on a bounded sample of the same synthetic workload, one thread."""
@@ -55,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -70,8 +83,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     k, L = args.k, args.read_len
@@ -82,13 +97,15 @@ def main():
     # ---- synthetic input, generated on the device (untimed) ------------------------------
     bases = torch.empty(nbytes, dtype=torch.uint8, device=device)
     free_b, total_b = torch.cuda.mem_get_info(device)
-    budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * 0.94)
+    # the exchange buffers of the multi-GPU path are torch tensors outside the library's arena
+    share = 0.80 if use_dist else 0.94
+    budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * share)
     ctx = g.Context(k, g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
     ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)
     torch.cuda.synchronize(device)
 
     def step():
-        if world == 1:
+        if not use_dist:
             ctx.reset()
             ctx.push_device(bases.data_ptr(), nbytes)
             c = ctx.finish()
@@ -99,7 +116,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -137,7 +154,9 @@ def main():
         # figure for the extraction kernel
         per_unit = b_per_window if dom == "extract" else 16.0
         achieved = per_unit * per_launch_units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        dev_ms = sum(v["ms"] for n, v in tim.items() if n != "emit") + tim["emit"]["ms"]
+        dev_ms = sum(v["ms"] for n, v in tim.items())
+        tr = measured_traffic(dom)
+        traffic = tr["bytes_per_unit"] * per_launch_units if tr else None
         out = {
             "metric": "M k-mers/s (canonical, counted) at k=%d, %d bp reads" % (k, L),
             "value": value,
@@ -159,7 +178,8 @@ def main():
                                                     "scan": "scan_*_kernel", "scatter": "radix_scatter_kernel",
                                                     "reduce": "heads_*_kernel"}.get(dom, dom),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
+                         "traffic_source": tr["source"] if tr else None,
                          "launch_avg_ms": avg_ms, "launches": d["launches"], "units_per_launch": per_launch_units,
                          "algorithmic_bytes_per_unit": per_unit,
                          "pipeline": {"algorithmic_bytes_per_kmer": b_per_window,
@@ -173,7 +193,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
