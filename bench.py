@@ -190,6 +190,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
+        # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -82,6 +82,7 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     uint64_t budget = 0;
     hipStream_t stream = nullptr;
@@ -221,7 +222,7 @@ void radix_pass_table(goss_gpu_ctx* c, const K* src, const uint32_t* vs, K* dst,
 
 template <class K, bool HAS_VAL>
 bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint64_t n, uint32_t ndigits,
-                uint32_t first_shift = 0)
+                uint32_t first_shift = 0, const unsigned long long* prehist = nullptr)
 {
     if (n < 2) return false;
     constexpr int tile = SortCfg<K, HAS_VAL>::kTile;
@@ -241,9 +242,12 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
         // scatter per digit
         hist = (unsigned long long*)c->arena.temp(ndigits * 256 * 8);
         ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
-        HIP_TRY(hipMemsetAsync(hist, 0, ndigits * 256 * 8, c->stream));
         HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
+        if (prehist)
+            HIP_TRY(hipMemcpyAsync(hist, prehist, ndigits * 256 * 8, hipMemcpyDeviceToDevice, c->stream));
+        else
         {
+            HIP_TRY(hipMemsetAsync(hist, 0, ndigits * 256 * 8, c->stream));
             PhaseTimer t(c, GOSS_T_HIST, n);
             uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + kTB - 1) / kTB);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<K>), dim3(grid), dim3(kTB), 0, c->stream,
@@ -350,16 +354,24 @@ void launch_extract(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint6
 
 template <class K>
 void extract_dispatch(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out);
+template <class K> bool use_segment_path(const goss_gpu_ctx*);
+template <> bool use_segment_path<Key1>(const goss_gpu_ctx* c);
 template <int MODE, int P, int G>
 void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
     constexpr int T = kTB * P * G;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G>), dim3(grid_for(nstarts, T)), dim3(kTB), 0, c->stream,
-                       aligned, mis, nstarts, navail, c->len, out, c->d_ctr);
+    const uint64_t nsuper = (nstarts + T - 1) / T;
+    // persistent grid: 4 workgroups per CU (LDS-limited), 256 CUs
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper ? nsuper : 1, 1024 * 2);
+    // fused digit histograms for the 16-bit partition that follows on the segment path
+    c->extract_hist_shift = use_segment_path<Key1>(c) ? 2 * c->len - kSegBits : 0xFFFFFFFFu;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G>), dim3(grid), dim3(kTB), 0, c->stream,
+                       aligned, mis, nstarts, navail, c->len, out, c->d_ctr, c->extract_hist_shift, nsuper);
 }
 template <>
 void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
+    c->extract_hist_shift = 0xFFFFFFFFu;
     if (c->extract_v1)
     {
         if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key1, 0, 16>(c, aligned, mis, nstarts, navail, out);
@@ -397,7 +409,8 @@ bool segment_count<Key1>(goss_gpu_ctx* c, Key1* ka, Key1* kb, uint64_t n, Run* o
     const uint32_t keybits = 2 * c->len;
     const uint32_t shift = keybits - kSegBits;
     uint64_t mark = c->arena.mark();
-    bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, n, 2, shift);
+    const unsigned long long* prehist = (c->extract_hist_shift == shift && c->lookback) ? c->d_ctr->hist : nullptr;
+    bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, n, 2, shift, prehist);
     // two passes: the data is back in ka
     if (in_b) throw StatusError{GOSS_ERR_INVALID_ARG, "internal: partition parity"};
     PhaseTimer t(c, GOSS_T_REDUCE, n);
@@ -458,7 +471,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
         t.stop();
     }
     ExtractCounters* h = (ExtractCounters*)c->h_pinned;
-    HIP_TRY(hipMemcpyAsync(h, c->d_ctr, sizeof(ExtractCounters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h, c->d_ctr, 16 /* keys_out, windows */, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t n = h->keys_out;
     const uint64_t nwin = n / S;              // S keys per valid window

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kTB) void scan_apply_kernel(uint64_t* __restrict__ 
 struct ExtractCounters {
     unsigned long long keys_out;   // dense output cursor (keys)
     unsigned long long windows;    // valid windows
+    unsigned long long hist[512];  // partition digit histograms (extract1_kernel)
 };
 
 template <class K> struct KeyOps;
@@ -285,9 +286,11 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 template <int MODE, int P, int G>
 __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
-                                                       Key1* __restrict__ out, ExtractCounters* __restrict__ ctr)
+                                                       Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
+                                                       uint32_t hist_shift, uint64_t nsuper)
 {
-    // A workgroup owns G consecutive sub-tiles of T = 256*P window starts and reserves the
+    // Persistent grid: a workgroup loops over super-tiles (blockIdx.x, +gridDim.x, ...).
+    // A super-tile is G consecutive sub-tiles of T = 256*P window starts and reserves the
     // output space of all of them with ONE atomicAdd: a single cursor word serves only ~88 M
     // returning atomics per second chip-wide, which bounded the one-reservation-per-tile form.
     constexpr int T = kTB * P;
@@ -299,9 +302,17 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
     __shared__ Key1 stage[T * S];
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ unsigned long long sh_base;
+    // histograms of the two partition digits (bits hist_shift.. and hist_shift+8..) of every key
+    // this workgroup emits: saves the sort's separate histogram read of all keys
+    __shared__ uint32_t lh[512];
 
-    const uint64_t tile_base = (uint64_t)blockIdx.x * (G * T);
     const uint32_t tid = threadIdx.x;
+    const bool do_hist = hist_shift != 0xFFFFFFFFu;
+    lh[tid] = 0; lh[tid + 256] = 0;
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+    const uint64_t tile_base = st * (uint64_t)(G * T);
 
     // ---- phase A: ASCII -> packed 2-bit codes + non-base mask, all G sub-tiles -------------
     for (uint32_t v = tid; v < NVEC; v += kTB)
@@ -419,9 +430,24 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
         }
         __syncthreads();
         const uint32_t nk = sub_cnt[g] * S;
-        for (uint32_t i = tid; i < nk; i += kTB) out[ob + i] = stage[i];
+        for (uint32_t i = tid; i < nk; i += kTB)
+        {
+            const Key1 k = stage[i];
+            out[ob + i] = k;
+            if (do_hist)
+            {
+                atomicAdd(&lh[(uint32_t)(k.lo >> hist_shift) & 0xFFu], 1u);
+                atomicAdd(&lh[256u + ((uint32_t)(k.lo >> (hist_shift + 8)) & 0xFFu)], 1u);
+            }
+        }
         ob += nk;
         __syncthreads();
+    }
+    }   // super-tile loop
+    if (do_hist)
+    {
+        if (lh[tid]) atomicAdd(&ctr->hist[tid], (unsigned long long)lh[tid]);
+        if (lh[tid + 256]) atomicAdd(&ctr->hist[tid + 256], (unsigned long long)lh[tid + 256]);
     }
 }
 
