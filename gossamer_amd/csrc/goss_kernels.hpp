@@ -1036,17 +1036,33 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
+#if defined(GOSS_ABL_NOADD)
+            if (kv[u] != kEmpty && seen[u] == kv[u]) { kv[u] = kEmpty; }
+#else
             if (kv[u] != kEmpty && seen[u] == kv[u]) { atomicAdd(&cnt[slots[u]], 1u); kv[u] = kEmpty; }
+#endif
         }
+        // slow path (home slot empty or taken by another key): every lane walks its OWN queue
+        // of leftover keys, one probe per wave iteration, so the wave iterates max-over-lanes of
+        // the lane totals instead of the sum over the eight keys of per-key maxima
+        uint32_t pend = 0;
 #pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u)
+        for (int u = 0; u < kSegUnroll; ++u) pend |= kv[u] != kEmpty ? (1u << u) : 0u;
+        unsigned long long key = kEmpty;
+        uint32_t slot = 0;
+        for (;;)
         {
-            const unsigned long long key = kv[u];
-            if (key == kEmpty) continue;
-            uint32_t slot = slots[u];
-            for (;;)
+            if (key == kEmpty && pend)
             {
-                // a plain read settles the common case (key already present) without a CAS
+                const uint32_t u = __ffs(pend) - 1;
+                pend &= pend - 1;
+#pragma unroll
+                for (int uu = 0; uu < kSegUnroll; ++uu)
+                    if (u == (uint32_t)uu) { key = kv[uu]; slot = slots[uu]; }
+            }
+            if (!__ballot(key != kEmpty)) break;
+            if (key != kEmpty)
+            {
                 unsigned long long cur = vtab[slot];
                 if (cur == kEmpty)
                 {
@@ -1058,10 +1074,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                         cur = key;
                     }
                 }
-                if (cur == key) { atomicAdd(&cnt[slot], 1u); break; }
-                slot = (slot + 1) & (kSegSlots - 1);
-                if (*vovf) break;
+                if (cur == key) { atomicAdd(&cnt[slot], 1u); key = kEmpty; }
+                else slot = (slot + 1) & (kSegSlots - 1);
             }
+            if (*vovf) break;
         }
         if (*vovf) break;
     }
@@ -1073,7 +1089,11 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     }
 
     // bitonic sort of the 4096 (key,count) slots by key; empty slots (all ones) sort last
+#if defined(GOSS_ABL_NOSORT)
+    for (uint32_t k2 = 2; k2 <= 2; k2 <<= 1)
+#else
     for (uint32_t k2 = 2; k2 <= kSegSlots; k2 <<= 1)
+#endif
     {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
         {
