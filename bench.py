@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--graph", action="store_true", help="build-graph instead of build-kmer-set (windows are (k+1)-mers, "
+                    "two keys per window); not the headline metric")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +102,7 @@ def main():
     # the exchange buffers of the multi-GPU path are torch tensors outside the library's arena
     share = 0.80 if use_dist else 0.94
     budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * share)
-    ctx = g.Context(k, g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
+    ctx = g.Context(k, g.MODE_GRAPH if args.graph else g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
     ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)
     torch.cuda.synchronize(device)
 
@@ -143,7 +145,9 @@ def main():
 
     if rank == 0:
         value = windows / dt / 1e6
-        b_per_window = algorithmic_bytes_per_window(k, L)
+        klen = k + 1 if args.graph else k
+        kbytes = 8 if 2 * klen <= 62 else 16
+        b_per_window = algorithmic_bytes_per_window(klen, L, kbytes, 2 if args.graph else 1)
         # dominant kernel class by device time over the timed region
         dom = max(tim, key=lambda n: tim[n]["ms"] if n != "emit" else -1.0)
         d = tim[dom]
@@ -158,7 +162,8 @@ def main():
         tr = measured_traffic(dom)
         traffic = tr["bytes_per_unit"] * per_launch_units if tr else None
         out = {
-            "metric": "M k-mers/s (canonical, counted) at k=%d, %d bp reads" % (k, L),
+            "metric": ("M rho-mer windows/s (both strands counted) at k=%d, %d bp reads" if args.graph
+                       else "M k-mers/s (canonical, counted) at k=%d, %d bp reads") % (k, L),
             "value": value,
             "unit": "M k-mers/s",
             "n_gpus": world,

@@ -287,6 +287,12 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
             // the source buffer is still intact: a chain that gave up is redone below
             HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+#if defined(GOSS_LB_STATS)
+            std::fprintf(stderr, "lookback pass d=%u: tiles=%llu walk_steps=%llu (%.2f/tile) spin_polls=%llu (%.2f/tile) max_depth=%llu\n", d,
+                         hctl->tiles, hctl->walk_steps, (double)hctl->walk_steps / (double)(hctl->tiles ? hctl->tiles : 1),
+                         hctl->spin_polls, (double)hctl->spin_polls / (double)(hctl->tiles ? hctl->tiles : 1), hctl->max_depth);
+            HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
+#endif
             if (hctl->error)
             {
                 std::fprintf(stderr, "libgossgpu: radix look-back chain gave up; redoing the pass with histogram tables\n");

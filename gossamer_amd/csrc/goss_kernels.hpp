@@ -643,6 +643,8 @@ __global__ __launch_bounds__(kTB) void scan_rows256_kernel(unsigned long long* _
 struct LookbackCtl {
     uint32_t ticket;       // next tile number
     uint32_t error;        // a look-back spin gave up (never expected)
+    // diagnostics (GOSS_LB_STATS builds only): per-tile sums recorded by digit 0's thread
+    unsigned long long walk_steps, spin_polls, max_depth, tiles;
 };
 
 constexpr uint64_t kLbFlagAgg = 1ULL << 62;      // tile's own count is published
@@ -798,12 +800,23 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
                     if (f == kLbFlagPrefix) found = true;
                 }
                 t -= used;
+#if defined(GOSS_LB_STATS)
+                if (tid == 0) { atomicAdd(&ctl->walk_steps, (unsigned long long)used); }
+#endif
                 if (!found && used < kLbBatch)
                 {
                     if (++spins > (1u << 20)) { atomicOr(&ctl->error, 1u); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+#if defined(GOSS_LB_STATS)
+            if (tid == 0)
+            {
+                atomicAdd(&ctl->spin_polls, (unsigned long long)spins);
+                atomicMax(&ctl->max_depth, (unsigned long long)((int64_t)tile - 1 - t));
+                atomicAdd(&ctl->tiles, 1ULL);
+            }
+#endif
             __hip_atomic_store(mine, kLbFlagPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t tile_total;
