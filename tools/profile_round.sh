@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile: bench JSON, rocprofv3 kernel stats of the same command, PMC passes.
+# usage (on the GPU box, through gpurun): bash tools/profile_round.sh r01
+R=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$R
+mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/trace.err
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc/$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc/$tag.json 2> $OUT/pmc/$tag.err
+done
+cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt
+# keep what is small enough to merge back
+rm -rf $OUT/trace/*/*kernel_trace.csv $OUT/pmc/*/*/*kernel_trace.csv
+ls -la $OUT
