@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--genome", type=int, default=100_000_000, help="genome length per GPU's worth of reads")
     ap.add_argument("-k", type=int, default=25)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
@@ -180,8 +180,8 @@ def main():
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
                        "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
             "roofline": {"bound": "hbm", "kernel": {"extract": "extract_kernel", "hist": "radix_hist_kernel",
-                                                    "scan": "scan_*_kernel", "scatter": "radix_scatter_kernel",
-                                                    "reduce": "heads_*_kernel"}.get(dom, dom),
+                                                    "scan": "scan_*_kernel", "scatter": "radix_onesweep_kernel",
+                                                    "reduce": "seg_hash_reduce_kernel"}.get(dom, dom),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": tr["source"] if tr else None,

@@ -82,6 +82,7 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    uint32_t segment_retries = 0;       // segment path attempts that overflowed an LDS table
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     uint64_t budget = 0;
@@ -360,8 +361,7 @@ void launch_extract(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint6
 
 template <class K>
 void extract_dispatch(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out);
-template <class K> bool use_segment_path(const goss_gpu_ctx*);
-template <> bool use_segment_path<Key1>(const goss_gpu_ctx* c);
+template <class K> bool use_segment_path(const goss_gpu_ctx* c);
 template <int MODE, int P, int G>
 void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
@@ -396,65 +396,157 @@ void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
 
 inline uint32_t key_digits(const goss_gpu_ctx* c) { return (2 * c->len + 7) / 8; }
 
-// ---- fast path: 16-bit partition + per-segment LDS hash table ---------------------------
-template <class K> bool use_segment_path(const goss_gpu_ctx*) { return false; }
-template <> bool use_segment_path<Key1>(const goss_gpu_ctx* c)
+// ---- fast path: radix partition on the top bits + per-segment LDS hash table -------------
+template <class K> bool use_segment_path(const goss_gpu_ctx* c)
 {
     if (c->path == 1) return false;                   // LSD only
-    return 2 * c->len >= 24;                          // enough key bits below the 16 partition bits
+    return 2 * c->len >= 24;                          // enough key bits below the partition bits
+}
+template bool use_segment_path<Key1>(const goss_gpu_ctx*);
+template bool use_segment_path<Key2>(const goss_gpu_ctx*);
+
+template <class K> struct SegCfg;
+template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; };
+template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
+
+inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, SegOut* so,
+                            uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc)
+{
+    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc);
+}
+inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, SegOut* so,
+                            uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc)
+{
+    hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc);
 }
 
-// Partition ka on its top 16 bits (result back in ka), count every segment in LDS.
-// Returns false (and leaves the keys, permuted, in ka) if some segment holds too many
-// distinct keys for the LDS table: the caller then runs the full LSD sort.
+// Number of distinct keys in the chunk, estimated from its first keys (reads arrive in no
+// particular order, so a prefix is a sample): with s sampled keys of which d are distinct,
+// M ~ s^2 / (2 (s - d)) (birthday estimate), never less than d.  Returns 0 when the sample has
+// no repeated key at all (M unknown, presumably of the order of n).
 template <class K>
-bool segment_count(goss_gpu_ctx*, K*, K*, uint64_t, Run*) { return false; }
-template <>
-bool segment_count<Key1>(goss_gpu_ctx* c, Key1* ka, Key1* kb, uint64_t n, Run* out)
+uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
+{
+    const uint64_t s = std::min<uint64_t>(n, 4u << 20);
+    if (s < 2) return s;
+    uint64_t mark = c->arena.mark();
+    K* a = (K*)c->arena.temp(s * sizeof(K));
+    K* b = (K*)c->arena.temp(s * sizeof(K));
+    HIP_TRY(hipMemcpyAsync(a, keys, s * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+    bool in_b = radix_sort<K, false>(c, a, b, nullptr, nullptr, s, key_digits(c));
+    const uint64_t ntiles = (s + kRedTile - 1) / kRedTile;
+    uint64_t* tile_counts = (uint64_t*)c->arena.temp((ntiles + 1) * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_count_kernel<K>), dim3(grid_for(s, kRedTile)), dim3(kTB), 0, c->stream,
+                       (const K*)(in_b ? b : a), s, tile_counts);
+    HIP_TRY(hipMemsetAsync(tile_counts + ntiles, 0, 8, c->stream));
+    exclusive_scan_u64(c, tile_counts, ntiles + 1);
+    uint64_t* h = (uint64_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, tile_counts + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t d = h[0];
+    c->arena.release(mark);
+    if (s == n) return d;
+    if (d == s) return 0;
+    const double est = (double)s * (double)s / (2.0 * (double)(s - d));
+    return std::max<uint64_t>(d, (uint64_t)est);
+}
+
+// Partition ka on its top `segbits` bits (result back in ka or kb), count every segment in LDS.
+// Returns 0 on success; 1 if some segment holds too many distinct keys (retry with more
+// partition bits); 2 if the staging area is too small (use the full sort).  The keys stay,
+// permuted, in ka or kb (*in_b_out).
+template <class K>
+int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, bool* in_b_out, Run* out)
 {
     const uint32_t keybits = 2 * c->len;
-    const uint32_t shift = keybits - kSegBits;
+    const uint32_t shift = keybits - segbits;
+    const uint32_t npass = (segbits + 7) / 8;
+    const uint32_t nseg = 1u << segbits;
     uint64_t mark = c->arena.mark();
-    const unsigned long long* prehist = (c->extract_hist_shift == shift && c->lookback) ? c->d_ctr->hist : nullptr;
-    bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, n, 2, shift, prehist);
-    // two passes: the data is back in ka
-    if (in_b) throw StatusError{GOSS_ERR_INVALID_ARG, "internal: partition parity"};
+    const unsigned long long* prehist =
+        (segbits == kSegBits && c->extract_hist_shift == shift && c->lookback && !*in_b_out) ? c->d_ctr->hist : nullptr;
+    K* src = *in_b_out ? kb : ka;
+    K* dst = *in_b_out ? ka : kb;
+    bool moved = radix_sort<K, false>(c, src, dst, nullptr, nullptr, n, npass, shift, prehist);
+    K* part = moved ? dst : src;          // partitioned keys
+    K* spare = moved ? src : dst;         // free half of the ping-pong: staging area
+    *in_b_out = (part == kb);
     PhaseTimer t(c, GOSS_T_REDUCE, n);
-    uint64_t* seg_off = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
-    uint64_t* seg_pos = (uint64_t*)c->arena.temp(kSegCount * 8);
-    uint64_t* seg_cnt = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
-    uint64_t* seg_dst = (uint64_t*)c->arena.temp((kSegCount + 1) * 8);
+    uint64_t* seg_off = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+    uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
+    uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+    uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
     SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
-    const uint64_t stage_cap = std::min<uint64_t>(n, (uint64_t)kSegCount * kSegLimit);
-    uint32_t* stage_counts = (uint32_t*)c->arena.temp(stage_cap * 4);
-    Key1* stage_keys = kb;                             // free half of the ping-pong
-    HIP_TRY(hipMemsetAsync(so, 0, sizeof(SegOut), c->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<Key1>), dim3(kSegCount / 256 + 1), dim3(256), 0, c->stream,
-                       (const Key1*)ka, n, shift, seg_off);
-    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(kSegCount), dim3(kTB), 0, c->stream,
-                       (const Key1*)ka, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+    // staged (key,count) pairs share the spare key buffer: cap entries of keys, then the counts
+    const uint64_t cap = n * sizeof(K) / (sizeof(K) + 4);
+    K* stage_keys = spare;
+    uint32_t* stage_counts = (uint32_t*)(spare + cap);
+    SegOut hso{};
+    hso.stage_cap = cap;
+    HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
+                       (const K*)part, n, shift, nseg, seg_off);
+    launch_seg_hash(c, nseg, (const K*)part, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts);
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (h->overflow)
     {
+        const int why = (h->overflow & 1u) ? 1 : 2;
         t.stop();
         c->arena.release(mark);
-        return false;
+        return why;
     }
     const uint64_t m = h->cursor;
-    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, kSegCount * 8, hipMemcpyDeviceToDevice, c->stream));
-    exclusive_scan_u64(c, seg_dst, kSegCount);
+    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nseg * 8, hipMemcpyDeviceToDevice, c->stream));
+    exclusive_scan_u64(c, seg_dst, nseg);
     out->m = m;
-    out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(Key1));
+    out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
     out->counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
-    hipLaunchKernelGGL(seg_gather_kernel, dim3(kSegCount), dim3(kTB), 0, c->stream,
-                       (const Key1*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
-                       (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (Key1*)out->keys, out->counts);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream,
+                       (const K*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
+                       (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)out->keys, out->counts);
     t.stop();
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena.release(mark);
-    return true;
+    return 0;
+}
+
+// Count a chunk of n extracted keys (in ka): segment path with as many partition bits as the
+// estimated number of distinct keys asks for, more bits after an overflow, finally the full
+// LSD sort + run compaction.
+template <class K>
+Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
+{
+    Run r{nullptr, nullptr, 0};
+    bool in_b = false;
+    if (use_segment_path<K>(c))
+    {
+        const uint32_t keybits = 2 * c->len;
+        const uint64_t limit = SegCfg<K>::kLimit;
+        const uint64_t m_est = n <= (uint64_t)(1u << kSegBits) * (limit / 2) ? n : estimate_distinct<K>(c, ka, n);
+        // worth it only with real duplication (and the staging area needs M <= ~2n/3)
+        if (m_est != 0 && (m_est <= n / 3 || n <= (uint64_t)(1u << kSegBits) * (limit / 2)))
+        {
+            uint32_t segbits = kSegBits;
+            while (segbits < kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;   // margin for skew
+            for (; segbits <= kSegBitsMax && segbits + 8 <= keybits; segbits += 4)
+            {
+                if ((m_est >> segbits) > limit) continue;
+                int rc = segment_count<K>(c, ka, kb, n, segbits, &in_b, &r);
+                if (rc == 0) return r;
+                if (rc == 2) break;
+                c->segment_retries++;
+            }
+        }
+    }
+    K* src = in_b ? kb : ka;
+    K* dst = in_b ? ka : kb;
+    bool moved = radix_sort<K, false>(c, src, dst, nullptr, nullptr, n, key_digits(c));
+    PhaseTimer t(c, GOSS_T_REDUCE, n);
+    r = reduce_runs<K>(c, moved ? dst : src, nullptr, n, moved ? src : dst);
+    t.stop();
+    return r;
 }
 
 // Process window starts [0, nstarts) of a device-resident byte string (navail readable bytes,
@@ -483,17 +575,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     const uint64_t nwin = n / S;              // S keys per valid window
     if (n)
     {
-        Run r{nullptr, nullptr, 0};
-        bool done = false;
-        if (use_segment_path<K>(c))
-            done = segment_count<K>(c, ka, kb, n, &r);     // ka keeps all keys either way
-        if (!done)
-        {
-            bool in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, n, key_digits(c));
-            PhaseTimer t(c, GOSS_T_REDUCE, n);
-            r = reduce_runs<K>(c, in_b ? kb : ka, nullptr, n, in_b ? ka : kb);
-            t.stop();
-        }
+        Run r = count_keys<K>(c, ka, kb, n);
         c->runs.push_back(r);
     }
     c->windows += nwin;           // only once the chunk has succeeded (it may be retried)
@@ -544,7 +626,7 @@ uint64_t chunk_capacity(goss_gpu_ctx* c, bool optimistic)
     double per_key;
     if (optimistic)
     {
-        const uint64_t fixed = (uint64_t)kSegCount * kSegLimit * (ksz + 4 + 4) + (64u << 20);
+        const uint64_t fixed = (uint64_t)(1u << kSegBits) * kSegLimit * (ksz + 4) + (256u << 20);
         if (avail <= fixed) return 0;
         avail -= fixed;
         per_key = 2.0 * ksz + 0.6;

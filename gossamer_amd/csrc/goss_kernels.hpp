@@ -964,17 +964,20 @@ __global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m,
 // kSegLimit distinct keys -- the high-coverage regime of read sets.  A segment that exceeds
 // the limit raises a flag and the caller falls back to the full LSD sort.
 
-constexpr int kSegBits = 16;
-constexpr int kSegCount = 1 << kSegBits;
-constexpr int kSegSlots = 4096;
+constexpr int kSegBits = 16;                 // default number of partition bits
+constexpr int kSegBitsMax = 24;
+constexpr int kSegSlots = 4096;              // one-word keys: 48 KB of LDS per workgroup
 constexpr int kSegLimit = 3072;
+constexpr int kSegSlots2 = 2048;             // two-word keys: 40 KB
+constexpr int kSegLimit2 = 1536;
 
-// seg_off[s] = first index whose top-16-bit value is >= s (s = 0..65536).
+// seg_off[s] = first index whose top-`segbits` value is >= s (s = 0..nseg).
 template <class K>
-__global__ void seg_bounds_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift, uint64_t* __restrict__ seg_off)
+__global__ void seg_bounds_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t nseg,
+                                  uint64_t* __restrict__ seg_off)
 {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > kSegCount) return;
+    if (s > nseg) return;
     uint64_t a = 0, b = n;
     while (a < b)
     {
@@ -986,8 +989,10 @@ __global__ void seg_bounds_kernel(const K* __restrict__ keys, uint64_t n, uint32
 
 struct SegOut {
     unsigned long long cursor;     // staging cursor (entries)
-    uint32_t overflow;             // some segment had more than kSegLimit distinct keys
+    uint32_t overflow;             // some segment had more distinct keys than the LDS table holds,
+                                   // or the staging area is full
     uint32_t count_overflow;
+    unsigned long long stage_cap;  // entries the staging area can take
 };
 
 __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
@@ -1125,15 +1130,17 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
             __syncthreads();
         }
     }
-    const uint32_t d = ndist;
+    uint32_t d = ndist;
     if (tid == 0)
     {
         sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
         seg_pos[s] = sh_base;
         seg_cnt[s] = d;
     }
     __syncthreads();
     const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
     for (uint32_t i = tid; i < d; i += kTB)
     {
         stage_keys[ob + i].lo = tab[i];
@@ -1141,11 +1148,153 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     }
 }
 
+// Two-word keys.  LDS has no 128-bit compare-and-swap, so a slot is claimed through its state
+// word: 0 = empty, kSegLock = being written, otherwise the count of a published key.  The
+// insert loop is a per-lane state machine with exactly one probe per wave iteration and no
+// wait inside an iteration: a lane that meets a locked slot simply looks again next iteration,
+// by which time the owner (which needs no other lane to make progress) has published.
+constexpr uint32_t kSegLock = 0x80000000u;
+
+__global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                               SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                               uint64_t* __restrict__ seg_cnt,
+                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+{
+    __shared__ unsigned long long tlo[kSegSlots2];
+    __shared__ unsigned long long thi[kSegSlots2];
+    __shared__ uint32_t st[kSegSlots2];
+    __shared__ uint32_t ndist;
+    __shared__ uint32_t ovf;
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_off[s + 1];
+    if (b == e)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    for (uint32_t i = tid; i < kSegSlots2; i += kTB) st[i] = 0;
+    if (tid == 0) { ndist = 0; ovf = 0; }
+    __syncthreads();
+
+    volatile uint32_t* vovf = &ovf;
+    volatile uint32_t* vst = st;
+    volatile unsigned long long* vlo = tlo;
+    volatile unsigned long long* vhi = thi;
+    constexpr int kU = 4;
+    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kU)
+    {
+        Key2 kv[kU];
+        uint32_t slots[kU];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+            uint64_t i = i0 + (uint64_t)u * kTB + tid;
+            if (i < e)
+            {
+                kv[u] = keys[i];
+                uint64_t h = (kv[u].lo ^ (kv[u].hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
+                slots[u] = (uint32_t)(h >> (64 - 11));
+                pend |= 1u << u;
+            }
+        }
+        Key2 key{0, 0};
+        uint32_t slot = 0;
+        bool have = false;
+        for (;;)
+        {
+            if (!have && pend)
+            {
+                const uint32_t u = __ffs(pend) - 1;
+                pend &= pend - 1;
+#pragma unroll
+                for (int uu = 0; uu < kU; ++uu)
+                    if (u == (uint32_t)uu) { key = kv[uu]; slot = slots[uu]; }
+                have = true;
+            }
+            if (!__ballot(have)) break;
+            if (have)
+            {
+                uint32_t state = vst[slot];
+                if (state == 0)
+                {
+                    uint32_t old = atomicCAS(&st[slot], 0u, kSegLock);
+                    if (old == 0)
+                    {
+                        vlo[slot] = key.lo;
+                        vhi[slot] = key.hi;
+                        vst[slot] = 1u;                      // publish (LDS ops of a lane are in order)
+                        uint32_t nd = atomicAdd(&ndist, 1u);
+                        if (nd + 1 > kSegLimit2) *vovf = 1;
+                        have = false;
+                    }
+                    // else: look at this slot again next iteration
+                }
+                else if (state != kSegLock)
+                {
+                    if (vlo[slot] == key.lo && vhi[slot] == key.hi) { atomicAdd(&st[slot], 1u); have = false; }
+                    else slot = (slot + 1) & (kSegSlots2 - 1);
+                }
+            }
+            if (*vovf) break;
+        }
+        if (*vovf) break;
+    }
+    __syncthreads();
+    if (ovf)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    // empty slots sort last: hi = all ones is never a key (2*len <= 126 bits)
+    for (uint32_t i = tid; i < kSegSlots2; i += kTB)
+        if (st[i] == 0) { thi[i] = ~0ULL; tlo[i] = ~0ULL; }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= kSegSlots2; k2 <<= 1)
+    {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+        {
+            for (uint32_t t = tid; t < kSegSlots2 / 2; t += kTB)
+            {
+                uint32_t i = 2 * t - (t & (j - 1));
+                uint32_t p = i + j;
+                bool up = (i & k2) == 0;
+                unsigned long long ah = thi[i], al = tlo[i], ch = thi[p], cl = tlo[p];
+                bool gt = ah > ch || (ah == ch && al > cl);
+                if (gt == up)
+                {
+                    thi[i] = ch; tlo[i] = cl; thi[p] = ah; tlo[p] = al;
+                    uint32_t ca = st[i]; st[i] = st[p]; st[p] = ca;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t d = ndist;
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
+    for (uint32_t i = tid; i < d; i += kTB)
+    {
+        stage_keys[ob + i] = Key2{tlo[i], thi[i]};
+        stage_counts[ob + i] = st[i];
+    }
+}
+
 // Restore segment order: out[seg_dst[s] + i] = stage[seg_pos[s] + i].
-__global__ __launch_bounds__(kTB) void seg_gather_kernel(const Key1* __restrict__ stage_keys, const uint32_t* __restrict__ stage_counts,
+template <class K>
+__global__ __launch_bounds__(kTB) void seg_gather_kernel(const K* __restrict__ stage_keys, const uint32_t* __restrict__ stage_counts,
                                                          const uint64_t* __restrict__ seg_pos, const uint64_t* __restrict__ seg_dst,
                                                          const uint64_t* __restrict__ seg_cnt_unscanned,
-                                                         Key1* __restrict__ out_keys, uint32_t* __restrict__ out_counts)
+                                                         K* __restrict__ out_keys, uint32_t* __restrict__ out_counts)
 {
     const uint32_t s = blockIdx.x;
     const uint64_t d = seg_cnt_unscanned[s];

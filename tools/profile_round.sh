@@ -3,7 +3,7 @@
 # usage (on the GPU box, through gpurun): bash tools/profile_round.sh r01
 R=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$R
-mkdir -p $OUT
+mkdir -p $OUT/pmc
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/trace.err
