@@ -82,6 +82,7 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
     bool mute_timing = false;           // set around auxiliary launches (the distinct-count estimate)
     uint32_t segment_retries = 0;       // segment path attempts that overflowed an LDS table
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
@@ -239,6 +240,7 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
     uint64_t* table = (uint64_t*)c->arena.temp(256ULL * ntiles * 8);
     unsigned long long* status = (unsigned long long*)table;
     unsigned long long* hist = nullptr;
+    unsigned long long* cursors = nullptr;
     LookbackCtl* ctl = nullptr;
     LookbackCtl* hctl = (LookbackCtl*)((uint8_t*)c->h_pinned + 128);
     bool lookback = c->lookback && ndigits <= 16;
@@ -248,6 +250,7 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
         // scatter per digit
         hist = (unsigned long long*)c->arena.temp(ndigits * 256 * 8);
         ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
+        cursors = (unsigned long long*)c->arena.temp(256 * kCursorStride * 8);
         HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
         if (prehist)
             HIP_TRY(hipMemcpyAsync(hist, prehist, ndigits * 256 * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -274,7 +277,10 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
         bool done = false;
         if (lookback)
         {
-            HIP_TRY(hipMemsetAsync(status, 0, ntiles * 256 * 8, c->stream));
+            // pass 0 may place tiles in any order: atomic bucket cursors instead of the chain
+            unsigned long long* cur = (di == 0 && c->cursor_pass0) ? cursors : nullptr;
+            if (cur) HIP_TRY(hipMemsetAsync(cursors, 0, 256 * kCursorStride * 8, c->stream));
+            else HIP_TRY(hipMemsetAsync(status, 0, ntiles * 256 * 8, c->stream));
             {
                 PhaseTimer t(c, GOSS_T_SCATTER, n);
                 if (c->ordered_tiles)
@@ -282,12 +288,12 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
                     HIP_TRY(hipMemsetAsync(&ctl->ticket, 0, 4, c->stream));
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, true>), dim3(grid_for(n, tile)), dim3(kTB), 0,
                                        c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d, first_shift,
-                                       (const unsigned long long*)(hist + di * 256), status, ctl);
+                                       (const unsigned long long*)(hist + di * 256), status, ctl, cur);
                 }
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, HAS_VAL, false>), dim3(grid_for(n, tile)), dim3(kTB), 0,
                                        c->stream, (const K*)src, (const uint32_t*)vs, dst, vd, n, d, first_shift,
-                                       (const unsigned long long*)(hist + di * 256), status, ctl);
+                                       (const unsigned long long*)(hist + di * 256), status, ctl, cur);
                 t.stop();
             }
             // the source buffer is still intact: a chain that gave up is redone below
@@ -1079,6 +1085,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
+    { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     int rc = guarded(c, [&]() {
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }

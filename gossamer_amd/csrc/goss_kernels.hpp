@@ -647,6 +647,7 @@ struct LookbackCtl {
     unsigned long long walk_steps, spin_polls, max_depth, tiles;
 };
 
+constexpr int kCursorStride = 32;                // u64 words between bucket cursors (256 B)
 constexpr uint64_t kLbFlagAgg = 1ULL << 62;      // tile's own count is published
 constexpr uint64_t kLbFlagPrefix = 2ULL << 62;   // inclusive prefix up to this tile is published
 constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
@@ -657,7 +658,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
                                                              uint64_t n, uint32_t digit, uint32_t sorted_lo,
                                                              const unsigned long long* __restrict__ bucket_base,
                                                              unsigned long long* __restrict__ status,
-                                                             LookbackCtl* __restrict__ ctl)
+                                                             LookbackCtl* __restrict__ ctl,
+                                                             unsigned long long* __restrict__ cursors)
 {
     constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
     constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
@@ -764,7 +766,14 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         }
         unsigned long long* mine = status + (uint64_t)tile * 256 + tid;
         uint64_t excl = 0;
-        if (tile == 0)
+        if (cursors)
+        {
+            // first pass of a sort: the order of tiles inside a bucket is irrelevant, so the
+            // tile just reserves its share of every bucket with one atomic per digit (cursor
+            // words 256 B apart: separate lines and channels) -- no chain, no waiting
+            excl = tot ? atomicAdd(&cursors[tid * kCursorStride], (unsigned long long)tot) : 0ULL;
+        }
+        else if (tile == 0)
         {
             __hip_atomic_store(mine, kLbFlagPrefix | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
