@@ -382,8 +382,22 @@ void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper ? nsuper : 1, 1024 * 2);
     // fused digit histograms for the 16-bit partition that follows on the segment path
     c->extract_hist_shift = use_segment_path<Key1>(c) ? 2 * c->len - kSegBits : 0xFFFFFFFFu;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G>), dim3(grid), dim3(kTB), 0, c->stream,
-                       aligned, mis, nstarts, navail, c->len, out, c->d_ctr, c->extract_hist_shift, nsuper);
+#define GOSS_LAUNCH_E1(NB)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G, NB>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, \
+                       nstarts, navail, c->len, out, c->d_ctr, c->extract_hist_shift, nsuper)
+    if (MODE == 1) { GOSS_LAUNCH_E1(8); return; }          // graph mode does not hash
+    switch ((2 * c->len + 7) / 8)
+    {
+        case 1: GOSS_LAUNCH_E1(1); break;
+        case 2: GOSS_LAUNCH_E1(2); break;
+        case 3: GOSS_LAUNCH_E1(3); break;
+        case 4: GOSS_LAUNCH_E1(4); break;
+        case 5: GOSS_LAUNCH_E1(5); break;
+        case 6: GOSS_LAUNCH_E1(6); break;
+        case 7: GOSS_LAUNCH_E1(7); break;
+        default: GOSS_LAUNCH_E1(8); break;
+    }
+#undef GOSS_LAUNCH_E1
 }
 template <>
 void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)

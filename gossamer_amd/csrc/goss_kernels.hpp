@@ -283,7 +283,9 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 // forward value is rolled, and it is valid iff the mask bits [i, i+len) are all zero.  No LDS
 // access and no per-base loop remains in the window loop.
 
-template <int MODE, int P, int G>
+// NB = number of significant key bytes, ceil(2*len / 8): the FNV rounds of the zero bytes above
+// them fold into one multiplication (goss_key.hpp, key_hash_short).
+template <int MODE, int P, int G, int NB>
 __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
                 if ((vm >> i) & 1u)
                 {
                     Key1 fk{f}, rk{(~e) & kmask};
-                    if (MODE == 0) stage[s++] = canonical(fk, rk);
+                    if (MODE == 0) stage[s++] = canonical_short<NB>(fk, rk);
                     else { stage[s++] = fk; stage[s++] = rk; }
                 }
             }

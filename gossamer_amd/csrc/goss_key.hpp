@@ -132,6 +132,30 @@ GK_HD uint64_t fnv_word(uint64_t w, uint64_t h)
 GK_HD uint64_t key_hash(const Key1& k) { return fnv_word(k.lo, kFnvSeed) * kFnvPrime8; }
 GK_HD uint64_t key_hash(const Key2& k) { return fnv_word(k.hi, fnv_word(k.lo, kFnvSeed)); }
 
+// One-word keys with nbytes significant bytes (2*len <= 8*nbytes): the remaining 16 - nbytes
+// bytes of the 16-byte image are zero, and a zero byte only multiplies by the prime, so they fold
+// into one multiplication by prime^(16 - nbytes) (tail).
+template <int NB>
+GK_HD uint64_t key_hash_short(uint64_t lo)
+{
+    uint64_t h = kFnvSeed;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+    {
+        h ^= (lo >> (8 * i)) & 0xFFULL;
+        h = fnv_mul(h);
+    }
+    return h * fnv_pow(16 - NB);
+}
+template <int NB>
+GK_HD Key1 canonical_short(const Key1& x, const Key1& rc)
+{
+    uint64_t h0 = key_hash_short<NB>(x.lo), h1 = key_hash_short<NB>(rc.lo);
+    if (h0 > h1) return rc;
+    if (h0 == h1 && rc < x) return rc;
+    return x;
+}
+
 // canonical(x) given rc = revcomp(x)
 template <class K>
 GK_HD K canonical(const K& x, const K& rc)
