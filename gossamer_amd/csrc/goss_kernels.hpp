@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                                                               uint64_t* __restrict__ seg_cnt,
                                                               Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
 {
-    __shared__ unsigned long long tab[kSegSlots];
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[kSegSlots];
     __shared__ uint32_t cnt[kSegSlots];
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
@@ -1051,34 +1051,35 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
             uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * kTB + tid;
             nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
         }
-        // fast path: probe the home slot of all keys of the batch at once (independent LDS
-        // reads); a key that is already there only needs its count bumped
-        volatile unsigned long long* vtab = tab;
-        uint32_t slots[kSegUnroll];
-        unsigned long long seen[kSegUnroll];
-#pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u)
-        {
-            slots[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - 12));
-            seen[u] = vtab[slots[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u)
-        {
-#if defined(GOSS_ABL_NOADD)
-            if (kv[u] != kEmpty && seen[u] == kv[u]) { kv[u] = kEmpty; }
-#else
-            if (kv[u] != kEmpty && seen[u] == kv[u]) { atomicAdd(&cnt[slots[u]], 1u); kv[u] = kEmpty; }
-#endif
-        }
-        // slow path (home slot empty or taken by another key): every lane walks its OWN queue
-        // of leftover keys, one probe per wave iteration, so the wave iterates max-over-lanes of
-        // the lane totals instead of the sum over the eight keys of per-key maxima
+        // The table is probed in buckets of two adjacent slots (one 16-byte LDS read): at a load
+        // of ~0.4 a present key is almost always in its home bucket.
+        // fast path: home buckets of all keys of the batch at once (independent LDS reads); a
+        // key that is already there only needs its count bumped
+        const volatile ulonglong2* vt2 = reinterpret_cast<const volatile ulonglong2*>(tab);
+        uint32_t bkt[kSegUnroll];
         uint32_t pend = 0;
 #pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u) pend |= kv[u] != kEmpty ? (1u << u) : 0u;
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - 11));
+            const unsigned long long s0 = vt2[bkt[u]].x, s1 = vt2[bkt[u]].y;
+            if (kv[u] != kEmpty)
+            {
+                if (s0 == kv[u]) atomicAdd(&cnt[2 * bkt[u]], 1u);
+                else if (s1 == kv[u]) atomicAdd(&cnt[2 * bkt[u] + 1], 1u);
+                else
+                {
+                    pend |= 1u << u;
+                    // a full home bucket cannot take the key: start at the next one
+                    if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (kSegSlots / 2 - 1);
+                }
+            }
+        }
+        // slow path (key absent from its home bucket): every lane walks its OWN queue of
+        // leftover keys, one probe per wave iteration, so the wave iterates max-over-lanes of the
+        // lane totals instead of the sum over the eight keys of per-key maxima
         unsigned long long key = kEmpty;
-        uint32_t slot = 0;
+        uint32_t bk = 0;
         for (;;)
         {
             if (key == kEmpty && pend)
@@ -1087,24 +1088,30 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                 pend &= pend - 1;
 #pragma unroll
                 for (int uu = 0; uu < kSegUnroll; ++uu)
-                    if (u == (uint32_t)uu) { key = kv[uu]; slot = slots[uu]; }
+                    if (u == (uint32_t)uu) { key = kv[uu]; bk = bkt[uu]; }
             }
             if (!__ballot(key != kEmpty)) break;
             if (key != kEmpty)
             {
-                unsigned long long cur = vtab[slot];
-                if (cur == kEmpty)
+                const unsigned long long s0 = vt2[bk].x, s1 = vt2[bk].y;
+                uint32_t hit = ~0u;                       // slot that holds (or now holds) the key
+                if (s0 == key) hit = 2 * bk;
+                else if (s1 == key) hit = 2 * bk + 1;
+                else if (s0 == kEmpty || s1 == kEmpty)
                 {
-                    cur = atomicCAS(&tab[slot], kEmpty, key);
-                    if (cur == kEmpty)
+                    const uint32_t slot = 2 * bk + (s0 == kEmpty ? 0u : 1u);
+                    const unsigned long long old = atomicCAS(&tab[slot], kEmpty, key);
+                    if (old == kEmpty)
                     {
                         uint32_t nd = atomicAdd(&ndist, 1u);
                         if (nd + 1 > kSegLimit) *vovf = 1;
-                        cur = key;
+                        hit = slot;
                     }
+                    else if (old == key) hit = slot;
+                    // else: somebody else took the slot; look at this bucket again
                 }
-                if (cur == key) { atomicAdd(&cnt[slot], 1u); key = kEmpty; }
-                else slot = (slot + 1) & (kSegSlots - 1);
+                else bk = (bk + 1) & (kSegSlots / 2 - 1);
+                if (hit != ~0u) { atomicAdd(&cnt[hit], 1u); key = kEmpty; }
             }
             if (*vovf) break;
         }
