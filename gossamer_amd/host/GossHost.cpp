@@ -7,8 +7,14 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <sys/mman.h>
+
+#include <atomic>
 #include <cerrno>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cstring>
 #include <iostream>
@@ -137,38 +143,54 @@ void LineReader::next() { getline(); }
 
 static std::string num(uint64_t v) { return std::to_string(v); }
 
+// A parse failure inside the shared FASTQ record loop: message text up to (not including) the
+// line number, and the line number relative to the first line the loop saw (1-based).
+struct FastqFail { const char* what; uint64_t line; };
+
 // FastqParser::next (FastqParser.hh:78-176); getLine strips one trailing '\r' (:62-75).
-uint64_t parseFastq(const std::string& name, const ReadSink& sink)
+// Src offers valid()/line()/len()/next()/offset() with PlainLineSource semantics.  Records are
+// parsed while the offset of their first line is < limit.  Returns false and fills *fail on a
+// parse error.  *lines = lines consumed.
+template <class Src, class Sink>
+bool fastqLoop(Src& src, uint64_t limit, Sink&& sink, uint64_t* reads, uint64_t* lines, FastqFail* fail)
 {
-    LineReader src(name);
-    uint64_t lineNum = 1, reads = 0;
+    uint64_t lineNum = 1;
     std::string label, seq;
     auto cur = [&](const char*& l, size_t& n) {
         l = src.line(); n = src.len();
         if (n > 0 && l[n - 1] == '\r') --n;
     };
+    auto bad = [&](const char* what) { fail->what = what; fail->line = lineNum; *lines = lineNum - 1; return false; };
     for (;;)
     {
-        if (!src.valid()) break;
+        if (!src.valid() || src.offset() >= limit) break;
         const char* l; size_t n;
         cur(l, n);
-        if (!(n > 0 && l[0] == '@'))
-            throw Error::Parse(name, "expected '@' at beginning of line " + num(lineNum));
+        if (!(n > 0 && l[0] == '@')) return bad("expected '@' at beginning of line ");
         label.assign(l + 1, n - 1);
+        // the common record has its sequence on one line: no copy then
+        const char* seq1 = nullptr; size_t seq1n = 0;
+        bool multi = false;
         seq.clear();
         for (;;)
         {
             src.next(); ++lineNum;
-            if (!src.valid())
-                throw Error::Parse(name, "expected sequence data or quality header at line " + num(lineNum));
+            if (!src.valid()) return bad("expected sequence data or quality header at line ");
             cur(l, n);
             if (n > 0 && (l[0] == '@' || l[0] == '+')) break;
-            seq.append(l, n);
+            if (!Src::kStableLines && !multi) { seq.assign(l, n); multi = true; }   // line() dies at next()
+            else if (!seq1 && !multi) { seq1 = l; seq1n = n; }
+            else
+            {
+                if (!multi) { seq.assign(seq1, seq1n); multi = true; }
+                seq.append(l, n);
+            }
         }
-        if (!(n > 0 && l[0] == '+'))
-            throw Error::Parse(name, "expected '+' at beginning of line " + num(lineNum));
+        if (!(n > 0 && l[0] == '+')) return bad("expected '+' at beginning of line ");
         if (n > 1 && !(n - 1 == label.size() && memcmp(l + 1, label.data(), n - 1) == 0))
-            throw Error::Parse(name, "quality title does not match sequence title at line " + num(lineNum));
+            return bad("quality title does not match sequence title at line ");
+        const char* sp = multi ? seq.data() : seq1;
+        const size_t sn = multi ? seq.size() : seq1n;
         size_t qual = 0;
         for (;;)
         {
@@ -179,17 +201,100 @@ uint64_t parseFastq(const std::string& name, const ReadSink& sink)
             {
                 // '@' may start a quality line: only a record boundary once enough quality
                 // has been seen
-                if (qual >= seq.size()) break;
+                if (qual >= sn) break;
             }
             qual += n;
         }
-        if (seq.size() != qual)
-            throw Error::Parse(name, "length mistmatch between sequence and quality data just before line " + num(lineNum));
-        ++reads;
-        sink(seq.data(), seq.size());
+        if (sn != qual) return bad("length mistmatch between sequence and quality data just before line ");
+        ++*reads;
+        sink(sp ? sp : "", sn);
     }
+    *lines = lineNum - 1;
+    return true;
+}
+
+uint64_t parseFastq(const std::string& name, const ReadSink& sink)
+{
+    LineReader src(name);
+    uint64_t reads = 0, lines = 0;
+    FastqFail f{};
+    if (!fastqLoop(src, ~0ULL, sink, &reads, &lines, &f)) throw Error::Parse(name, f.what + num(f.line));
     return reads;
 }
+
+// ---- parallel FASTQ parsing of a plain file -------------------------------------------------
+//
+// The file is mapped and cut into chunks; workers parse chunks concurrently with the SAME record
+// loop as the serial parser.  A worker must start at a record boundary, which it guesses (a line
+// starting with '@', a '+' line two lines on, equal sequence/quality lengths, '@' or end of file
+// after that).  Guesses are verified, not trusted: chunk i is accepted only if it started exactly
+// where chunk i-1 ended; the first mismatch makes the caller parse the rest of the file serially
+// from the last verified boundary, so the framing is always the reference's.
+
+namespace {
+
+struct MemLines {
+    static constexpr bool kStableLines = true;
+    const char* p; size_t n, at; bool good; const char* l; size_t ln; size_t off;
+    MemLines(const char* base, size_t size, size_t start) : p(base), n(size), at(start), good(true), l(base), ln(0), off(start) { next(); }
+    bool valid() const { return good || ln; }
+    const char* line() const { return l; }
+    size_t len() const { return ln; }
+    uint64_t offset() const { return off; }
+    void next()
+    {
+        l = p + at; ln = 0; off = at;
+        if (!good) return;
+        if (at >= n) { good = false; return; }
+        const char* nl = (const char*)memchr(p + at, '\n', n - at);
+        if (nl) { ln = (size_t)(nl - (p + at)); at += ln + 1; }
+        else { ln = n - at; at = n; good = false; }
+    }
+};
+
+// First plausible record start at or after `from` (a line start), or npos.
+size_t guessRecordStart(const char* p, size_t n, size_t from)
+{
+    size_t at = from;
+    if (at > 0)
+    {
+        const char* nl = (const char*)memchr(p + at - 1, '\n', n - (at - 1));
+        if (!nl) return (size_t)-1;
+        at = (size_t)(nl - p) + 1;
+    }
+    for (int tries = 0; tries < 256 && at < n; ++tries)
+    {
+        size_t ls[5]; size_t ll[5]; size_t q = at; int got = 0;
+        for (; got < 5 && q <= n; ++got)
+        {
+            ls[got] = q;
+            if (q >= n) { ll[got] = 0; ++got; break; }
+            const char* nl = (const char*)memchr(p + q, '\n', n - q);
+            size_t e = nl ? (size_t)(nl - p) : n;
+            ll[got] = e - q; if (ll[got] && p[e - 1] == '\r') --ll[got];
+            q = nl ? e + 1 : n + 1;
+        }
+        if (got >= 4 && ll[0] > 0 && p[ls[0]] == '@' && ll[2] > 0 && p[ls[2]] == '+' && ll[1] == ll[3]
+            && !(ll[1] > 0 && (p[ls[1]] == '@' || p[ls[1]] == '+'))
+            && (got == 4 || ls[4] >= n || p[ls[4]] == '@'))
+            return at;
+        const char* nl = (const char*)memchr(p + at, '\n', n - at);
+        if (!nl) break;
+        at = (size_t)(nl - p) + 1;
+    }
+    return (size_t)-1;
+}
+
+struct ChunkResult {
+    std::vector<char> bases;
+    uint64_t reads = 0, lines = 0;
+    size_t start = (size_t)-1, end = 0;
+    bool ok = false;
+    FastqFail fail{};
+    bool done = false;
+};
+
+}  // namespace
 
 // FastaParser::next (FastaParser.hh:51-87); no '\r' stripping; line numbers start at 0.
 uint64_t parseFasta(const std::string& name, const ReadSink& sink)
@@ -264,8 +369,130 @@ void writeFile(const std::string& path, const std::string& objName, GpuCtx& g, u
     if (fclose(fp) != 0) throw Error::Write(objName);
 }
 
+// Bytes of file per parser work item (GOSS_PARSE_CHUNK overrides: tests use small chunks).
+size_t parseChunkBytes()
+{
+    const char* e = std::getenv("GOSS_PARSE_CHUNK");
+    if (e && *e) { long v = atol(e); if (v >= 256) return (size_t)v; }
+    return 32u << 20;
+}
+
+// Parse a plain FASTQ file with `threads` workers (see "parallel FASTQ parsing" above).  Batches of
+// bases go to `push` in file order.  Returns the number of reads, or ~0 if the file is not eligible
+// (too small, not a regular file) and the caller should use the serial parser.
+uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t chunkBytes,
+                            const std::function<void(const char*, size_t)>& push)
+{
+    if (threads < 2 || name == "-" || endsWith(name, ".gz")) return ~0ULL;
+    int fd = ::open(name.c_str(), O_RDONLY);
+    if (fd < 0) throw Error::Errno(name, errno);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < 2 * chunkBytes) { ::close(fd); return ~0ULL; }
+    const size_t size = (size_t)st.st_size;
+    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return ~0ULL;
+    madvise(map, size, MADV_SEQUENTIAL);
+    const char* p = (const char*)map;
+    struct Unmap { void* m; size_t n; ~Unmap() { munmap(m, n); } } unmap{map, size};
+
+    const size_t nchunks = (size + chunkBytes - 1) / chunkBytes;
+    std::vector<ChunkResult> res(nchunks);
+    std::atomic<size_t> nextChunk{0};
+    std::atomic<bool> abortAll{false};
+    size_t accepted = 0;                       // chunks consumed by the main thread (under m)
+    std::mutex m;
+    std::condition_variable cv;
+
+    auto worker = [&]() {
+        for (;;)
+        {
+            size_t i = nextChunk.fetch_add(1);
+            if (i >= nchunks || abortAll.load()) return;
+            {
+                // do not run too far ahead of the consumer: bounds the memory held in results
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return abortAll.load() || i < accepted + 3 * (size_t)threads; });
+                if (abortAll.load()) return;
+            }
+            ChunkResult r;
+            const size_t begin = i * chunkBytes, limit = std::min(size, begin + chunkBytes);
+            r.start = i == 0 ? 0 : guessRecordStart(p, size, begin);
+            if (r.start == (size_t)-1 || r.start >= limit) { r.end = r.start; r.ok = true; r.start = (size_t)-1; }
+            else
+            {
+                r.bases.reserve(chunkBytes / 2 + (1u << 16));
+                MemLines src(p, size, r.start);
+                auto sink = [&](const char* seq, size_t len) {
+                    r.bases.insert(r.bases.end(), seq, seq + len);
+                    r.bases.push_back('\n');
+                };
+                r.ok = fastqLoop(src, limit, sink, &r.reads, &r.lines, &r.fail);
+                r.end = src.valid() ? (size_t)src.offset() : size;
+            }
+            r.done = true;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                res[i] = std::move(r);
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
+    struct Join { std::vector<std::thread>& p; std::atomic<bool>& a; std::condition_variable& c;
+                  ~Join() { a.store(true); c.notify_all(); for (auto& t : p) if (t.joinable()) t.join(); } } join{pool, abortAll, cv};
+
+    uint64_t reads = 0, baseLine = 1;
+    size_t expected = 0;
+    bool serialRest = false;
+    for (size_t i = 0; i < nchunks && !serialRest; ++i)
+    {
+        ChunkResult r;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return res[i].done; });
+            r = std::move(res[i]);
+            accepted = i + 1;
+        }
+        cv.notify_all();
+        const size_t limit = std::min(size, (i + 1) * chunkBytes);
+        if (r.start == (size_t)-1)
+        {
+            // the chunk found no record start: fine only if the previous record ran past it
+            if (expected < limit) serialRest = true;
+            continue;
+        }
+        if (r.start != expected) { serialRest = true; break; }
+        if (!r.ok) throw Error::Parse(name, r.fail.what + num(baseLine + r.fail.line - 1));
+        if (!r.bases.empty()) push(r.bases.data(), r.bases.size());
+        reads += r.reads;
+        baseLine += r.lines;
+        expected = r.end;
+    }
+    if (serialRest || expected < size)
+    {
+        // a boundary guess did not line up (wrapped records, '@' starting quality lines, ...):
+        // the rest of the file is framed serially from the last verified record boundary
+        abortAll.store(true);
+        cv.notify_all();
+        std::vector<char> batch;
+        batch.reserve(chunkBytes);
+        MemLines src(p, size, expected);
+        auto sink = [&](const char* seq, size_t len) {
+            batch.insert(batch.end(), seq, seq + len);
+            batch.push_back('\n');
+            if (batch.size() >= chunkBytes) { push(batch.data(), batch.size()); batch.clear(); }
+        };
+        uint64_t lines = 0; FastqFail f{};
+        if (!fastqLoop(src, ~0ULL, sink, &reads, &lines, &f)) throw Error::Parse(name, f.what + num(baseLine + f.line - 1));
+        if (!batch.empty()) push(batch.data(), batch.size());
+    }
+    return reads;
+}
+
 void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string& out, const strings& fastas,
-              const strings& fastqs, const strings& lines, BuildStats& stats)
+              const strings& fastqs, const strings& lines, uint64_t threads, BuildStats& stats)
 {
     auto t0 = std::chrono::steady_clock::now();
     Logger& log = cxt.log;
@@ -273,8 +500,32 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     if (K > maxK || K == 0)
         throw Error::General("unable to build a graph with k=" + num(K));      // KmerSet.hh:89-95, Graph.cc:152-158
 
+    // HBM budget: mapping the whole device takes seconds, so size the arena from the input when
+    // the caller gave no budget: ~1 base per FASTQ byte/2 (FASTA, lines: per byte), two key
+    // buffers + tables per key, compressed input expands ~4x
+    uint64_t budget = cxt.hbmBudget;
+    if (budget == 0)
+    {
+        uint64_t bases = 0; bool unknown = false;
+        auto add = [&](const std::string& f, double basesPerByte) {
+            struct stat st;
+            if (f == "-" || ::stat(f.c_str(), &st) != 0) { unknown = true; return; }
+            double b = (double)st.st_size * basesPerByte;
+            if (endsWith(f, ".gz")) b *= 4.5;
+            bases += (uint64_t)b;
+        };
+        for (auto& f : lines) add(f, 1.0);
+        for (auto& f : fastas) add(f, 1.0);
+        for (auto& f : fastqs) add(f, 0.5);
+        if (!unknown)
+        {
+            const uint64_t keyBytes = (2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) <= 62) ? 8 : 16;
+            const uint64_t perBase = (mode == GOSS_MODE_GRAPH ? 2 : 1) * (2 * keyBytes + 2) + 1;
+            budget = bases * perBase + (6ULL << 30);      // the library clamps to the free memory
+        }
+    }
     GpuCtx g;
-    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, cxt.hbmBudget, nullptr), "creating the GPU context");
+    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
 
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));
@@ -294,7 +545,16 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     // same order as the reference: line, fasta, fastq (GossCmdBuildKmerSet.cc:118-141)
     for (auto& f : lines) { log(info, "parsing sequences from " + f); reads += parseLines(f, sink); }
     for (auto& f : fastas) { log(info, "parsing sequences from " + f); reads += parseFasta(f, sink); }
-    for (auto& f : fastqs) { log(info, "parsing sequences from " + f); reads += parseFastq(f, sink); }
+    for (auto& f : fastqs)
+    {
+        log(info, "parsing sequences from " + f);
+        flush();
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), [&](const char* p, size_t n) {
+            g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
+        });
+        if (r == ~0ULL) r = parseFastq(f, sink);
+        reads += r;
+    }
     if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
     flush();
 
@@ -326,12 +586,12 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
 
 void GossCmdBuildKmerSet::operator()(const GossCmdContext& pCxt)
 {
-    runBuild(pCxt, mK, GOSS_MODE_KMER_SET, mKmerSetName, mFastaNames, mFastqNames, mLineNames, mStats);
+    runBuild(pCxt, mK, GOSS_MODE_KMER_SET, mKmerSetName, mFastaNames, mFastqNames, mLineNames, mT, mStats);
 }
 
 void GossCmdBuildGraph::operator()(const GossCmdContext& pCxt)
 {
-    runBuild(pCxt, mK, GOSS_MODE_GRAPH, mGraphName, mFastaNames, mFastqNames, mLineNames, mStats);
+    runBuild(pCxt, mK, GOSS_MODE_GRAPH, mGraphName, mFastaNames, mFastqNames, mLineNames, mT, mStats);
 }
 
 // --------------------------------------------------------------------------------------
@@ -628,7 +888,16 @@ int gossMain(int argc, char* argv[])
             {
                 for (auto& f : lines) reads += parseLines(f, sink);
                 for (auto& f : fastas) reads += parseFasta(f, sink);
-                for (auto& f : fastqs) reads += parseFastq(f, sink);
+                uint64_t T = 1;
+                chk.optionalU64("num-threads", T);
+                for (auto& f : fastqs)
+                {
+                    // -T > 1 exercises the parallel parser (same byte stream, file order)
+                    uint64_t r = parseFastqParallel(f, (unsigned)T, parseChunkBytes(),
+                                                    [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); });
+                    if (r == ~0ULL) r = parseFastq(f, sink);
+                    reads += r;
+                }
             }
             catch (Error& e) { e.cmd = cmdName; throw; }
             fflush(stdout);

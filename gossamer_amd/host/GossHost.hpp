@@ -83,6 +83,8 @@ public:
     size_t len() const { return mLen; }
     void next();                                  // operator++
     const std::string& name() const { return mFile.name(); }
+    uint64_t offset() const { return 0; }         // streams have no record-boundary limit
+    static constexpr bool kStableLines = false;   // line() is only valid until next()
 private:
     void getline();
     bool refill();

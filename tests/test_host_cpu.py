@@ -182,3 +182,54 @@ def test_fastqs_in_list_expansion(tmp_path, oracle):
     (tmp_path / "list.txt").write_text("%s\n%s\n%s" % (tmp_path / "one.fq", tmp_path / "two.fq", tmp_path / "three.fq"))
     rc, out, err = run_goss("dump-bases", "-f", str(tmp_path / "list.txt"))
     assert rc == 0 and out == b"ACGTA\nTTTTT\n", err
+
+
+def test_parallel_fastq_parser_matches_serial(tmp_path):
+    """The multi-threaded FASTQ path (chunks parsed concurrently from guessed record boundaries,
+    every guess verified against the previous chunk's end) must hand over exactly the serial
+    parser's byte stream -- including files with wrapped records and quality lines that start with
+    '@' or '+', where guesses fail and the parser falls back to serial framing -- and report the
+    same error text with the same global line number."""
+    rng = random.Random(17)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTN") for _ in range(n))
+
+    def plain(i):
+        s = seq(rng.randint(20, 150))
+        return "@r%d\n%s\n+\n%s\n" % (i, s, "".join(rng.choice("I5#") for _ in s))
+
+    def nasty(i):
+        s = seq(rng.randint(20, 150))
+        q = "@" + "".join(rng.choice("+@I") for _ in s[1:])
+        if i % 2:
+            cut = len(s) // 2
+            return "@r%d\n%s\n%s\n+r%d\n%s\n%s\n" % (i, s[:cut], s[cut:], i, q[:cut], q[cut:])
+        return "@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, s, q)
+
+    files = {
+        "plain.fq": "".join(plain(i) for i in range(6000)),
+        "mixed.fq": "".join(nasty(i) if i % 50 == 0 else plain(i) for i in range(6000)),
+        "nasty.fq": "".join(nasty(i) for i in range(3000)),
+        "notrail.fq": "".join(plain(i) for i in range(3000)).rstrip("\n"),
+    }
+    env = dict(os.environ, GOSS_PARSE_CHUNK="4096")
+    for name, text in files.items():
+        p = tmp_path / name
+        p.write_text(text, newline="")
+        serial = subprocess.run([GOSS, "dump-bases", "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert serial.returncode == 0, serial.stderr
+        for T in ("2", "5"):
+            par = subprocess.run([GOSS, "dump-bases", "-T", T, "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert par.returncode == 0, par.stderr
+            assert par.stdout == serial.stdout, (name, T)
+    # an error deep in the file: same message, same line number
+    bad = files["plain.fq"].split("\n")
+    bad[4 * 4000 + 2] = "-"             # the '+' line of record 4000
+    p = tmp_path / "bad.fq"
+    p.write_text("\n".join(bad), newline="")
+    serial = subprocess.run([GOSS, "dump-bases", "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    par = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert serial.returncode == 1 and par.returncode == 1
+    assert b"expected '+' at beginning of line 16005" in serial.stderr
+    assert par.stderr == serial.stderr
