@@ -530,9 +530,15 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));
     uint64_t reads = 0;
+    double pushSeconds = 0;
+    auto timedPush = [&](const char* p, size_t n) {
+        auto a = std::chrono::steady_clock::now();
+        g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
+        pushSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+    };
     auto flush = [&]() {
         if (batch.empty()) return;
-        g.check(goss_gpu_push_bases_host(g.h, batch.data(), batch.size()), "counting k-mers");
+        timedPush(batch.data(), batch.size());
         batch.clear();
     };
     uint64_t progress = 0;
@@ -549,19 +555,21 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     {
         log(info, "parsing sequences from " + f);
         flush();
-        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), [&](const char* p, size_t n) {
-            g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
-        });
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
     if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
     flush();
+    auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "
+        << pushSeconds << "s)"; log(info, o.str()); }
 
     log(info, "sorting the hashtable...");
     goss_gpu_counts counts;
     g.check(goss_gpu_finish(g.h, &counts), "sorting");
     log(info, "sorting done.");
+    { std::ostringstream o; o << "merged at " << secs() << "s"; log(info, o.str()); }
     log(info, "writing out graph.");
     g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
     uint32_t nfiles = 0;

@@ -11,5 +11,5 @@ echo "== parse only (dump-bases > /dev/null)"
 time ./gossamer_amd/goss dump-bases -i $D/reads.fq > /dev/null
 echo "== build-kmer-set $@"
 time ./gossamer_amd/goss build-kmer-set -k 25 -i $D/reads.fq -O $D/ks -v "$@" 2> $D/log.txt
-grep -E "total build|windows" $D/log.txt
+grep -E "total build|windows|parsed and|merged at" $D/log.txt
 rm -rf $D
