@@ -82,6 +82,8 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    uint8_t* stage = nullptr;           // staging buffer for host pushes (top of the arena)
+    uint64_t stage_cap = 0, stage_fill = 0;
     bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
     bool mute_timing = false;           // set around auxiliary launches (the distinct-count estimate)
     uint32_t segment_retries = 0;       // segment path attempts that overflowed an LDS table
@@ -1128,11 +1130,23 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
     delete c;
 }
 
+// Host pushes are gathered in a staging buffer in HBM and counted together: every counted chunk
+// becomes a sorted run that has to be merged later, so many small chunks are far more expensive
+// than one large one.  Pushes are separated by one non-base byte (windows never span pushes).
+static void flush_staging(goss_gpu_ctx* c)
+{
+    if (!c->stage || c->stage_fill == 0) return;
+    const uint64_t n = c->stage_fill;
+    c->stage_fill = 0;
+    if (c->words == 1) push_device<Key1>(c, c->stage, n); else push_device<Key2>(c, c->stage, n);
+}
+
 int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes)
 {
     if (!c || (!d_bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
     return guarded(c, [&]() {
+        flush_staging(c);
         if (c->words == 1) push_device<Key1>(c, (const uint8_t*)d_bases, nbytes);
         else push_device<Key2>(c, (const uint8_t*)d_bases, nbytes);
     });
@@ -1145,24 +1159,37 @@ int goss_gpu_push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes
     return guarded(c, [&]() {
         if (nbytes < c->len) return;
         ensure_arena(c);
-        // stage the bytes in HBM in pieces of at most 1/8 of the free arena; pieces overlap
-        // by len-1 bytes so that no window is lost at a cut
-        uint64_t done = 0;
-        const uint64_t nstarts_total = nbytes - c->len + 1;
-        while (done < nstarts_total)
+        if (!c->stage)
         {
-            uint64_t piece = std::max<uint64_t>(c->arena.avail() / 8, 1 << 20);
-            piece &= ~4095ULL;
-            uint64_t ns = std::min(piece, nstarts_total - done);
-            uint64_t nb = ns + c->len - 1;
-            uint64_t mark = c->arena.mark();
-            uint8_t* d = (uint8_t*)c->arena.temp(nb + 16);
-            HIP_TRY(hipMemcpyAsync(d, bases + done, nb, hipMemcpyHostToDevice, c->stream));
-            if (c->words == 1) push_device<Key1>(c, d, nb); else push_device<Key2>(c, d, nb);
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->arena.release(mark);
-            done += ns;
+            // 1/24 of the arena: with ~17 bytes of key workspace per base the staged bases then
+            // fill about three quarters of the rest when they are counted
+            c->stage_cap = std::max<uint64_t>(c->arena.avail() / 24, 1u << 20) & ~4095ULL;
+            c->stage = (uint8_t*)c->arena.temp(c->stage_cap + 16);
+            c->stage_fill = 0;
         }
+        if (nbytes + 1 > c->stage_cap)
+        {
+            // larger than the staging buffer: count it on its own, in pieces that overlap by
+            // len-1 bytes so that no window is lost at a cut
+            flush_staging(c);
+            uint64_t done = 0;
+            const uint64_t nstarts_total = nbytes - c->len + 1;
+            while (done < nstarts_total)
+            {
+                uint64_t ns = std::min<uint64_t>(c->stage_cap - c->len, nstarts_total - done);
+                uint64_t nb = ns + c->len - 1;
+                HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->stream));
+                if (c->words == 1) push_device<Key1>(c, c->stage, nb); else push_device<Key2>(c, c->stage, nb);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                done += ns;
+            }
+            return;
+        }
+        if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging(c);
+        HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));       // the caller may reuse its buffer
+        c->stage_fill += nbytes + 1;
     });
 }
 
@@ -1172,6 +1199,8 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
     if (c->finished) { c->last_error = "finish called twice"; return GOSS_ERR_STATE; }
     int rc = guarded(c, [&]() {
         ensure_arena(c);
+        flush_staging(c);
+        if (c->stage) { c->stage = nullptr; c->arena.hi = c->arena.size; }    // staging no longer needed
         if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
         if (!c->runs.empty()) { c->res_keys = c->runs[0].keys; c->res_counts = c->runs[0].counts; c->M = c->runs[0].m; }
         else { c->res_keys = c->arena.perm(16); c->res_counts = (uint32_t*)c->arena.perm(16); c->M = 0; }
@@ -1306,6 +1335,7 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         c->finished = c->emitted = false;
         c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;
         c->arena.lo = 0; c->arena.hi = c->arena.size;
+        c->stage = nullptr; c->stage_fill = 0;
         HIP_TRY(hipMemsetAsync(c->d_flags, 0, 16, c->stream));
     });
 }
