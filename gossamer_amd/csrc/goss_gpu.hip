@@ -1317,6 +1317,19 @@ int goss_gpu_timing_reset(goss_gpu_ctx* c)
     return rc;
 }
 
+int goss_gpu_host_alloc(void** p, size_t bytes)
+{
+    if (!p || bytes == 0) return GOSS_ERR_INVALID_ARG;
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    return e == hipSuccess ? GOSS_OK : GOSS_ERR_OOM;
+}
+
+void goss_gpu_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int goss_gpu_set_path(goss_gpu_ctx* c, int path)
 {
     if (!c || path < 0 || path > 1) return GOSS_ERR_INVALID_ARG;

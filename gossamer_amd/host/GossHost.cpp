@@ -286,7 +286,8 @@ size_t guessRecordStart(const char* p, size_t n, size_t from)
 }
 
 struct ChunkResult {
-    std::vector<char> bases;
+    char* buf = nullptr;               // from the buffer pool (pinned when a GPU is attached)
+    size_t len = 0;
     uint64_t reads = 0, lines = 0;
     size_t start = (size_t)-1, end = 0;
     bool ok = false;
@@ -380,8 +381,13 @@ size_t parseChunkBytes()
 // Parse a plain FASTQ file with `threads` workers (see "parallel FASTQ parsing" above).  Batches of
 // bases go to `push` in file order.  Returns the number of reads, or ~0 if the file is not eligible
 // (too small, not a regular file) and the caller should use the serial parser.
+struct HostAlloc {                       // how the chunk buffers are obtained (pinned under a GPU)
+    std::function<void*(size_t)> alloc;
+    std::function<void(void*)> release;
+};
+
 uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t chunkBytes,
-                            const std::function<void(const char*, size_t)>& push)
+                            const std::function<void(const char*, size_t)>& push, const HostAlloc& ha)
 {
     if (threads < 2 || name == "-" || endsWith(name, ".gz")) return ~0ULL;
     int fd = ::open(name.c_str(), O_RDONLY);
@@ -400,32 +406,47 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     std::vector<ChunkResult> res(nchunks);
     std::atomic<size_t> nextChunk{0};
     std::atomic<bool> abortAll{false};
-    size_t accepted = 0;                       // chunks consumed by the main thread (under m)
     std::mutex m;
     std::condition_variable cv;
+    // a bounded pool of reusable output buffers (a chunk of file yields at most as many bases):
+    // bounds the memory in flight and keeps the pages warm / pinned for the copy to the device
+    const size_t bufCap = chunkBytes + (1u << 16);
+    const size_t nbuf = 2 * (size_t)threads + 2;
+    std::vector<char*> freeBufs;
+    std::vector<void*> allBufs;
+    struct FreeAll { std::vector<void*>& v; const HostAlloc& h; ~FreeAll() { for (void* b : v) h.release(b); } } freeAll{allBufs, ha};
+    for (size_t i = 0; i < nbuf; ++i)
+    {
+        void* b = ha.alloc(bufCap);
+        if (!b) throw Error::General("cannot allocate parser buffers\n");
+        allBufs.push_back(b); freeBufs.push_back((char*)b);
+    }
 
     auto worker = [&]() {
         for (;;)
         {
-            size_t i = nextChunk.fetch_add(1);
-            if (i >= nchunks || abortAll.load()) return;
-            {
-                // do not run too far ahead of the consumer: bounds the memory held in results
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return abortAll.load() || i < accepted + 3 * (size_t)threads; });
-                if (abortAll.load()) return;
-            }
             ChunkResult r;
+            size_t i;
+            {
+                // buffer first, chunk number second (both under the lock): every outstanding chunk
+                // then owns a buffer and the in-order consumer can always make progress
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return abortAll.load() || !freeBufs.empty(); });
+                if (abortAll.load()) return;
+                i = nextChunk.fetch_add(1);
+                if (i >= nchunks) return;
+                r.buf = freeBufs.back(); freeBufs.pop_back();
+            }
             const size_t begin = i * chunkBytes, limit = std::min(size, begin + chunkBytes);
             r.start = i == 0 ? 0 : guessRecordStart(p, size, begin);
             if (r.start == (size_t)-1 || r.start >= limit) { r.end = r.start; r.ok = true; r.start = (size_t)-1; }
             else
             {
-                r.bases.reserve(chunkBytes / 2 + (1u << 16));
                 MemLines src(p, size, r.start);
                 auto sink = [&](const char* seq, size_t len) {
-                    r.bases.insert(r.bases.end(), seq, seq + len);
-                    r.bases.push_back('\n');
+                    // a chunk's reads are shorter than the chunk's bytes (titles, '+', qualities)
+                    if (r.len + len + 1 <= bufCap) { memcpy(r.buf + r.len, seq, len); r.len += len; r.buf[r.len++] = '\n'; }
+                    else r.len = bufCap + 1;                 // cannot happen for a record-aligned chunk
                 };
                 r.ok = fastqLoop(src, limit, sink, &r.reads, &r.lines, &r.fail);
                 r.end = src.valid() ? (size_t)src.offset() : size;
@@ -433,7 +454,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             r.done = true;
             {
                 std::lock_guard<std::mutex> lk(m);
-                res[i] = std::move(r);
+                res[i] = r;
             }
             cv.notify_all();
         }
@@ -452,20 +473,27 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         {
             std::unique_lock<std::mutex> lk(m);
             cv.wait(lk, [&] { return res[i].done; });
-            r = std::move(res[i]);
-            accepted = i + 1;
+            r = res[i];
         }
-        cv.notify_all();
         const size_t limit = std::min(size, (i + 1) * chunkBytes);
         if (r.start == (size_t)-1)
         {
             // the chunk found no record start: fine only if the previous record ran past it
+            { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
+            cv.notify_all();
             if (expected < limit) serialRest = true;
             continue;
         }
-        if (r.start != expected) { serialRest = true; break; }
+        auto giveBack = [&]() {
+            if (!r.buf) return;
+            { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
+            r.buf = nullptr;
+            cv.notify_all();
+        };
+        if (r.start != expected || r.len > bufCap) { giveBack(); serialRest = true; break; }
         if (!r.ok) throw Error::Parse(name, r.fail.what + num(baseLine + r.fail.line - 1));
-        if (!r.bases.empty()) push(r.bases.data(), r.bases.size());
+        if (r.len) push(r.buf, r.len);
+        giveBack();
         reads += r.reads;
         baseLine += r.lines;
         expected = r.end;
@@ -530,6 +558,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));
     uint64_t reads = 0;
+    HostAlloc pinned{[](size_t n) { void* p = nullptr; return goss_gpu_host_alloc(&p, n) == GOSS_OK ? p : nullptr; },
+                     [](void* p) { goss_gpu_host_free(p); }};
     double pushSeconds = 0;
     auto timedPush = [&](const char* p, size_t n) {
         auto a = std::chrono::steady_clock::now();
@@ -555,7 +585,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     {
         log(info, "parsing sequences from " + f);
         flush();
-        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush);
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
@@ -901,8 +931,9 @@ int gossMain(int argc, char* argv[])
                 for (auto& f : fastqs)
                 {
                     // -T > 1 exercises the parallel parser (same byte stream, file order)
+                    HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }};
                     uint64_t r = parseFastqParallel(f, (unsigned)T, parseChunkBytes(),
-                                                    [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); });
+                                                    [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); }, heap);
                     if (r == ~0ULL) r = parseFastq(f, sink);
                     reads += r;
                 }

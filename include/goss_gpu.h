@@ -163,6 +163,13 @@ int goss_gpu_timing_reset(goss_gpu_ctx* ctx);
 int goss_gpu_reset(goss_gpu_ctx* ctx);
 
 /*
+ * Page-locked host memory for the buffers handed to goss_gpu_push_bases_host (the copy to the
+ * device then runs at PCIe speed instead of going through the driver's bounce buffers).
+ */
+int goss_gpu_host_alloc(void** p, size_t bytes);
+void goss_gpu_host_free(void* p);
+
+/*
  * Counting strategy.  0 (default): partition on the top 16 key bits, then count every segment
  * in an LDS hash table, falling back to the full LSD radix sort when a segment holds too many
  * distinct keys.  1: always the full LSD radix sort + run compaction.  The result is the same;
