@@ -82,6 +82,8 @@ struct goss_gpu_ctx {
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
+    uint64_t emit_estimate = 0;         // SparseArray estimate M for the next emit (merges)
+    bool has_emit_estimate = false;
     uint8_t* stage = nullptr;           // staging buffer for host pushes (top of the arena)
     uint64_t stage_cap = 0, stage_fill = 0;
     bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
@@ -910,7 +912,7 @@ void add_host_file(goss_gpu_ctx* c, const std::string& suffix, const void* p, si
 }
 
 // VariableByteArray + counts histogram (VariableByteArray.hh:76-118, Graph.cc:115-134).
-void emit_counts(goss_gpu_ctx* c, const uint32_t* counts, uint64_t m, const std::string& out_counts, const std::string& out_hist)
+void emit_counts(goss_gpu_ctx* c, const uint32_t* counts, uint64_t m, uint64_t num_items, const std::string& out_counts, const std::string& out_hist)
 {
     uint64_t mark = c->arena.mark();
     uint8_t* ord0 = (uint8_t*)c->arena.perm(std::max<uint64_t>(m, 8));
@@ -952,10 +954,10 @@ void emit_counts(goss_gpu_ctx* c, const uint32_t* counts, uint64_t m, const std:
     if (!ord1) ord1 = (uint8_t*)c->arena.perm(8);
     if (!ord2) ord2 = (uint16_t*)c->arena.perm(8);
     { OutFile f; f.suffix = out_counts + ".ord0"; f.size = m; f.dev = ord0; c->files.push_back(std::move(f)); }
-    const uint64_t mest = (uint64_t)((double)m * 0.001);
-    emit_sparse_array<Key1>(c, pos1, n1, m, 0, mest, m, 0, out_counts + ".ord1p");
+    const uint64_t mest = (uint64_t)((double)num_items * 0.001);
+    emit_sparse_array<Key1>(c, pos1, n1, num_items, 0, mest, m, 0, out_counts + ".ord1p");
     { OutFile f; f.suffix = out_counts + ".ord1"; f.size = n1; f.dev = ord1; c->files.push_back(std::move(f)); }
-    emit_sparse_array<Key1>(c, pos2, n2, m, 0, mest, n1, 0, out_counts + ".ord2p");
+    emit_sparse_array<Key1>(c, pos2, n2, num_items, 0, mest, n1, 0, out_counts + ".ord2p");
     { OutFile f; f.suffix = out_counts + ".ord2"; f.size = n2 * 2; f.dev = (const uint8_t*)ord2; c->files.push_back(std::move(f)); }
 
     // histogram of counts: sort the counts as keys, run-length them, format on the host
@@ -1002,13 +1004,16 @@ void emit_object(goss_gpu_ctx* c)
 {
     const K* keys = (const K*)c->res_keys;
     const uint64_t m = c->M;
+    // the SparseArray estimate: the exact distinct count (single-pass build) unless the caller
+    // gave one (merges use the sum of the inputs' counts, GossCmdMerge.tcc:256-258,296)
+    const uint64_t est = c->has_emit_estimate ? c->emit_estimate : m;
     PhaseTimer t(c, GOSS_T_EMIT, m);
     if (c->mode == GOSS_MODE_KMER_SET)
     {
         // N = 4^K (KmerSet.hh:84,72)
         uint32_t bits = 2 * c->k;
         uint64_t nlo = bits < 64 ? (1ULL << bits) : 0, nhi = bits >= 64 ? (1ULL << (bits - 64)) : 0;
-        emit_sparse_array<K>(c, keys, m, nlo, nhi, m, nlo, nhi, ".kmers");
+        emit_sparse_array<K>(c, keys, m, nlo, nhi, est, nlo, nhi, ".kmers");
         uint64_t hdr[3] = {2011101701ULL, c->k, m};
         add_host_file(c, ".header", hdr, sizeof hdr);
     }
@@ -1018,8 +1023,8 @@ void emit_object(goss_gpu_ctx* c)
         add_host_file(c, ".header", hdr, sizeof hdr);
         uint32_t bits = 2 * c->k + 2;
         uint64_t nlo = bits < 64 ? (1ULL << bits) : 0, nhi = bits >= 64 ? (1ULL << (bits - 64)) : 0;
-        emit_sparse_array<K>(c, keys, m, nlo, nhi, m, nlo, nhi, "-edges");
-        emit_counts(c, c->res_counts, m, "-counts", "-counts-hist.txt");
+        emit_sparse_array<K>(c, keys, m, nlo, nhi, est, nlo, nhi, "-edges");
+        emit_counts(c, c->res_counts, m, est, "-counts", "-counts-hist.txt");
     }
     t.stop();
 }
@@ -1373,6 +1378,76 @@ int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t
         // which the caller accounts for; windows are not known here.
         (void)sum;
     });
+}
+
+int goss_gpu_push_run_host(goss_gpu_ctx* c, const uint64_t* keys, const uint32_t* counts, uint64_t m)
+{
+    if (!c || (m && (!keys || !counts))) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (m == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        flush_staging(c);
+        const uint64_t ksz = c->words * 8;
+        Run r{nullptr, nullptr, m};
+        r.keys = c->arena.perm(m * ksz);
+        r.counts = (uint32_t*)c->arena.perm(m * 4);
+        HIP_TRY(hipMemcpyAsync(r.keys, keys, m * ksz, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(r.counts, counts, m * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->runs.push_back(r);
+    });
+}
+
+int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
+{
+    if (!c || !s || s->ncols == 0 || s->ncols > 4 || (s->count && !s->high_bits)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (s->count == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        flush_staging(c);
+        const uint64_t m = s->count, ksz = c->words * 8;
+        Run r{nullptr, nullptr, m};
+        r.keys = c->arena.perm(m * ksz);
+        r.counts = (uint32_t*)c->arena.perm(m * 4);
+        uint64_t mark = c->arena.mark();
+        uint64_t* words = (uint64_t*)c->arena.temp(s->high_words * 8);
+        uint64_t* prefix = (uint64_t*)c->arena.temp(s->high_words * 8);
+        HIP_TRY(hipMemcpyAsync(words, s->high_bits, s->high_words * 8, hipMemcpyHostToDevice, c->stream));
+        EfColumnsIn cols{};
+        cols.n = s->ncols;
+        for (uint32_t i = 0; i < s->ncols; ++i)
+        {
+            uint8_t* d = (uint8_t*)c->arena.temp(m * s->col_bytes[i] + 16);
+            HIP_TRY(hipMemcpyAsync(d, s->col[i], m * s->col_bytes[i], hipMemcpyHostToDevice, c->stream));
+            cols.src[i] = d; cols.bytes[i] = s->col_bytes[i]; cols.shift[i] = s->col_shift[i];
+        }
+        hipLaunchKernelGGL(popc_words_kernel, dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
+                           (const uint64_t*)words, s->high_words, prefix);
+        exclusive_scan_u64(c, prefix, s->high_words);
+        if (c->words == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<Key1>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
+                               (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, (Key1*)r.keys);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<Key2>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
+                               (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, (Key2*)r.keys);
+        if (s->counts) HIP_TRY(hipMemcpyAsync(r.counts, s->counts, m * 4, hipMemcpyHostToDevice, c->stream));
+        else hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, r.counts, m, 1u);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+        c->runs.push_back(r);
+    });
+}
+
+int goss_gpu_emit_estimate(goss_gpu_ctx* c, uint64_t m_estimate)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    c->emit_estimate = m_estimate;
+    c->has_emit_estimate = true;
+    int rc = goss_gpu_emit(c);
+    c->has_emit_estimate = false;
+    return rc;
 }
 
 int goss_gpu_synth_reads(goss_gpu_ctx* c, void* d_out, uint64_t nreads, uint32_t read_len, uint64_t genome_len,

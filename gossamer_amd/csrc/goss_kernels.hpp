@@ -1590,6 +1590,64 @@ __global__ void widen_counts_kernel(const uint32_t* __restrict__ counts, uint64_
 }
 
 // --------------------------------------------------------------------------------------
+// SparseArray decode (SparseArray::LazyIterator, SparseArray.hh:185-224): the i-th one of the
+// high-bits bitmap at position p gives the key ((p - i) << D) + low[i].  Used to read existing
+// KmerSet / Graph objects back as sorted runs (merge-kmer-sets, merge-graphs).
+// --------------------------------------------------------------------------------------
+
+__global__ void popc_words_kernel(const uint64_t* __restrict__ words, uint64_t nwords, uint64_t* __restrict__ counts)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) counts[w] = (uint64_t)__popcll(words[w]);
+}
+
+struct EfColumnsIn { const uint8_t* src[4]; uint32_t bytes[4]; uint32_t shift[4]; uint32_t n; };
+
+template <class K>
+__global__ void ef_decode_kernel(const uint64_t* __restrict__ words, uint64_t nwords, const uint64_t* __restrict__ prefix,
+                                 uint32_t D, EfColumnsIn cols, uint64_t count, K* __restrict__ out)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t x = words[w];
+    uint64_t r = prefix[w];
+    while (x)
+    {
+        const uint32_t b = (uint32_t)__ffsll((unsigned long long)x) - 1;
+        x &= x - 1;
+        if (r >= count) break;
+        unsigned __int128 low = 0;
+        for (uint32_t c = 0; c < cols.n; ++c)
+        {
+            uint64_t v = 0;
+            const uint8_t* p = cols.src[c] + r * cols.bytes[c];
+            switch (cols.bytes[c])
+            {
+                case 1: v = *p; break;
+                case 2: v = *reinterpret_cast<const uint16_t*>(p); break;
+                case 4: v = *reinterpret_cast<const uint32_t*>(p); break;
+                default: v = *reinterpret_cast<const uint64_t*>(p); break;
+            }
+            low |= (unsigned __int128)v << cols.shift[c];
+        }
+        unsigned __int128 pos = (unsigned __int128)(w * 64 + b - r);
+        pos = D >= 128 ? 0 : (pos << D);
+        pos += low;
+        K k;
+        k.lo = (uint64_t)pos;
+        if (K::kWords == 2) reinterpret_cast<uint64_t*>(&k)[K::kWords - 1] = (uint64_t)(pos >> 64);
+        out[r] = k;
+        ++r;
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t* __restrict__ a, uint64_t n, uint32_t v)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+// --------------------------------------------------------------------------------------
 // synthetic reads
 // --------------------------------------------------------------------------------------
 

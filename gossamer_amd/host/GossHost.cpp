@@ -849,7 +849,9 @@ void printHelp(const std::string& cmdName, const OptTable* t)
     std::cerr << "goss <command> [options]\n\ncommands implemented by this build:\n"
               << "  build-graph      create a new graph\n"
               << "  build-kmer-set   create a new graph\n"
-              << "  help             print a summary of all the commands.\n";
+              << "  help             print a summary of all the commands.\n"
+              << "  merge-graphs     create a new graph by merging zero or more existing graphs\n"
+              << "  merge-kmer-sets  create a new graph by merging zero or more existing graphs\n";
     if (t)
     {
         std::cerr << "\n" << cmdName << "\n" << t->describe() << std::endl;
@@ -872,6 +874,58 @@ int gossMain(int argc, char* argv[])
         else { cmdName = argv[1]; if (argv[1][0] != '-') argsToSkip = 1; }
 
         const bool isKmerSet = cmdName == "build-kmer-set", isGraph = cmdName == "build-graph";
+        if (cmdName == "merge-kmer-sets" || cmdName == "merge-graphs")
+        {
+            // GossCmdFactoryMerge<T>::create (GossCmdMerge.tcc:329-378)
+            static const OptDef kMerge[] = {
+                {"graph-in", "G", kStrings, "name of the input graph object"},
+                {"graphs-in", "", kString, "read graph names (one per line) from the given file."},
+                {"graph-out", "O", kString, "name of the output graph object"},
+                {"max-merge", "", kU64, "The maximum number of graphs to merge at once."},
+            };
+            OptTable t;
+            for (auto& d : kGlobal) t.defs.push_back(d);
+            for (auto& d : kMerge) t.defs.push_back(d);
+            for (auto& d : kGpuSpecific) t.defs.push_back(d);
+            Parsed opts; std::string bad;
+            parseArgs(argc, argv, 2, t, opts, bad);
+            if (!bad.empty())
+            {
+                if (opts.count("help")) { std::cerr << bad; printHelp(cmdName, &t); return 1; }
+                throw Error::Usage(bad);
+            }
+            Severity sev = opts.count("verbose") ? info : warning;
+            std::unique_ptr<Logger> logger;
+            if (opts.count("log-file"))
+            {
+                FILE* fp = fopen(opts.str("log-file").c_str(), "w");
+                if (!fp) throw Error::Errno(opts.str("log-file"), errno);
+                logger.reset(new Logger(fp, sev, true));
+            }
+            else logger.reset(new Logger(stderr, sev));
+            Checker chk{opts, std::string(), false};
+            strings ins;
+            if (opts.count("graph-in")) ins = opts.strs("graph-in");
+            chk.expand("graphs-in", ins);
+            if (ins.empty()) chk.errors += "At least one input graph must be supplied either using --graph-in or --graphs-in.\n";
+            uint64_t maxMerge = 8;
+            chk.optionalU64("max-merge", maxMerge);
+            std::string outName;
+            chk.mandatoryOut("graph-out", outName);
+            if (opts.count("help")) { printHelp(cmdName, &t); return 1; }
+            chk.throwIfNecessary();
+            GossCmdContext cxt{*logger, cmdName};
+            uint64_t dev = 0, budgetGb = 0;
+            if (chk.optionalU64("device", dev)) cxt.device = (int)dev;
+            if (chk.optionalU64("hbm-budget", budgetGb)) cxt.hbmBudget = budgetGb << 30;
+            try
+            {
+                if (cmdName == "merge-kmer-sets") { GossCmdMergeKmerSets cmd(ins, maxMerge, outName); cmd(cxt); }
+                else { GossCmdMergeGraphs cmd(ins, maxMerge, outName); cmd(cxt); }
+            }
+            catch (Error& e) { e.cmd = cmdName; throw; }
+            return 0;
+        }
         if (cmdName == "synth-reads")
         {
             // goss synth-reads <nreads> <read_len> <genome_len> <seed> <out.fq>: the bench's
@@ -915,7 +969,7 @@ int gossMain(int argc, char* argv[])
             uint64_t reads = 0;
             ReadSink sink = [&](const char* seq, size_t len) { fwrite(seq, 1, len, stdout); fputc('\n', stdout); };
             strings fastas, fastqs, lines;
-            Checker chk{opts};
+            Checker chk{opts, std::string(), false};
             chk.repeatingIn("fasta-in", fastas);
             chk.expand("fastas-in", fastas);
             chk.repeatingIn("fastq-in", fastqs);
@@ -979,7 +1033,7 @@ int gossMain(int argc, char* argv[])
             for (auto& d : opts.strs("debug")) (*logger)(warning, "unknown debug: " + d);
 
         // the factory (GossCmdBuildKmerSet.cc:151-198, GossCmdBuildGraph.cc:428-476)
-        Checker chk{opts};
+        Checker chk{opts, std::string(), false};
         uint64_t K = 0;
         chk.mandatoryU64("kmer-size", K, isGraph ? 62 : 63);
         uint64_t B = 2;

@@ -153,7 +153,26 @@ private:
     BuildStats mStats;
 };
 
-// App::main for the two commands (App.cc:176-417).
+// merge-kmer-sets / merge-graphs: GossCmdMerge<T>(ins, maxMerge, out) (GossCmdMerge.hh:22-37).
+class GossCmdMergeKmerSets {
+public:
+    GossCmdMergeKmerSets(const strings& pIns, const uint64_t& pMaxMerge, const std::string& pOut)
+        : mIns(pIns), mMaxMerge(pMaxMerge), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const strings mIns; const uint64_t mMaxMerge; const std::string mOut;
+};
+
+class GossCmdMergeGraphs {
+public:
+    GossCmdMergeGraphs(const strings& pIns, const uint64_t& pMaxMerge, const std::string& pOut)
+        : mIns(pIns), mMaxMerge(pMaxMerge), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const strings mIns; const uint64_t mMaxMerge; const std::string mOut;
+};
+
+// App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);
 
 }  // namespace gosshost

@@ -1,0 +1,346 @@
+// GossMerge.cpp -- `goss merge-kmer-sets` / `goss merge-graphs` (GossCmdMerge.tcc:151-326,
+// GossCmdMergeKmerSets.hh, GossCmdMergeGraphs.hh): k-way merge of existing objects, equal keys'
+// counts summed, the result built with the estimate M = sum of the inputs' counts.
+//
+// The inputs are read in their on-disk form and decoded on the device
+// (goss_gpu_push_run_sparse); the merge itself is the library's merge of sorted runs; the output
+// files are the device-built images, as for the build commands.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstring>
+#include <deque>
+#include <sstream>
+
+#include "../../include/goss_gpu.h"
+#include "GossHost.hpp"
+
+namespace gosshost {
+
+namespace {
+
+std::string num(uint64_t v) { return std::to_string(v); }
+
+// A whole file mapped read-only.
+struct Mapped {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    Mapped() = default;
+    Mapped(const Mapped&) = delete;
+    Mapped& operator=(const Mapped&) = delete;
+    Mapped(Mapped&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    ~Mapped() { if (p && n) munmap((void*)p, n); }
+    void open(const std::string& name)
+    {
+        int fd = ::open(name.c_str(), O_RDONLY);
+        if (fd < 0) throw Error::Errno(name, errno);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { int e = errno; ::close(fd); throw Error::Errno(name, e); }
+        n = (size_t)st.st_size;
+        if (n)
+        {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { int e = errno; ::close(fd); throw Error::Errno(name, e); }
+            p = (const uint8_t*)m;
+        }
+        ::close(fd);
+    }
+};
+
+struct Col { std::string suffix; uint32_t bytes; uint32_t shift; };
+
+// IntegerArray::builder column layout (IntegerArray.cc:259-357, StackedArray.hh:152-178).
+bool layout(uint32_t bits, const std::string& prefix, uint32_t shift, std::vector<Col>& out)
+{
+    uint32_t ub = 0, lb = 0;
+    switch (bits)
+    {
+        case 8: case 16: case 32: case 64: out.push_back({prefix, bits / 8, shift}); return true;
+        case 24: ub = 8; lb = 16; break;
+        case 40: ub = 8; lb = 32; break;
+        case 48: ub = 16; lb = 32; break;
+        case 56: ub = 8; lb = 48; break;
+        case 72: ub = 8; lb = 64; break;
+        case 80: ub = 16; lb = 64; break;
+        case 88: ub = 8; lb = 80; break;
+        case 96: ub = 32; lb = 64; break;
+        case 104: ub = 8; lb = 96; break;
+        case 112: ub = 16; lb = 96; break;
+        case 120: ub = 24; lb = 96; break;
+        case 128: ub = 64; lb = 64; break;
+        default: return false;
+    }
+    return layout(ub, prefix + ".upr", shift + lb, out) && layout(lb, prefix + ".lwr", shift, out);
+}
+
+struct SparseFiles {
+    uint64_t D = 0, qD = 0, count = 0;
+    Mapped high;
+    std::vector<Col> cols;
+    std::vector<Mapped> colFiles;
+};
+
+// SparseArray(base, fac) (SparseArray.cc:175-194): header version check, files of the array.
+void openSparse(const std::string& base, SparseFiles& s)
+{
+    Mapped hdr; hdr.open(base + ".header");
+    if (hdr.n < 64) throw Error::General("\tfile '" + base + ".header' is too short to be a SparseArray header\n");
+    uint64_t h[8]; memcpy(h, hdr.p, 64);
+    if (h[0] != 2012030501ULL)
+        throw Error::General("\ta version mismatch was detected. goss expected 2012030501 but found " + num(h[0]) + ".\n");
+    s.D = h[1]; s.qD = h[2]; s.count = h[7];
+    s.high.open(base + ".high-bits");
+    if (!layout((uint32_t)s.qD, "", 0, s.cols))
+        throw Error::General("IntegerArray::create: unsupported integer width " + num(s.qD));
+    s.colFiles.resize(s.cols.size());
+    for (size_t i = 0; i < s.cols.size(); ++i)
+    {
+        s.colFiles[i].open(base + ".low-bits" + s.cols[i].suffix);
+        if (s.colFiles[i].n < s.count * s.cols[i].bytes)
+            throw Error::General("\tfile '" + base + ".low-bits" + s.cols[i].suffix + "' is shorter than its header says\n");
+    }
+}
+
+// Positions of a small SparseArray of 64-bit positions, decoded on the host
+// (SparseArray::LazyIterator): the ord1p / ord2p presence maps of a VariableByteArray.
+std::vector<uint64_t> decodeSmallSparse(const std::string& base)
+{
+    SparseFiles s;
+    openSparse(base, s);
+    std::vector<uint64_t> out;
+    out.reserve(s.count);
+    const uint64_t* w = (const uint64_t*)s.high.p;
+    const uint64_t nw = s.high.n / 8;
+    uint64_t i = 0;
+    for (uint64_t k = 0; k < nw && i < s.count; ++k)
+    {
+        uint64_t x = w[k];
+        while (x && i < s.count)
+        {
+            uint64_t b = (uint64_t)__builtin_ctzll(x);
+            x &= x - 1;
+            uint64_t low = 0;
+            for (size_t c = 0; c < s.cols.size(); ++c)
+            {
+                uint64_t v = 0;
+                memcpy(&v, s.colFiles[c].p + i * s.cols[c].bytes, s.cols[c].bytes);
+                if (s.cols[c].shift < 64) low |= v << s.cols[c].shift;
+            }
+            uint64_t hi = k * 64 + b - i;
+            out.push_back((s.D >= 64 ? 0 : (hi << s.D)) + low);
+            ++i;
+        }
+    }
+    return out;
+}
+
+// VariableByteArray::GeneralIterator over the whole array (VariableByteArray.hh:120-195).
+std::vector<uint32_t> decodeCounts(const std::string& base, uint64_t n)
+{
+    Mapped o0, o1, o2;
+    o0.open(base + ".ord0"); o1.open(base + ".ord1"); o2.open(base + ".ord2");
+    if (o0.n < n) throw Error::General("\tfile '" + base + ".ord0' is shorter than the edge count\n");
+    std::vector<uint64_t> p1 = decodeSmallSparse(base + ".ord1p"), p2 = decodeSmallSparse(base + ".ord2p");
+    std::vector<uint32_t> c(n);
+    for (uint64_t i = 0; i < n; ++i) c[i] = o0.p[i];
+    for (size_t j = 0; j < p1.size() && j < o1.n; ++j)
+        if (p1[j] < n) c[p1[j]] |= (uint32_t)o1.p[j] << 8;
+    for (size_t j = 0; j < p2.size() && 2 * j + 2 <= o2.n; ++j)
+    {
+        uint16_t w; memcpy(&w, o2.p + 2 * j, 2);
+        if (p2[j] < p1.size() && p1[p2[j]] < n) c[p1[p2[j]]] |= (uint32_t)w << 16;
+    }
+    return c;
+}
+
+struct GpuCtx {
+    goss_gpu_ctx* h = nullptr;
+    ~GpuCtx() { if (h) goss_gpu_destroy(h); }
+    void check(int rc, const char* what)
+    {
+        if (rc == GOSS_OK) return;
+        std::string msg = std::string(what) + ": " + goss_gpu_strerror(rc);
+        const char* d = h ? goss_gpu_last_error(h) : "";
+        if (d && *d) msg += std::string(" (") + d + ")";
+        throw Error::General(msg + "\n");
+    }
+};
+
+struct ObjectInfo { uint64_t K = 0, count = 0; bool asymmetric = false; };
+
+// Header of an object: T::LazyIterator(name, fac).K() / .count() / .asymmetric().
+ObjectInfo objectInfo(const std::string& name, bool graph)
+{
+    ObjectInfo o;
+    Mapped hdr; hdr.open(name + ".header");
+    if (hdr.n < 24) throw Error::General("\tunable to open graph '" + name + "'\n");
+    uint64_t h[3]; memcpy(h, hdr.p, 24);
+    const uint64_t want = graph ? 2011101014ULL : 2011101701ULL;
+    if (h[0] != want)
+        throw Error::General("\ta version mismatch was detected. goss expected " + num(want) + " but found " + num(h[0]) + ".\n");
+    o.K = h[1];
+    if (!graph) { o.count = h[2]; return o; }
+    o.asymmetric = h[2] & 1;
+    // Graph::LazyIterator: count = sum of the frequencies in <name>-counts-hist.txt (Graph.cc:195-216)
+    Mapped hist; hist.open(name + "-counts-hist.txt");
+    const char* p = (const char*)hist.p; const char* e = p + hist.n;
+    std::string text(p ? p : "", hist.n);
+    std::istringstream in(text);
+    uint64_t m, c;
+    while (in >> m >> c) o.count += c;
+    (void)e;
+    return o;
+}
+
+// Decode one object into the context as a run.
+void pushObject(GpuCtx& g, const std::string& name, bool graph)
+{
+    SparseFiles s;
+    openSparse(graph ? name + "-edges" : name + ".kmers", s);
+    std::vector<uint32_t> counts;
+    if (graph) counts = decodeCounts(name + "-counts", s.count);
+    goss_gpu_sparse_run r{};
+    r.D = s.D; r.count = s.count;
+    r.high_bits = (const uint64_t*)s.high.p; r.high_words = s.high.n / 8;
+    r.ncols = (uint32_t)s.cols.size();
+    for (size_t i = 0; i < s.cols.size(); ++i)
+    {
+        r.col[i] = s.colFiles[i].p; r.col_bytes[i] = s.cols[i].bytes; r.col_shift[i] = s.cols[i].shift;
+    }
+    r.counts = graph ? counts.data() : nullptr;
+    g.check(goss_gpu_push_run_sparse(g.h, &r), "reading an input object");
+}
+
+struct HostRun { std::vector<uint64_t> keys; std::vector<uint32_t> counts; uint64_t m = 0; };
+
+struct Item { std::string name; bool temp = false; HostRun run; uint64_t count = 0; };
+
+void writeOut(GpuCtx& g, const std::string& out)
+{
+    uint32_t nfiles = 0;
+    g.check(goss_gpu_file_count(g.h, &nfiles), "listing output files");
+    for (uint32_t i = 0; i < nfiles; ++i)
+    {
+        char suffix[256]; uint64_t size = 0;
+        g.check(goss_gpu_file_info(g.h, i, suffix, sizeof suffix, &size), "listing output files");
+        FILE* fp = fopen((out + suffix).c_str(), "wb");
+        if (!fp) throw Error::Write(out);
+        const uint64_t piece = 64u << 20;
+        std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
+        for (uint64_t off = 0; off < size; off += piece)
+        {
+            uint64_t n = std::min(piece, size - off);
+            g.check(goss_gpu_file_read(g.h, i, off, buf.data(), n), "reading device file");
+            if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { fclose(fp); throw Error::Write(out); }
+        }
+        if (fclose(fp) != 0) throw Error::Write(out);
+    }
+}
+
+void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_t maxMerge, const std::string& out)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = cxt.log;
+    if (ins.empty()) throw Error::General("At least one input graph must be supplied either using --graph-in or --graphs-in.\n");
+    if (maxMerge < 2) maxMerge = 2;
+
+    // all inputs must agree on k (and on sense): GossCmdMerge.tcc:219-262.  The reference checks
+    // inside every merge() call; the groups are disjoint, so checking all pairs against the first
+    // member of their group is what it does -- done up front here, with the same text.
+    std::vector<ObjectInfo> infos;
+    uint64_t bytes = 0;
+    for (auto& n : ins)
+    {
+        infos.push_back(objectInfo(n, graph));
+        struct stat st;
+        for (const char* suf : {".kmers.high-bits", "-edges.high-bits"})
+            if (::stat((n + suf).c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
+        bytes += infos.back().count * 24;
+    }
+    const uint64_t K = infos[0].K;
+    const uint64_t maxK = graph ? 62 : 63;
+    if (K > maxK || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
+
+    uint64_t budget = cxt.hbmBudget ? cxt.hbmBudget : bytes * 6 + (4ULL << 30);
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, graph ? GOSS_MODE_GRAPH : GOSS_MODE_KMER_SET, budget, nullptr),
+            "creating the GPU context");
+    const size_t words = (2 * (K + (graph ? 1 : 0)) <= 62) ? 1 : 2;
+
+    std::deque<Item> todo;
+    for (size_t i = 0; i < ins.size(); ++i) { Item it; it.name = ins[i]; it.count = infos[i].count; todo.push_back(std::move(it)); }
+    std::deque<ObjectInfo> tinfo(infos.begin(), infos.end());
+
+    // one GossCmdMerge::merge(): returns the estimate `tot` it would give the Builder
+    auto mergeGroup = [&](std::vector<Item>& group, std::vector<ObjectInfo>& ginfo) -> uint64_t {
+        uint64_t tot = 0;
+        for (size_t i = 0; i < group.size(); ++i)
+        {
+            if (ginfo[i].K != ginfo[0].K)
+                throw Error::General("all graphs involved in a merge must have the same kmer-size.\n" + group[0].name + " has k="
+                                     + num(ginfo[0].K) + ".\n" + group[i].name + " has k=" + num(ginfo[i].K) + ".\n");
+            if (ginfo[i].asymmetric != ginfo[0].asymmetric)
+                throw Error::General("graphs involved in a merge must either all preserve sense or not.\n" + group[0].name
+                                     + (ginfo[0].asymmetric ? " preserves sense" : " does not preserve sense") + ".\n" + group[i].name
+                                     + (ginfo[i].asymmetric ? " preserves sense" : " does not preserve sense") + ".\n");
+            log(info, " " + group[i].name + " " + num(group[i].count));
+            tot += group[i].count;
+        }
+        g.check(goss_gpu_reset(g.h), "resetting the GPU context");
+        for (auto& it : group)
+        {
+            if (it.temp) g.check(goss_gpu_push_run_host(g.h, it.run.keys.data(), it.run.counts.data(), it.run.m), "re-reading a partial merge");
+            else pushObject(g, it.name, graph);
+        }
+        log(info, "starting graph merge");
+        goss_gpu_counts counts;
+        g.check(goss_gpu_finish(g.h, &counts), "merging");
+        return tot;
+    };
+
+    uint64_t serial = 0;
+    while (todo.size() > maxMerge)
+    {
+        std::vector<Item> group; std::vector<ObjectInfo> ginfo;
+        for (uint64_t i = 0; i < maxMerge; ++i)
+        {
+            group.push_back(std::move(todo.front())); todo.pop_front();
+            ginfo.push_back(tinfo.front()); tinfo.pop_front();
+        }
+        mergeGroup(group, ginfo);
+        // the temporary object of the reference stays in host memory here
+        Item t; t.temp = true; t.name = "<temporary " + num(serial++) + ">";
+        const void* dk; const uint32_t* dc; uint64_t m = 0;
+        g.check(goss_gpu_result(g.h, &dk, &dc, &m), "reading a partial merge");
+        t.run.m = m; t.run.keys.resize(m * words); t.run.counts.resize(m);
+        g.check(goss_gpu_result_copy(g.h, 0, m, t.run.keys.data(), t.run.counts.data()), "reading a partial merge");
+        t.count = m;
+        ObjectInfo ti = ginfo[0]; ti.count = m;
+        todo.push_back(std::move(t)); tinfo.push_back(ti);
+        log(info, "finishing graph merge");
+    }
+    std::vector<Item> group; std::vector<ObjectInfo> ginfo;
+    while (!todo.empty())
+    {
+        group.push_back(std::move(todo.front())); todo.pop_front();
+        ginfo.push_back(tinfo.front()); tinfo.pop_front();
+    }
+    const uint64_t tot = mergeGroup(group, ginfo);
+    g.check(goss_gpu_emit_estimate(g.h, tot), "building the on-disk arrays");
+    writeOut(g, out);
+    log(info, "finishing graph merge");
+    std::ostringstream os;
+    os << "total build time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    log(info, os.str());
+}
+
+}  // namespace
+
+void GossCmdMergeKmerSets::operator()(const GossCmdContext& pCxt) { runMerge(pCxt, false, mIns, mMaxMerge, mOut); }
+void GossCmdMergeGraphs::operator()(const GossCmdContext& pCxt) { runMerge(pCxt, true, mIns, mMaxMerge, mOut); }
+
+}  // namespace gosshost

@@ -163,6 +163,35 @@ int goss_gpu_timing_reset(goss_gpu_ctx* ctx);
 int goss_gpu_reset(goss_gpu_ctx* ctx);
 
 /*
+ * Feed an existing object as a run: a SparseArray in its on-disk form (host pointers to the
+ * high-bits words and the low-bits column files, D and count from its 64-byte header), decoded on
+ * the device the way SparseArray::LazyIterator walks it (SparseArray.hh:185-224), with one u32
+ * count per key or NULL for all ones (KmerSet::LazyIterator, KmerSet.hh:147-150).  This is how
+ * merge-kmer-sets / merge-graphs read their inputs (GossCmdMerge.tcc:52-69).
+ */
+typedef struct {
+    uint64_t D;
+    uint64_t count;
+    const uint64_t* high_bits;
+    uint64_t high_words;
+    uint32_t ncols;
+    uint32_t reserved;
+    const void* col[4];          /* low-bits column files */
+    uint32_t col_bytes[4];       /* element size of each column file */
+    uint32_t col_shift[4];       /* bit position of the column inside the low bits */
+    const uint32_t* counts;      /* count entries, or NULL */
+} goss_gpu_sparse_run;
+int goss_gpu_push_run_sparse(goss_gpu_ctx* ctx, const goss_gpu_sparse_run* run);
+
+/* A run in host memory (key_words u64 per key, strictly increasing) with u32 counts. */
+int goss_gpu_push_run_host(goss_gpu_ctx* ctx, const uint64_t* keys, const uint32_t* counts, uint64_t m);
+
+/* goss_gpu_emit with the SparseArray size estimate M given by the caller instead of the exact
+ * distinct count: GossCmdMerge builds with M = sum of the inputs' counts
+ * (GossCmdMerge.tcc:256-258,296), which changes D. */
+int goss_gpu_emit_estimate(goss_gpu_ctx* ctx, uint64_t m_estimate);
+
+/*
  * Page-locked host memory for the buffers handed to goss_gpu_push_bases_host (the copy to the
  * device then runs at PCIe speed instead of going through the driver's bounce buffers).
  */

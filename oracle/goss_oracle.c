@@ -1427,3 +1427,218 @@ uint64_t go_vbyte_decode(const uint8_t* in, size_t* used)
     *used = 1 + v;
     return x;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* merge-kmer-sets / merge-graphs (GossCmdMerge.tcc:151-326)                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* SparseArray::LazyIterator over the whole array: the i-th one of the high-bits bitmap at
+ * position p gives ((p - i) << D) + low[i].  SparseArray.hh:185-224,
+ * WordyBitVector::LazyIterator1. */
+static int sparse_decode_all(const go_fs* fs, const char* base, go_key** out, uint64_t* n, char* err, size_t errcap)
+{
+    go_sparse* s = go_sparse_open(fs, base, err, errcap);
+    if (!s) return -1;
+    uint64_t cnt = 0;
+    for (uint64_t w = 0; w < s->hi.nwords; ++w) cnt += (uint64_t)__builtin_popcountll(s->hi.w[w]);
+    go_key* k = (go_key*)malloc((cnt ? cnt : 1) * sizeof(go_key));
+    uint64_t i = 0;
+    for (uint64_t w = 0; w < s->hi.nwords; ++w)
+    {
+        uint64_t x = s->hi.w[w];
+        while (x)
+        {
+            uint64_t b = (uint64_t)__builtin_ctzll(x);
+            x &= x - 1;
+            u128 pos = (u128)(w * 64 + b - i);
+            pos = s->h.D >= 128 ? 0 : (pos << s->h.D);
+            pos += sa_low(s, i);
+            k[i++] = u2k(pos);
+        }
+    }
+    go_sparse_close(s);
+    *out = k; *n = cnt;
+    return 0;
+}
+
+/* VariableByteArray::GeneralIterator over the whole array.  VariableByteArray.hh:120-195 */
+static int vba_decode_all(const go_fs* fs, const char* base, uint64_t n, uint32_t** out, char* err, size_t errcap)
+{
+    char name[4096]; size_t n0, n1, n2;
+    snprintf(name, sizeof name, "%s.ord0", base);
+    const uint8_t* o0 = fs_get(fs, name, &n0, err, errcap); if (!o0) return -1;
+    snprintf(name, sizeof name, "%s.ord1", base);
+    const uint8_t* o1 = fs_get(fs, name, &n1, err, errcap); if (!o1) return -1;
+    snprintf(name, sizeof name, "%s.ord2", base);
+    const uint8_t* o2 = fs_get(fs, name, &n2, err, errcap); if (!o2) return -1;
+    if (n0 < n) { snprintf(err, errcap, "%s.ord0 too short", base); return -1; }
+    go_key *p1 = NULL, *p2 = NULL; uint64_t c1 = 0, c2 = 0;
+    snprintf(name, sizeof name, "%s.ord1p", base);
+    if (sparse_decode_all(fs, name, &p1, &c1, err, errcap)) return -1;
+    snprintf(name, sizeof name, "%s.ord2p", base);
+    if (sparse_decode_all(fs, name, &p2, &c2, err, errcap)) { free(p1); return -1; }
+    uint32_t* c = (uint32_t*)malloc((n ? n : 1) * 4);
+    uint64_t i1 = 0, i2 = 0;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        uint32_t v = o0[i];
+        while (i1 < c1 && p1[i1].lo < i) ++i1;
+        if (i1 < c1 && p1[i1].lo == i)
+        {
+            v |= (uint32_t)o1[i1] << 8;
+            while (i2 < c2 && p2[i2].lo < i1) ++i2;
+            if (i2 < c2 && p2[i2].lo == i1)
+            {
+                uint16_t w; memcpy(&w, o2 + 2 * i2, 2);
+                v |= (uint32_t)w << 16;
+            }
+        }
+        c[i] = v;
+    }
+    free(p1); free(p2);
+    *out = c;
+    return 0;
+}
+
+typedef struct { go_key* k; uint64_t* c; uint64_t n; } merge_item;
+
+static void merge_item_free(merge_item* m) { free(m->k); free(m->c); m->k = NULL; m->c = NULL; m->n = 0; }
+
+/* Load one object: keys + counts (KmerSet::LazyIterator yields count 1, KmerSet.hh:147-150;
+ * Graph::LazyIterator the VariableByteArray value, Graph.hh:288-291). */
+static int merge_load(const go_fs* fs, const char* name, int kind, uint64_t* K, uint64_t* cnt, merge_item* out, char* err, size_t errcap)
+{
+    char base[4096];
+    uint64_t hdrK = 0, x = 0;
+    if (kind == 0)
+    {
+        int rc = go_kmer_set_header(fs, name, &hdrK, &x);
+        if (rc) { snprintf(err, errcap, rc == -2 ? "%s: version mismatch" : "unable to open graph '%s'", name); return -1; }
+        snprintf(base, sizeof base, "%s.kmers", name);
+    }
+    else
+    {
+        int rc = go_graph_header(fs, name, &hdrK, &x);
+        if (rc) { snprintf(err, errcap, rc == -2 ? "%s: version mismatch" : "unable to open graph '%s'", name); return -1; }
+        snprintf(base, sizeof base, "%s-edges", name);
+    }
+    *K = hdrK;
+    uint64_t n = 0;
+    if (sparse_decode_all(fs, base, &out->k, &n, err, errcap)) return -1;
+    out->n = n;
+    out->c = (uint64_t*)malloc((n ? n : 1) * 8);
+    if (kind == 0)
+    {
+        for (uint64_t i = 0; i < n; ++i) out->c[i] = 1;
+        *cnt = x;                                       /* header count: KmerSet.hh:180-183 */
+    }
+    else
+    {
+        uint32_t* c32 = NULL;
+        snprintf(base, sizeof base, "%s-counts", name);
+        if (vba_decode_all(fs, base, n, &c32, err, errcap)) return -1;
+        for (uint64_t i = 0; i < n; ++i) out->c[i] = c32[i];
+        free(c32);
+        /* count() = sum of the frequencies in <name>-counts-hist.txt.  Graph.cc:195-216 */
+        snprintf(base, sizeof base, "%s-counts-hist.txt", name);
+        int fi = go_fs_find(fs, base);
+        if (fi < 0) { snprintf(err, errcap, "missing file %s", base); return -1; }
+        uint64_t tot = 0;
+        const char* p = (const char*)fs->files[fi].data; const char* e = p + fs->files[fi].size;
+        while (p < e)
+        {
+            char* q; unsigned long long m = strtoull(p, &q, 10);
+            if (q == p) break;
+            p = q;
+            unsigned long long c = strtoull(p, &q, 10);
+            if (q == p) break;
+            p = q; (void)m;
+            tot += c;
+        }
+        *cnt = tot;
+    }
+    return 0;
+}
+
+/* One GossCmdMerge::merge (GossCmdMerge.tcc:207-326): k-way merge of the items, equal keys
+ * summed (saturating at 2^63), estimate M = tot. */
+static void merge_many(merge_item* items, size_t n, merge_item* out)
+{
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += items[i].n;
+    go_key* k = (go_key*)malloc((total ? total : 1) * sizeof(go_key));
+    uint64_t* c = (uint64_t*)malloc((total ? total : 1) * 8);
+    size_t* at = (size_t*)calloc(n ? n : 1, sizeof(size_t));
+    uint64_t m = 0;
+    for (;;)
+    {
+        int best = -1;
+        for (size_t i = 0; i < n; ++i)
+        {
+            if (at[i] >= items[i].n) continue;
+            if (best < 0 || k2u(items[i].k[at[i]]) < k2u(items[best].k[at[best]])) best = (int)i;
+        }
+        if (best < 0) break;
+        go_key key = items[best].k[at[best]];
+        uint64_t cnt = items[best].c[at[best]];
+        ++at[best];
+        if (m && k[m - 1].lo == key.lo && k[m - 1].hi == key.hi)
+        {
+            uint64_t s = c[m - 1] + cnt;
+            if (s > (1ULL << 63) || s < cnt) s = 1ULL << 63;
+            c[m - 1] = s;
+        }
+        else { k[m] = key; c[m] = cnt; ++m; }
+    }
+    free(at);
+    out->k = k; out->c = c; out->n = m;
+}
+
+int go_merge(const go_fs* in, const char* const* names, size_t nin, int kind, uint64_t max_merge,
+             go_fs* outfs, const char* out_name, char* err, size_t errcap)
+{
+    if (nin == 0) { snprintf(err, errcap, "At least one input graph must be supplied either using --graph-in or --graphs-in.\n"); return -1; }
+    if (max_merge < 2) max_merge = 2;
+    /* todo list: (item, count used for the estimate).  GossCmdMerge.tcc:151-205 */
+    merge_item* todo = (merge_item*)calloc(nin * 2 + 2, sizeof(merge_item));
+    uint64_t* todo_cnt = (uint64_t*)calloc(nin * 2 + 2, sizeof(uint64_t));
+    size_t head = 0, tail = 0;
+    uint64_t K0 = 0;
+    int rc = 0;
+    for (size_t i = 0; i < nin; ++i)
+    {
+        uint64_t K = 0;
+        if (merge_load(in, names[i], kind, &K, &todo_cnt[tail], &todo[tail], err, errcap)) { rc = -1; goto out; }
+        if (i == 0) K0 = K;
+        else if (K != K0)
+        {
+            snprintf(err, errcap, "all graphs involved in a merge must have the same kmer-size.\n%s has k=%llu.\n%s has k=%llu.\n",
+                     names[0], (unsigned long long)K0, names[i], (unsigned long long)K);
+            ++tail; rc = -1; goto out;
+        }
+        ++tail;
+    }
+    while (tail - head > max_merge)
+    {
+        merge_item m;
+        merge_many(todo + head, (size_t)max_merge, &m);
+        for (size_t i = 0; i < max_merge; ++i) merge_item_free(&todo[head + i]);
+        head += (size_t)max_merge;
+        if (tail >= nin * 2 + 2) { rc = -1; snprintf(err, errcap, "internal: todo overflow"); merge_item_free(&m); goto out; }
+        todo[tail] = m; todo_cnt[tail] = m.n; ++tail;       /* count() of the temporary object */
+    }
+    {
+        uint64_t tot = 0;
+        for (size_t i = head; i < tail; ++i) tot += todo_cnt[i];
+        merge_item m;
+        merge_many(todo + head, tail - head, &m);
+        if (kind == 0) rc = go_write_kmer_set(outfs, out_name, (unsigned)K0, m.k, m.n, tot);
+        else rc = go_write_graph(outfs, out_name, (unsigned)K0, m.k, m.c, m.n, tot);
+        if (rc) snprintf(err, errcap, "write error");
+        merge_item_free(&m);
+    }
+out:
+    for (size_t i = head; i < tail; ++i) merge_item_free(&todo[i]);
+    free(todo); free(todo_cnt);
+    return rc ? -1 : 0;
+}

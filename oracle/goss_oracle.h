@@ -110,6 +110,12 @@ int      go_vba_get(const go_fs* fs, const char* base, uint64_t i, uint32_t* out
 int      go_kmer_set_header(const go_fs* fs, const char* base, uint64_t* K, uint64_t* count);
 int      go_graph_header(const go_fs* fs, const char* base, uint64_t* K, uint64_t* flags);
 
+/* merge-kmer-sets (kind 0) / merge-graphs (kind 1): GossCmdMerge.tcc:151-326.  Inputs are
+ * objects in `in`, the result is written to `out`; the estimate M is the sum of the inputs'
+ * counts, groups of max_merge are merged first when there are more inputs than that. */
+int go_merge(const go_fs* in, const char* const* names, size_t nin, int kind, uint64_t max_merge,
+             go_fs* out, const char* out_name, char* err, size_t errcap);
+
 /* VByte (spill-run private format; golden bytes in testVByteCodec.cc) */
 size_t   go_vbyte_encode(uint64_t x, uint8_t* out /* >= 9 */);  /* VByteCodec.hh:24-104 */
 uint64_t go_vbyte_decode(const uint8_t* in, size_t* used);

@@ -344,3 +344,18 @@ def vbyte_decode(b):
     used = C.c_size_t(0)
     v = lib().go_vbyte_decode(buf, C.byref(used))
     return v, used.value
+
+
+def merge(files, names, kind, out, max_merge=8):
+    """merge-kmer-sets (kind 0) / merge-graphs (kind 1) over objects held in `files`."""
+    L = lib()
+    L.go_merge.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint64, C.c_void_p, C.c_char_p,
+                           C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    dst = FileSet()
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    err = C.create_string_buffer(1024)
+    rc = L.go_merge(src.handle, arr, len(names), kind, max_merge, dst.handle, out.encode(), err, 1024)
+    if rc:
+        raise OracleError(err.value.decode())
+    return dst.files()

@@ -354,3 +354,65 @@ def test_distributed_path_world1(oracle):
             assert got[name] == exp[name], name
     finally:
         dist.destroy_process_group()
+
+
+def test_goss_merge_commands(oracle, tmp_path):
+    """goss merge-kmer-sets / merge-graphs (GossCmdMerge.tcc:151-326): objects built by the product
+    are decoded on the device, merged, and written with the estimate M = sum of the input counts;
+    every output file must equal the oracle's restatement of the reference merge, for one- and
+    two-word keys, a full merge and --max-merge 2 (intermediate objects change the estimate)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    goss = os.path.join(root, "gossamer_amd", "goss")
+    rng = random.Random(41)
+    parts = []
+    for p in range(4):
+        reads = make_reads(rng, 400, (60, 150), 20000 if p < 3 else 500)
+        txt = "\n".join(reads) + "\n"
+        (tmp_path / ("p%d.txt" % p)).write_text(txt)
+        parts.append(txt)
+
+    def run(args):
+        p = subprocess.run([goss] + args + ["--hbm-budget", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        return p
+
+    def disk(base):
+        return {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path)
+                if n.startswith(base + ".") or n.startswith(base + "-")}
+
+    for cmd_b, cmd_m, kind, k in (("build-kmer-set", "merge-kmer-sets", 0, 25), ("build-graph", "merge-graphs", 1, 27),
+                                  ("build-kmer-set", "merge-kmer-sets", 0, 51), ("build-graph", "merge-graphs", 1, 55)):
+        tag = "%s%d" % ("gr" if kind else "ks", k)
+        files = {}
+        names = []
+        for i in range(4):
+            base = "%s_%d" % (tag, i)
+            p = run([cmd_b, "-k", str(k), "--line-in", str(tmp_path / ("p%d.txt" % i)), "-O", str(tmp_path / base)])
+            assert p.returncode == 0, p.stderr.decode()
+            files.update(disk(base))
+            names.append(base)
+        (tmp_path / "list.txt").write_text("".join(str(tmp_path / n) + "\n" for n in names[2:]))
+        for mm in (8, 2):
+            out = "%s_m%d" % (tag, mm)
+            exp = oracle.merge(files, names, kind, out, max_merge=mm)
+            args = [cmd_m, "-G", str(tmp_path / names[0]), "-G", str(tmp_path / names[1]),
+                    "--graphs-in", str(tmp_path / "list.txt"), "-O", str(tmp_path / out), "--max-merge", str(mm), "-v"]
+            p = run(args)
+            assert p.returncode == 0, p.stderr.decode()
+            got = disk(out)
+            assert sorted(got) == sorted(exp), (cmd_m, k, mm)
+            for name in exp:
+                assert got[name] == exp[name], (cmd_m, k, mm, name)
+    # a single input is a re-encode with M = its own count
+    exp = oracle.merge(files, names[:1], 1, "one")
+    p = run(["merge-graphs", "-G", str(tmp_path / names[0]), "-O", str(tmp_path / "one")])
+    assert p.returncode == 0, p.stderr.decode()
+    got = disk("one")
+    assert sorted(got) == sorted(exp) and all(got[n] == exp[n] for n in exp)
+    # error texts
+    p = run(["merge-graphs", "-O", str(tmp_path / "x")])
+    assert p.returncode == 1
+    assert "At least one input graph must be supplied either using --graph-in or --graphs-in." in p.stderr.decode()
+    p = run(["merge-graphs", "-G", str(tmp_path / "gr27_0"), "-G", str(tmp_path / "gr55_0"), "-O", str(tmp_path / "x")])
+    assert p.returncode == 1 and "must have the same kmer-size" in p.stderr.decode()

@@ -275,3 +275,59 @@ def test_build_commands_end_to_end(oracle):
         oracle.build_kmer_set([(oracle.FASTQ, "r.fq", fq)], 64)
     with pytest.raises(oracle.OracleError, match="unable to build a graph with k=63"):
         oracle.build_graph([(oracle.FASTQ, "r.fq", fq)], 63)
+
+
+def test_merge_commands(oracle):
+    """GossCmdMerge.tcc:151-326: union of the keys, counts summed, estimate M = sum of the input
+    counts (so D differs from a direct build), groups of --max-merge first."""
+    rng = random.Random(23)
+    genome = "".join(rng.choice("ACGT") for _ in range(3000))
+    parts = []
+    for p in range(3):
+        reads = [genome[s:s + 80] for s in (rng.randrange(0, 2920) for _ in range(150))]
+        parts.append("\n".join(reads) + "\n")
+    k = 21
+    files = {}
+    sets = []
+    for i, txt in enumerate(parts):
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "r", txt)], k, out="ks%d" % i)
+        files.update(f)
+        r = oracle.SparseReader(f, "ks%d.kmers" % i)
+        sets.append([r.select(j) for j in range(r.count())])
+    merged = oracle.merge(files, ["ks0", "ks1", "ks2"], 0, "m")
+    r = oracle.SparseReader(merged, "m.kmers")
+    union = sorted(set().union(*sets))
+    assert [r.select(j) for j in range(r.count())] == union
+    assert oracle.kmer_set_header(merged, "m") == (k, len(union))
+    D = struct.unpack("<Q", merged["m.kmers.header"][8:16])[0]
+    tot = sum(len(s) for s in sets)
+    assert D == oracle.lib().go_sparse_d(oracle.key(4 ** k), tot)
+    # max-merge 2: ks0+ks1 first, then ks2 + temp: the estimate is |ks2| + |ks0 u ks1|
+    merged2 = oracle.merge(files, ["ks0", "ks1", "ks2"], 0, "m", max_merge=2)
+    r2 = oracle.SparseReader(merged2, "m.kmers")
+    assert [r2.select(j) for j in range(r2.count())] == union
+    D2 = struct.unpack("<Q", merged2["m.kmers.header"][8:16])[0]
+    assert D2 == oracle.lib().go_sparse_d(oracle.key(4 ** k), len(sets[2]) + len(set(sets[0]) | set(sets[1])))
+    # graphs: counts add up
+    gfiles = {}
+    expect = {}
+    for i, txt in enumerate(parts):
+        f, _ = oracle.build_graph([(oracle.LINE, "r", txt)], k, out="g%d" % i)
+        gfiles.update(f)
+        keys, _, _ = oracle.collect([(oracle.LINE, "r", txt)], k + 1, 1)
+        for x in keys:
+            expect[x] = expect.get(x, 0) + 1
+    mg = oracle.merge(gfiles, ["g0", "g1", "g2"], 1, "mg")
+    r = oracle.SparseReader(mg, "mg-edges")
+    ek = sorted(expect)
+    assert [r.select(j) for j in range(r.count())] == ek
+    for j in sorted(rng.sample(range(len(ek)), 200)):
+        assert oracle.vba_get(mg, "mg-counts", j) == expect[ek[j]]
+    hist = {}
+    for c in expect.values():
+        hist[c] = hist.get(c, 0) + 1
+    assert mg["mg-counts-hist.txt"].decode() == "".join("%d\t%d\n" % (c, hist[c]) for c in sorted(hist))
+    with pytest.raises(oracle.OracleError, match="must have the same kmer-size"):
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "r", parts[0])], 19, out="other")
+        files.update(f)
+        oracle.merge(files, ["ks0", "other"], 0, "x")
