@@ -1433,10 +1433,67 @@ int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<Key2>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
                                (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, (Key2*)r.keys);
         if (s->counts) HIP_TRY(hipMemcpyAsync(r.counts, s->counts, m * 4, hipMemcpyHostToDevice, c->stream));
-        else hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, r.counts, m, 1u);
+        else hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, r.counts, m, s->weight ? s->weight : 1u);
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->arena.release(mark);
         c->runs.push_back(r);
+    });
+}
+
+extern "C++" {
+template <class K>
+static void select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
+{
+    const uint64_t n = c->M;
+    if (n == 0) return;
+    uint64_t mark = c->arena.mark();
+    const uint64_t ntiles = (n + kRedTile - 1) / kRedTile;
+    uint64_t* tile_counts = (uint64_t*)c->arena.temp((ntiles + 1) * 8);
+    hipLaunchKernelGGL(select_count_kernel, dim3(grid_for(n, kRedTile)), dim3(kTB), 0, c->stream,
+                       (const uint32_t*)c->res_counts, n, lo, hi, tile_counts);
+    HIP_TRY(hipMemsetAsync(tile_counts + ntiles, 0, 8, c->stream));
+    exclusive_scan_u64(c, tile_counts, ntiles + 1);
+    uint64_t* h = (uint64_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, tile_counts + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t m = h[0];
+    K* keys = (K*)c->arena.perm(std::max<uint64_t>(m * sizeof(K), 16));
+    uint32_t* counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m * 4, 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(select_write_kernel<K>), dim3(grid_for(n, kRedTile)), dim3(kTB), 0, c->stream,
+                       (const K*)c->res_keys, (const uint32_t*)c->res_counts, n, lo, hi, (const uint64_t*)tile_counts, keys, counts);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+    c->res_keys = keys; c->res_counts = counts; c->M = m;
+}
+}  // extern "C++"
+
+int goss_gpu_select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
+{
+    if (!c || lo > hi) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished || c->emitted) { c->last_error = "select_counts belongs between finish and emit"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        PhaseTimer t(c, GOSS_T_REDUCE, c->M);
+        if (c->words == 1) select_counts<Key1>(c, lo, hi); else select_counts<Key2>(c, lo, hi);
+        t.stop();
+    });
+}
+
+int goss_gpu_emit_count_bits(goss_gpu_ctx* c, uint32_t mask, const char* suffix)
+{
+    if (!c || !suffix || !mask) return GOSS_ERR_INVALID_ARG;
+    if (!c->emitted) { c->last_error = "emit_count_bits follows emit"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        // WordyBitVector::Builder after M push_backX calls and end(): floor((M-1)/64)+1 words,
+        // one (zero) word when nothing was pushed (WordyBitVector.hh:90-116, .cc:18-29)
+        const uint64_t m = c->M, nwords = m ? (m - 1) / 64 + 1 : 1;
+        uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
+        if (m == 0) HIP_TRY(hipMemsetAsync(words, 0, 8, c->stream));
+        else
+            hipLaunchKernelGGL(count_bits_kernel, dim3(grid_for((nwords + 63) / 64 * 64, 256)), dim3(256), 0, c->stream,
+                               (const uint32_t*)c->res_counts, m, mask, words, nwords);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        OutFile f; f.suffix = suffix; f.size = nwords * 8; f.dev = (const uint8_t*)words;
+        c->files.push_back(std::move(f));
     });
 }
 

@@ -963,6 +963,99 @@ __global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m,
     counts[j] = (uint32_t)s;
 }
 
+// Selection by count: keeps the (key,count) items with lo <= count <= hi, order preserved.
+// The set algebra of intersect-kmer-sets / subtract-kmer-set is a merge of weighted runs
+// followed by this filter (GossCmdIntersectKmerSets.cc:29-79, GossCmdSubtractKmerSet.cc:47-66).
+__global__ __launch_bounds__(kTB) void select_count_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                           uint32_t lo, uint32_t hi, uint64_t* __restrict__ tile_counts)
+{
+    __shared__ uint32_t sh[kWaves + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * kRedTile;
+    uint32_t c = 0;
+#pragma unroll 4
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) { uint32_t v = counts[i]; c += (v >= lo && v <= hi) ? 1u : 0u; }
+    }
+    uint32_t tot;
+    block_excl_scan<uint32_t>(c, sh, &tot);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+template <class K>
+__global__ __launch_bounds__(kTB) void select_write_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ counts,
+                                                           uint64_t n, uint32_t lo, uint32_t hi,
+                                                           const uint64_t* __restrict__ tile_offsets,
+                                                           K* __restrict__ out_keys, uint32_t* __restrict__ out_counts)
+{
+    __shared__ uint32_t cnt[kRedItems * kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kRedTile;
+    const uint32_t lane = lane_id(), w = wave_id();
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+    K key[kRedItems];
+    uint32_t val[kRedItems];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        bool keep = false;
+        if (i < n)
+        {
+            key[j] = keys[i];
+            val[j] = counts[i];
+            keep = val[j] >= lo && val[j] <= hi;
+        }
+        if (keep) flags |= 1u << j;
+        uint64_t bal = __ballot(keep);
+        if (lane == 0) cnt[j * kWaves + w] = __popcll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+    {
+        uint32_t c = cnt[threadIdx.x];
+        uint32_t inc = wave_incl_scan(c);
+        cnt[threadIdx.x] = inc - c;
+    }
+    __syncthreads();
+    const uint64_t tile_off = tile_offsets[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kRedItems; ++j)
+    {
+        bool keep = (flags >> j) & 1u;
+        uint64_t bal = __ballot(keep);
+        if (keep)
+        {
+            uint64_t o = tile_off + cnt[j * kWaves + w] + __popcll(bal & lt_mask);
+            out_keys[o] = key[j];
+            out_counts[o] = val[j];
+        }
+    }
+}
+
+// One bit per item: bit i = (counts[i] & mask) != 0, WordyBitVector word layout (bit b of word w
+// = position 64w+b).  One wave per 64 words: lane l ballots item (word*64 + l).
+__global__ __launch_bounds__(256) void count_bits_kernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t mask,
+                                                         uint64_t* __restrict__ words, uint64_t nwords)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t w0 = wave * 64;
+    if (w0 >= nwords) return;
+    uint64_t mine = 0;
+    for (uint32_t j = 0; j < 64; ++j)
+    {
+        uint64_t w = w0 + j;
+        if (w >= nwords) break;                      // uniform across the wave
+        uint64_t i = w * 64 + lane;
+        bool bit = i < n && (counts[i] & mask) != 0;
+        uint64_t bal = __ballot(bit);
+        if (lane == j) mine = bal;
+    }
+    if (w0 + lane < nwords) words[w0 + lane] = mine;
+}
+
 // --------------------------------------------------------------------------------------
 // K3/K5 fast path: per-segment counting in an LDS hash table
 // --------------------------------------------------------------------------------------

@@ -850,8 +850,11 @@ void printHelp(const std::string& cmdName, const OptTable* t)
               << "  build-graph      create a new graph\n"
               << "  build-kmer-set   create a new graph\n"
               << "  help             print a summary of all the commands.\n"
+              << "  intersect-kmer-sets  generate the intersection of the given k-mer sets\n"
+              << "  merge-and-annotate-kmer-sets  Decorate a graph with an assignment of kmers to graphs.\n"
               << "  merge-graphs     create a new graph by merging zero or more existing graphs\n"
-              << "  merge-kmer-sets  create a new graph by merging zero or more existing graphs\n";
+              << "  merge-kmer-sets  create a new graph by merging zero or more existing graphs\n"
+              << "  subtract-kmer-set  subtract the second k-mer set from the first\n";
     if (t)
     {
         std::cerr << "\n" << cmdName << "\n" << t->describe() << std::endl;
@@ -874,12 +877,18 @@ int gossMain(int argc, char* argv[])
         else { cmdName = argv[1]; if (argv[1][0] != '-') argsToSkip = 1; }
 
         const bool isKmerSet = cmdName == "build-kmer-set", isGraph = cmdName == "build-graph";
-        if (cmdName == "merge-kmer-sets" || cmdName == "merge-graphs")
+        const bool isMerge = cmdName == "merge-kmer-sets" || cmdName == "merge-graphs";
+        const bool isIntersect = cmdName == "intersect-kmer-sets", isSubtract = cmdName == "subtract-kmer-set";
+        const bool isAnnotate = cmdName == "merge-and-annotate-kmer-sets";
+        if (isMerge || isIntersect || isSubtract || isAnnotate)
         {
+            // GossCmdFactoryIntersectKmerSets::create (GossCmdIntersectKmerSets.cc:131-150),
+            // GossCmdFactorySubtractKmerSet::create (GossCmdSubtractKmerSet.cc:88-113),
+            // GossCmdFactoryMergeAndAnnotateKmerSets::create (GossCmdMergeAndAnnotateKmerSets.cc:209-224),
             // GossCmdFactoryMerge<T>::create (GossCmdMerge.tcc:329-378)
             static const OptDef kMerge[] = {
                 {"graph-in", "G", kStrings, "name of the input graph object"},
-                {"graphs-in", "", kString, "read graph names (one per line) from the given file."},
+                {"graphs-in", "", kStrings, "read graph names (one per line) from the given file."},
                 {"graph-out", "O", kString, "name of the output graph object"},
                 {"max-merge", "", kU64, "The maximum number of graphs to merge at once."},
             };
@@ -905,13 +914,27 @@ int gossMain(int argc, char* argv[])
             else logger.reset(new Logger(stderr, sev));
             Checker chk{opts, std::string(), false};
             strings ins;
-            if (opts.count("graph-in")) ins = opts.strs("graph-in");
-            chk.expand("graphs-in", ins);
-            if (ins.empty()) chk.errors += "At least one input graph must be supplied either using --graph-in or --graphs-in.\n";
             uint64_t maxMerge = 8;
-            chk.optionalU64("max-merge", maxMerge);
             std::string outName;
-            chk.mandatoryOut("graph-out", outName);
+            if (isAnnotate)
+            {
+                if (!opts.count("graph-in")) { chk.errors += "mandatory option graph-in was not given.\n"; chk.suggestUsage = true; }
+                else if (opts.strs("graph-in").size() != 2)
+                { chk.errors += "mandatory option graph-in must be supplied exactly twice.\n"; chk.suggestUsage = true; }
+                else ins = opts.strs("graph-in");
+                if (!opts.count("graph-out")) { chk.errors += "mandatory option graph-out was not given.\n"; chk.suggestUsage = true; }
+                else outName = opts.str("graph-out");
+            }
+            else
+            {
+                if (opts.count("graph-in")) ins = opts.strs("graph-in");
+                chk.expand("graphs-in", ins);
+                if (isMerge && ins.empty())
+                    chk.errors += "At least one input graph must be supplied either using --graph-in or --graphs-in.\n";
+                if (isMerge) chk.optionalU64("max-merge", maxMerge);
+                chk.mandatoryOut("graph-out", outName);
+                if (isSubtract && ins.size() != 2) chk.errors += "Exactly two input k-mer sets required!";
+            }
             if (opts.count("help")) { printHelp(cmdName, &t); return 1; }
             chk.throwIfNecessary();
             GossCmdContext cxt{*logger, cmdName};
@@ -921,7 +944,10 @@ int gossMain(int argc, char* argv[])
             try
             {
                 if (cmdName == "merge-kmer-sets") { GossCmdMergeKmerSets cmd(ins, maxMerge, outName); cmd(cxt); }
-                else { GossCmdMergeGraphs cmd(ins, maxMerge, outName); cmd(cxt); }
+                else if (isMerge) { GossCmdMergeGraphs cmd(ins, maxMerge, outName); cmd(cxt); }
+                else if (isIntersect) { GossCmdIntersectKmerSets cmd(ins, outName); cmd(cxt); }
+                else if (isSubtract) { GossCmdSubtractKmerSet cmd(ins, outName); cmd(cxt); }
+                else { GossCmdMergeAndAnnotateKmerSets cmd(ins[0], ins[1], outName); cmd(cxt); }
             }
             catch (Error& e) { e.cmd = cmdName; throw; }
             return 0;

@@ -172,6 +172,33 @@ private:
     const strings mIns; const uint64_t mMaxMerge; const std::string mOut;
 };
 
+// Set algebra on existing k-mer sets: GossCmdIntersectKmerSets.hh:23, GossCmdSubtractKmerSet.hh:23,
+// GossCmdMergeAndAnnotateKmerSets.hh:21 (same constructor arguments).
+class GossCmdIntersectKmerSets {
+public:
+    GossCmdIntersectKmerSets(const strings& pIns, const std::string& pOut) : mIns(pIns), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const strings mIns; const std::string mOut;
+};
+
+class GossCmdSubtractKmerSet {
+public:
+    GossCmdSubtractKmerSet(const strings& pIns, const std::string& pOut) : mIns(pIns), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const strings mIns; const std::string mOut;
+};
+
+class GossCmdMergeAndAnnotateKmerSets {
+public:
+    GossCmdMergeAndAnnotateKmerSets(const std::string& pLhs, const std::string& pRhs, const std::string& pOut)
+        : mLhs(pLhs), mRhs(pRhs), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const std::string mLhs, mRhs, mOut;
+};
+
 // App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);
 

@@ -197,7 +197,7 @@ ObjectInfo objectInfo(const std::string& name, bool graph)
 }
 
 // Decode one object into the context as a run.
-void pushObject(GpuCtx& g, const std::string& name, bool graph)
+void pushObject(GpuCtx& g, const std::string& name, bool graph, uint32_t weight = 1)
 {
     SparseFiles s;
     openSparse(graph ? name + "-edges" : name + ".kmers", s);
@@ -212,6 +212,7 @@ void pushObject(GpuCtx& g, const std::string& name, bool graph)
         r.col[i] = s.colFiles[i].p; r.col_bytes[i] = s.cols[i].bytes; r.col_shift[i] = s.cols[i].shift;
     }
     r.counts = graph ? counts.data() : nullptr;
+    r.weight = weight;
     g.check(goss_gpu_push_run_sparse(g.h, &r), "reading an input object");
 }
 
@@ -338,7 +339,145 @@ void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_
     log(info, os.str());
 }
 
+// The estimate of HBM needed to hold the decoded inputs and merge them.
+uint64_t setBudget(const GossCmdContext& cxt, const strings& ins, std::vector<ObjectInfo>& infos)
+{
+    uint64_t bytes = 0;
+    for (auto& n : ins)
+    {
+        infos.push_back(objectInfo(n, false));
+        struct stat st;
+        if (::stat((n + ".kmers.high-bits").c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
+        bytes += infos.back().count * 24;
+    }
+    return cxt.hbmBudget ? cxt.hbmBudget : bytes * 6 + (4ULL << 30);
+}
+
+std::string elapsed(std::chrono::steady_clock::time_point t0)
+{
+    std::ostringstream os;
+    os << "total elapsed time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return os.str();
+}
+
+// Every input must fit the key width chosen from the first input's K.  The reference compares
+// the raw values whatever their K (GossCmdIntersectKmerSets.cc:112-116 takes K from the first
+// set only); mixing k-mer sizes is meaningless, so it is an error here.
+void requireSameK(const strings& ins, const std::vector<ObjectInfo>& infos)
+{
+    for (size_t i = 1; i < ins.size(); ++i)
+        if (infos[i].K != infos[0].K)
+            throw Error::General("all k-mer sets must have the same kmer-size.\n" + ins[0] + " has k=" + num(infos[0].K) + ".\n"
+                                 + ins[i] + " has k=" + num(infos[i].K) + ".\n");
+}
+
 }  // namespace
+
+// GossCmdIntersectKmerSets::operator() (GossCmdIntersectKmerSets.cc:96-128): the k-mers present
+// in every non-empty input, built with the exact count.  Each set is one run of weight 1; after
+// the merge the k-mers whose count equals the number of sets are kept.
+void GossCmdIntersectKmerSets::operator()(const GossCmdContext& pCxt)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = pCxt.log;
+    if (mIns.empty())
+    {
+        log(info, "no input k-mer sets!");
+        log(info, elapsed(t0));
+        return;
+    }
+    std::vector<ObjectInfo> infos;
+    const uint64_t budget = setBudget(pCxt, mIns, infos);
+    requireSameK(mIns, infos);
+    const uint64_t K = infos[0].K;
+    if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    log(info, "counting k-mers");
+    uint32_t sets = 0;
+    for (size_t i = 0; i < mIns.size(); ++i)
+    {
+        if (infos[i].count == 0) continue;           // an invalid iterator is not kept (:38-41)
+        pushObject(g, mIns[i], false, 1);
+        ++sets;
+    }
+    // every input empty: the reference's loop dereferences an empty vector; here the result is
+    // the empty set
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "merging");
+    g.check(goss_gpu_select_counts(g.h, sets ? sets : 1, sets ? sets : 1), "selecting the common k-mers");
+    uint64_t m = 0;
+    g.check(goss_gpu_result(g.h, nullptr, nullptr, &m), "counting");
+    log(info, "found " + num(m) + " k-mers");
+    log(info, "building intersection");
+    g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
+    writeOut(g, mOut);
+    log(info, elapsed(t0));
+}
+
+// GossCmdSubtractKmerSet::operator() (GossCmdSubtractKmerSet.cc:32-85): lhs weight 1, rhs
+// weight 2; a merged count of exactly 1 means "in lhs only".
+void GossCmdSubtractKmerSet::operator()(const GossCmdContext& pCxt)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = pCxt.log;
+    if (mIns.size() != 2) throw Error::General("Exactly two input k-mer sets required!");
+    std::vector<ObjectInfo> infos;
+    const uint64_t budget = setBudget(pCxt, mIns, infos);
+    requireSameK(mIns, infos);
+    const uint64_t K = infos[0].K;
+    if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    log(info, "calculating difference");
+    pushObject(g, mIns[0], false, 1);
+    pushObject(g, mIns[1], false, 2);
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "merging");
+    g.check(goss_gpu_select_counts(g.h, 1, 1), "selecting the difference");
+    uint64_t m = 0;
+    g.check(goss_gpu_result(g.h, nullptr, nullptr, &m), "counting");
+    log(info, "found " + num(m) + " k-mers in difference");
+    log(info, "building difference set");
+    g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
+    writeOut(g, mOut);
+    log(info, elapsed(t0));
+}
+
+// GossCmdMergeAndAnnotateKmerSets::operator() (GossCmdMergeAndAnnotateKmerSets.cc:30-206): the
+// union of two k-mer sets built with the exact count, plus one membership bitmap per side.
+void GossCmdMergeAndAnnotateKmerSets::operator()(const GossCmdContext& pCxt)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = pCxt.log;
+    strings ins{mLhs, mRhs};
+    std::vector<ObjectInfo> infos;
+    const uint64_t budget = setBudget(pCxt, ins, infos);
+    if (infos[0].count == 0 || infos[1].count == 0) throw "nonsense";      // :40-43
+    if (infos[0].K != infos[1].K) throw "nonsense";                        // :45-48
+    const uint64_t K = infos[0].K;
+    if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    log(info, "counting kmers.");
+    pushObject(g, mLhs, false, 1);
+    pushObject(g, mRhs, false, 2);
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "merging");
+    uint64_t n = 0;
+    g.check(goss_gpu_result(g.h, nullptr, nullptr, &n), "counting");
+    const uint64_t common = infos[0].count + infos[1].count - n;
+    log(info, "writing out " + num(n) + " kmers.");
+    log(info, "of which " + num(common) + " are common.");
+    g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
+    g.check(goss_gpu_emit_count_bits(g.h, 1, ".lhs-bits"), "building the annotation");
+    g.check(goss_gpu_emit_count_bits(g.h, 2, ".rhs-bits"), "building the annotation");
+    writeOut(g, mOut);
+    printf("%llu\t%llu\t%llu\n", (unsigned long long)infos[0].count, (unsigned long long)infos[1].count,
+           (unsigned long long)common);
+    fflush(stdout);
+    log(info, elapsed(t0));
+}
 
 void GossCmdMergeKmerSets::operator()(const GossCmdContext& pCxt) { runMerge(pCxt, false, mIns, mMaxMerge, mOut); }
 void GossCmdMergeGraphs::operator()(const GossCmdContext& pCxt) { runMerge(pCxt, true, mIns, mMaxMerge, mOut); }

@@ -175,7 +175,7 @@ typedef struct {
     const uint64_t* high_bits;
     uint64_t high_words;
     uint32_t ncols;
-    uint32_t reserved;
+    uint32_t weight;             /* count given to every key when counts is NULL; 0 means 1 */
     const void* col[4];          /* low-bits column files */
     uint32_t col_bytes[4];       /* element size of each column file */
     uint32_t col_shift[4];       /* bit position of the column inside the low bits */
@@ -190,6 +190,23 @@ int goss_gpu_push_run_host(goss_gpu_ctx* ctx, const uint64_t* keys, const uint32
  * distinct count: GossCmdMerge builds with M = sum of the inputs' counts
  * (GossCmdMerge.tcc:256-258,296), which changes D. */
 int goss_gpu_emit_estimate(goss_gpu_ctx* ctx, uint64_t m_estimate);
+
+/*
+ * Between finish and emit: keep only the result items whose count lies in [lo, hi] (order
+ * preserved).  With one run per input set pushed with weights, this is the set algebra of
+ * intersect-kmer-sets (every set weight 1, keep count == number of sets;
+ * GossCmdIntersectKmerSets.cc:29-79) and subtract-kmer-set (weights 1 and 2, keep count == 1;
+ * GossCmdSubtractKmerSet.cc:47-66).
+ */
+int goss_gpu_select_counts(goss_gpu_ctx* ctx, uint32_t lo, uint32_t hi);
+
+/*
+ * After emit: append a file `suffix` holding one bit per result item, set where
+ * (count & mask) != 0, in WordyBitVector layout -- the <out>.lhs-bits / <out>.rhs-bits
+ * annotation of GossCmdMergeAndAnnotateKmerSets.cc:126-201 when the two sets were pushed with
+ * weights 1 and 2.
+ */
+int goss_gpu_emit_count_bits(goss_gpu_ctx* ctx, uint32_t mask, const char* suffix);
 
 /*
  * Page-locked host memory for the buffers handed to goss_gpu_push_bases_host (the copy to the

@@ -1642,3 +1642,150 @@ out:
     free(todo); free(todo_cnt);
     return rc ? -1 : 0;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* intersect-kmer-sets / subtract-kmer-set / merge-and-annotate-kmer-sets                */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { go_key* k; uint64_t n; uint64_t at; } set_iter;
+
+/* The visiting loop of GossCmdIntersectKmerSets.cc:29-79: iterators of empty sets are left
+ * out (:38-41); targetKmer starts at zero; a k-mer is visited when every iterator sits on it. */
+static uint64_t intersect_visit(set_iter* it, size_t n, go_key* out)
+{
+    for (size_t i = 0; i < n; ++i) it[i].at = 0;
+    uint64_t m = 0;
+    int done = 0;
+    u128 target = 0;
+    while (!done)
+    {
+        size_t i = 0;
+        for (; i < n;)
+        {
+            set_iter* s = &it[i];
+            while (s->at < s->n && k2u(s->k[s->at]) < target) ++s->at;
+            if (s->at >= s->n) { done = 1; break; }
+            if (k2u(s->k[s->at]) == target) { ++i; continue; }
+            target = k2u(s->k[s->at]);
+            i = 0;
+        }
+        if (i >= n)
+        {
+            if (out) out[m] = u2k(target);
+            ++m;
+            ++it[0].at;
+        }
+    }
+    return m;
+}
+
+int go_intersect_kmer_sets(const go_fs* in, const char* const* names, size_t nin, go_fs* outfs, const char* out_name,
+                           char* err, size_t errcap)
+{
+    if (nin == 0) return 0;                        /* "no input k-mer sets!" (:104-110) */
+    set_iter* it = (set_iter*)calloc(nin, sizeof(set_iter));
+    size_t n = 0;
+    uint64_t K0 = 0;
+    int rc = 0;
+    for (size_t i = 0; i < nin; ++i)
+    {
+        uint64_t K = 0, cnt = 0;
+        merge_item m = {0};
+        if (merge_load(in, names[i], 0, &K, &cnt, &m, err, errcap)) { rc = -1; goto out; }
+        if (i == 0) K0 = K;                        /* K of the first input only (:112-116) */
+        free(m.c);
+        if (m.n == 0) { free(m.k); continue; }     /* invalid iterators are dropped */
+        it[n].k = m.k; it[n].n = m.n; ++n;
+    }
+    if (n == 0) { snprintf(err, errcap, "every input k-mer set is empty (undefined in the reference)"); rc = -1; goto out; }
+    {
+        uint64_t cnt = intersect_visit(it, n, NULL);          /* Counter pass */
+        go_key* keys = (go_key*)malloc((cnt ? cnt : 1) * sizeof(go_key));
+        intersect_visit(it, n, keys);
+        rc = go_write_kmer_set(outfs, out_name, (unsigned)K0, keys, cnt, cnt);
+        if (rc) snprintf(err, errcap, "write error");
+        free(keys);
+    }
+out:
+    for (size_t i = 0; i < n; ++i) free(it[i].k);
+    free(it);
+    return rc ? -1 : 0;
+}
+
+/* GossCmdSubtractKmerSet.cc:32-85 */
+int go_subtract_kmer_set(const go_fs* in, const char* lhs, const char* rhs, go_fs* outfs, const char* out_name,
+                         char* err, size_t errcap)
+{
+    uint64_t K = 0, K1 = 0, c0 = 0, c1 = 0;
+    merge_item a = {0}, b = {0};
+    if (merge_load(in, lhs, 0, &K, &c0, &a, err, errcap)) return -1;
+    if (merge_load(in, rhs, 0, &K1, &c1, &b, err, errcap)) { merge_item_free(&a); return -1; }
+    uint8_t* rem = (uint8_t*)calloc(a.n ? a.n : 1, 1);
+    uint64_t remd = 0, j = 0;
+    for (uint64_t i = 0; i < a.n; ++i)
+    {
+        u128 t = k2u(a.k[i]);
+        while (j < b.n && k2u(b.k[j]) < t) ++j;
+        if (j >= b.n) break;
+        if (k2u(b.k[j]) == t) { rem[i] = 1; ++remd; }
+    }
+    go_key* keys = (go_key*)malloc((a.n ? a.n : 1) * sizeof(go_key));
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < a.n; ++i) if (!rem[i]) keys[m++] = a.k[i];
+    int rc = go_write_kmer_set(outfs, out_name, (unsigned)K, keys, m, c0 - remd);
+    if (rc) snprintf(err, errcap, "write error");
+    free(keys); free(rem);
+    merge_item_free(&a); merge_item_free(&b);
+    return rc ? -1 : 0;
+}
+
+/* GossCmdMergeAndAnnotateKmerSets.cc:30-206: union of two k-mer sets built with the exact count,
+ * plus <out>.lhs-bits / <out>.rhs-bits (WordyBitVector, one bit per k-mer of the union).
+ * stats = { lhs count, rhs count, common } (the line printed on stdout, :204). */
+int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_fs* outfs, const char* out_name,
+                          uint64_t stats[3], char* err, size_t errcap)
+{
+    uint64_t K = 0, K1 = 0, c0 = 0, c1 = 0;
+    merge_item a = {0}, b = {0};
+    if (merge_load(in, lhs, 0, &K, &c0, &a, err, errcap)) return -1;
+    if (merge_load(in, rhs, 0, &K1, &c1, &b, err, errcap)) { merge_item_free(&a); return -1; }
+    if (a.n == 0 || b.n == 0 || K != K1)
+    {
+        snprintf(err, errcap, "nonsense");
+        merge_item_free(&a); merge_item_free(&b);
+        return -1;
+    }
+    go_key* keys = (go_key*)malloc((a.n + b.n) * sizeof(go_key));
+    uint8_t* side = (uint8_t*)malloc(a.n + b.n);
+    uint64_t l = 0, r = 0, n = 0, c = 0;
+    while (l < a.n && r < b.n)
+    {
+        u128 le = k2u(a.k[l]), re = k2u(b.k[r]);
+        if (le < re) { keys[n] = a.k[l]; side[n++] = 1; ++l; continue; }
+        if (le > re) { keys[n] = b.k[r]; side[n++] = 2; ++r; continue; }
+        keys[n] = a.k[l]; side[n++] = 3; ++c; ++l; ++r;
+    }
+    while (l < a.n) { keys[n] = a.k[l]; side[n++] = 1; ++l; }
+    while (r < b.n) { keys[n] = b.k[r]; side[n++] = 2; ++r; }
+    int rc = go_write_kmer_set(outfs, out_name, (unsigned)K, keys, n, n);
+    if (!rc)
+    {
+        char name[4096];
+        wbv_builder lb, rb;
+        snprintf(name, sizeof name, "%s.lhs-bits", out_name);
+        wbv_init(&lb, outfs, name);
+        snprintf(name, sizeof name, "%s.rhs-bits", out_name);
+        wbv_init(&rb, outfs, name);
+        for (uint64_t i = 0; i < n; ++i)
+        {
+            wbv_push_backx(&lb, side[i] & 1);
+            wbv_push_backx(&rb, (side[i] >> 1) & 1);
+        }
+        wbv_end(&lb); wbv_end(&rb);
+    }
+    else snprintf(err, errcap, "write error");
+    if (stats) { stats[0] = l; stats[1] = r; stats[2] = c; }
+    free(keys); free(side);
+    merge_item_free(&a); merge_item_free(&b);
+    return rc ? -1 : 0;
+}

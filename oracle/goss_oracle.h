@@ -116,6 +116,16 @@ int      go_graph_header(const go_fs* fs, const char* base, uint64_t* K, uint64_
 int go_merge(const go_fs* in, const char* const* names, size_t nin, int kind, uint64_t max_merge,
              go_fs* out, const char* out_name, char* err, size_t errcap);
 
+/* intersect-kmer-sets (GossCmdIntersectKmerSets.cc:29-128), subtract-kmer-set
+ * (GossCmdSubtractKmerSet.cc:32-85), merge-and-annotate-kmer-sets
+ * (GossCmdMergeAndAnnotateKmerSets.cc:30-206; stats = lhs count, rhs count, common). */
+int go_intersect_kmer_sets(const go_fs* in, const char* const* names, size_t nin, go_fs* out, const char* out_name,
+                           char* err, size_t errcap);
+int go_subtract_kmer_set(const go_fs* in, const char* lhs, const char* rhs, go_fs* out, const char* out_name,
+                         char* err, size_t errcap);
+int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_fs* out, const char* out_name,
+                          uint64_t stats[3], char* err, size_t errcap);
+
 /* VByte (spill-run private format; golden bytes in testVByteCodec.cc) */
 size_t   go_vbyte_encode(uint64_t x, uint8_t* out /* >= 9 */);  /* VByteCodec.hh:24-104 */
 uint64_t go_vbyte_decode(const uint8_t* in, size_t* used);

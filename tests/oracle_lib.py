@@ -359,3 +359,41 @@ def merge(files, names, kind, out, max_merge=8):
     if rc:
         raise OracleError(err.value.decode())
     return dst.files()
+
+
+def intersect_kmer_sets(files, names, out):
+    L = lib()
+    L.go_intersect_kmer_sets.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_void_p, C.c_char_p,
+                                         C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    dst = FileSet()
+    arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+    err = C.create_string_buffer(1024)
+    if L.go_intersect_kmer_sets(src.handle, arr, len(names), dst.handle, out.encode(), err, 1024):
+        raise OracleError(err.value.decode())
+    return dst.files()
+
+
+def subtract_kmer_set(files, lhs, rhs, out):
+    L = lib()
+    L.go_subtract_kmer_set.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    dst = FileSet()
+    err = C.create_string_buffer(1024)
+    if L.go_subtract_kmer_set(src.handle, lhs.encode(), rhs.encode(), dst.handle, out.encode(), err, 1024):
+        raise OracleError(err.value.decode())
+    return dst.files()
+
+
+def merge_and_annotate(files, lhs, rhs, out):
+    """Returns (files, (lhs count, rhs count, common))."""
+    L = lib()
+    L.go_merge_and_annotate.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p,
+                                        C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    dst = FileSet()
+    err = C.create_string_buffer(1024)
+    stats = (C.c_uint64 * 3)()
+    if L.go_merge_and_annotate(src.handle, lhs.encode(), rhs.encode(), dst.handle, out.encode(), stats, err, 1024):
+        raise OracleError(err.value.decode())
+    return dst.files(), tuple(stats)

@@ -416,3 +416,74 @@ def test_goss_merge_commands(oracle, tmp_path):
     assert "At least one input graph must be supplied either using --graph-in or --graphs-in." in p.stderr.decode()
     p = run(["merge-graphs", "-G", str(tmp_path / "gr27_0"), "-G", str(tmp_path / "gr55_0"), "-O", str(tmp_path / "x")])
     assert p.returncode == 1 and "must have the same kmer-size" in p.stderr.decode()
+
+
+def test_goss_set_algebra_commands(oracle, tmp_path):
+    """goss intersect-kmer-sets / subtract-kmer-set / merge-and-annotate-kmer-sets on sets built by
+    the product, every output file compared with the oracle's restatement of the reference loops
+    (GossCmdIntersectKmerSets.cc, GossCmdSubtractKmerSet.cc, GossCmdMergeAndAnnotateKmerSets.cc);
+    one- and two-word keys, an empty input, identical inputs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    goss = os.path.join(root, "gossamer_amd", "goss")
+    rng = random.Random(43)
+    genome = "".join(rng.choice("ACGT") for _ in range(30000))
+    for p in range(3):
+        lo = 5000 * p
+        reads = [genome[s:s + 120] for s in (rng.randrange(lo, lo + 18000) for _ in range(1500))]
+        (tmp_path / ("p%d.txt" % p)).write_text("\n".join(reads) + "\n")
+    (tmp_path / "p3.txt").write_text("ACGTACGT\n")          # too short for any k used: an empty set
+
+    def run(args):
+        return subprocess.run([goss] + args + ["--hbm-budget", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+    def disk(base):
+        return {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".")}
+
+    def same(base, exp, what):
+        got = disk(base)
+        assert sorted(got) == sorted(exp), what
+        for name in exp:
+            assert got[name] == exp[name], (what, name)
+
+    for k in (25, 45):
+        files = {}
+        names = []
+        for i in range(4):
+            base = "s%d_%d" % (k, i)
+            p = run(["build-kmer-set", "-k", str(k), "--line-in", str(tmp_path / ("p%d.txt" % i)), "-O", str(tmp_path / base)])
+            assert p.returncode == 0, p.stderr.decode()
+            files.update(disk(base))
+            names.append(base)
+        P = [str(tmp_path / n) for n in names]
+        # intersection of three sets, and with the empty set in the list (skipped by the reference)
+        for sel, tag in (((0, 1, 2), "x3"), ((0, 3, 1), "xe"), ((2,), "x1")):
+            out = "i%d_%s" % (k, tag)
+            exp = oracle.intersect_kmer_sets(files, [names[j] for j in sel], out)
+            args = ["intersect-kmer-sets", "-O", str(tmp_path / out)]
+            for j in sel:
+                args += ["-G", P[j]]
+            p = run(args)
+            assert p.returncode == 0, p.stderr.decode()
+            same(out, exp, (k, tag))
+        # differences
+        for a, b, tag in ((0, 1, "ab"), (1, 0, "ba"), (0, 3, "ae"), (0, 0, "aa"), (3, 0, "ea")):
+            out = "d%d_%s" % (k, tag)
+            exp = oracle.subtract_kmer_set(files, names[a], names[b], out)
+            p = run(["subtract-kmer-set", "-G", P[a], "-G", P[b], "-O", str(tmp_path / out)])
+            assert p.returncode == 0, p.stderr.decode()
+            same(out, exp, (k, tag))
+        # annotated union
+        out = "u%d" % k
+        exp, stats = oracle.merge_and_annotate(files, names[0], names[1], out)
+        p = run(["merge-and-annotate-kmer-sets", "-G", P[0], "-G", P[1], "-O", str(tmp_path / out)])
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout.decode() == "%d\t%d\t%d\n" % stats
+        same(out, exp, (k, "annotate"))
+        p = run(["merge-and-annotate-kmer-sets", "-G", P[0], "-G", P[3], "-O", str(tmp_path / "bad")])
+        assert p.returncode == 1 and p.stderr.decode() == "caught unknown exception\n"
+    p = run(["subtract-kmer-set", "-G", P[0], "-O", str(tmp_path / "bad")])
+    assert p.returncode == 1 and "Exactly two input k-mer sets required!" in p.stderr.decode()
+    p = run(["merge-and-annotate-kmer-sets", "-G", P[0], "-O", str(tmp_path / "bad")])
+    assert p.returncode == 1 and "mandatory option graph-in must be supplied exactly twice." in p.stderr.decode()

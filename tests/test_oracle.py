@@ -331,3 +331,64 @@ def test_merge_commands(oracle):
         f, _ = oracle.build_kmer_set([(oracle.LINE, "r", parts[0])], 19, out="other")
         files.update(f)
         oracle.merge(files, ["ks0", "other"], 0, "x")
+
+
+def test_set_algebra_commands(oracle):
+    """intersect-kmer-sets, subtract-kmer-set, merge-and-annotate-kmer-sets against Python sets:
+    results are built with the exact count as the estimate (GossCmdIntersectKmerSets.cc:118-126,
+    GossCmdSubtractKmerSet.cc:72-74, GossCmdMergeAndAnnotateKmerSets.cc:124)."""
+    rng = random.Random(29)
+    genome = "".join(rng.choice("ACGT") for _ in range(4000))
+    k = 23
+    files = {}
+    sets = []
+    for i in range(3):
+        lo = 600 * i
+        reads = [genome[s:s + 90] for s in (rng.randrange(lo, lo + 2500) for _ in range(200))]
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "r", "\n".join(reads) + "\n")], k, out="s%d" % i)
+        files.update(f)
+        r = oracle.SparseReader(f, "s%d.kmers" % i)
+        sets.append([r.select(j) for j in range(r.count())])
+    f, _ = oracle.build_kmer_set([(oracle.LINE, "r", "ACGT\n")], k, out="empty")      # no 23-mers: an empty set
+    files.update(f)
+
+    def keys_of(fs, base):
+        r = oracle.SparseReader(fs, base + ".kmers")
+        return [r.select(j) for j in range(r.count())]
+
+    def check_exact(fs, base, keys):
+        assert keys_of(fs, base) == keys
+        assert oracle.kmer_set_header(fs, base) == (k, len(keys))
+        D = struct.unpack("<Q", fs[base + ".kmers.header"][8:16])[0]
+        assert D == oracle.lib().go_sparse_d(oracle.key(4 ** k), len(keys))
+
+    inter = sorted(set(sets[0]) & set(sets[1]) & set(sets[2]))
+    assert inter
+    got = oracle.intersect_kmer_sets(files, ["s0", "s1", "s2"], "x")
+    check_exact(got, "x", inter)
+    # empty inputs are skipped by the reference's loop (invalid iterators are not kept)
+    got = oracle.intersect_kmer_sets(files, ["s0", "empty", "s1"], "x")
+    check_exact(got, "x", sorted(set(sets[0]) & set(sets[1])))
+    # one input: a copy
+    got = oracle.intersect_kmer_sets(files, ["s2"], "x")
+    check_exact(got, "x", sets[2])
+    assert oracle.intersect_kmer_sets(files, [], "x") == {}
+
+    got = oracle.subtract_kmer_set(files, "s0", "s1", "d")
+    check_exact(got, "d", sorted(set(sets[0]) - set(sets[1])))
+    got = oracle.subtract_kmer_set(files, "s0", "empty", "d")
+    check_exact(got, "d", sets[0])
+    got = oracle.subtract_kmer_set(files, "s0", "s0", "d")
+    check_exact(got, "d", [])
+
+    got, stats = oracle.merge_and_annotate(files, "s0", "s1", "u")
+    union = sorted(set(sets[0]) | set(sets[1]))
+    check_exact(got, "u", union)
+    assert stats == (len(sets[0]), len(sets[1]), len(set(sets[0]) & set(sets[1])))
+    nw = (len(union) + 63) // 64
+    for name, members in (("u.lhs-bits", set(sets[0])), ("u.rhs-bits", set(sets[1]))):
+        words = struct.unpack("<%dQ" % nw, got[name])
+        for i, x in enumerate(union):
+            assert ((words[i // 64] >> (i % 64)) & 1) == (x in members)
+    with pytest.raises(oracle.OracleError, match="nonsense"):
+        oracle.merge_and_annotate(files, "s0", "empty", "u")
