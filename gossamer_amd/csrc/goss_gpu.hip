@@ -1478,6 +1478,92 @@ int goss_gpu_select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
     });
 }
 
+int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished) { c->last_error = "dump before finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        c->files.clear();
+        PhaseTimer t(c, GOSS_T_EMIT, c->M);
+        const uint64_t m = c->M;
+        const uint32_t len = c->len;
+        // "#<version>\nK\tcount\n" (GossCmdDumpKmerSet.cc:44-45) / "#<version>\nK\tcount\tflags\n"
+        // (GossCmdDumpGraph.cc:50-51)
+        char head[128];
+        int hl = c->mode == GOSS_MODE_KMER_SET
+                     ? std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\n", 2011101701ULL, c->k, (unsigned long long)m)
+                     : std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\t%llu\n", 2011101014ULL, c->k, (unsigned long long)m,
+                                     (unsigned long long)flags);
+        uint64_t body = 0;
+        uint64_t mark = c->arena.mark();
+        uint64_t* offs = nullptr;
+        if (c->mode == GOSS_MODE_KMER_SET) body = m * (len + 1ULL);
+        else if (m)
+        {
+            offs = (uint64_t*)c->arena.temp((m + 1) * 8);
+            hipLaunchKernelGGL(dump_line_len_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                               (const uint32_t*)c->res_counts, m, len, offs);
+            HIP_TRY(hipMemsetAsync(offs + m, 0, 8, c->stream));
+            exclusive_scan_u64(c, offs, m + 1);
+            uint64_t* h = (uint64_t*)c->h_pinned;
+            HIP_TRY(hipMemcpyAsync(h, offs + m, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            body = h[0];
+        }
+        uint8_t* text = (uint8_t*)c->arena.perm(hl + body + 16);
+        HIP_TRY(hipMemcpyAsync(text, head, hl, hipMemcpyHostToDevice, c->stream));
+        if (m)
+        {
+            if (c->mode == GOSS_MODE_KMER_SET)
+            {
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_for(body, 256), 256 * 64);
+                if (c->words == 1)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_kmers_kernel<Key1>), dim3(grid), dim3(256), 0, c->stream,
+                                       (const Key1*)c->res_keys, m, len, text + hl);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_kmers_kernel<Key2>), dim3(grid), dim3(256), 0, c->stream,
+                                       (const Key2*)c->res_keys, m, len, text + hl);
+            }
+            else if (c->words == 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_edges_kernel<Key1>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                                   (const Key1*)c->res_keys, (const uint32_t*)c->res_counts, (const uint64_t*)offs, m, len, text + hl);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_edges_kernel<Key2>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                                   (const Key2*)c->res_keys, (const uint32_t*)c->res_counts, (const uint64_t*)offs, m, len, text + hl);
+        }
+        t.stop();
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+        OutFile f; f.suffix = ".dump"; f.size = hl + body; f.dev = text;
+        c->files.push_back(std::move(f));
+    });
+}
+
+int goss_gpu_lint(goss_gpu_ctx* c, int asymmetric, goss_gpu_lint_report* out)
+{
+    if (!c || !out) return GOSS_ERR_INVALID_ARG;
+    static_assert(sizeof(goss_gpu_lint_report) == sizeof(LintReport), "lint report layout");
+    if (!c->finished) { c->last_error = "lint before finish"; return GOSS_ERR_STATE; }
+    if (c->mode != GOSS_MODE_GRAPH) { c->last_error = "lint checks a graph"; return GOSS_ERR_STATE; }
+    std::memset(out, 0, sizeof *out);
+    if (c->M == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        uint64_t mark = c->arena.mark();
+        LintReport* rep = (LintReport*)c->arena.temp(sizeof(LintReport));
+        HIP_TRY(hipMemsetAsync(rep, 0, sizeof(LintReport), c->stream));
+        if (c->words == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lint_edges_kernel<Key1>), dim3(grid_for(c->M, 256)), dim3(256), 0, c->stream,
+                               (const Key1*)c->res_keys, (const uint32_t*)c->res_counts, c->M, c->len, asymmetric, rep);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lint_edges_kernel<Key2>), dim3(grid_for(c->M, 256)), dim3(256), 0, c->stream,
+                               (const Key2*)c->res_keys, (const uint32_t*)c->res_counts, c->M, c->len, asymmetric, rep);
+        HIP_TRY(hipMemcpyAsync(out, rep, sizeof(LintReport), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+        if (out->nexamples > 32) out->nexamples = 32;
+    });
+}
+
 int goss_gpu_emit_count_bits(goss_gpu_ctx* c, uint32_t mask, const char* suffix)
 {
     if (!c || !suffix || !mask) return GOSS_ERR_INVALID_ARG;

@@ -849,7 +849,11 @@ void printHelp(const std::string& cmdName, const OptTable* t)
     std::cerr << "goss <command> [options]\n\ncommands implemented by this build:\n"
               << "  build-graph      create a new graph\n"
               << "  build-kmer-set   create a new graph\n"
+              << "  dump-graph       write out the graph in a robust text representation.\n"
+              << "  dump-kmer-set    write out the graph in a robust text representation.\n"
               << "  help             print a summary of all the commands.\n"
+              << "  lint-graph       verify that a graph structure is internally consistent\n"
+              << "  restore-graph    read in a graph from a robust text representation.\n"
               << "  intersect-kmer-sets  generate the intersection of the given k-mer sets\n"
               << "  merge-and-annotate-kmer-sets  Decorate a graph with an assignment of kmers to graphs.\n"
               << "  merge-graphs     create a new graph by merging zero or more existing graphs\n"
@@ -880,8 +884,13 @@ int gossMain(int argc, char* argv[])
         const bool isMerge = cmdName == "merge-kmer-sets" || cmdName == "merge-graphs";
         const bool isIntersect = cmdName == "intersect-kmer-sets", isSubtract = cmdName == "subtract-kmer-set";
         const bool isAnnotate = cmdName == "merge-and-annotate-kmer-sets";
-        if (isMerge || isIntersect || isSubtract || isAnnotate)
+        const bool isDump = cmdName == "dump-kmer-set" || cmdName == "dump-graph";
+        const bool isRestore = cmdName == "restore-graph", isLint = cmdName == "lint-graph";
+        if (isMerge || isIntersect || isSubtract || isAnnotate || isDump || isRestore || isLint)
         {
+            // GossCmdFactoryDumpKmerSet/DumpGraph::create (GossCmdDumpKmerSet.cc:58-73,
+            // GossCmdDumpGraph.cc:64-79), GossCmdFactoryRestoreGraph::create (GossCmdRestoreGraph.cc:138-152),
+            // GossCmdFactoryLintGraph::create (GossCmdLintGraph.cc:278-292),
             // GossCmdFactoryIntersectKmerSets::create (GossCmdIntersectKmerSets.cc:131-150),
             // GossCmdFactorySubtractKmerSet::create (GossCmdSubtractKmerSet.cc:88-113),
             // GossCmdFactoryMergeAndAnnotateKmerSets::create (GossCmdMergeAndAnnotateKmerSets.cc:209-224),
@@ -891,6 +900,9 @@ int gossMain(int argc, char* argv[])
                 {"graphs-in", "", kStrings, "read graph names (one per line) from the given file."},
                 {"graph-out", "O", kString, "name of the output graph object"},
                 {"max-merge", "", kU64, "The maximum number of graphs to merge at once."},
+                {"input-file", "f", kString, "input file name ('-' for standard input)"},
+                {"output-file", "o", kString, "output file name ('-' for standard output)"},
+                {"dump-properties", "", kFlag, "show the internal properties of the graph"},
             };
             OptTable t;
             for (auto& d : kGlobal) t.defs.push_back(d);
@@ -916,7 +928,35 @@ int gossMain(int argc, char* argv[])
             strings ins;
             uint64_t maxMerge = 8;
             std::string outName;
-            if (isAnnotate)
+            std::string textName = "-";
+            if (isDump || isLint)
+            {
+                // getRepeatingOnce("graph-in") (GossOptionChecker.hh:235-254)
+                if (!opts.count("graph-in")) { chk.errors += "mandatory option graph-in was not given.\n"; chk.suggestUsage = true; }
+                else if (opts.strs("graph-in").size() != 1)
+                { chk.errors += "mandatory option graph-in must be supplied exactly once.\n"; chk.suggestUsage = true; }
+                else ins = opts.strs("graph-in");
+                if (isDump && opts.count("output-file"))
+                {
+                    textName = opts.str("output-file");
+                    if (textName != "-")
+                    {
+                        FILE* fp = fopen(textName.c_str(), "wb");      // FileCreateCheck(fac, false)
+                        if (!fp)
+                        {
+                            chk.errors += "The given value of the option output-file was invalid.\n";
+                            chk.errors += "\tcannot create file '" + textName + "'\n";
+                        }
+                        else fclose(fp);
+                    }
+                }
+            }
+            else if (isRestore)
+            {
+                if (opts.count("input-file")) textName = opts.str("input-file");
+                chk.mandatoryOut("graph-out", outName);
+            }
+            else if (isAnnotate)
             {
                 if (!opts.count("graph-in")) { chk.errors += "mandatory option graph-in was not given.\n"; chk.suggestUsage = true; }
                 else if (opts.strs("graph-in").size() != 2)
@@ -947,6 +987,10 @@ int gossMain(int argc, char* argv[])
                 else if (isMerge) { GossCmdMergeGraphs cmd(ins, maxMerge, outName); cmd(cxt); }
                 else if (isIntersect) { GossCmdIntersectKmerSets cmd(ins, outName); cmd(cxt); }
                 else if (isSubtract) { GossCmdSubtractKmerSet cmd(ins, outName); cmd(cxt); }
+                else if (cmdName == "dump-kmer-set") { GossCmdDumpKmerSet cmd(ins[0], textName); cmd(cxt); }
+                else if (cmdName == "dump-graph") { GossCmdDumpGraph cmd(ins[0], textName); cmd(cxt); }
+                else if (isRestore) { GossCmdRestoreGraph cmd(textName, outName); cmd(cxt); }
+                else if (isLint) { GossCmdLintGraph cmd(ins[0], opts.count("dump-properties") != 0); cmd(cxt); }
                 else { GossCmdMergeAndAnnotateKmerSets cmd(ins[0], ins[1], outName); cmd(cxt); }
             }
             catch (Error& e) { e.cmd = cmdName; throw; }

@@ -199,6 +199,41 @@ private:
     const std::string mLhs, mRhs, mOut;
 };
 
+// Text form and self-check of existing objects: GossCmdDumpKmerSet.hh, GossCmdDumpGraph.hh,
+// GossCmdRestoreGraph.hh (in = text file, out = graph), GossCmdLintGraph.hh.  "-" = stdin/stdout.
+class GossCmdDumpKmerSet {
+public:
+    GossCmdDumpKmerSet(const std::string& pIn, const std::string& pOut) : mIn(pIn), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const std::string mIn, mOut;
+};
+
+class GossCmdDumpGraph {
+public:
+    GossCmdDumpGraph(const std::string& pIn, const std::string& pOut) : mIn(pIn), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const std::string mIn, mOut;
+};
+
+class GossCmdRestoreGraph {
+public:
+    GossCmdRestoreGraph(const std::string& pIn, const std::string& pOut) : mIn(pIn), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const std::string mIn, mOut;
+};
+
+class GossCmdLintGraph {
+public:
+    GossCmdLintGraph(const std::string& pIn, bool pDumpProperties) : mIn(pIn), mDumpProperties(pDumpProperties) {}
+    void operator()(const GossCmdContext& pCxt);
+    uint64_t problems() const { return mProblems; }
+private:
+    const std::string mIn; const bool mDumpProperties; uint64_t mProblems = 0;
+};
+
 // App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);
 

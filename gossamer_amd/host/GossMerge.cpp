@@ -10,6 +10,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cctype>
 #include <cerrno>
 #include <chrono>
 #include <cstring>
@@ -477,6 +479,240 @@ void GossCmdMergeAndAnnotateKmerSets::operator()(const GossCmdContext& pCxt)
            (unsigned long long)common);
     fflush(stdout);
     log(info, elapsed(t0));
+}
+
+namespace {
+
+// Decode one object into a fresh context and finish: the sorted (key,count) list in HBM.
+void loadObject(const GossCmdContext& cxt, GpuCtx& g, const std::string& name, bool graph, ObjectInfo& o)
+{
+    o = objectInfo(name, graph);
+    const uint64_t maxK = graph ? 62 : 63;
+    if (o.K > maxK || o.K == 0) throw Error::General("unable to build a graph with k=" + num(o.K));
+    struct stat st;
+    uint64_t bytes = 0;
+    if (::stat((name + (graph ? "-edges.high-bits" : ".kmers.high-bits")).c_str(), &st) == 0) bytes = (uint64_t)st.st_size * 4;
+    if (::stat((name + (graph ? "-counts.ord0" : ".kmers.low-bits")).c_str(), &st) == 0) bytes += (uint64_t)st.st_size * 64;
+    const uint64_t budget = cxt.hbmBudget ? cxt.hbmBudget : bytes + (4ULL << 30);
+    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)o.K, graph ? GOSS_MODE_GRAPH : GOSS_MODE_KMER_SET, budget, nullptr),
+            "creating the GPU context");
+    pushObject(g, name, graph);
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "decoding");
+}
+
+// FileFactory::out(name): "-" is standard output (PhysicalFileFactory.cc:279-298).
+void writeText(GpuCtx& g, const std::string& out)
+{
+    FILE* fp = out == "-" ? stdout : fopen(out.c_str(), "wb");
+    if (!fp) throw Error::Errno(out, errno);
+    uint64_t size = 0; char suffix[32];
+    g.check(goss_gpu_file_info(g.h, 0, suffix, sizeof suffix, &size), "listing output files");
+    const uint64_t piece = 64u << 20;
+    std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
+    for (uint64_t off = 0; off < size; off += piece)
+    {
+        uint64_t n = std::min(piece, size - off);
+        g.check(goss_gpu_file_read(g.h, 0, off, buf.data(), n), "reading device file");
+        if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { if (fp != stdout) fclose(fp); throw Error::Write(out); }
+    }
+    if (fp == stdout) fflush(stdout);
+    else if (fclose(fp) != 0) throw Error::Write(out);
+}
+
+std::string edgeText(const uint64_t* w, size_t words, uint64_t len)
+{
+    std::string s;
+    for (uint64_t i = 0; i < len; ++i)
+    {
+        uint64_t sh = 2 * (len - 1 - i);
+        uint64_t v = sh < 64 ? (w[0] >> sh) : (words > 1 ? (w[1] >> (sh - 64)) : 0);
+        s += "ACGT"[v & 3];
+    }
+    return s;
+}
+
+}  // namespace
+
+// GossCmdDumpKmerSet::operator() (GossCmdDumpKmerSet.cc:31-55)
+void GossCmdDumpKmerSet::operator()(const GossCmdContext& pCxt)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    GpuCtx g; ObjectInfo o;
+    loadObject(pCxt, g, mIn, false, o);
+    g.check(goss_gpu_emit_dump(g.h, 0), "formatting");
+    writeText(g, mOut);
+    pCxt.log(info, elapsed(t0));
+}
+
+// GossCmdDumpGraph::operator() (GossCmdDumpGraph.cc:31-61)
+void GossCmdDumpGraph::operator()(const GossCmdContext& pCxt)
+{
+    GpuCtx g; ObjectInfo o;
+    loadObject(pCxt, g, mIn, true, o);
+    g.check(goss_gpu_emit_dump(g.h, o.asymmetric ? 1 : 0), "formatting");
+    writeText(g, mOut);
+}
+
+// GossCmdRestoreGraph::operator() (GossCmdRestoreGraph.cc:72-135): "#version" line, then
+// "K n flags", then "<edge> <count>" pairs until one does not parse; the graph is built with the
+// estimate n of the text's header.
+void GossCmdRestoreGraph::operator()(const GossCmdContext& pCxt)
+{
+    std::string all;
+    {
+        InFile in(mIn);
+        std::vector<char> buf(16u << 20);
+        size_t got;
+        while ((got = in.read(buf.data(), buf.size())) > 0) all.append(buf.data(), got);
+    }
+    size_t p = all.find('\n');
+    if (p == std::string::npos) { Error e = Error::General("unexpected end of file"); e.file = mIn; throw e; }
+    ++p;
+    auto skipWs = [&]() { while (p < all.size() && isspace((unsigned char)all[p])) ++p; };
+    auto readU64 = [&](uint64_t& v) -> bool {
+        skipWs();
+        size_t b = p; v = 0;
+        while (p < all.size() && isdigit((unsigned char)all[p])) { v = v * 10 + (uint64_t)(all[p] - '0'); ++p; }
+        return p > b;
+    };
+    uint64_t k = 0, n = 0, flags = 0;
+    // `in >> k >> n >> flags; if (!in.good())`: the stream must still be good after the flags,
+    // i.e. something (at least the newline) follows them
+    if (!readU64(k) || !readU64(n) || !readU64(flags) || p >= all.size())
+    { Error e = Error::General("unexpected end of file"); e.file = mIn; throw e; }
+    if (k > 62 || k == 0) throw Error::General("unable to build a graph with k=" + num(k));
+    const bool asymmetric = flags & 1;
+    const size_t words = 2 * (k + 1) <= 62 ? 1 : 2;
+    std::vector<uint64_t> keys; std::vector<uint32_t> counts;
+    for (;;)
+    {
+        skipWs();
+        size_t b = p;
+        while (p < all.size() && !isspace((unsigned char)all[p])) ++p;
+        if (p == b) break;
+        const size_t xl = p - b;
+        skipWs();
+        size_t cb = p; uint64_t c = 0;
+        while (p < all.size() && isdigit((unsigned char)all[p]) && c <= 0xFFFFFFFFULL) { c = c * 10 + (uint64_t)(all[p] - '0'); ++p; }
+        // `in >> x >> c; if (!in.good()) break;` -- a count that does not parse, overflows u32,
+        // or is the very last token of the stream (eof reached while reading it) ends the loop
+        if (p == cb || c > 0xFFFFFFFFULL || p >= all.size()) break;
+        if (xl != k + 1) { Error e = Error::General("sequence " + all.substr(b, xl) + " has wrong length"); e.file = mIn; throw e; }
+        uint64_t w[2] = {0, 0};
+        for (size_t i = 0; i < xl; ++i)
+        {
+            uint64_t code;
+            switch (all[b + i])
+            {
+                case 'A': case 'a': code = 0; break;
+                case 'C': case 'c': code = 1; break;
+                case 'G': case 'g': code = 2; break;
+                case 'T': case 't': code = 3; break;
+                default: throw Error::General("invalid sequence " + all.substr(b, xl));
+            }
+            w[1] = (w[1] << 2) | (w[0] >> 62);
+            w[0] = (w[0] << 2) | code;
+        }
+        if (!keys.empty())
+        {
+            const uint64_t* prev = &keys[keys.size() - words];
+            bool inc = words == 1 ? prev[0] < w[0] : (prev[1] < w[1] || (prev[1] == w[1] && prev[0] < w[0]));
+            if (!inc) throw Error::General("edges must be in strictly increasing order: " + all.substr(b, xl) + "\n");
+        }
+        keys.push_back(w[0]); if (words == 2) keys.push_back(w[1]);
+        counts.push_back((uint32_t)c);
+    }
+    GpuCtx g;
+    const uint64_t budget = pCxt.hbmBudget ? pCxt.hbmBudget : counts.size() * 64 + (4ULL << 30);
+    g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)k, GOSS_MODE_GRAPH, budget, nullptr), "creating the GPU context");
+    g.check(goss_gpu_push_run_host(g.h, keys.data(), counts.data(), counts.size()), "loading the edges");
+    goss_gpu_counts gc;
+    g.check(goss_gpu_finish(g.h, &gc), "loading the edges");
+    g.check(goss_gpu_emit_estimate(g.h, n), "building the on-disk arrays");
+    writeOut(g, mOut);
+    if (asymmetric)
+    {
+        // Graph::Builder(..., pAsymmetric) sets the flag in the 24-byte header (Graph.cc:162)
+        FILE* fp = fopen((mOut + ".header").c_str(), "r+b");
+        if (!fp) throw Error::Write(mOut);
+        uint64_t f = 1;
+        if (fseek(fp, 16, SEEK_SET) != 0 || fwrite(&f, 8, 1, fp) != 1) { fclose(fp); throw Error::Write(mOut); }
+        fclose(fp);
+    }
+}
+
+// GossCmdLintGraph::operator() (GossCmdLintGraph.cc:110-275).  Pass 1 runs on the device over the
+// decoded edge list; pass 2 (iterator against select / rank) becomes the strict-ordering check of
+// the same list.  At most 32 offending edges are printed, in edge order.
+void GossCmdLintGraph::operator()(const GossCmdContext& pCxt)
+{
+    Logger& log = pCxt.log;
+    GpuCtx g; ObjectInfo o;
+    loadObject(pCxt, g, mIn, true, o);
+    uint64_t m = 0;
+    g.check(goss_gpu_result(g.h, nullptr, nullptr, &m), "counting");
+    if (mDumpProperties)
+    {
+        log(info, "Graph properties:");
+        log(info, " K " + num(o.K));
+        log(info, " count " + num(m));
+        log(info, " asymmetric " + num(o.asymmetric ? 1 : 0));
+    }
+    log(info, "Pass 1: Checking counts are sane.");
+    goss_gpu_lint_report rep;
+    g.check(goss_gpu_lint(g.h, o.asymmetric ? 1 : 0, &rep), "checking");
+    const size_t words = 2 * (o.K + 1) <= 62 ? 1 : 2;
+    std::vector<uint32_t> order(rep.nexamples);
+    for (uint32_t i = 0; i < rep.nexamples; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rep.ex_index[a] < rep.ex_index[b]; });
+    auto edgeAt = [&](uint64_t idx, uint32_t& mult) {
+        uint64_t w[2] = {0, 0};
+        g.check(goss_gpu_result_copy(g.h, idx, 1, w, &mult), "reading an edge");
+        return edgeText(w, words, o.K + 1);
+    };
+    for (uint32_t j : order)
+    {
+        const uint64_t i = rep.ex_index[j];
+        uint32_t mult = 0, mp = 0;
+        std::string fwd = edgeAt(i, mult);
+        switch (rep.ex_kind[j])
+        {
+            case 1:
+                log(warning, "No reverse complement for the following edge exists:");
+                log(warning, "  edge number " + num(i));
+                log(warning, "  fwd edge    " + fwd + " " + num(mult));
+                break;
+            case 2:
+            {
+                std::string rev = edgeAt(rep.ex_other[j], mp);
+                log(warning, o.asymmetric ? "neither fwd nor rev edge has a nonzero multiplicity:" : "counts on fwd and rev edges are not equal:");
+                log(warning, "  edge number " + num(i));
+                log(warning, "  fwd edge    " + fwd + " " + num(mult));
+                log(warning, "  rev edge    " + rev + " " + num(mp));
+                if (!o.asymmetric && mult == 0) log(warning, num(mult) + " !> 0");
+                break;
+            }
+            case 3:
+                log(warning, num(mult) + " !> 0");
+                break;
+            default: break;
+        }
+    }
+    log(info, "Pass 2: Checking traversal is sane.");
+    for (uint32_t j : order)
+        if (rep.ex_kind[j] == 4)
+        {
+            uint32_t mult = 0;
+            log(warning, "iterator and rank conflict.");
+            log(warning, "    " + edgeAt(rep.ex_index[j], mult));
+            log(warning, "iterator: " + num(rep.ex_index[j]));
+        }
+    mProblems = rep.missing_rc + rep.count_mismatch + rep.zero_count + rep.order_violation;
+    if (mProblems > rep.nexamples)
+        log(warning, num(mProblems) + " problems in total (" + num(rep.missing_rc) + " missing reverse complements, "
+                     + num(rep.count_mismatch) + " unequal counts, " + num(rep.zero_count) + " zero counts, "
+                     + num(rep.order_violation) + " out of order); the first " + num(rep.nexamples) + " found are shown");
 }
 
 void GossCmdMergeKmerSets::operator()(const GossCmdContext& pCxt) { runMerge(pCxt, false, mIns, mMaxMerge, mOut); }

@@ -209,6 +209,30 @@ int goss_gpu_select_counts(goss_gpu_ctx* ctx, uint32_t lo, uint32_t hi);
 int goss_gpu_emit_count_bits(goss_gpu_ctx* ctx, uint32_t mask, const char* suffix);
 
 /*
+ * After finish: the text form of the object as one device-built file (suffix ".dump") --
+ * "#<version>\nK\tcount\n" and one k-mer per line for a k-mer set (GossCmdDumpKmerSet.cc:31-55),
+ * "#<version>\nK\tcount\tflags\n" and "<edge>\t<multiplicity>" per line for a graph
+ * (GossCmdDumpGraph.cc:31-61).  Replaces the file list; read it with goss_gpu_file_read.
+ */
+int goss_gpu_emit_dump(goss_gpu_ctx* ctx, uint64_t flags);
+
+/*
+ * After finish, graph mode: the checks of lint-graph's first pass (GossCmdLintGraph.cc:131-199)
+ * over the edge list held by the context -- reverse complement present, equal multiplicities
+ * (asymmetric: not both zero), positive multiplicities -- plus strict ordering of the list.
+ * Up to 32 offending edges are returned: kind 1 = no reverse complement, 2 = multiplicities
+ * differ, 3 = zero multiplicity, 4 = out of order; `other` = index of the reverse complement
+ * or ~0.
+ */
+typedef struct {
+    uint64_t missing_rc, count_mismatch, zero_count, order_violation;
+    uint32_t nexamples, pad;
+    uint64_t ex_index[32], ex_other[32];
+    uint32_t ex_kind[32];
+} goss_gpu_lint_report;
+int goss_gpu_lint(goss_gpu_ctx* ctx, int asymmetric, goss_gpu_lint_report* out);
+
+/*
  * Page-locked host memory for the buffers handed to goss_gpu_push_bases_host (the copy to the
  * device then runs at PCIe speed instead of going through the driver's bounce buffers).
  */

@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include "goss_oracle.h"
 
+#include <ctype.h>
 #include <dirent.h>
 #include <math.h>
 #include <stdio.h>
@@ -1787,5 +1788,133 @@ int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_
     if (stats) { stats[0] = l; stats[1] = r; stats[2] = c; }
     free(keys); free(side);
     merge_item_free(&a); merge_item_free(&b);
+    return rc ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* dump-kmer-set / dump-graph / restore-graph                                            */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { char* p; size_t n, cap; } text_buf;
+
+static void tb_put(text_buf* t, const char* s, size_t n)
+{
+    if (t->n + n + 1 > t->cap)
+    {
+        t->cap = (t->n + n + 1) * 2 + 64;
+        t->p = (char*)realloc(t->p, t->cap);
+    }
+    memcpy(t->p + t->n, s, n);
+    t->n += n;
+    t->p[t->n] = 0;
+}
+
+/* kmerToString (RankSelect.hh:299-308) */
+static void tb_kmer(text_buf* t, go_key x, unsigned len)
+{
+    char s[80];
+    u128 v = k2u(x);
+    for (unsigned i = 0; i < len; ++i) s[i] = "ACGT"[(unsigned)(v >> (2 * (len - 1 - i))) & 3];
+    tb_put(t, s, len);
+}
+
+/* GossCmdDumpKmerSet.cc:31-55 (kind 0) / GossCmdDumpGraph.cc:31-61 (kind 1).  The caller frees
+ * *text. */
+int go_dump(const go_fs* fs, const char* name, int kind, char** text, size_t* len, char* err, size_t errcap)
+{
+    uint64_t K = 0, cnt = 0;
+    merge_item m = {0};
+    if (merge_load(fs, name, kind, &K, &cnt, &m, err, errcap)) return -1;
+    text_buf t = {0};
+    char line[128];
+    if (kind == 0)
+    {
+        int n = snprintf(line, sizeof line, "#%llu\n%llu\t%llu\n", 2011101701ULL, (unsigned long long)K, (unsigned long long)cnt);
+        tb_put(&t, line, (size_t)n);
+        for (uint64_t i = 0; i < m.n; ++i) { tb_kmer(&t, m.k[i], (unsigned)K); tb_put(&t, "\n", 1); }
+    }
+    else
+    {
+        uint64_t flags = 0, hk = 0;
+        go_graph_header(fs, name, &hk, &flags);
+        int n = snprintf(line, sizeof line, "#%llu\n%llu\t%llu\t%llu\n", 2011101014ULL, (unsigned long long)K,
+                         (unsigned long long)m.n, (unsigned long long)(flags & 1));
+        tb_put(&t, line, (size_t)n);
+        for (uint64_t i = 0; i < m.n; ++i)
+        {
+            tb_kmer(&t, m.k[i], (unsigned)K + 1);
+            n = snprintf(line, sizeof line, "\t%llu\n", (unsigned long long)m.c[i]);
+            tb_put(&t, line, (size_t)n);
+        }
+    }
+    merge_item_free(&m);
+    *text = t.p; *len = t.n;
+    return 0;
+}
+
+/* GossCmdRestoreGraph.cc:72-135: the first line is skipped, then "K n flags", then
+ * "<edge> <count>" pairs while the stream stays good; Graph::Builder(k, out, fac, n, asymmetric). */
+int go_restore_graph(const char* text, size_t len, go_fs* outfs, const char* out_name, char* err, size_t errcap)
+{
+    size_t p = 0;
+    while (p < len && text[p] != '\n') ++p;
+    if (p >= len) { snprintf(err, errcap, "unexpected end of file"); return -1; }
+    ++p;
+    uint64_t hdr[3];
+    for (int f = 0; f < 3; ++f)
+    {
+        while (p < len && isspace((unsigned char)text[p])) ++p;
+        size_t b = p; uint64_t v = 0;
+        while (p < len && isdigit((unsigned char)text[p])) { v = v * 10 + (uint64_t)(text[p] - '0'); ++p; }
+        if (p == b) { snprintf(err, errcap, "unexpected end of file"); return -1; }
+        hdr[f] = v;
+    }
+    if (p >= len) { snprintf(err, errcap, "unexpected end of file"); return -1; }
+    const uint64_t k = hdr[0], n = hdr[1], flags = hdr[2];
+    size_t cap = 1024, m = 0;
+    go_key* keys = (go_key*)malloc(cap * sizeof(go_key));
+    uint64_t* counts = (uint64_t*)malloc(cap * 8);
+    int rc = 0;
+    for (;;)
+    {
+        while (p < len && isspace((unsigned char)text[p])) ++p;
+        size_t b = p;
+        while (p < len && !isspace((unsigned char)text[p])) ++p;
+        if (p == b) break;
+        size_t xl = p - b;
+        while (p < len && isspace((unsigned char)text[p])) ++p;
+        size_t cb = p; uint64_t c = 0;
+        while (p < len && isdigit((unsigned char)text[p]) && c <= 0xFFFFFFFFULL) { c = c * 10 + (uint64_t)(text[p] - '0'); ++p; }
+        if (p == cb || c > 0xFFFFFFFFULL || p >= len) break;
+        if (xl != k + 1) { snprintf(err, errcap, "sequence %.*s has wrong length", (int)xl, text + b); rc = -1; break; }
+        u128 x = 0;
+        for (size_t i = 0; i < xl && !rc; ++i)
+        {
+            switch (text[b + i])
+            {
+                case 'A': case 'a': x = (x << 2) | 0; break;
+                case 'C': case 'c': x = (x << 2) | 1; break;
+                case 'G': case 'g': x = (x << 2) | 2; break;
+                case 'T': case 't': x = (x << 2) | 3; break;
+                default: snprintf(err, errcap, "invalid sequence %.*s", (int)xl, text + b); rc = -1;
+            }
+        }
+        if (rc) break;
+        if (m == cap) { cap *= 2; keys = (go_key*)realloc(keys, cap * sizeof(go_key)); counts = (uint64_t*)realloc(counts, cap * 8); }
+        keys[m] = u2k(x); counts[m] = c; ++m;
+    }
+    if (!rc)
+    {
+        rc = go_write_graph(outfs, out_name, (unsigned)k, keys, counts, m, n);
+        if (rc) snprintf(err, errcap, "write error");
+        else if (flags & 1)
+        {
+            char name[4096];
+            snprintf(name, sizeof name, "%s.header", out_name);
+            int fi = go_fs_find(outfs, name);
+            if (fi >= 0 && outfs->files[fi].size >= 24) { uint64_t f = 1; memcpy(outfs->files[fi].data + 16, &f, 8); }
+        }
+    }
+    free(keys); free(counts);
     return rc ? -1 : 0;
 }

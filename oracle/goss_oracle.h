@@ -126,6 +126,11 @@ int go_subtract_kmer_set(const go_fs* in, const char* lhs, const char* rhs, go_f
 int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_fs* out, const char* out_name,
                           uint64_t stats[3], char* err, size_t errcap);
 
+/* dump-kmer-set (kind 0, GossCmdDumpKmerSet.cc:31-55) / dump-graph (kind 1, GossCmdDumpGraph.cc:31-61):
+ * malloc'ed text; restore-graph (GossCmdRestoreGraph.cc:72-135). */
+int go_dump(const go_fs* fs, const char* name, int kind, char** text, size_t* len, char* err, size_t errcap);
+int go_restore_graph(const char* text, size_t len, go_fs* out, const char* out_name, char* err, size_t errcap);
+
 /* VByte (spill-run private format; golden bytes in testVByteCodec.cc) */
 size_t   go_vbyte_encode(uint64_t x, uint8_t* out /* >= 9 */);  /* VByteCodec.hh:24-104 */
 uint64_t go_vbyte_decode(const uint8_t* in, size_t* used);

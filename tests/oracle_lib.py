@@ -361,6 +361,32 @@ def merge(files, names, kind, out, max_merge=8):
     return dst.files()
 
 
+def dump(files, name, kind):
+    """dump-kmer-set (kind 0) / dump-graph (kind 1) text."""
+    L = lib()
+    L.go_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    text, n = C.c_void_p(), C.c_size_t()
+    err = C.create_string_buffer(1024)
+    if L.go_dump(src.handle, name.encode(), kind, C.byref(text), C.byref(n), err, 1024):
+        raise OracleError(err.value.decode())
+    out = C.string_at(text, n.value)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(text)
+    return out
+
+
+def restore_graph(text, out):
+    L = lib()
+    L.go_restore_graph.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    dst = FileSet()
+    err = C.create_string_buffer(1024)
+    if L.go_restore_graph(text, len(text), dst.handle, out.encode(), err, 1024):
+        raise OracleError(err.value.decode())
+    return dst.files()
+
+
 def intersect_kmer_sets(files, names, out):
     L = lib()
     L.go_intersect_kmer_sets.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_void_p, C.c_char_p,

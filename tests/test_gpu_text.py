@@ -1,0 +1,99 @@
+"""goss dump-kmer-set / dump-graph / restore-graph / lint-graph on the GPU against the oracle."""
+import os
+import random
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOSS = os.path.join(ROOT, "gossamer_amd", "goss")
+
+
+def run(args, **kw):
+    return subprocess.run([GOSS] + args + ["--hbm-budget", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, **kw)
+
+
+def disk(tmp_path, base):
+    return {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
+
+
+def test_dump_restore_lint(oracle, tmp_path):
+    rng = random.Random(47)
+    genome = "".join(rng.choice("ACGT") for _ in range(20000))
+    reads = [genome[s:s + 130] for s in (rng.randrange(0, 19870) for _ in range(4000))]
+    reads += ["A" * 150] * 300                         # a multiplicity above 255: exercises ord1
+    txt = "\n".join(reads) + "\n"
+    (tmp_path / "r.txt").write_text(txt)
+    for k in (25, 40):
+        ks, gr = "ks%d" % k, "gr%d" % k
+        assert run(["build-kmer-set", "-k", str(k), "--line-in", str(tmp_path / "r.txt"), "-O", str(tmp_path / ks)]).returncode == 0
+        assert run(["build-graph", "-k", str(k), "--line-in", str(tmp_path / "r.txt"), "-O", str(tmp_path / gr)]).returncode == 0
+        # dump to stdout and to a file
+        p = run(["dump-kmer-set", "-G", str(tmp_path / ks)])
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == oracle.dump(disk(tmp_path, ks), ks, 0)
+        p = run(["dump-graph", "-G", str(tmp_path / gr), "-o", str(tmp_path / "g.txt")])
+        assert p.returncode == 0, p.stderr.decode()
+        text = (tmp_path / "g.txt").read_bytes()
+        assert text == oracle.dump(disk(tmp_path, gr), gr, 1)
+        assert ("A" * (k + 1) + "\t%d\n" % (300 * (150 - k))).encode() in text
+        # restore: byte-identical to the oracle's restore, and to the original graph
+        back = "back%d" % k
+        p = run(["restore-graph", "-f", str(tmp_path / "g.txt"), "-O", str(tmp_path / back)])
+        assert p.returncode == 0, p.stderr.decode()
+        exp = oracle.restore_graph(text, back)
+        got = disk(tmp_path, back)
+        assert sorted(got) == sorted(exp)
+        for name in exp:
+            assert got[name] == exp[name], (k, name)
+        orig = disk(tmp_path, gr)
+        for name in orig:
+            assert got[back + name[len(gr):]] == orig[name], (k, name)
+        # restore from stdin, asymmetric flag set
+        flagged = text.replace(b"\t0\n", b"\t1\n", 1)
+        p = run(["restore-graph", "-O", str(tmp_path / "asym")], input=flagged)
+        assert p.returncode == 0, p.stderr.decode()
+        exp = oracle.restore_graph(flagged, "asym")
+        got = disk(tmp_path, "asym")
+        assert all(got[n] == exp[n] for n in exp) and sorted(got) == sorted(exp)
+        # lint: a graph built from reads is symmetric by construction
+        p = run(["lint-graph", "-G", str(tmp_path / gr), "-v"])
+        assert p.returncode == 0, p.stderr.decode()
+        err = p.stderr.decode()
+        assert "Pass 1: Checking counts are sane." in err and "Pass 2: Checking traversal is sane." in err
+        assert "warning" not in err
+        # break the symmetry: drop one edge / change one count in the text, restore, lint
+        lines = text.split(b"\n")
+        comp = {65: "T", 67: "G", 71: "C", 84: "A"}
+
+        def revcomp(seq):
+            return "".join(comp[b] for b in reversed(seq))
+
+        victim = next(i for i in range(2, len(lines) - 2)
+                      if lines[i] and revcomp(lines[i].split(b"\t")[0]).encode() != lines[i].split(b"\t")[0]
+                      and revcomp(lines[i + 1].split(b"\t")[0]).encode() != lines[i + 1].split(b"\t")[0])
+        broken = b"\n".join(lines[:victim] + lines[victim + 1:])
+        p = run(["restore-graph", "-O", str(tmp_path / "brk")], input=broken)
+        assert p.returncode == 0, p.stderr.decode()
+        p = run(["lint-graph", "-G", str(tmp_path / "brk")])
+        err = p.stderr.decode()
+        assert p.returncode == 0
+        assert err.count("No reverse complement for the following edge exists:") == 1
+        seq, c = lines[victim].split(b"\t")
+        rc = revcomp(seq)
+        assert ("  fwd edge    %s %s" % (rc, c.decode())) in err
+        seq2, c2 = lines[victim + 1].split(b"\t")
+        bumped = b"\n".join(lines[:victim + 1] + [seq2 + b"\t" + str(int(c2) + 1).encode()] + lines[victim + 2:])
+        p = run(["restore-graph", "-O", str(tmp_path / "bmp")], input=bumped)
+        assert p.returncode == 0, p.stderr.decode()
+        p = run(["lint-graph", "-G", str(tmp_path / "bmp")])
+        err = p.stderr.decode()
+        # the edge and its reverse complement both report the mismatch
+        assert err.count("counts on fwd and rev edges are not equal:") == 2
+    # errors
+    p = run(["dump-graph"])
+    assert p.returncode == 1 and "mandatory option graph-in was not given." in p.stderr.decode()
+    p = run(["restore-graph", "-O", str(tmp_path / "bad")], input=b"#v\n25\t1\t0\nACGT\t1\n")
+    assert p.returncode == 1 and "sequence ACGT has wrong length" in p.stderr.decode()
