@@ -134,6 +134,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tim = ctx.timing().as_dict()
+    w_local = windows
+    fused = ctx.stat("fused_chunks") > 0
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -153,10 +155,16 @@ def main():
         d = tim[dom]
         per_launch_units = d["units"] / max(1, d["launches"])
         avg_ms = d["ms"] / max(1, d["launches"])
-        # algorithmic bytes of one launch: the key traffic term of section 8(d) (one write and
-        # one read of every key = 2*W bytes per key) for the sort kernels; the full per-window
-        # figure for the extraction kernel
-        per_unit = b_per_window if dom == "extract" else 16.0
+        # algorithmic bytes of one launch, from section 8(d)'s per-window figure
+        # L/(L-k+1)*3/8 + 2*W*s: a partition / counting kernel moves the key term (one read and
+        # one write of every key = 2*W per key); the extraction kernel's share is the read
+        # term plus ONE write of the window's keys (W*s), counted per valid window
+        if dom == "extract":
+            keys_per_window = 2 if args.graph else 1
+            per_unit = L / (L - klen + 1) * 3.0 / 8.0 + kbytes * keys_per_window
+            per_launch_units = w_local / args.steps / max(1, d["launches"] / args.steps)
+        else:
+            per_unit = 16.0
         achieved = per_unit * per_launch_units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         dev_ms = sum(v["ms"] for n, v in tim.items())
         tr = measured_traffic(dom)
@@ -179,7 +187,8 @@ def main():
                                    "sort-count, KmerSet SparseArray emitted" % (k, nreads, L, genome_len, args.seed),
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
                        "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
-            "roofline": {"bound": "hbm", "kernel": {"extract": "extract_kernel", "hist": "radix_hist_kernel",
+            "roofline": {"bound": "hbm", "kernel": {"extract": "extract1_part_kernel" if fused else "extract1_kernel",
+                                                    "hist": "radix_hist_kernel",
                                                     "scan": "scan_*_kernel", "scatter": "radix_onesweep_kernel",
                                                     "reduce": "seg_hash_reduce_kernel"}.get(dom, dom),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

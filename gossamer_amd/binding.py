@@ -21,7 +21,7 @@ SYMBOLS = [
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
-    "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint",
+    "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat",
 ]
 
 
@@ -156,6 +156,13 @@ class Context:
 
     def reset(self):
         self._check(self._L.goss_gpu_reset(self._h))
+
+    def stat(self, name):
+        """A diagnostic counter of the context (goss_gpu_stat)."""
+        v = C.c_uint64()
+        self._L.goss_gpu_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
+        self._check(self._L.goss_gpu_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def finish(self):
         c = Counts()

@@ -91,6 +91,12 @@ struct goss_gpu_ctx {
     uint32_t segment_retries = 0;       // segment path attempts that overflowed an LDS table
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
+    bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
+    uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
+    uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
+    uint32_t fused_chunks = 0;          // chunks counted by the fused path
+    bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
+    double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
     uint64_t budget = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -453,10 +459,10 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, co
 // particular order, so a prefix is a sample): with s sampled keys of which d are distinct,
 // M ~ s^2 / (2 (s - d)) (birthday estimate), never less than d.  Returns 0 when the sample has
 // no repeated key at all (M unknown, presumably of the order of n).
+// Exact number of distinct keys among the first s keys (sorts a copy of them).
 template <class K>
-uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
+uint64_t count_distinct_sample(goss_gpu_ctx* c, const K* keys, uint64_t s)
 {
-    const uint64_t s = std::min<uint64_t>(n, 4u << 20);
     if (s < 2) return s;
     uint64_t mark = c->arena.mark();
     K* a = (K*)c->arena.temp(s * sizeof(K));
@@ -479,10 +485,25 @@ uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t d = h[0];
     c->arena.release(mark);
-    if (s == n) return d;
-    if (d == s) return 0;
+    return d;
+}
+
+// M ~ s^2 / (2 (s - d)) for a sample of s keys with d distinct; 0 = no repeated key (unknown).
+inline uint64_t birthday_estimate(uint64_t s, uint64_t d)
+{
+    if (d >= s) return 0;
     const double est = (double)s * (double)s / (2.0 * (double)(s - d));
     return std::max<uint64_t>(d, (uint64_t)est);
+}
+
+template <class K>
+uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
+{
+    const uint64_t s = std::min<uint64_t>(n, 4u << 20);
+    if (s < 2) return s;
+    const uint64_t d = count_distinct_sample<K>(c, keys, s);
+    if (s == n) return d;
+    return birthday_estimate(s, d);
 }
 
 // Partition ka on its top `segbits` bits (result back in ka or kb), count every segment in LDS.
@@ -490,12 +511,14 @@ uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
 // partition bits); 2 if the staging area is too small (use the full sort).  The keys stay,
 // permuted, in ka or kb (*in_b_out).
 template <class K>
+int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out);
+
+template <class K>
 int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, bool* in_b_out, Run* out)
 {
     const uint32_t keybits = 2 * c->len;
     const uint32_t shift = keybits - segbits;
     const uint32_t npass = (segbits + 7) / 8;
-    const uint32_t nseg = 1u << segbits;
     uint64_t mark = c->arena.mark();
     const unsigned long long* prehist =
         (segbits == kSegBits && c->extract_hist_shift == shift && c->lookback && !*in_b_out) ? c->d_ctr->hist : nullptr;
@@ -505,6 +528,18 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
     K* part = moved ? dst : src;          // partitioned keys
     K* spare = moved ? src : dst;         // free half of the ping-pong: staging area
     *in_b_out = (part == kb);
+    c->arena.release(mark);
+    return segment_reduce<K>(c, part, spare, n, segbits, out);
+}
+
+// Count every segment of the partitioned keys `part` in LDS; `spare` (n keys) is the staging area.
+template <class K>
+int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out)
+{
+    const uint32_t keybits = 2 * c->len;
+    const uint32_t shift = keybits - segbits;
+    const uint32_t nseg = 1u << segbits;
+    uint64_t mark = c->arena.mark();
     PhaseTimer t(c, GOSS_T_REDUCE, n);
     uint64_t* seg_off = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
     uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
@@ -583,6 +618,192 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
     return r;
 }
 
+// ---- fused extraction + first partition pass (one-word canonical keys) ----------------------
+// Returns true when it counted the chunk (run appended, counters updated); false = not
+// applicable or a bucket region overflowed / a later stage asked for a retry: the caller then
+// runs the unfused sequence on the same (untouched) input.
+bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, Key1* ka, uint64_t ka_slots,
+                         Key1* kb)
+{
+    const uint32_t keybits = 2 * c->len;
+    if (!c->fused || c->words != 1 || c->mode != GOSS_MODE_KMER_SET || c->path != 0 || !c->lookback || c->ordered_tiles ||
+        c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
+        return false;
+    constexpr int kTile = SortCfg<Key1, false>::kTile;
+    uint64_t mark = c->arena.mark();
+    struct Release { goss_gpu_ctx* c; uint64_t m; ~Release() { c->arena.release(m); } } release{c, mark};
+
+    // 1. a sample of the keys: slices spread evenly over the chunk, extracted with the plain kernel
+    constexpr uint64_t kSlices = 32, kSliceStarts = 128u << 10;
+    auto decline = [&](const char* why) {
+        if (c->debug) std::fprintf(stderr, "libgossgpu: fused path declined (%s), %llu window starts\n", why, (unsigned long long)nstarts);
+        return false;
+    };
+    if (nstarts < 4 * kSlices * kSliceStarts) return decline("chunk smaller than the sample");
+    c->mute_timing = true;
+    HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
+    for (uint64_t j = 0; j < kSlices; ++j)
+    {
+        const uint64_t off = (nstarts - kSliceStarts) / (kSlices - 1) * j;
+        const uintptr_t addr = (uintptr_t)(d_bases + off);
+        const uint32_t mis = (uint32_t)(addr & 15u);
+        extract_dispatch<Key1>(c, (const uint8_t*)(addr - mis), mis, kSliceStarts, navail - off, ka);
+    }
+    c->extract_hist_shift = 0xFFFFFFFFu;
+    ExtractCounters* hc = (ExtractCounters*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hc, c->d_ctr, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t ns = hc->keys_out;
+    c->mute_timing = false;
+    if (ns < (1u << 20)) return decline("mostly non-bases");
+    const uint64_t d_s = count_distinct_sample<Key1>(c, ka, ns);
+    const uint64_t m_est = birthday_estimate(ns, d_s);
+    const double scale = (double)nstarts / (double)(kSlices * kSliceStarts);
+    const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
+    if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
+    const uint64_t limit = SegCfg<Key1>::kLimit;
+    uint32_t segbits = kSegBits;
+    while (segbits < (uint32_t)kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;
+    if ((m_est >> segbits) > limit || segbits + 8 > keybits) return decline("too many distinct keys per segment");
+    const uint32_t shift = keybits - segbits;
+    const uint32_t npass = (segbits + 7) / 8;
+
+    // 2. bucket regions from the sample's histogram of the first partition digit
+    unsigned long long* shist = (unsigned long long*)c->arena.temp(256 * 8);
+    HIP_TRY(hipMemsetAsync(shist, 0, 256 * 8, c->stream));
+    c->mute_timing = true;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<Key1>), dim3(256), dim3(kTB), 0, c->stream, (const Key1*)ka, ns, shift, 1u, shist);
+    c->mute_timing = false;
+    std::vector<unsigned long long> hh(256);
+    HIP_TRY(hipMemcpyAsync(hh.data(), shist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // expected size of every bucket plus five standard deviations of the sample count; whatever
+    // room the key buffer has beyond that (up to 25 %) is handed out proportionally, so that a
+    // mildly non-stationary input still fits
+    GapTable gt{};
+    double base[256], base_sum = 0;
+    for (int d = 0; d < 256; ++d)
+    {
+        const double h = (double)hh[d];
+        base[d] = (h + 5.0 * std::sqrt(h + 1.0) + 16.0) * scale + 1024.0;
+        base_sum += base[d];
+    }
+    double slack = std::min(1.25, ((double)ka_slots - 256.0 * 16.0) / base_sum);
+    if (slack < 1.02) return decline("bucket regions do not fit the key buffer");
+    slack *= c->fused_capscale;
+    uint64_t at = 0;
+    for (int d = 0; d < 256; ++d)
+    {
+        uint64_t cap = ((uint64_t)(base[d] * slack) + 15) & ~15ULL;
+        gt.reg_start[d] = at; gt.reg_cap[d] = cap;
+        at += cap;
+    }
+
+    // 3. extraction that partitions
+    GapTable* dgt = (GapTable*)c->arena.temp(sizeof(GapTable));
+    PartCounters* pc = (PartCounters*)c->arena.temp(sizeof(PartCounters));
+    HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(pc, 0, sizeof(PartCounters), c->stream));
+    const uintptr_t addr = (uintptr_t)d_bases;
+    const uint32_t mis = (uint32_t)(addr & 15u);
+    const uint8_t* aligned = (const uint8_t*)(addr - mis);
+    {
+#ifndef GOSS_FUSED_G
+#define GOSS_FUSED_G 1
+#endif
+        constexpr uint64_t kSuper = GOSS_FUSED_G * kTB * 16;
+        const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 768 : 512);
+        PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
+#define GOSS_LAUNCH_EP(NB)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis,   \
+                       nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper, npass - 1)
+        switch ((2 * c->len + 7) / 8)
+        {
+            case 3: GOSS_LAUNCH_EP(3); break;
+            case 4: GOSS_LAUNCH_EP(4); break;
+            case 5: GOSS_LAUNCH_EP(5); break;
+            case 6: GOSS_LAUNCH_EP(6); break;
+            case 7: GOSS_LAUNCH_EP(7); break;
+            default: GOSS_LAUNCH_EP(8); break;
+        }
+#undef GOSS_LAUNCH_EP
+        t.stop();
+    }
+    std::vector<unsigned long long> hpc(sizeof(PartCounters) / 8);
+    HIP_TRY(hipMemcpyAsync(hpc.data(), pc, sizeof(PartCounters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const PartCounters* hp = (const PartCounters*)hpc.data();
+    if (hp->overflow) { c->fused_overflows++; return decline("a bucket region overflowed"); }
+    const uint64_t n = hp->keys_out;
+    if (n == 0) return false;
+    uint64_t tiles = 0, sum = 0;
+    for (int d = 0; d < 256; ++d)
+    {
+        gt.cnt[d] = hp->cursors[d * kCursorStride];
+        gt.tile_first[d] = tiles;
+        tiles += (gt.cnt[d] + kTile - 1) / kTile;
+        sum += gt.cnt[d];
+    }
+    gt.tile_first[256] = tiles;
+    if (sum != n) throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
+    HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
+
+    // 4. remaining partition passes: the first reads the bucket regions, the others are dense
+    const uint64_t ntiles_dense = (n + kTile - 1) / kTile;
+    unsigned long long* status = (unsigned long long*)c->arena.temp(256ULL * std::max(tiles, ntiles_dense) * 8);
+    LookbackCtl* ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
+    LookbackCtl* hctl = (LookbackCtl*)((uint8_t*)c->h_pinned + 128);
+    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
+    {
+        PhaseTimer t(c, GOSS_T_SCAN, 512);
+        hipLaunchKernelGGL(scan_rows256_kernel, dim3(2), dim3(kTB), 0, c->stream, pc->hist);
+        t.stop();
+    }
+    Key1* src = ka; Key1* dst = kb;
+    for (uint32_t di = 1; di < npass; ++di)
+    {
+        const uint32_t d = shift + 8 * di;
+        const bool gapped = di == 1;
+        const uint64_t nt = gapped ? tiles : ntiles_dense;
+        HIP_TRY(hipMemsetAsync(status, 0, nt * 256 * 8, c->stream));
+        {
+            PhaseTimer t(c, GOSS_T_SCATTER, n);
+            if (gapped)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                   c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                                   (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
+                                   (unsigned long long*)nullptr, (const GapTable*)dgt);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, false>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                   c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                                   (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
+                                   (unsigned long long*)nullptr, (const GapTable*)nullptr);
+            t.stop();
+        }
+        HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hctl->error)
+        {
+            std::fprintf(stderr, "libgossgpu: radix look-back chain gave up in the fused path; redoing the chunk unfused\n");
+            c->lookback_failures++;
+            c->ordered_tiles = true;
+            return false;
+        }
+        std::swap(src, dst);
+    }
+    // src = partitioned keys (dense unless npass == 1, which the 16-bit minimum excludes), dst = spare
+    Run r{nullptr, nullptr, 0};
+    c->arena.release(mark); release.m = c->arena.mark();
+    const int rc = segment_reduce<Key1>(c, src, dst, n, segbits, &r);
+    if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
+    c->runs.push_back(r);
+    c->windows += hp->windows;
+    c->keys_total += n;
+    c->fused_chunks++;
+    return true;
+}
+
 // Process window starts [0, nstarts) of a device-resident byte string (navail readable bytes,
 // navail >= nstarts): extract -> sort -> reduce -> append a run.
 template <class K>
@@ -591,8 +812,22 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     const uint32_t S = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
     const uint64_t cap = nstarts * S;              // upper bound on keys
     uint64_t mark = c->arena.mark();
-    K* ka = (K*)c->arena.temp(cap * sizeof(K));
+    // the fused path wants room for its bucket regions (expected keys + slack): up to cap/8 more
+    // slots in the first buffer when the arena can spare them beyond the two buffers and the
+    // partition / segment tables
+    uint64_t ka_slots = cap;
+    if (std::is_same<K, Key1>::value && c->fused && nstarts >= c->fused_min)
+    {
+        const uint64_t extra = cap / 8 + 256 * 16;
+        const uint64_t need = (2 * cap + extra) * sizeof(K) + cap / 2 + (uint64_t)(1u << kSegBits) * kSegLimit * 12 + (64u << 20);
+        if (c->arena.avail() >= need) ka_slots = cap + extra;
+    }
+    K* ka = (K*)c->arena.temp(ka_slots * sizeof(K));
     K* kb = (K*)c->arena.temp(cap * sizeof(K));
+    if constexpr (std::is_same<K, Key1>::value)
+    {
+        if (process_chunk_fused(c, d_bases, nstarts, navail, ka, ka_slots, kb)) { c->arena.release(mark); return; }
+    }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     uintptr_t addr = (uintptr_t)d_bases;
     uint32_t mis = (uint32_t)(addr & 15u);
@@ -1107,6 +1342,10 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
+    { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
+    { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }
+    { const char* e = std::getenv("GOSS_GPU_DEBUG"); if (e && *e == '1') c->debug = true; }
     int rc = guarded(c, [&]() {
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -1476,6 +1715,19 @@ int goss_gpu_select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
         if (c->words == 1) select_counts<Key1>(c, lo, hi); else select_counts<Key2>(c, lo, hi);
         t.stop();
     });
+}
+
+int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
+{
+    if (!c || !name || !value) return GOSS_ERR_INVALID_ARG;
+    const std::string n = name;
+    if (n == "fused_chunks") *value = c->fused_chunks;
+    else if (n == "fused_overflows") *value = c->fused_overflows;
+    else if (n == "segment_retries") *value = c->segment_retries;
+    else if (n == "lookback_failures") *value = c->lookback_failures;
+    else if (n == "runs") *value = c->runs.size();
+    else return GOSS_ERR_INVALID_ARG;
+    return GOSS_OK;
 }
 
 int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)

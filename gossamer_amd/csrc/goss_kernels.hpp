@@ -454,6 +454,216 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 }
 
 // --------------------------------------------------------------------------------------
+// K2+K4 fused, one-word canonical keys: extraction that writes its keys already partitioned on
+// the first partition digit
+// --------------------------------------------------------------------------------------
+//
+// The first partition pass of the segment path may place tiles inside a bucket in any order, so
+// it needs no scan over tiles -- only room in every bucket.  This kernel therefore partitions
+// the keys of a super-tile (G*256*P window starts, at most 8192 keys) while they are still in
+// registers: rank by LDS atomics on the digit at bit `shift`, reserve the tile's share of every
+// bucket region with one atomic per digit, sort through LDS, store coalesced bucket runs.  That
+// removes one write and one read of every key (16 of the 48 bytes per k-mer the unfused pipeline
+// moves).  Bucket regions are sized by the host from a sample of the input (GapTable); a region
+// that turns out too small raises `overflow` and the host redoes the chunk with the unfused
+// kernels.  The histograms of the next two digits are accumulated for the passes that follow.
+
+constexpr int kCursorStride = 32;                // u64 words between bucket cursors (256 B)
+
+struct GapTable {
+    unsigned long long reg_start[256];   // first key slot of bucket d
+    unsigned long long reg_cap[256];     // slots reserved for bucket d
+    unsigned long long cnt[256];         // keys actually in bucket d (filled by the host after extraction)
+    unsigned long long tile_first[257];  // first tile of bucket d when its keys are cut into sort tiles
+};
+
+struct PartCounters {
+    unsigned long long keys_out, windows, overflow, pad;
+    unsigned long long hist[512];                        // digits at shift+8 and shift+16
+    unsigned long long cursors[256 * kCursorStride];     // keys placed in bucket d so far
+};
+
+template <int NB, int G>
+__global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                            uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                            Key1* __restrict__ out, PartCounters* __restrict__ pc,
+                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
+                                                            uint32_t nhist)
+{
+    constexpr int P = 16;
+    constexpr int T = kTB * P;
+    constexpr int NVEC = G * T / 16 + 4;
+    constexpr int NK = G * P;                    // keys per thread
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key1 sorted[G * T];
+    __shared__ uint32_t dh[256];                 // keys of this super-tile per digit (and rank counter)
+    __shared__ uint32_t dstart[256];
+    __shared__ uint64_t gbase[256];              // global slot of sorted[i] with digit d = gbase[d] + i
+    __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t lh[512];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+
+    const uint32_t tid = threadIdx.x;
+    lh[tid] = 0; lh[tid + 256] = 0;
+    dh[tid] = 0;
+    if (tid == 0) sh_ovf = 0;
+    const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t bits = 2 * len;
+    const uint64_t kmask = (1ULL << bits) - 1;               // len <= 31
+    const uint64_t lmask = (1ULL << len) - 1;
+    unsigned long long nvalid = 0;
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        const uint64_t tile_base = st * (uint64_t)(G * T);
+
+        // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
+        for (uint32_t v = tid; v < NVEC; v += kTB)
+        {
+            uint64_t byte0 = tile_base + (uint64_t)v * 16;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            if (byte0 + 16 <= navail + mis)
+            {
+                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            }
+            else if (byte0 < navail + mis)
+            {
+                for (int j = 0; j < 16; ++j)
+                {
+                    uint64_t b = byte0 + j;
+                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+            }
+            uint32_t codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                uint32_t l = w[i] | 0x20202020u;
+                uint32_t x = (l >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                uint32_t b1 = bad >> 7;
+                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                codes |= c8 << (8 * i);
+                bads |= b4 << (4 * i);
+            }
+            pk[v] = codes;
+            iv[v] = bads;
+        }
+        __syncthreads();
+
+        // ---- phase B: windows out of registers, canonical keys, rank inside their digit ---------
+        Key1 kreg[NK];
+        uint16_t rk[NK];
+        uint32_t vm[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+            uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+            const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                bool ok = ((inv >> i) & lmask) == 0 && (p0 + i < nstarts);
+                m |= ok ? (1u << i) : 0u;
+            }
+            vm[g] = m;
+            nvalid += __popc(m);
+            if (m)
+            {
+                uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
+                uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+                const uint32_t s2 = 2 * sh;
+                const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+                const uint64_t bhi = hi >> s2;
+                uint64_t f = rev64(blo & kmask) >> (64 - bits);
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                {
+                    uint64_t e = i ? ((blo >> (2 * i)) | (bhi << (64 - 2 * i))) : blo;
+                    e &= kmask;
+                    if (i)
+                    {
+                        uint32_t pos = 2 * (i + len - 1);
+                        uint64_t nb = (pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                        f = ((f << 2) | nb) & kmask;
+                    }
+                    if ((m >> i) & 1u)
+                    {
+                        Key1 fk{f}, rck{(~e) & kmask};
+                        const Key1 k = canonical_short<NB>(fk, rck);
+                        kreg[g * P + i] = k;
+                        rk[g * P + i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: reserve the tile's share of every bucket (thread tid owns digit tid) -------
+        uint32_t total;
+        {
+            const uint32_t cnt = dh[tid];
+            const uint32_t start = block_excl_scan<uint32_t>(cnt, sh_scan, &total);
+            dstart[tid] = start;
+            unsigned long long at = cnt ? atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)cnt) : 0ULL;
+            gbase[tid] = my_start + at - start;
+            // a region that is too small: nothing of this super-tile is stored, the host redoes the chunk
+            if (cnt && at + cnt > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+        }
+        __syncthreads();
+        dh[tid] = 0;                                   // ready for the next super-tile
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+                if ((vm[g] >> i) & 1u)
+                {
+                    const Key1 k = kreg[g * P + i];
+                    sorted[dstart[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[g * P + i]] = k;
+                }
+        }
+        __syncthreads();
+
+        // ---- phase D: coalesced bucket runs + histograms of the next two digits -----------------
+        if (!sh_ovf)
+        {
+            if (nhist > 1)
+                for (uint32_t i = tid; i < total; i += kTB)
+                {
+                    const Key1 k = sorted[i];
+                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
+                    atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
+                    atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
+                }
+            else
+                for (uint32_t i = tid; i < total; i += kTB)
+                {
+                    const Key1 k = sorted[i];
+                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
+                    atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
+                }
+        }
+        __syncthreads();
+    }
+    if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]);
+    if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]);
+    // valid windows of this workgroup
+    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
+    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid); atomicAdd(&pc->windows, nvalid); }
+}
+
+// --------------------------------------------------------------------------------------
 // K4: LSD radix sort, 8-bit digits: per-tile histogram, scan (above), stable scatter
 // --------------------------------------------------------------------------------------
 
@@ -649,19 +859,22 @@ struct LookbackCtl {
     unsigned long long walk_steps, spin_polls, max_depth, tiles;
 };
 
-constexpr int kCursorStride = 32;                // u64 words between bucket cursors (256 B)
 constexpr uint64_t kLbFlagAgg = 1ULL << 62;      // tile's own count is published
 constexpr uint64_t kLbFlagPrefix = 2ULL << 62;   // inclusive prefix up to this tile is published
 constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
 
-template <class K, bool HAS_VAL, bool ORDERED>
+// GAPPED: the input is the output of extract1_part_kernel -- 256 bucket regions with unused
+// slots between them (GapTable); tile t is the (t - tile_first[b])-th tile of bucket b.  Every
+// tile then lies inside one bucket of the previous digit, so no tile needs a stable rank.
+template <class K, bool HAS_VAL, bool ORDERED, bool GAPPED = false>
 __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              uint64_t n, uint32_t digit, uint32_t sorted_lo,
                                                              const unsigned long long* __restrict__ bucket_base,
                                                              unsigned long long* __restrict__ status,
                                                              LookbackCtl* __restrict__ ctl,
-                                                             unsigned long long* __restrict__ cursors)
+                                                             unsigned long long* __restrict__ cursors,
+                                                             const GapTable* __restrict__ gt = nullptr)
 {
     constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
     constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
@@ -672,6 +885,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     __shared__ uint32_t vstage[HAS_VAL ? kSortTile : 1];
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ uint32_t sh_tile;
+    __shared__ uint32_t sh_bucket;
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
     // Tile number.  ORDERED: a ticket (one returning atomic per tile: every lower-numbered tile
@@ -680,12 +894,26 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     // blockIdx order in practice; HIP does not promise it, so the look-back spin is bounded and
     // a give-up makes the host redo the pass with the histogram-table kernels.
     if (ORDERED) { if (tid == 0) sh_tile = atomicAdd(&ctl->ticket, 1u); }
+    if (GAPPED && !ORDERED)
+    {
+        const unsigned long long t = blockIdx.x;
+        if (gt->tile_first[tid] <= t && t < gt->tile_first[tid + 1]) sh_bucket = tid;
+    }
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
     __syncthreads();
     const uint32_t tile = ORDERED ? sh_tile : blockIdx.x;
-    const uint64_t tile_base = (uint64_t)tile * kSortTile;
-    const uint32_t tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
+    uint64_t tile_base = (uint64_t)tile * kSortTile;
+    uint32_t tile_n = 0;
+    if (GAPPED)
+    {
+        const uint32_t b = sh_bucket;
+        const uint64_t j = (uint64_t)tile - gt->tile_first[b];
+        const uint64_t left = gt->cnt[b] - j * kSortTile;
+        tile_base = gt->reg_start[b] + j * kSortTile;
+        tile_n = (uint32_t)(left < (uint64_t)kSortTile ? left : (uint64_t)kSortTile);
+    }
+    else tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
 
     K key[kSortItems];
     uint32_t val[HAS_VAL ? kSortItems : 1];
@@ -708,7 +936,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     // keys all share them -- almost every tile of the second partition pass -- may be ranked in
     // any order, which costs one LDS atomic per key instead of eight ballots.
     bool stable = false;
-    if (digit > sorted_lo)
+    if (!GAPPED && digit > sorted_lo)
     {
         const uint32_t nb = digit - sorted_lo;
         if (nb > 56) stable = true;

@@ -209,6 +209,13 @@ int goss_gpu_select_counts(goss_gpu_ctx* ctx, uint32_t lo, uint32_t hi);
 int goss_gpu_emit_count_bits(goss_gpu_ctx* ctx, uint32_t mask, const char* suffix);
 
 /*
+ * Diagnostic counters of the context, by name: "fused_chunks" (chunks counted by the extraction
+ * that partitions), "fused_overflows" (chunks redone unfused because a bucket region was too
+ * small), "segment_retries", "lookback_failures", "runs".
+ */
+int goss_gpu_stat(goss_gpu_ctx* ctx, const char* name, uint64_t* value);
+
+/*
  * After finish: the text form of the object as one device-built file (suffix ".dump") --
  * "#<version>\nK\tcount\n" and one k-mer per line for a k-mer set (GossCmdDumpKmerSet.cc:31-55),
  * "#<version>\nK\tcount\tflags\n" and "<edge>\t<multiplicity>" per line for a graph

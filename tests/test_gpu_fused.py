@@ -1,0 +1,97 @@
+"""The extraction that partitions (extract1_part_kernel + gapped first look-back pass): same files
+as the oracle when it runs, when a bucket region overflows and the chunk is redone unfused, and
+when it declines the input."""
+import os
+
+import pytest
+
+import gossamer_amd as g
+
+pytestmark = pytest.mark.gpu
+
+
+def _suffix_map(files, prefix):
+    return {k[len(prefix):]: v for k, v in files.items()}
+
+
+def _build(reads, k, env=None, budget=8 << 30):
+    old = {}
+    for name, val in (env or {}).items():
+        old[name] = os.environ.get(name)
+        os.environ[name] = val
+    try:
+        with g.Context(k, g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+            ctx.push_host(reads)
+            c = ctx.finish()
+            files = ctx.emit()
+            stats = {n: ctx.stat(n) for n in ("fused_chunks", "fused_overflows", "segment_retries", "lookback_failures")}
+        return c, files, stats
+    finally:
+        for name, val in old.items():
+            if val is None:
+                del os.environ[name]
+            else:
+                os.environ[name] = val
+
+
+def _same(got, exp):
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
+def test_fused_path_runs_and_matches_oracle(oracle):
+    reads = g.synth_reads_host(300000, 150, 1500000, seed=11)          # 45 M window starts, ~30x coverage
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
+    exp = _suffix_map(exp, "ks")
+    c, got, st = _build(reads, 25)
+    assert st["fused_chunks"] == 1 and st["fused_overflows"] == 0 and st["lookback_failures"] == 0
+    assert c.windows == nwin
+    _same(got, exp)
+    # regions made too small on purpose: the chunk must be redone by the unfused kernels
+    c, got, st = _build(reads, 25, env={"GOSS_GPU_FUSED_CAPSCALE": "0.6"})
+    assert st["fused_chunks"] == 0 and st["fused_overflows"] == 1
+    assert c.windows == nwin
+    _same(got, exp)
+    # switched off
+    c, got, st = _build(reads, 25, env={"GOSS_GPU_NO_FUSED": "1"})
+    assert st["fused_chunks"] == 0 and st["fused_overflows"] == 0
+    _same(got, exp)
+
+
+@pytest.mark.parametrize("k", [16, 31])
+def test_fused_path_other_k(oracle, k):
+    """Shortest key width with a fused path worth taking (32 bits) and the longest one-word key (62 bits)."""
+    reads = g.synth_reads_host(250000, 150, 1000000, seed=12)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], k, out="ks")
+    c, got, st = _build(reads, k)
+    assert st["fused_chunks"] == 1
+    assert c.windows == nwin
+    _same(got, _suffix_map(exp, "ks"))
+
+
+def test_fused_path_contiguous_sequence(oracle):
+    """Long sequences (almost every byte starts a window): the bucket regions need the larger key
+    buffer; 40 copies of one 1 Mbp sequence."""
+    import random
+    rng = random.Random(5)
+    seq = "".join(rng.choice("ACGT") for _ in range(1_000_000))
+    reads = ("\n".join([seq] * 40) + "\n").encode()
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 27, out="ks")
+    c, got, st = _build(reads, 27)
+    assert st["fused_chunks"] == 1
+    assert c.windows == nwin
+    _same(got, _suffix_map(exp, "ks"))
+
+
+def test_fused_path_declines_unique_input(oracle):
+    """No duplication (every k-mer once): the sample says so and the plain sequence runs."""
+    import numpy as np
+    rng = np.random.default_rng(6)
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 40_000_000)].tobytes() + b"\n"
+    with g.Context(25, g.MODE_KMER_SET, hbm_budget=8 << 30) as ctx:
+        ctx.push_host(reads)
+        c = ctx.finish()
+        assert ctx.stat("fused_chunks") == 0
+        assert c.windows == 40_000_000 - 24
+        assert c.distinct > 0.98 * c.windows
