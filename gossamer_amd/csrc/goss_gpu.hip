@@ -445,12 +445,12 @@ template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; 
 template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
 
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, SegOut* so,
-                            uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc)
+                            uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits)
 {
-    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc);
+    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc, rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, SegOut* so,
-                            uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc)
+                            uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t)
 {
     hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc);
 }
@@ -555,7 +555,7 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
                        (const K*)part, n, shift, nseg, seg_off);
-    launch_seg_hash(c, nseg, (const K*)part, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+    launch_seg_hash(c, nseg, (const K*)part, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift);
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -713,11 +713,17 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
 #endif
         constexpr uint64_t kSuper = GOSS_FUSED_G * kTB * 16;
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 768 : 512);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 1024 : 512);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
 #define GOSS_LAUNCH_EP(NB)                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis,   \
-                       nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper, npass - 1)
+    do {                                                                                                              \
+        if (npass > 2)                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, 2>), dim3(grid), dim3(kTB), 0, c->stream,    \
+                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper);   \
+        else                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, 1>), dim3(grid), dim3(kTB), 0, c->stream,    \
+                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper);   \
+    } while (0)
         switch ((2 * c->len + 7) / 8)
         {
             case 3: GOSS_LAUNCH_EP(3); break;

@@ -483,12 +483,11 @@ struct PartCounters {
     unsigned long long cursors[256 * kCursorStride];     // keys placed in bucket d so far
 };
 
-template <int NB, int G>
+template <int NB, int G, int NH>
 __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
-                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
-                                                            uint32_t nhist)
+                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper)
 {
     constexpr int P = 16;
     constexpr int T = kTB * P;
@@ -498,14 +497,14 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     __shared__ uint32_t iv[NVEC];
     __shared__ Key1 sorted[G * T];
     __shared__ uint32_t dh[256];                 // keys of this super-tile per digit (and rank counter)
-    __shared__ uint32_t dstart[256];
     __shared__ uint64_t gbase[256];              // global slot of sorted[i] with digit d = gbase[d] + i
     __shared__ uint32_t sh_ovf;
-    __shared__ uint32_t lh[512];
+    __shared__ uint32_t lh[256 * NH];            // histograms of the next NH digits
     __shared__ uint32_t sh_scan[kWaves + 1];
 
     const uint32_t tid = threadIdx.x;
-    lh[tid] = 0; lh[tid + 256] = 0;
+    lh[tid] = 0;
+    if (NH > 1) lh[tid + 256] = 0;
     dh[tid] = 0;
     if (tid == 0) sh_ovf = 0;
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
@@ -614,14 +613,13 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         {
             const uint32_t cnt = dh[tid];
             const uint32_t start = block_excl_scan<uint32_t>(cnt, sh_scan, &total);
-            dstart[tid] = start;
+            dh[tid] = start;                           // the counter becomes the digit's first slot in `sorted`
             unsigned long long at = cnt ? atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)cnt) : 0ULL;
             gbase[tid] = my_start + at - start;
             // a region that is too small: nothing of this super-tile is stored, the host redoes the chunk
             if (cnt && at + cnt > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
         }
         __syncthreads();
-        dh[tid] = 0;                                   // ready for the next super-tile
 #pragma unroll
         for (int g = 0; g < G; ++g)
         {
@@ -630,15 +628,16 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 if ((vm[g] >> i) & 1u)
                 {
                     const Key1 k = kreg[g * P + i];
-                    sorted[dstart[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[g * P + i]] = k;
+                    sorted[dh[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[g * P + i]] = k;
                 }
         }
         __syncthreads();
 
         // ---- phase D: coalesced bucket runs + histograms of the next two digits -----------------
+        dh[tid] = 0;                                   // ready for the next super-tile
         if (!sh_ovf)
         {
-            if (nhist > 1)
+            if (NH > 1)
                 for (uint32_t i = tid; i < total; i += kTB)
                 {
                     const Key1 k = sorted[i];
@@ -657,7 +656,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         __syncthreads();
     }
     if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]);
-    if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]);
+    if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     // valid windows of this workgroup
     for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
     if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid); atomicAdd(&pc->windows, nvalid); }
@@ -1072,7 +1071,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         if (li < tile_n)
         {
             uint32_t d = key_digit(key[r], digit);
-            uint32_t pos = digit_start[d] + wave_hist[w][d] + rank[r];
+            // unstable ranks are tile-wide already: no per-wave offset to read
+            uint32_t pos = digit_start[d] + rank[r] + (stable ? wave_hist[w][d] : 0u);
             stage[pos] = key[r];
             if (HAS_VAL) vstage[pos] = val[r];
         }
@@ -1433,7 +1433,8 @@ struct SegOut {
 __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                               SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                               uint64_t* __restrict__ seg_cnt,
-                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                              uint32_t rem_bits)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long tab[kSegSlots];
     __shared__ uint32_t cnt[kSegSlots];
@@ -1548,28 +1549,98 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
         return;
     }
 
-    // bitonic sort of the 4096 (key,count) slots by key; empty slots (all ones) sort last
-#if defined(GOSS_ABL_NOSORT)
-    for (uint32_t k2 = 2; k2 <= 2; k2 <<= 1)
-#else
-    for (uint32_t k2 = 2; k2 <= kSegSlots; k2 <<= 1)
-#endif
+    // Order the occupied slots.  Every thread takes its 16 slots into registers (all reads happen
+    // before any write), then the entries are bucket-sorted in place on the 10 bits below the
+    // segment bits: rank inside the bucket by an LDS atomic, exclusive scan of the 1024 bucket
+    // sizes, scatter, and an insertion sort of every bucket (1.5 keys on average at kSegLimit/2).
+    // Five barriers instead of the 66 of a bitonic network over 2048 slots; a bucket with more
+    // than 24 keys (skewed low bits) falls back to the bitonic sort of the compacted entries.
+    constexpr int kPer = kSegSlots / kTB;
+    constexpr int kBins = 1024, kBinsPer = kBins / kTB;
+    __shared__ uint32_t bins[kBins];
+    __shared__ uint32_t sh_scan2[kWaves + 1];
+    __shared__ uint32_t big;
+    unsigned long long ck[kPer];
+    uint32_t cc[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
     {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+        ck[j] = tab[tid * kPer + j];
+        cc[j] = cnt[tid * kPer + j];
+    }
+    for (uint32_t i = tid; i < kBins; i += kTB) bins[i] = 0;
+    if (tid == 0) big = 0;
+    __syncthreads();
+    const uint32_t bsh = rem_bits > 10 ? rem_bits - 10 : 0;
+    uint32_t rnk[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (ck[j] != kEmpty) rnk[j] = atomicAdd(&bins[(uint32_t)(ck[j] >> bsh) & (kBins - 1)], 1u);
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan<uint32_t>(mine, sh_scan2, &tot_occ);
+    volatile uint32_t* vbig = &big;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        if (bn[q] > 24) *vbig = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (ck[j] != kEmpty)
         {
-            for (uint32_t t = tid; t < kSegSlots / 2; t += kTB)
+            const uint32_t pos = bins[(uint32_t)(ck[j] >> bsh) & (kBins - 1)] + rnk[j];
+            tab[pos] = ck[j]; cnt[pos] = cc[j];
+        }
+    __syncthreads();
+    if (!big)
+    {
+#pragma unroll
+        for (int q = 0; q < kBinsPer; ++q)
+            for (uint32_t i = 1; i < bn[q]; ++i)
             {
-                uint32_t i = 2 * t - (t & (j - 1));       // element with bit j clear
-                uint32_t p = i + j;
-                bool up = (i & k2) == 0;
-                unsigned long long a = tab[i], c = tab[p];
-                if ((a > c) == up)
+                const unsigned long long kk = tab[bs[q] + i];
+                const uint32_t vv = cnt[bs[q] + i];
+                uint32_t j = i;
+                while (j > 0 && tab[bs[q] + j - 1] > kk)
                 {
-                    tab[i] = c; tab[p] = a;
-                    uint32_t ca = cnt[i]; cnt[i] = cnt[p]; cnt[p] = ca;
+                    tab[bs[q] + j] = tab[bs[q] + j - 1]; cnt[bs[q] + j] = cnt[bs[q] + j - 1];
+                    --j;
                 }
+                tab[bs[q] + j] = kk; cnt[bs[q] + j] = vv;
             }
-            __syncthreads();
+        __syncthreads();
+    }
+    else
+    {
+        uint32_t nsort = 512;
+        while (nsort < tot_occ) nsort <<= 1;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += kTB) tab[i] = kEmpty;
+        __syncthreads();
+        // bitonic sort of the first nsort (key,count) slots by key; empty slots (all ones) sort last
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+        {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += kTB)
+                {
+                    uint32_t i = 2 * t - (t & (j - 1));       // element with bit j clear
+                    uint32_t p = i + j;
+                    bool up = (i & k2) == 0;
+                    unsigned long long a = tab[i], c = tab[p];
+                    if ((a > c) == up)
+                    {
+                        tab[i] = c; tab[p] = a;
+                        uint32_t ca = cnt[i]; cnt[i] = cnt[p]; cnt[p] = ca;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     uint32_t d = ndist;

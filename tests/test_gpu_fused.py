@@ -84,6 +84,31 @@ def test_fused_path_contiguous_sequence(oracle):
     _same(got, _suffix_map(exp, "ks"))
 
 
+def test_segment_sort_skewed_low_bits(oracle):
+    """Keys of one segment that also agree on the ten bits below the segment bits overflow the
+    bucket sort's insertion-sort limit: the bitonic fallback of seg_hash_reduce_kernel must give
+    the same order.  Reads = one fixed 18-base prefix + 7 random bases, k = 25."""
+    import random
+    rng = random.Random(8)
+    prefix = "ACGTTGCAAGCTTAGGCA"
+    reads = [prefix + "".join(rng.choice("ACGT") for _ in range(7)) for _ in range(3000)]
+    reads += [rng.choice(reads) for _ in range(3000)]                  # repeats: counts above one
+    txt = "\n".join(reads) + "\n"
+    for k, build in ((25, oracle.build_kmer_set),):
+        exp, nwin = build([(oracle.LINE, "reads", txt)], k, out="ks")
+        c, got, st = _build(txt.encode(), k)
+        assert c.windows == nwin == 6000
+        _same(got, _suffix_map(exp, "ks"))
+    # the same through build-graph (both strands, counts kept)
+    exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], 24, out="gr")
+    with g.Context(24, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
+        ctx.push_host(txt.encode())
+        c = ctx.finish()
+        got = ctx.emit()
+    assert c.windows == nwin
+    _same(got, _suffix_map(exp, "gr"))
+
+
 def test_fused_path_declines_unique_input(oracle):
     """No duplication (every k-mer once): the sample says so and the plain sequence runs."""
     import numpy as np
