@@ -995,6 +995,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         }
         unsigned long long* mine = status + (uint64_t)tile * 256 + tid;
         uint64_t excl = 0;
+        const bool chain = !cursors && tile != 0;
         if (cursors)
         {
             // first pass of a sort: the order of tiles inside a bucket is irrelevant, so the
@@ -1003,12 +1004,32 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
             excl = tot ? atomicAdd(&cursors[tid * kCursorStride], (unsigned long long)tot) : 0ULL;
         }
         else if (tile == 0)
-        {
             __hip_atomic_store(mine, kLbFlagPrefix | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         else
-        {
             __hip_atomic_store(mine, kLbFlagAgg | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t tile_total;
+        const uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
+        digit_start[tid] = start;
+        __syncthreads();
+
+        // the keys go to their sorted place in LDS before the look-back: that work needs only the
+        // tile's own counts, and the predecessors get time to publish theirs
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+        {
+            uint32_t li = wbase + r * 64 + lane;
+            if (li < tile_n)
+            {
+                uint32_t d = key_digit(key[r], digit);
+                // unstable ranks are tile-wide already: no per-wave offset to read
+                uint32_t pos = digit_start[d] + rank[r] + (stable ? wave_hist[w][d] : 0u);
+                stage[pos] = key[r];
+                if (HAS_VAL) vstage[pos] = val[r];
+            }
+        }
+
+        if (chain)
+        {
             // Walk back over the predecessors kLbBatch tiles at a time: the loads of one batch
             // are independent, so a deep walk costs one memory latency per batch instead of
             // one per tile.
@@ -1057,25 +1078,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 #endif
             __hip_atomic_store(mine, kLbFlagPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint32_t tile_total;
-        uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
-        digit_start[tid] = start;
         global_base[tid] = bucket_base[tid] + excl - start;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r)
-    {
-        uint32_t li = wbase + r * 64 + lane;
-        if (li < tile_n)
-        {
-            uint32_t d = key_digit(key[r], digit);
-            // unstable ranks are tile-wide already: no per-wave offset to read
-            uint32_t pos = digit_start[d] + rank[r] + (stable ? wave_hist[w][d] : 0u);
-            stage[pos] = key[r];
-            if (HAS_VAL) vstage[pos] = val[r];
-        }
     }
     __syncthreads();
 
