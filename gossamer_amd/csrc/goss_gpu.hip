@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +95,7 @@ struct goss_gpu_ctx {
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
+    uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
@@ -179,8 +181,10 @@ void ensure_arena(goss_gpu_ctx* c)
     if (budget == 0) budget = (uint64_t)((double)free_b * 0.8);
     if (budget > (uint64_t)((double)free_b * 0.92)) budget = (uint64_t)((double)free_b * 0.92);   // a request, not a demand
     void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, budget);
     if (e != hipSuccess) throw StatusError{GOSS_ERR_OOM, std::string("hipMalloc(budget) failed: ") + hipGetErrorString(e)};
+    c->arena_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->arena.base = (uint8_t*)p;
     c->arena.size = budget;
     c->arena.lo = 0;
@@ -1732,6 +1736,8 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "segment_retries") *value = c->segment_retries;
     else if (n == "lookback_failures") *value = c->lookback_failures;
     else if (n == "runs") *value = c->runs.size();
+    else if (n == "arena_ms") *value = c->arena_ms;
+    else if (n == "arena_bytes") *value = c->arena.size;
     else return GOSS_ERR_INVALID_ARG;
     return GOSS_OK;
 }

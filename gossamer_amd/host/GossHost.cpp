@@ -551,6 +551,13 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
             const uint64_t perBase = (mode == GOSS_MODE_GRAPH ? 2 : 1) * (2 * keyBytes + 2) + 1;
             budget = bases * perBase + (6ULL << 30);      // the library clamps to the free memory
         }
+        // Mapping HBM costs up to 30 ms/GB when the driver has to clear pages a previous process
+        // left behind (measured: 264 GB in 7.7 s, or 0.2 s when clean), while counting in
+        // ~2 G-window chunks that overlap the parser costs nothing measurable (100 M reads:
+        // 1.5 s with 32 GB and with 264 GB): stay small unless told otherwise.
+        const bool wide = 2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) > 62;      // two-word keys
+        const uint64_t kDefaultCap = (wide ? 96ULL : 48ULL) << 30;
+        if (budget == 0 || budget > kDefaultCap) budget = kDefaultCap;
     }
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
@@ -594,6 +601,12 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "
         << pushSeconds << "s)"; log(info, o.str()); }
+    {
+        uint64_t ms = 0, bytes = 0;
+        goss_gpu_stat(g.h, "arena_ms", &ms); goss_gpu_stat(g.h, "arena_bytes", &bytes);
+        std::ostringstream o; o << "HBM arena: " << (bytes >> 30) << " GB mapped in " << ms / 1000.0 << "s";
+        log(info, o.str());
+    }
 
     log(info, "sorting the hashtable...");
     goss_gpu_counts counts;
