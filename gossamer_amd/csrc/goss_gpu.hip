@@ -96,6 +96,8 @@ struct goss_gpu_ctx {
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
+    bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
+    uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
@@ -448,15 +450,16 @@ template <class K> struct SegCfg;
 template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; };
 template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
 
-inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, SegOut* so,
-                            uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits)
+inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits)
 {
-    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc, rem_bits);
+    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
+                       rem_bits);
 }
-inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, SegOut* so,
-                            uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t)
+inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t)
 {
-    hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, so, seg_pos, seg_cnt, sk, sc);
+    hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
 }
 
 // Number of distinct keys in the chunk, estimated from its first keys (reads arrive in no
@@ -515,7 +518,8 @@ uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
 // partition bits); 2 if the staging area is too small (use the full sort).  The keys stay,
 // permuted, in ka or kb (*in_b_out).
 template <class K>
-int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out);
+int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg = nullptr,
+                   const uint64_t* seg_end = nullptr);
 
 template <class K>
 int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, bool* in_b_out, Run* out)
@@ -537,8 +541,11 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
 }
 
 // Count every segment of the partitioned keys `part` in LDS; `spare` (n keys) is the staging area.
+// Segment s is part[seg_beg[s], seg_end[s]) when the bounds are given (sub-region layout), else
+// the bounds are found by binary search in the dense, partitioned array.
 template <class K>
-int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out)
+int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
+                   const uint64_t* seg_end)
 {
     const uint32_t keybits = 2 * c->len;
     const uint32_t shift = keybits - segbits;
@@ -557,9 +564,13 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     SegOut hso{};
     hso.stage_cap = cap;
     HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
-                       (const K*)part, n, shift, nseg, seg_off);
-    launch_seg_hash(c, nseg, (const K*)part, (const uint64_t*)seg_off, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift);
+    if (!seg_beg)
+    {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
+                           (const K*)part, n, shift, nseg, seg_off);
+        seg_beg = seg_off; seg_end = seg_off + 1;
+    }
+    launch_seg_hash(c, nseg, (const K*)part, seg_beg, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift);
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -624,10 +635,22 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
 
 // ---- fused extraction + first partition pass (one-word canonical keys) ----------------------
 // Returns true when it counted the chunk (run appended, counters updated); false = not
-// applicable or a bucket region overflowed / a later stage asked for a retry: the caller then
-// runs the unfused sequence on the same (untouched) input.
+// applicable or a region overflowed / a later stage asked for a retry: the caller then runs the
+// unfused sequence on the same (untouched) input.
+//
+// Two forms.  LSD (any number of partition digits): the fused kernel partitions on the lowest
+// partition digit into 256 bucket regions, the remaining digits are look-back passes (the first
+// of them reads the regions).  MSD (exactly two digits, the common case): the fused kernel
+// partitions on the HIGH digit and the second pass places the keys of region b by their LOW digit
+// into 65 536 sub-regions -- the segments of the counting kernel -- with atomic cursors: no
+// look-back chain and no digit histograms at all.  Region and sub-region sizes come from a sample
+// of the input (the whole chunk when it is small), with 5 / 6 standard deviations of slack.
+template <class K>
+int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
+                   const uint64_t* seg_end);
+
 bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, Key1* ka, uint64_t ka_slots,
-                         Key1* kb)
+                         Key1* kb, uint64_t kb_slots)
 {
     const uint32_t keybits = 2 * c->len;
     if (!c->fused || c->words != 1 || c->mode != GOSS_MODE_KMER_SET || c->path != 0 || !c->lookback || c->ordered_tiles ||
@@ -636,22 +659,29 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     constexpr int kTile = SortCfg<Key1, false>::kTile;
     uint64_t mark = c->arena.mark();
     struct Release { goss_gpu_ctx* c; uint64_t m; ~Release() { c->arena.release(m); } } release{c, mark};
-
-    // 1. a sample of the keys: slices spread evenly over the chunk, extracted with the plain kernel
-    constexpr uint64_t kSlices = 32, kSliceStarts = 128u << 10;
     auto decline = [&](const char* why) {
         if (c->debug) std::fprintf(stderr, "libgossgpu: fused path declined (%s), %llu window starts\n", why, (unsigned long long)nstarts);
         return false;
     };
-    if (nstarts < 4 * kSlices * kSliceStarts) return decline("chunk smaller than the sample");
+
+    // 1. a sample of the keys: slices spread evenly over the chunk, extracted with the plain
+    //    kernel.  The two-level form needs the joint histogram of two digits (65 536 bins), hence
+    //    a larger sample: 1/64 of the chunk but at least 160 M window starts; a chunk of up to 640 M
+    //    window starts is sampled whole (exact sizes, +4 % extraction work at most).
+    const bool want_msd = c->fused_msd;
+    uint64_t sample_starts = 4u << 20;
+    if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
+    const uint64_t nslices = sample_starts >= nstarts ? 1 : 64;
+    const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : (sample_starts / nslices) & ~4095ULL;
+    if (nslices > 1 && nstarts < 4 * nslices * slice_starts) return decline("chunk smaller than the sample");
     c->mute_timing = true;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
-    for (uint64_t j = 0; j < kSlices; ++j)
+    for (uint64_t j = 0; j < nslices; ++j)
     {
-        const uint64_t off = (nstarts - kSliceStarts) / (kSlices - 1) * j;
+        const uint64_t off = nslices > 1 ? (nstarts - slice_starts) / (nslices - 1) * j : 0;
         const uintptr_t addr = (uintptr_t)(d_bases + off);
         const uint32_t mis = (uint32_t)(addr & 15u);
-        extract_dispatch<Key1>(c, (const uint8_t*)(addr - mis), mis, kSliceStarts, navail - off, ka);
+        extract_dispatch<Key1>(c, (const uint8_t*)(addr - mis), mis, slice_starts, navail - off, ka);
     }
     c->extract_hist_shift = 0xFFFFFFFFu;
     ExtractCounters* hc = (ExtractCounters*)c->h_pinned;
@@ -660,9 +690,11 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const uint64_t ns = hc->keys_out;
     c->mute_timing = false;
     if (ns < (1u << 20)) return decline("mostly non-bases");
-    const uint64_t d_s = count_distinct_sample<Key1>(c, ka, ns);
-    const uint64_t m_est = birthday_estimate(ns, d_s);
-    const double scale = (double)nstarts / (double)(kSlices * kSliceStarts);
+    const bool exact = nslices == 1;                                   // the sample is the chunk
+    const uint64_t s4 = std::min<uint64_t>(ns, 4u << 20);
+    const uint64_t d_s = count_distinct_sample<Key1>(c, ka, s4);
+    const uint64_t m_est = birthday_estimate(s4, d_s);
+    const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
     const uint64_t limit = SegCfg<Key1>::kLimit;
@@ -672,18 +704,69 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const uint32_t shift = keybits - segbits;
     const uint32_t npass = (segbits + 7) / 8;
 
-    // 2. bucket regions from the sample's histogram of the first partition digit
-    unsigned long long* shist = (unsigned long long*)c->arena.temp(256 * 8);
-    HIP_TRY(hipMemsetAsync(shist, 0, 256 * 8, c->stream));
-    c->mute_timing = true;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<Key1>), dim3(256), dim3(kTB), 0, c->stream, (const Key1*)ka, ns, shift, 1u, shist);
-    c->mute_timing = false;
-    std::vector<unsigned long long> hh(256);
-    HIP_TRY(hipMemcpyAsync(hh.data(), shist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // expected size of every bucket plus five standard deviations of the sample count; whatever
-    // room the key buffer has beyond that (up to 25 %) is handed out proportionally, so that a
-    // mildly non-stationary input still fits
+    // 2. histograms of the sample: joint over both digits for the two-level form, else of the
+    //    first partition digit only
+    std::vector<unsigned long long> hh(256, 0);          // the fused kernel's digit
+    std::vector<uint64_t> joint;                         // [high*256 + low], two-level form only
+    bool msd = want_msd && segbits == 16;
+    if (msd)
+    {
+        // order the sample by its top 16 bits (kept out of the per-kernel timing) and read the
+        // segment bounds
+        c->mute_timing = true;
+        const bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, ns, 2, shift);
+        uint64_t* soff = (uint64_t*)c->arena.temp(65537 * 8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<Key1>), dim3(65536 / 256 + 1), dim3(256), 0, c->stream,
+                           (const Key1*)(in_b ? kb : ka), ns, shift, 65536u, soff);
+        c->mute_timing = false;
+        std::vector<uint64_t> ho(65537);
+        HIP_TRY(hipMemcpyAsync(ho.data(), soff, 65537 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        joint.resize(65536);
+        for (uint32_t i = 0; i < 65536; ++i) { joint[i] = ho[i + 1] - ho[i]; hh[i >> 8] += joint[i]; }
+    }
+    else
+    {
+        unsigned long long* shist = (unsigned long long*)c->arena.temp(256 * 8);
+        HIP_TRY(hipMemsetAsync(shist, 0, 256 * 8, c->stream));
+        c->mute_timing = true;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<Key1>), dim3(256), dim3(kTB), 0, c->stream, (const Key1*)ka, ns, shift, 1u, shist);
+        c->mute_timing = false;
+        HIP_TRY(hipMemcpyAsync(hh.data(), shist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+
+    // sub-regions of the second buffer (two-level form): expected size + six standard deviations
+    // of the sample count; they must fit, else the one-level form is used
+    std::vector<SubTable> hsub;
+    if (msd)
+    {
+        hsub.resize(1);
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < 65536; ++i)
+        {
+            const double h = (double)joint[i];
+            const double want = exact ? h + 16.0 : (h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0;
+            const uint64_t cap = ((uint64_t)(want * c->fused_capscale) + 15) & ~15ULL;
+            hsub[0].start[i] = at; hsub[0].cap[i] = cap;
+            at += cap;
+        }
+        if (at > kb_slots)
+        {
+            if (c->debug) std::fprintf(stderr, "libgossgpu: sub-regions need %llu slots of %llu: one-level form\n",
+                                       (unsigned long long)at, (unsigned long long)kb_slots);
+            msd = false;
+            // the one-level form partitions on the LOW digit: its marginal histogram
+            std::fill(hh.begin(), hh.end(), 0ULL);
+            for (uint32_t i = 0; i < 65536; ++i) hh[i & 255u] += joint[i];
+            hsub.clear();
+        }
+    }
+    const uint32_t part_shift = msd ? keybits - 8 : shift;           // the fused kernel's digit
+
+    // bucket regions of the first buffer: expected size of every bucket plus five standard
+    // deviations of the sample count; whatever room the key buffer has beyond that (up to 25 %)
+    // is handed out proportionally, so that a mildly non-stationary input still fits
     GapTable gt{};
     double base[256], base_sum = 0;
     for (int d = 0; d < 256; ++d)
@@ -718,15 +801,16 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         constexpr uint64_t kSuper = GOSS_FUSED_G * kTB * 16;
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 1024 : 512);
+        const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
+#define GOSS_LAUNCH_EP2(NB, NH)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, NH>), dim3(grid), dim3(kTB), 0, c->stream,           \
+                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
 #define GOSS_LAUNCH_EP(NB)                                                                                            \
     do {                                                                                                              \
-        if (npass > 2)                                                                                                \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, 2>), dim3(grid), dim3(kTB), 0, c->stream,    \
-                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper);   \
-        else                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, 1>), dim3(grid), dim3(kTB), 0, c->stream,    \
-                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, shift, nsuper);   \
+        if (nh == 0) GOSS_LAUNCH_EP2(NB, 0);                                                                          \
+        else if (nh == 1) GOSS_LAUNCH_EP2(NB, 1);                                                                     \
+        else GOSS_LAUNCH_EP2(NB, 2);                                                                                  \
     } while (0)
         switch ((2 * c->len + 7) / 8)
         {
@@ -738,6 +822,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
             default: GOSS_LAUNCH_EP(8); break;
         }
 #undef GOSS_LAUNCH_EP
+#undef GOSS_LAUNCH_EP2
         t.stop();
     }
     std::vector<unsigned long long> hpc(sizeof(PartCounters) / 8);
@@ -759,54 +844,83 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     if (sum != n) throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
     HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
 
-    // 4. remaining partition passes: the first reads the bucket regions, the others are dense
-    const uint64_t ntiles_dense = (n + kTile - 1) / kTile;
-    unsigned long long* status = (unsigned long long*)c->arena.temp(256ULL * std::max(tiles, ntiles_dense) * 8);
     LookbackCtl* ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
     LookbackCtl* hctl = (LookbackCtl*)((uint8_t*)c->h_pinned + 128);
     HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
+    Run r{nullptr, nullptr, 0};
+    if (msd)
     {
-        PhaseTimer t(c, GOSS_T_SCAN, 512);
-        hipLaunchKernelGGL(scan_rows256_kernel, dim3(2), dim3(kTB), 0, c->stream, pc->hist);
-        t.stop();
-    }
-    Key1* src = ka; Key1* dst = kb;
-    for (uint32_t di = 1; di < npass; ++di)
-    {
-        const uint32_t d = shift + 8 * di;
-        const bool gapped = di == 1;
-        const uint64_t nt = gapped ? tiles : ntiles_dense;
-        HIP_TRY(hipMemsetAsync(status, 0, nt * 256 * 8, c->stream));
+        // 4a. second level: keys of region b go to sub-region (b, low digit) by atomic cursors
+        SubTable* dsub = (SubTable*)c->arena.temp(sizeof(SubTable));
+        unsigned long long* cur2 = (unsigned long long*)c->arena.temp(65536ULL * kSubCursorStride * 8);
+        uint64_t* seg_beg = (uint64_t*)c->arena.temp(65536 * 8);
+        uint64_t* seg_end = (uint64_t*)c->arena.temp(65536 * 8);
+        HIP_TRY(hipMemcpyAsync(dsub, hsub.data(), sizeof(SubTable), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(cur2, 0, 65536ULL * kSubCursorStride * 8, c->stream));
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
-            if (gapped)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)nt), dim3(kTB), 0,
-                                   c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
-                                   (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
-                                   (unsigned long long*)nullptr, (const GapTable*)dgt);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, false>), dim3((uint32_t)nt), dim3(kTB), 0,
-                                   c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
-                                   (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
-                                   (unsigned long long*)nullptr, (const GapTable*)nullptr);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)tiles), dim3(kTB), 0,
+                               c->stream, (const Key1*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
+                               (const unsigned long long*)nullptr, (unsigned long long*)nullptr, ctl, cur2,
+                               (const GapTable*)dgt, (const SubTable*)dsub);
             t.stop();
         }
+        hipLaunchKernelGGL(sub_bounds_kernel, dim3(256), dim3(256), 0, c->stream, (const SubTable*)dsub,
+                           (const unsigned long long*)cur2, seg_beg, seg_end);
         HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (hctl->error)
-        {
-            std::fprintf(stderr, "libgossgpu: radix look-back chain gave up in the fused path; redoing the chunk unfused\n");
-            c->lookback_failures++;
-            c->ordered_tiles = true;
-            return false;
-        }
-        std::swap(src, dst);
+        if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
+        const int rc = segment_reduce<Key1>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
+        if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
+        c->fused_msd_chunks++;
     }
-    // src = partitioned keys (dense unless npass == 1, which the 16-bit minimum excludes), dst = spare
-    Run r{nullptr, nullptr, 0};
-    c->arena.release(mark); release.m = c->arena.mark();
-    const int rc = segment_reduce<Key1>(c, src, dst, n, segbits, &r);
-    if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
+    else
+    {
+        // 4b. remaining partition passes: the first reads the bucket regions, the others are dense
+        const uint64_t ntiles_dense = (n + kTile - 1) / kTile;
+        unsigned long long* status = (unsigned long long*)c->arena.temp(256ULL * std::max(tiles, ntiles_dense) * 8);
+        {
+            PhaseTimer t(c, GOSS_T_SCAN, 512);
+            hipLaunchKernelGGL(scan_rows256_kernel, dim3(2), dim3(kTB), 0, c->stream, pc->hist);
+            t.stop();
+        }
+        Key1* src = ka; Key1* dst = kb;
+        for (uint32_t di = 1; di < npass; ++di)
+        {
+            const uint32_t d = shift + 8 * di;
+            const bool gapped = di == 1;
+            const uint64_t nt = gapped ? tiles : ntiles_dense;
+            HIP_TRY(hipMemsetAsync(status, 0, nt * 256 * 8, c->stream));
+            {
+                PhaseTimer t(c, GOSS_T_SCATTER, n);
+                if (gapped)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                       c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                                       (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
+                                       (unsigned long long*)nullptr, (const GapTable*)dgt, (const SubTable*)nullptr);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, false>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                       c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                                       (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
+                                       (unsigned long long*)nullptr, (const GapTable*)nullptr, (const SubTable*)nullptr);
+                t.stop();
+            }
+            HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (hctl->error)
+            {
+                std::fprintf(stderr, "libgossgpu: radix look-back chain gave up in the fused path; redoing the chunk unfused\n");
+                c->lookback_failures++;
+                c->ordered_tiles = true;
+                return false;
+            }
+            std::swap(src, dst);
+        }
+        // src = partitioned keys (dense: npass >= 2), dst = spare
+        c->arena.release(mark); release.m = c->arena.mark();
+        const int rc = segment_reduce<Key1>(c, src, dst, n, segbits, &r, nullptr, nullptr);
+        if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
+    }
     c->runs.push_back(r);
     c->windows += hp->windows;
     c->keys_total += n;
@@ -836,7 +950,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     K* kb = (K*)c->arena.temp(cap * sizeof(K));
     if constexpr (std::is_same<K, Key1>::value)
     {
-        if (process_chunk_fused(c, d_bases, nstarts, navail, ka, ka_slots, kb)) { c->arena.release(mark); return; }
+        if (process_chunk_fused(c, d_bases, nstarts, navail, ka, ka_slots, kb, cap)) { c->arena.release(mark); return; }
     }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     uintptr_t addr = (uintptr_t)d_bases;
@@ -1353,6 +1467,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }
     { const char* e = std::getenv("GOSS_GPU_DEBUG"); if (e && *e == '1') c->debug = true; }
@@ -1733,6 +1848,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     const std::string n = name;
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
+    else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "segment_retries") *value = c->segment_retries;
     else if (n == "lookback_failures") *value = c->lookback_failures;
     else if (n == "runs") *value = c->runs.size();

@@ -483,6 +483,18 @@ struct PartCounters {
     unsigned long long cursors[256 * kCursorStride];     // keys placed in bucket d so far
 };
 
+// Second level of the same idea (used when exactly two partition digits are needed): the fused
+// kernel partitions on the HIGH digit, and the next pass places the keys of region b by their
+// LOW digit into sub-regions (b, d) of the second key buffer, again by atomic cursors -- no
+// look-back chain, no digit histograms.  Sub-region (b, d) IS segment b*256+d of the counting
+// kernel.  Capacities come from the joint histogram of a larger sample; an overflow anywhere
+// makes the host redo the chunk with the exact (look-back) sequence.
+constexpr int kSubCursorStride = 4;              // u64 words between sub-region cursors (32 B)
+struct SubTable {
+    unsigned long long start[65536];     // first slot of sub-region (b, d), index b*256+d
+    unsigned long long cap[65536];
+};
+
 template <int NB, int G, int NH>
 __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
@@ -499,11 +511,11 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     __shared__ uint32_t dh[256];                 // keys of this super-tile per digit (and rank counter)
     __shared__ uint64_t gbase[256];              // global slot of sorted[i] with digit d = gbase[d] + i
     __shared__ uint32_t sh_ovf;
-    __shared__ uint32_t lh[256 * NH];            // histograms of the next NH digits
+    __shared__ uint32_t lh[NH ? 256 * NH : 1];   // histograms of the next NH digits
     __shared__ uint32_t sh_scan[kWaves + 1];
 
     const uint32_t tid = threadIdx.x;
-    lh[tid] = 0;
+    if (NH > 0) lh[tid] = 0;
     if (NH > 1) lh[tid + 256] = 0;
     dh[tid] = 0;
     if (tid == 0) sh_ovf = 0;
@@ -645,17 +657,23 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                     atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
                     atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
                 }
-            else
+            else if (NH == 1)
                 for (uint32_t i = tid; i < total; i += kTB)
                 {
                     const Key1 k = sorted[i];
                     out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
                     atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
                 }
+            else
+                for (uint32_t i = tid; i < total; i += kTB)
+                {
+                    const Key1 k = sorted[i];
+                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
+                }
         }
         __syncthreads();
     }
-    if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]);
+    if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
     if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     // valid windows of this workgroup
     for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
@@ -873,7 +891,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
                                                              unsigned long long* __restrict__ status,
                                                              LookbackCtl* __restrict__ ctl,
                                                              unsigned long long* __restrict__ cursors,
-                                                             const GapTable* __restrict__ gt = nullptr)
+                                                             const GapTable* __restrict__ gt = nullptr,
+                                                             const SubTable* __restrict__ sub = nullptr)
 {
     constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
     constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
@@ -885,6 +904,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ uint32_t sh_tile;
     __shared__ uint32_t sh_bucket;
+    __shared__ uint32_t sh_skip;
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
     // Tile number.  ORDERED: a ticket (one returning atomic per tile: every lower-numbered tile
@@ -893,6 +913,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     // blockIdx order in practice; HIP does not promise it, so the look-back spin is bounded and
     // a give-up makes the host redo the pass with the histogram-table kernels.
     if (ORDERED) { if (tid == 0) sh_tile = atomicAdd(&ctl->ticket, 1u); }
+    if (tid == 0) sh_skip = 0;
     if (GAPPED && !ORDERED)
     {
         const unsigned long long t = blockIdx.x;
@@ -996,7 +1017,17 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         unsigned long long* mine = status + (uint64_t)tile * 256 + tid;
         uint64_t excl = 0;
         const bool chain = !cursors && tile != 0;
-        if (cursors)
+        uint64_t sub_start = 0;
+        if (GAPPED && sub)
+        {
+            // sub-region mode: the tile's keys of low digit tid go to sub-region (bucket, tid)
+            const uint32_t sidx = sh_bucket * 256u + tid;
+            excl = tot ? atomicAdd(&cursors[(uint64_t)sidx * kSubCursorStride], (unsigned long long)tot) : 0ULL;
+            sub_start = sub->start[sidx];
+            // too small a sub-region: nothing of this tile is stored, the host redoes the chunk
+            if (tot && excl + tot > sub->cap[sidx]) { atomicOr(&ctl->error, 2u); sh_skip = 1; }
+        }
+        else if (cursors)
         {
             // first pass of a sort: the order of tiles inside a bucket is irrelevant, so the
             // tile just reserves its share of every bucket with one atomic per digit (cursor
@@ -1078,10 +1109,11 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 #endif
             __hip_atomic_store(mine, kLbFlagPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        global_base[tid] = bucket_base[tid] + excl - start;
+        global_base[tid] = ((GAPPED && sub) ? sub_start : bucket_base[tid]) + excl - start;
     }
     __syncthreads();
 
+    if (GAPPED && sh_skip) return;
     for (uint32_t i = tid; i < tile_n; i += kTB)
     {
         K k = stage[i];
@@ -1089,6 +1121,16 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         keys_out[o] = k;
         if (HAS_VAL) vals_out[o] = vstage[i];
     }
+}
+
+// Segment bounds of the sub-region layout: segment s holds cursors[s] keys from start[s].
+__global__ void sub_bounds_kernel(const SubTable* __restrict__ sub, const unsigned long long* __restrict__ cursors,
+                                  uint64_t* __restrict__ seg_beg, uint64_t* __restrict__ seg_end)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 65536u) return;
+    seg_beg[s] = sub->start[s];
+    seg_end[s] = sub->start[s] + cursors[(uint64_t)s * kSubCursorStride];
 }
 
 // --------------------------------------------------------------------------------------
@@ -1434,7 +1476,7 @@ struct SegOut {
 };
 
 __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
-                                                              SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                              const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                               uint64_t* __restrict__ seg_cnt,
                                                               Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
                                                               uint32_t rem_bits)
@@ -1445,7 +1487,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const uint64_t b = seg_off[s], e = seg_off[s + 1];
+    const uint64_t b = seg_off[s], e = seg_end[s];
     if (b == e)
     {
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
@@ -1672,7 +1714,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 constexpr uint32_t kSegLock = 0x80000000u;
 
 __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
-                                                               SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                                uint64_t* __restrict__ seg_cnt,
                                                                Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
 {
@@ -1683,7 +1725,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const uint64_t b = seg_off[s], e = seg_off[s + 1];
+    const uint64_t b = seg_off[s], e = seg_end[s];
     if (b == e)
     {
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }

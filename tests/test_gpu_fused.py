@@ -84,6 +84,46 @@ def test_fused_path_contiguous_sequence(oracle):
     _same(got, _suffix_map(exp, "ks"))
 
 
+def test_two_level_form_with_sampled_regions():
+    """4.6 M reads (695 M window starts): the regions and sub-regions come from a real sample
+    (160 M window starts in 64 slices), not from the whole chunk.  The two-level form, the
+    one-level form and the unfused sequence must give the same keys and counts."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 4_600_000, 150, 5_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for env, want in (({}, "msd"), ({"GOSS_GPU_NO_MSD": "1"}, "lsd"), ({"GOSS_GPU_NO_FUSED": "1"}, "plain")):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=21)
+            # skew: the last fifth of the input is one read repeated 920 000 times (126 k-mers with
+            # huge counts, all at the end of the chunk)
+            one = buf[: L + 1].clone()
+            buf.view(n, L + 1)[n - n // 5:] = one
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert ctx.stat("fused_overflows") == 0
+        assert ctx.stat("fused_chunks") == (0 if want == "plain" else 1)
+        assert ctx.stat("fused_msd_chunks") == (1 if want == "msd" else 0)
+        kp, cp, m = ctx.result_ptrs()
+        res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    for other in res[1:]:
+        assert other[2] == res[0][2]
+        assert torch.equal(other[0], res[0][0]) and torch.equal(other[1], res[0][1])
+    assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
+
+
 def test_segment_sort_skewed_low_bits(oracle):
     """Keys of one segment that also agree on the ten bits below the segment bits overflow the
     bucket sort's insertion-sort limit: the bitonic fallback of seg_hash_reduce_kernel must give
