@@ -664,6 +664,14 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         return false;
     };
 
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!c->debug) return;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::fprintf(stderr, "libgossgpu: fused path: %-28s at %8.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+
     // 1. a sample of the keys: slices spread evenly over the chunk, extracted with the plain
     //    kernel.  The two-level form needs the joint histogram of two digits (65 536 bins), hence
     //    a larger sample: 1/64 of the chunk but at least 160 M window starts; a chunk of up to 640 M
@@ -671,17 +679,38 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const bool want_msd = c->fused_msd;
     uint64_t sample_starts = 4u << 20;
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
+    // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
+    // of 16 bytes apart, so that ONE strided launch extracts them all
+    constexpr uint64_t kPlainSuper = 8ULL * kTB * 16;
     const uint64_t nslices = sample_starts >= nstarts ? 1 : 64;
-    const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : (sample_starts / nslices) & ~4095ULL;
+    const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : (sample_starts / nslices) / kPlainSuper * kPlainSuper;
     if (nslices > 1 && nstarts < 4 * nslices * slice_starts) return decline("chunk smaller than the sample");
+    const uint64_t slice_stride = nslices > 1 ? ((nstarts - slice_starts) / (nslices - 1)) & ~15ULL : 0;
     c->mute_timing = true;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
-    for (uint64_t j = 0; j < nslices; ++j)
     {
-        const uint64_t off = nslices > 1 ? (nstarts - slice_starts) / (nslices - 1) * j : 0;
-        const uintptr_t addr = (uintptr_t)(d_bases + off);
-        const uint32_t mis = (uint32_t)(addr & 15u);
-        extract_dispatch<Key1>(c, (const uint8_t*)(addr - mis), mis, slice_starts, navail - off, ka);
+        const uintptr_t addr0 = (uintptr_t)d_bases;
+        const uint32_t mis0 = (uint32_t)(addr0 & 15u);
+        if (nslices == 1) extract_dispatch<Key1>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
+        else
+        {
+            const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
+#define GOSS_LAUNCH_ES(NB)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, NB>), dim3(grid), dim3(kTB), 0, c->stream,              \
+                       (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper, \
+                       slice_tiles, slice_stride)
+            switch ((2 * c->len + 7) / 8)
+            {
+                case 3: GOSS_LAUNCH_ES(3); break;
+                case 4: GOSS_LAUNCH_ES(4); break;
+                case 5: GOSS_LAUNCH_ES(5); break;
+                case 6: GOSS_LAUNCH_ES(6); break;
+                case 7: GOSS_LAUNCH_ES(7); break;
+                default: GOSS_LAUNCH_ES(8); break;
+            }
+#undef GOSS_LAUNCH_ES
+        }
     }
     c->extract_hist_shift = 0xFFFFFFFFu;
     ExtractCounters* hc = (ExtractCounters*)c->h_pinned;
@@ -690,10 +719,12 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const uint64_t ns = hc->keys_out;
     c->mute_timing = false;
     if (ns < (1u << 20)) return decline("mostly non-bases");
+    lap("sample extracted");
     const bool exact = nslices == 1;                                   // the sample is the chunk
     const uint64_t s4 = std::min<uint64_t>(ns, 4u << 20);
     const uint64_t d_s = count_distinct_sample<Key1>(c, ka, s4);
     const uint64_t m_est = birthday_estimate(s4, d_s);
+    lap("distinct keys estimated");
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
@@ -763,6 +794,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         }
     }
     const uint32_t part_shift = msd ? keybits - 8 : shift;           // the fused kernel's digit
+    lap("sample histograms");
 
     // bucket regions of the first buffer: expected size of every bucket plus five standard
     // deviations of the sample count; whatever room the key buffer has beyond that (up to 25 %)
@@ -830,6 +862,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     HIP_TRY(hipStreamSynchronize(c->stream));
     const PartCounters* hp = (const PartCounters*)hpc.data();
     if (hp->overflow) { c->fused_overflows++; return decline("a bucket region overflowed"); }
+    lap("extraction + first level");
     const uint64_t n = hp->keys_out;
     if (n == 0) return false;
     uint64_t tiles = 0, sum = 0;
@@ -870,6 +903,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
+        lap("second level");
         const int rc = segment_reduce<Key1>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
         c->fused_msd_chunks++;
@@ -921,6 +955,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         const int rc = segment_reduce<Key1>(c, src, dst, n, segbits, &r, nullptr, nullptr);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
     }
+    lap("segments counted");
     c->runs.push_back(r);
     c->windows += hp->windows;
     c->keys_total += n;

@@ -289,7 +289,8 @@ template <int MODE, int P, int G, int NB>
 __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
-                                                       uint32_t hist_shift, uint64_t nsuper)
+                                                       uint32_t hist_shift, uint64_t nsuper,
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
 {
     // Persistent grid: a workgroup loops over super-tiles (blockIdx.x, +gridDim.x, ...).
     // A super-tile is G consecutive sub-tiles of T = 256*P window starts and reserves the
@@ -314,7 +315,10 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
     {
-    const uint64_t tile_base = st * (uint64_t)(G * T);
+    // sampling mode (slice_tiles != 0): super-tile st is the (st % slice_tiles)-th of slice
+    // st / slice_tiles, slices lie slice_stride window starts apart (a multiple of 16)
+    const uint64_t tile_base = slice_tiles ? (st / slice_tiles) * slice_stride + (st % slice_tiles) * (uint64_t)(G * T)
+                                           : st * (uint64_t)(G * T);
 
     // ---- phase A: ASCII -> packed 2-bit codes + non-base mask, all G sub-tiles -------------
     for (uint32_t v = tid; v < NVEC; v += kTB)
