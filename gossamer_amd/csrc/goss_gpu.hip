@@ -682,8 +682,10 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
     constexpr uint64_t kPlainSuper = 8ULL * kTB * 16;
-    const uint64_t nslices = sample_starts >= nstarts ? 1 : 64;
-    const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : (sample_starts / nslices) / kPlainSuper * kPlainSuper;
+    // a slice is ONE super-tile (~217 reads of 150 bp): thousands of slices follow a drifting
+    // k-mer distribution (sorted inputs) far better than a few long ones
+    const uint64_t nslices = sample_starts >= nstarts ? 1 : std::max<uint64_t>(64, sample_starts / kPlainSuper);
+    const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : kPlainSuper;
     if (nslices > 1 && nstarts < 4 * nslices * slice_starts) return decline("chunk smaller than the sample");
     const uint64_t slice_stride = nslices > 1 ? ((nstarts - slice_starts) / (nslices - 1)) & ~15ULL : 0;
     c->mute_timing = true;
