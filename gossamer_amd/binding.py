@@ -21,7 +21,7 @@ SYMBOLS = [
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
-    "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat",
+    "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
 ]
 
 
@@ -206,6 +206,55 @@ class Context:
         self._check(self._L.goss_gpu_emit_sparse_array(self._h, C.c_void_p(dev_ptr), key_words, n, N & mask, N >> 64, M,
                                                        N_end & mask, N_end >> 64))
         return self.files()
+
+    def check_index(self, files, base=""):
+        """goss_gpu_check_index on a SparseArray given as {suffix: bytes} (files[base + ".header"]
+        ...): the context must hold the array's decoded elements (push_run + finish).  Returns a
+        dict of the mismatch counts."""
+        import struct
+
+        def layout(bits, prefix, shift, out):
+            # IntegerArray::builder column files (IntegerArray.cc:259-357)
+            split = {24: (8, 16), 40: (8, 32), 48: (16, 32), 56: (8, 48), 72: (8, 64), 80: (16, 64), 88: (8, 80),
+                     96: (32, 64), 104: (8, 96), 112: (16, 96), 120: (24, 96), 128: (64, 64)}
+            if bits in (8, 16, 32, 64):
+                out.append((prefix, bits // 8, shift))
+                return
+            ub, lb = split[bits]
+            layout(ub, prefix + ".upr", shift + lb, out)
+            layout(lb, prefix + ".lwr", shift, out)
+
+        class SparseFiles(C.Structure):
+            _fields_ = [("D", C.c_uint64), ("count", C.c_uint64), ("size_lo", C.c_uint64), ("size_hi", C.c_uint64),
+                        ("high_bits", C.c_char_p), ("high_words", C.c_uint64),
+                        ("d0", C.c_char_p), ("d0_bytes", C.c_uint64), ("d1", C.c_char_p), ("d1_bytes", C.c_uint64),
+                        ("ncols", C.c_uint32), ("pad", C.c_uint32),
+                        ("col", C.c_char_p * 4), ("col_bytes", C.c_uint32 * 4), ("col_shift", C.c_uint32 * 4)]
+
+        class IndexReport(C.Structure):
+            _fields_ = [("select_mismatch", C.c_uint64), ("rank_mismatch", C.c_uint64), ("access_miss", C.c_uint64),
+                        ("failures", C.c_uint64), ("nexamples", C.c_uint32), ("pad", C.c_uint32),
+                        ("ex_index", C.c_uint64 * 16), ("ex_kind", C.c_uint32 * 16)]
+
+        h = struct.unpack("<8Q", files[base + ".header"][:64])
+        f = SparseFiles()
+        f.D, qd, f.size_lo, f.size_hi, f.count = h[1], h[2], h[5], h[6], h[7]
+        hb = files[base + ".high-bits"]
+        f.high_bits, f.high_words = hb, len(hb) // 8
+        f.d0, f.d0_bytes = files[base + "-d0"], len(files[base + "-d0"])
+        f.d1, f.d1_bytes = files[base + "-d1"], len(files[base + "-d1"])
+        cols = []
+        layout(qd, "", 0, cols)
+        f.ncols = len(cols)
+        for i, (suffix, nbytes, shift) in enumerate(cols):
+            f.col[i] = files[base + ".low-bits" + suffix] or b"\0"
+            f.col_bytes[i] = nbytes
+            f.col_shift[i] = shift
+        rep = IndexReport()
+        self._L.goss_gpu_check_index.argtypes = [C.c_void_p, C.POINTER(SparseFiles), C.POINTER(IndexReport)]
+        self._check(self._L.goss_gpu_check_index(self._h, C.byref(f), C.byref(rep)))
+        return {"select": rep.select_mismatch, "rank": rep.rank_mismatch, "access": rep.access_miss, "failures": rep.failures,
+                "examples": [(rep.ex_index[i], rep.ex_kind[i]) for i in range(rep.nexamples)]}
 
     def files(self):
         n = C.c_uint32()

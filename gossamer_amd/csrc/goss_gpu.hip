@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "goss_kernels.hpp"
+#include "goss_reader.hpp"
 
 using namespace goss;
 
@@ -1876,6 +1877,67 @@ int goss_gpu_select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
         PhaseTimer t(c, GOSS_T_REDUCE, c->M);
         if (c->words == 1) select_counts<Key1>(c, lo, hi); else select_counts<Key2>(c, lo, hi);
         t.stop();
+    });
+}
+
+// DenseSelect::DenseSelect (DenseArray.cc:36-91): header checks, then the device view of the file
+static RdDenseSelect open_dense_select(goss_gpu_ctx* c, const void* host, uint64_t size, int invert)
+{
+    if (!host || size < sizeof(DsHeader)) throw StatusError{GOSS_ERR_INVALID_ARG, "DenseSelect file too short"};
+    DsHeader h;
+    std::memcpy(&h, host, sizeof h);
+    if (h.version != 2012092701ULL) throw StatusError{GOSS_ERR_INVALID_ARG, "DenseSelect version mismatch"};
+    if (h.logBlockSize > 40 || h.logSampleRate > h.logBlockSize || (1ULL << h.logBlockSize) != h.blockSize ||
+        (1ULL << h.logSampleRate) != h.sampleRate || h.smallBlocks + h.intermediateBlocks + h.largeBlocks != h.numBlocks)
+        throw StatusError{GOSS_ERR_INVALID_ARG, "Corrupt DenseSelect index header"};
+    if ((int)(h.flags & 1) != invert) throw StatusError{GOSS_ERR_INVALID_ARG, "DenseSelect index does not have the expected sense"};
+    if (h.indexArrayOffset + h.numBlocks * 8 > size || h.rankArrayOffset + h.numBlocks * 8 > size)
+        throw StatusError{GOSS_ERR_INVALID_ARG, "DenseSelect arrays lie outside the file"};
+    uint8_t* d = (uint8_t*)c->arena.temp(size + 16);
+    HIP_TRY(hipMemcpyAsync(d, host, size, hipMemcpyHostToDevice, c->stream));
+    RdDenseSelect r{};
+    r.data = d; r.size = size; r.flags = h.flags; r.indexArrayOffset = h.indexArrayOffset; r.rankArrayOffset = h.rankArrayOffset;
+    r.logBlockSize = h.logBlockSize; r.blockSize = h.blockSize; r.logSampleRate = h.logSampleRate; r.sampleRate = h.sampleRate;
+    r.numBlocks = h.numBlocks;
+    return r;
+}
+
+int goss_gpu_check_index(goss_gpu_ctx* c, const goss_gpu_sparse_files* f, goss_gpu_index_report* out)
+{
+    if (!c || !f || !out || f->ncols == 0 || f->ncols > 4) return GOSS_ERR_INVALID_ARG;
+    static_assert(sizeof(goss_gpu_index_report) == sizeof(IndexReport), "index report layout");
+    if (!c->finished) { c->last_error = "check_index before finish"; return GOSS_ERR_STATE; }
+    std::memset(out, 0, sizeof *out);
+    if (c->M != f->count) { c->last_error = "the object's count differs from the number of decoded elements"; return GOSS_ERR_STATE; }
+    if (c->M == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        uint64_t mark = c->arena.mark();
+        RdSparse s{};
+        s.D = f->D; s.count = f->count; s.size_lo = f->size_lo; s.size_hi = f->size_hi;
+        uint64_t* hw = (uint64_t*)c->arena.temp(f->high_words * 8 + 16);
+        HIP_TRY(hipMemcpyAsync(hw, f->high_bits, f->high_words * 8, hipMemcpyHostToDevice, c->stream));
+        s.hi.w = hw; s.hi.nwords = f->high_words;
+        s.d0 = open_dense_select(c, f->d0, f->d0_bytes, 1);
+        s.d1 = open_dense_select(c, f->d1, f->d1_bytes, 0);
+        s.ncols = f->ncols;
+        for (uint32_t i = 0; i < f->ncols; ++i)
+        {
+            uint8_t* d = (uint8_t*)c->arena.temp(f->count * f->col_bytes[i] + 16);
+            HIP_TRY(hipMemcpyAsync(d, f->col[i], f->count * f->col_bytes[i], hipMemcpyHostToDevice, c->stream));
+            s.col[i] = d; s.col_bytes[i] = f->col_bytes[i]; s.col_shift[i] = f->col_shift[i];
+        }
+        IndexReport* rep = (IndexReport*)c->arena.temp(sizeof(IndexReport));
+        HIP_TRY(hipMemsetAsync(rep, 0, sizeof(IndexReport), c->stream));
+        if (c->words == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(check_index_kernel<Key1>), dim3(grid_for(c->M, 256)), dim3(256), 0, c->stream, s,
+                               (const Key1*)c->res_keys, c->M, rep);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(check_index_kernel<Key2>), dim3(grid_for(c->M, 256)), dim3(256), 0, c->stream, s,
+                               (const Key2*)c->res_keys, c->M, rep);
+        HIP_TRY(hipMemcpyAsync(out, rep, sizeof(IndexReport), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+        if (out->nexamples > 16) out->nexamples = 16;
     });
 }
 

@@ -708,7 +708,46 @@ void GossCmdLintGraph::operator()(const GossCmdContext& pCxt)
             log(warning, "    " + edgeAt(rep.ex_index[j], mult));
             log(warning, "iterator: " + num(rep.ex_index[j]));
         }
-    mProblems = rep.missing_rc + rep.count_mismatch + rep.zero_count + rep.order_violation;
+    // the object's own select / rank structures against the decoded list (GossCmdLintGraph.cc:201-243)
+    goss_gpu_index_report irep{};
+    {
+        SparseFiles s;
+        openSparse(mIn + "-edges", s);
+        Mapped hdr, d0, d1;
+        hdr.open(mIn + "-edges.header"); d0.open(mIn + "-edges-d0"); d1.open(mIn + "-edges-d1");
+        uint64_t h[8]; memcpy(h, hdr.p, 64);
+        goss_gpu_sparse_files f{};
+        f.D = s.D; f.count = s.count; f.size_lo = h[5]; f.size_hi = h[6];
+        f.high_bits = (const uint64_t*)s.high.p; f.high_words = s.high.n / 8;
+        f.d0 = d0.p; f.d0_bytes = d0.n; f.d1 = d1.p; f.d1_bytes = d1.n;
+        f.ncols = (uint32_t)s.cols.size();
+        for (size_t i = 0; i < s.cols.size(); ++i)
+        { f.col[i] = s.colFiles[i].p; f.col_bytes[i] = s.cols[i].bytes; f.col_shift[i] = s.cols[i].shift; }
+        g.check(goss_gpu_check_index(g.h, &f, &irep), "checking the select / rank indexes");
+    }
+    {
+        std::vector<uint32_t> io(irep.nexamples);
+        for (uint32_t i = 0; i < irep.nexamples; ++i) io[i] = i;
+        std::sort(io.begin(), io.end(), [&](uint32_t a, uint32_t b) { return irep.ex_index[a] < irep.ex_index[b]; });
+        for (uint32_t j : io)
+        {
+            uint32_t mult = 0;
+            const std::string e = edgeAt(irep.ex_index[j], mult);
+            if (irep.ex_kind[j] == 1) { log(warning, "iterator and select conflict."); log(warning, "    " + e); }
+            else
+            {
+                log(warning, "iterator and rank conflict.");
+                log(warning, "    " + e);
+                log(warning, "iterator: " + num(irep.ex_index[j]));
+            }
+        }
+    }
+    const uint64_t indexProblems = irep.select_mismatch + irep.rank_mismatch + irep.access_miss + irep.failures;
+    if (indexProblems > irep.nexamples)
+        log(warning, num(indexProblems) + " index problems in total (" + num(irep.select_mismatch) + " select, "
+                     + num(irep.rank_mismatch) + " rank, " + num(irep.access_miss) + " lookups that miss, "
+                     + num(irep.failures) + " walks off the index)");
+    mProblems = rep.missing_rc + rep.count_mismatch + rep.zero_count + rep.order_violation + indexProblems;
     if (mProblems > rep.nexamples)
         log(warning, num(mProblems) + " problems in total (" + num(rep.missing_rc) + " missing reverse complements, "
                      + num(rep.count_mismatch) + " unequal counts, " + num(rep.zero_count) + " zero counts, "

@@ -209,6 +209,31 @@ int goss_gpu_select_counts(goss_gpu_ctx* ctx, uint32_t lo, uint32_t hi);
 int goss_gpu_emit_count_bits(goss_gpu_ctx* ctx, uint32_t mask, const char* suffix);
 
 /*
+ * After finish, with the context holding the decoded elements of an object (pushed through
+ * goss_gpu_push_run_sparse): evaluate the object's OWN index structures on the device -- for
+ * every i, SparseArray::select(i) through the -d1 DenseSelect must give element i, and
+ * SparseArray::rank / access of element i through the -d0 DenseSelect must give i / true
+ * (SparseArray.hh:246-364, DenseArray.cc:134-258, WordyBitVector.tcc:17-54).  This is the
+ * iterator-against-select-and-rank pass of lint-graph (GossCmdLintGraph.cc:201-243).
+ * Example kinds: 1 select differs, 2 rank differs, 3 element not found, 4 index walk failed.
+ */
+typedef struct {
+    uint64_t D, count, size_lo, size_hi;            /* SparseArray header fields */
+    const uint64_t* high_bits; uint64_t high_words;
+    const void* d0; uint64_t d0_bytes;               /* "<base>-d0" file image */
+    const void* d1; uint64_t d1_bytes;               /* "<base>-d1" file image */
+    uint32_t ncols, pad;
+    const void* col[4]; uint32_t col_bytes[4]; uint32_t col_shift[4];
+} goss_gpu_sparse_files;
+typedef struct {
+    uint64_t select_mismatch, rank_mismatch, access_miss, failures;
+    uint32_t nexamples, pad;
+    uint64_t ex_index[16];
+    uint32_t ex_kind[16];
+} goss_gpu_index_report;
+int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, goss_gpu_index_report* out);
+
+/*
  * Diagnostic counters of the context, by name: "fused_chunks" (chunks counted by the extraction
  * that partitions), "fused_overflows" (chunks redone unfused because a bucket region was too
  * small), "segment_retries", "lookback_failures", "runs".

@@ -64,6 +64,21 @@ def test_dump_restore_lint(oracle, tmp_path):
         err = p.stderr.decode()
         assert "Pass 1: Checking counts are sane." in err and "Pass 2: Checking traversal is sane." in err
         assert "warning" not in err
+        # damage the select index of a copy (the second block of -edges-d1 starts one position late):
+        # pass 2 evaluates the object's own select / rank on the device and must notice
+        import shutil
+        import struct
+        for n in os.listdir(tmp_path):
+            if n.startswith(gr + ".") or n.startswith(gr + "-"):
+                shutil.copy(tmp_path / n, tmp_path / ("dmg" + n[len(gr):]))
+        b = bytearray((tmp_path / "dmg-edges-d1").read_bytes())
+        rank_off = struct.unpack("<Q", b[24:32])[0]
+        v = struct.unpack("<Q", b[rank_off + 8: rank_off + 16])[0]
+        b[rank_off + 8: rank_off + 16] = struct.pack("<Q", v + 1)
+        (tmp_path / "dmg-edges-d1").write_bytes(bytes(b))
+        p = run(["lint-graph", "-G", str(tmp_path / "dmg")])
+        assert p.returncode == 0
+        assert "iterator and select conflict." in p.stderr.decode()
         # break the symmetry: drop one edge / change one count in the text, restore, lint
         lines = text.split(b"\n")
         comp = {65: "T", 67: "G", 71: "C", 84: "A"}
