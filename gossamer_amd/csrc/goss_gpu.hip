@@ -654,7 +654,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
                          Key1* kb, uint64_t kb_slots)
 {
     const uint32_t keybits = 2 * c->len;
-    if (!c->fused || c->words != 1 || c->mode != GOSS_MODE_KMER_SET || c->path != 0 || !c->lookback || c->ordered_tiles ||
+    if (!c->fused || c->words != 1 || c->path != 0 || !c->lookback || c->ordered_tiles ||
         c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
         return false;
     constexpr int kTile = SortCfg<Key1, false>::kTile;
@@ -682,7 +682,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
-    constexpr uint64_t kPlainSuper = 8ULL * kTB * 16;
+    const bool graph_mode = c->mode == GOSS_MODE_GRAPH;
+    const uint64_t kPlainSuper = 8ULL * kTB * (graph_mode ? 8 : 16);
     // a slice is ONE super-tile (~217 reads of 150 bp): thousands of slices follow a drifting
     // k-mer distribution (sorted inputs) far better than a few long ones
     const uint64_t nslices = sample_starts >= nstarts ? 1 : std::max<uint64_t>(64, sample_starts / kPlainSuper);
@@ -703,6 +704,11 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, NB>), dim3(grid), dim3(kTB), 0, c->stream,              \
                        (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper, \
                        slice_tiles, slice_stride)
+            if (graph_mode)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<1, 8, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
+                                   slice_tiles, slice_stride);
+            else
             switch ((2 * c->len + 7) / 8)
             {
                 case 3: GOSS_LAUNCH_ES(3); break;
@@ -833,31 +839,42 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
 #ifndef GOSS_FUSED_G
 #define GOSS_FUSED_G 1
 #endif
-        constexpr uint64_t kSuper = GOSS_FUSED_G * kTB * 16;
+        const bool graph = c->mode == GOSS_MODE_GRAPH;
+        const uint64_t kSuper = (uint64_t)GOSS_FUSED_G * kTB * (graph ? 8 : 16);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 1024 : 512);
         const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
-#define GOSS_LAUNCH_EP2(NB, NH)                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<NB, GOSS_FUSED_G, NH>), dim3(grid), dim3(kTB), 0, c->stream,           \
+#define GOSS_LAUNCH_EP3(MODE, NB, NH)                                                                                 \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NB, GOSS_FUSED_G, NH>), dim3(grid), dim3(kTB), 0, c->stream,     \
                        aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
+#define GOSS_LAUNCH_EP2(NB, NH) GOSS_LAUNCH_EP3(0, NB, NH)
 #define GOSS_LAUNCH_EP(NB)                                                                                            \
     do {                                                                                                              \
         if (nh == 0) GOSS_LAUNCH_EP2(NB, 0);                                                                          \
         else if (nh == 1) GOSS_LAUNCH_EP2(NB, 1);                                                                     \
         else GOSS_LAUNCH_EP2(NB, 2);                                                                                  \
     } while (0)
-        switch ((2 * c->len + 7) / 8)
+        if (graph)
         {
-            case 3: GOSS_LAUNCH_EP(3); break;
-            case 4: GOSS_LAUNCH_EP(4); break;
-            case 5: GOSS_LAUNCH_EP(5); break;
-            case 6: GOSS_LAUNCH_EP(6); break;
-            case 7: GOSS_LAUNCH_EP(7); break;
-            default: GOSS_LAUNCH_EP(8); break;
+            // graph mode does not hash: one instantiation serves every key width
+            if (nh == 0) GOSS_LAUNCH_EP3(1, 8, 0);
+            else if (nh == 1) GOSS_LAUNCH_EP3(1, 8, 1);
+            else GOSS_LAUNCH_EP3(1, 8, 2);
         }
+        else
+            switch ((2 * c->len + 7) / 8)
+            {
+                case 3: GOSS_LAUNCH_EP(3); break;
+                case 4: GOSS_LAUNCH_EP(4); break;
+                case 5: GOSS_LAUNCH_EP(5); break;
+                case 6: GOSS_LAUNCH_EP(6); break;
+                case 7: GOSS_LAUNCH_EP(7); break;
+                default: GOSS_LAUNCH_EP(8); break;
+            }
 #undef GOSS_LAUNCH_EP
 #undef GOSS_LAUNCH_EP2
+#undef GOSS_LAUNCH_EP3
         t.stop();
     }
     std::vector<unsigned long long> hpc(sizeof(PartCounters) / 8);

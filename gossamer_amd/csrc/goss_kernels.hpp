@@ -499,19 +499,22 @@ struct SubTable {
     unsigned long long cap[65536];
 };
 
-template <int NB, int G, int NH>
+template <int MODE, int NB, int G, int NH>
 __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
                                                             const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper)
 {
-    constexpr int P = 16;
+    // MODE 0: canonical key per window, 16 windows per thread.  MODE 1 (graph): forward key and
+    // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
+    constexpr int S = MODE == 1 ? 2 : 1;
+    constexpr int P = 16 / S;
     constexpr int T = kTB * P;
     constexpr int NVEC = G * T / 16 + 4;
-    constexpr int NK = G * P;                    // keys per thread
+    constexpr int NK = G * P * S;                // keys per thread
     __shared__ uint32_t pk[NVEC];
     __shared__ uint32_t iv[NVEC];
-    __shared__ Key1 sorted[G * T];
+    __shared__ Key1 sorted[G * T * S];
     __shared__ uint32_t dh[256];                 // keys of this super-tile per digit (and rank counter)
     __shared__ uint64_t gbase[256];              // global slot of sorted[i] with digit d = gbase[d] + i
     __shared__ uint32_t sh_ovf;
@@ -615,9 +618,19 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                     if ((m >> i) & 1u)
                     {
                         Key1 fk{f}, rck{(~e) & kmask};
-                        const Key1 k = canonical_short<NB>(fk, rck);
-                        kreg[g * P + i] = k;
-                        rk[g * P + i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
+                        if (MODE == 0)
+                        {
+                            const Key1 k = canonical_short<NB>(fk, rck);
+                            kreg[g * P + i] = k;
+                            rk[g * P + i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
+                        }
+                        else
+                        {
+                            kreg[(g * P + i) * 2] = fk;
+                            rk[(g * P + i) * 2] = (uint16_t)atomicAdd(&dh[(uint32_t)(fk.lo >> shift) & 0xFFu], 1u);
+                            kreg[(g * P + i) * 2 + 1] = rck;
+                            rk[(g * P + i) * 2 + 1] = (uint16_t)atomicAdd(&dh[(uint32_t)(rck.lo >> shift) & 0xFFu], 1u);
+                        }
                     }
                 }
             }
@@ -643,8 +656,12 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             for (int i = 0; i < P; ++i)
                 if ((vm[g] >> i) & 1u)
                 {
-                    const Key1 k = kreg[g * P + i];
-                    sorted[dh[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[g * P + i]] = k;
+#pragma unroll
+                    for (int q = 0; q < S; ++q)
+                    {
+                        const Key1 k = kreg[(g * P + i) * S + q];
+                        sorted[dh[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[(g * P + i) * S + q]] = k;
+                    }
                 }
         }
         __syncthreads();
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     // valid windows of this workgroup
     for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
-    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid); atomicAdd(&pc->windows, nvalid); }
+    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
 }
 
 // --------------------------------------------------------------------------------------

@@ -14,17 +14,18 @@ def _suffix_map(files, prefix):
     return {k[len(prefix):]: v for k, v in files.items()}
 
 
-def _build(reads, k, env=None, budget=8 << 30):
+def _build(reads, k, env=None, budget=8 << 30, mode=None):
     old = {}
     for name, val in (env or {}).items():
         old[name] = os.environ.get(name)
         os.environ[name] = val
     try:
-        with g.Context(k, g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+        with g.Context(k, g.MODE_KMER_SET if mode is None else mode, hbm_budget=budget) as ctx:
             ctx.push_host(reads)
             c = ctx.finish()
             files = ctx.emit()
-            stats = {n: ctx.stat(n) for n in ("fused_chunks", "fused_overflows", "segment_retries", "lookback_failures")}
+            stats = {n: ctx.stat(n) for n in ("fused_chunks", "fused_msd_chunks", "fused_overflows", "segment_retries",
+                                              "lookback_failures")}
         return c, files, stats
     finally:
         for name, val in old.items():
@@ -68,6 +69,19 @@ def test_fused_path_other_k(oracle, k):
     assert st["fused_chunks"] == 1
     assert c.windows == nwin
     _same(got, _suffix_map(exp, "ks"))
+
+
+@pytest.mark.parametrize("k,env,form", [(27, {}, "msd"), (24, {"GOSS_GPU_NO_MSD": "1"}, "lsd")])
+def test_fused_path_graph_mode(oracle, k, env, form):
+    """build-graph with one-word keys (k <= 30): both strands of every (k+1)-mer go through the
+    extraction that partitions; files against the oracle."""
+    reads = g.synth_reads_host(260000, 150, 1200000, seed=13)
+    exp, nwin = oracle.build_graph([(oracle.LINE, "reads", reads)], k, out="gr")
+    c, got, st = _build(reads, k, env=env, mode=g.MODE_GRAPH)
+    assert st["fused_chunks"] == 1 and st["fused_overflows"] == 0
+    assert st["fused_msd_chunks"] == (1 if form == "msd" else 0)
+    assert c.windows == nwin and c.keys == 2 * nwin
+    _same(got, _suffix_map(exp, "gr"))
 
 
 def test_fused_path_contiguous_sequence(oracle):
