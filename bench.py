@@ -100,7 +100,7 @@ def main():
     bases = torch.empty(nbytes, dtype=torch.uint8, device=device)
     free_b, total_b = torch.cuda.mem_get_info(device)
     # the exchange buffers of the multi-GPU path are torch tensors outside the library's arena
-    share = 0.80 if use_dist else 0.94
+    share = 0.84 if use_dist else 0.94
     budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * share)
     ctx = g.Context(k, g.MODE_GRAPH if args.graph else g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
     ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)

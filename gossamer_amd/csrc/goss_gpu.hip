@@ -429,11 +429,26 @@ void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
     if (c->mode == GOSS_MODE_KMER_SET) launch_extract1<0, 16, 8>(c, aligned, mis, nstarts, navail, out);
     else launch_extract1<1, 8, 8>(c, aligned, mis, nstarts, navail, out);
 }
+template <int MODE, int P, int G>
+void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
+{
+    constexpr int T = kTB * P * G;
+    const uint64_t nsuper = (nstarts + T - 1) / T;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper ? nsuper : 1, 1024 * 2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, navail,
+                       c->len, out, c->d_ctr, nsuper);
+}
 template <>
 void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
 {
-    if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key2, 0, 8>(c, aligned, mis, nstarts, navail, out);
-    else launch_extract<Key2, 1, 4>(c, aligned, mis, nstarts, navail, out);
+    if (c->extract_v1)
+    {
+        if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key2, 0, 8>(c, aligned, mis, nstarts, navail, out);
+        else launch_extract<Key2, 1, 4>(c, aligned, mis, nstarts, navail, out);
+        return;
+    }
+    if (c->mode == GOSS_MODE_KMER_SET) launch_extract2<0, 8, 8>(c, aligned, mis, nstarts, navail, out);
+    else launch_extract2<1, 4, 8>(c, aligned, mis, nstarts, navail, out);
 }
 
 inline uint32_t key_digits(const goss_gpu_ctx* c) { return (2 * c->len + 7) / 8; }

@@ -458,6 +458,161 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 }
 
 // --------------------------------------------------------------------------------------
+// K2, two-word keys (32 <= len <= 63): the same windows-out-of-registers scheme with a 192-bit
+// buffer of 2-bit codes per thread (96 bases >= 15 + P - 1 + 63)
+// --------------------------------------------------------------------------------------
+template <int MODE, int P, int G>
+__global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                       uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                       Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper)
+{
+    constexpr int T = kTB * P;
+    constexpr int NVEC = G * T / 16 + 6;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    static_assert(P <= 16, "96 bases per thread");
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key2 stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bits = 2 * len;                                       // 64..126
+    const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
+    const uint64_t lmask = (1ULL << len) - 1;                            // len <= 63
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        const uint64_t tile_base = st * (uint64_t)(G * T);
+        // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
+        for (uint32_t v = tid; v < NVEC; v += kTB)
+        {
+            uint64_t byte0 = tile_base + (uint64_t)v * 16;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            if (byte0 + 16 <= navail + mis)
+            {
+                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            }
+            else if (byte0 < navail + mis)
+            {
+                for (int j = 0; j < 16; ++j)
+                {
+                    uint64_t b = byte0 + j;
+                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+            }
+            uint32_t codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                uint32_t l = w[i] | 0x20202020u;
+                uint32_t x = (l >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                uint32_t b1 = bad >> 7;
+                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                codes |= c8 << (8 * i);
+                bads |= b4 << (4 * i);
+            }
+            pk[v] = codes;
+            iv[v] = bads;
+        }
+        __syncthreads();
+
+        // ---- phase B: validity masks and compacted slots of every sub-tile ---------------------
+        uint32_t vmask[G], slot[G], sub_cnt[G];
+        uint32_t total = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+            const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
+            const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t t = sh + i;                               // 0..30
+                const uint64_t win = t ? ((inv_lo >> t) | (inv_hi << (64 - t))) : inv_lo;
+                bool ok = (win & lmask) == 0 && (p0 + i < nstarts);
+                m |= ok ? (1u << i) : 0u;
+            }
+            vmask[g] = m;
+            uint32_t tc;
+            slot[g] = block_excl_scan<uint32_t>(__popc(m), sh_scan, &tc);
+            sub_cnt[g] = tc;
+            total += tc;
+        }
+        if (tid == 0)
+        {
+            unsigned long long b = 0;
+            if (total) b = atomicAdd(&ctr->keys_out, (unsigned long long)total * S);
+            sh_base = b;
+        }
+        __syncthreads();
+        uint64_t ob = sh_base;
+
+        // ---- phase C: per sub-tile, cut the windows out of registers, stage, store --------------
+#pragma unroll 1
+        for (int g = 0; g < G; ++g)
+        {
+            const uint32_t vm = vmask[g];
+            if (vm)
+            {
+                const uint32_t q0 = (g * kTB + tid) * P + mis;
+                const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+                const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
+                const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
+                const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
+                uint32_t s = slot[g] * S;
+                Key2 f{0, 0};
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                {
+                    // field of window i: bits [2(sh+i), 2(sh+i) + 2len) of the 192-bit buffer
+                    const uint32_t t2 = 2 * (sh + i);                    // 0..60
+                    Key2 e;
+                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
+                    if (i == 0)
+                    {
+                        // forward value of window 0: base-4 reversal of its field
+                        const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);   // reversed 128 bits = {rhi:rlo}
+                        const uint32_t sft = 128 - bits;                        // 2..64
+                        if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                        else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                    }
+                    else
+                    {
+                        const uint32_t pos = 2 * (sh + i + len - 1);     // new last base, bit position in the buffer
+                        const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
+                        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+                        f.lo = (f.lo << 2) | nb;
+                    }
+                    if ((vm >> i) & 1u)
+                    {
+                        const Key2 rk{~e.lo, (~e.hi) & mask_hi};
+                        if (MODE == 0) stage[s++] = canonical(f, rk);
+                        else { stage[s++] = f; stage[s++] = rk; }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nk = sub_cnt[g] * S;
+            for (uint32_t i = tid; i < nk; i += kTB) out[ob + i] = stage[i];
+            ob += nk;
+            __syncthreads();
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // K2+K4 fused, one-word canonical keys: extraction that writes its keys already partitioned on
 // the first partition digit
 // --------------------------------------------------------------------------------------
