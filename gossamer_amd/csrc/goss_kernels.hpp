@@ -1981,24 +1981,45 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
         if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    // empty slots sort last: hi = all ones is never a key (2*len <= 126 bits)
-    for (uint32_t i = tid; i < kSegSlots2; i += kTB)
-        if (st[i] == 0) { thi[i] = ~0ULL; tlo[i] = ~0ULL; }
+    // Compact the occupied slots to the front (every thread takes its 8 slots into registers, then
+    // all write) and sort only the next power of two above the number of distinct keys: a segment
+    // of a high-coverage input holds far fewer keys than the table has slots.  Empty slots sort
+    // last: hi = all ones is never a key (2*len <= 126 bits).
+    constexpr int kPer2 = kSegSlots2 / kTB;
+    __shared__ uint32_t sh_scan2[kWaves + 1];
+    unsigned long long cl[kPer2], ch[kPer2];
+    uint32_t cs[kPer2];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPer2; ++j)
+    {
+        cl[j] = tlo[tid * kPer2 + j]; ch[j] = thi[tid * kPer2 + j]; cs[j] = st[tid * kPer2 + j];
+        mine += cs[j] != 0 ? 1u : 0u;
+    }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan<uint32_t>(mine, sh_scan2, &tot_occ);      // syncs: every slot has been read
+    uint32_t nsort = 64;
+    while (nsort < tot_occ) nsort <<= 1;
+#pragma unroll
+    for (int j = 0; j < kPer2; ++j)
+        if (cs[j] != 0) { tlo[at] = cl[j]; thi[at] = ch[j]; st[at] = cs[j]; ++at; }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= kSegSlots2; k2 <<= 1)
+    for (uint32_t i = tot_occ + tid; i < nsort; i += kTB) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
     {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
         {
-            for (uint32_t t = tid; t < kSegSlots2 / 2; t += kTB)
+            for (uint32_t t = tid; t < nsort / 2; t += kTB)
             {
                 uint32_t i = 2 * t - (t & (j - 1));
                 uint32_t p = i + j;
                 bool up = (i & k2) == 0;
-                unsigned long long ah = thi[i], al = tlo[i], ch = thi[p], cl = tlo[p];
-                bool gt = ah > ch || (ah == ch && al > cl);
+                unsigned long long ah = thi[i], al = tlo[i], bh = thi[p], bl = tlo[p];
+                bool gt = ah > bh || (ah == bh && al > bl);
                 if (gt == up)
                 {
-                    thi[i] = ch; tlo[i] = cl; thi[p] = ah; tlo[p] = al;
+                    thi[i] = bh; tlo[i] = bl; thi[p] = ah; tlo[p] = al;
                     uint32_t ca = st[i]; st[i] = st[p]; st[p] = ca;
                 }
             }
