@@ -863,11 +863,14 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
 #ifndef GOSS_SORT_ITEMS1
 #define GOSS_SORT_ITEMS1 32
 #endif
+#ifndef GOSS_SORT_ITEMS2
+#define GOSS_SORT_ITEMS2 16
+#endif
 #ifndef GOSS_LB_BATCH
 #define GOSS_LB_BATCH 1
 #endif
 template <class K, bool HAS_VAL = false> struct SortCfg {
-    static constexpr int kItems = sizeof(K) == 8 ? (HAS_VAL ? 16 : GOSS_SORT_ITEMS1) : 8;   // keys per thread
+    static constexpr int kItems = sizeof(K) == 8 ? (HAS_VAL ? 16 : GOSS_SORT_ITEMS1) : (HAS_VAL ? 8 : GOSS_SORT_ITEMS2);   // keys per thread
     static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
 };
 
