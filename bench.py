@@ -202,6 +202,17 @@ def main():
                          "device_ms_per_step": {n: v["ms"] / args.steps for n, v in tim.items()},
                          "device_ms_total_per_step": dev_ms / args.steps},
         }
+        # the other kernel classes against their own algorithmic bytes (same definitions)
+        keys_per_step = w_local * (2 if args.graph else 1) / args.steps
+        others = {}
+        for name, per_key in (("scatter", 2.0 * kbytes), ("reduce", 1.0 * kbytes)):
+            ms = tim[name]["ms"] / args.steps
+            if ms > 0:
+                gbs = per_key * keys_per_step * max(1, round(tim[name]["launches"] / args.steps)) / (ms * 1e-3) / 1e9 \
+                    if name == "scatter" else per_key * keys_per_step / (ms * 1e-3) / 1e9
+                others[name] = {"ms_per_step": ms, "launches_per_step": tim[name]["launches"] / args.steps,
+                                "algorithmic_bytes_per_key_per_launch": per_key, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+        out["roofline"]["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
         # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
