@@ -1,6 +1,8 @@
 /*
  * goss_oracle.h -- CPU restatement (plain C) of data61/gossamer's k-mer counting /
- * de Bruijn edge-set build path.  TEST INFRASTRUCTURE ONLY.
+ * de Bruijn edge-set build path, of the reference's readers of the objects it writes, and of
+ * the commands around it that the product also implements (merge-*, intersect / subtract /
+ * merge-and-annotate, dump-*, restore-graph).  TEST INFRASTRUCTURE ONLY.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library; the product path (libgossgpu.so, the goss CLI) never links or calls it.
