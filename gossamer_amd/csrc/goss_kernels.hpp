@@ -1672,6 +1672,13 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
+    if (e - b > 0xFFFFFFFFULL)
+    {
+        // a 32-bit slot count could wrap: leave this chunk to the full sort, whose run lengths
+        // saturate and report the overflow
+        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
     constexpr unsigned long long kEmpty = ~0ULL;
     for (uint32_t i = tid; i < kSegSlots; i += kTB) { tab[i] = kEmpty; cnt[i] = 0; }
     if (tid == 0) { ndist = 0; ovf = 0; }
@@ -1908,6 +1915,13 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     if (b == e)
     {
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    if (e - b > 0xFFFFFFFFULL)
+    {
+        // a 32-bit slot count could wrap: leave this chunk to the full sort, whose run lengths
+        // saturate and report the overflow
+        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
     for (uint32_t i = tid; i < kSegSlots2; i += kTB) st[i] = 0;

@@ -174,3 +174,31 @@ def test_fused_path_declines_unique_input(oracle):
         assert ctx.stat("fused_chunks") == 0
         assert c.windows == 40_000_000 - 24
         assert c.distinct > 0.98 * c.windows
+
+
+def test_extreme_skew_one_kmer_five_billion_times():
+    """4.6 G 'A's: one canonical 25-mer, 4.6e9 times.  Every key lands in one bucket, one
+    sub-region and one segment; the segment is too long for 32-bit slot counts, so the chunk goes
+    down to the full sort, whose run length saturates -- a k-mer set stores no counts and must
+    come out with exactly one k-mer.  A graph with the same shape (2 x 1e8 windows) keeps exact
+    counts."""
+    import torch
+    n = 4_600_000_000
+    buf = torch.full((n + 1,), 65, dtype=torch.uint8, device="cuda")
+    buf[-1] = 10
+    with g.Context(25, g.MODE_KMER_SET, hbm_budget=100 << 30) as ctx:
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert c.windows == n - 24 and c.distinct == 1
+        keys, counts = ctx.result()
+        assert keys == [0] and counts[0] == 0xFFFFFFFF
+        files = ctx.emit()
+        import struct
+        assert struct.unpack("<QQQ", files[".header"]) == (2011101701, 25, 1)
+    m = 100_000_000
+    with g.Context(27, g.MODE_GRAPH, hbm_budget=16 << 30) as ctx:
+        ctx.push_device(buf.data_ptr(), m + 1)          # the byte after the m A's is another A: m + 1 - 28 + 1 windows
+        c = ctx.finish()
+        keys, counts = ctx.result()
+        assert c.distinct == 2 and keys == [0, 4 ** 28 - 1]
+        assert counts[0] == counts[1] == m + 1 - 27
