@@ -1933,18 +1933,33 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     volatile unsigned long long* vlo = tlo;
     volatile unsigned long long* vhi = thi;
     constexpr int kU = 4;
+    // software pipeline: the next batch's loads are in flight while this one is inserted
+    // (hi = all ones marks "no key": 2*len <= 126 bits)
+    Key2 nxt[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+    {
+        uint64_t i = b + (uint64_t)u * kTB + tid;
+        nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+    }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kU)
     {
         Key2 kv[kU];
         uint32_t slots[kU];
         uint32_t pend = 0;
 #pragma unroll
+        for (int u = 0; u < kU; ++u) kv[u] = nxt[u];
+#pragma unroll
         for (int u = 0; u < kU; ++u)
         {
-            uint64_t i = i0 + (uint64_t)u * kTB + tid;
-            if (i < e)
+            uint64_t i = i0 + (uint64_t)(kU + u) * kTB + tid;
+            nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+            if (kv[u].hi != ~0ULL)
             {
-                kv[u] = keys[i];
                 uint64_t h = (kv[u].lo ^ (kv[u].hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
                 slots[u] = (uint32_t)(h >> (64 - 11));
                 pend |= 1u << u;
