@@ -511,12 +511,21 @@ uint64_t count_distinct_sample(goss_gpu_ctx* c, const K* keys, uint64_t s)
     return d;
 }
 
-// M ~ s^2 / (2 (s - d)) for a sample of s keys with d distinct; 0 = no repeated key (unknown).
+// Number of equally likely keys M from which s draws show d distinct ones: the root of
+// d = M (1 - exp(-s / M)) (~ s^2 / (2 (s - d)) when almost every draw is new, ~ d when the
+// sample saturates the population).  0 = no repeated key at all (unknown, at least of the order of s).
 inline uint64_t birthday_estimate(uint64_t s, uint64_t d)
 {
     if (d >= s) return 0;
-    const double est = (double)s * (double)s / (2.0 * (double)(s - d));
-    return std::max<uint64_t>(d, (uint64_t)est);
+    double lo = (double)d, hi = (double)d;
+    auto seen = [&](double m) { return m * -std::expm1(-(double)s / m); };
+    while (seen(hi) < (double)d && hi < 1e19) hi *= 2.0;
+    for (int it = 0; it < 80; ++it)
+    {
+        const double mid = 0.5 * (lo + hi);
+        if (seen(mid) < (double)d) lo = mid; else hi = mid;
+    }
+    return std::max<uint64_t>(d, (uint64_t)hi);
 }
 
 template <class K>
@@ -693,7 +702,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     //    a larger sample: 1/64 of the chunk but at least 160 M window starts; a chunk of up to 640 M
     //    window starts is sampled whole (exact sizes, +4 % extraction work at most).
     const bool want_msd = c->fused_msd;
-    uint64_t sample_starts = 4u << 20;
+    uint64_t sample_starts = nstarts <= (16u << 20) ? nstarts : (4u << 20);
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
@@ -801,8 +810,9 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         for (uint32_t i = 0; i < 65536; ++i)
         {
             const double h = (double)joint[i];
-            const double want = exact ? h + 16.0 : (h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0;
-            const uint64_t cap = ((uint64_t)(want * c->fused_capscale) + 15) & ~15ULL;
+            // exact counts need no slack (and a small chunk cannot afford 65 536 paddings)
+            const uint64_t cap = exact ? (uint64_t)(h * c->fused_capscale)
+                                       : (((uint64_t)(((h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0) * c->fused_capscale) + 15) & ~15ULL);
             hsub[0].start[i] = at; hsub[0].cap[i] = cap;
             at += cap;
         }

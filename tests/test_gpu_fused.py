@@ -202,3 +202,41 @@ def test_extreme_skew_one_kmer_five_billion_times():
         keys, counts = ctx.result()
         assert c.distinct == 2 and keys == [0, 4 ** 28 - 1]
         assert counts[0] == counts[1] == m + 1 - 27
+
+
+@pytest.mark.parametrize("k,mode,form", [(13, "kmer", "msd"), (16, "kmer", "lsd"), (25, "kmer", "msd"), (31, "kmer", "lsd"),
+                                         (12, "graph", "msd"), (24, "graph", "lsd"), (30, "graph", "msd")])
+def test_fused_kernels_on_ragged_reads(oracle, k, mode, form):
+    """The fused kernels on reads that are nothing like the synthetic set: lengths 20..180 (some
+    shorter than k), 2 % non-ACGT bytes of several kinds, lower case, heavy duplication.
+    GOSS_GPU_FUSED_MIN=0 sends this small input (about 4.5 M window starts) down the fused path;
+    files against the oracle."""
+    import random
+    rng = random.Random(1000 + k)
+    genome = "".join(rng.choice("ACGT") for _ in range(30000))
+    reads = []
+    for _ in range(45000):
+        L = rng.randint(20, 180)
+        p = rng.randint(0, len(genome) - L)
+        r = list(genome[p:p + L])
+        for i in range(L):
+            x = rng.random()
+            if x < 0.02:
+                r[i] = rng.choice("NnRY.-*")
+            elif x < 0.3:
+                r[i] = r[i].lower()
+        reads.append("".join(r))
+    txt = "\n".join(reads) + "\n"
+    env = {"GOSS_GPU_FUSED_MIN": "0"}
+    if form == "lsd":
+        env["GOSS_GPU_NO_MSD"] = "1"
+    if mode == "kmer":
+        exp, nwin = oracle.build_kmer_set([(oracle.LINE, "r", txt)], k, out="o")
+        c, got, st = _build(txt.encode(), k, env=env, budget=1 << 30)
+    else:
+        exp, nwin = oracle.build_graph([(oracle.LINE, "r", txt)], k, out="o")
+        c, got, st = _build(txt.encode(), k, env=env, budget=1 << 30, mode=g.MODE_GRAPH)
+    assert st["fused_chunks"] == 1 and st["fused_overflows"] == 0, st
+    assert st["fused_msd_chunks"] == (1 if form == "msd" else 0)
+    assert c.windows == nwin
+    _same(got, _suffix_map(exp, "o"))
