@@ -1,0 +1,67 @@
+"""BASELINE config C2 at full size (k = 25, 100 M x 150 bp reads, 12.58 G k-mers) on one GPU:
+size-independent properties where the oracle cannot go.
+
+* the default pipeline (fused extraction, two-level partition by atomic cursors) and the unfused
+  one (dense extraction, two partition passes with look-back) are independent code paths down to
+  the counting kernel: they must give identical keys and counts;
+* counts add up to the number of windows, keys are strictly increasing;
+* the emitted KmerSet passes its own index check: select / rank / access of all 10^8 elements
+  through the -d1 / -d0 DenseSelect images (goss_gpu_check_index), and its headers are consistent.
+"""
+import os
+import struct
+
+import pytest
+
+import gossamer_amd as g
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_full_size_properties():
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 250 * (1 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    n, L, G = 100_000_000, 150, 100_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    budget = int((free_b - buf.numel()) * 0.90)
+    res = []
+    for env in ({}, {"GOSS_GPU_NO_FUSED": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=budget)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=1)
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert ctx.stat("fused_msd_chunks") == (0 if env else 1)
+        kp, cp, m = ctx.result_ptrs()
+        keys = gd.device_view(kp, m, torch.int64, "cuda").clone()
+        counts = gd.device_view(cp, m, torch.int32, "cuda").clone()
+        assert m == c.distinct and c.keys == c.windows
+        if not res:
+            assert bool((keys[1:] > keys[:-1]).all().item())
+            assert int(counts.to(torch.int64).sum().item()) == c.windows
+            # windows: every read has 126, minus the ones an 'N' removes (one N in every 97th read)
+            assert n * 126 * 0.99 < c.windows <= n * 126
+            files = ctx.emit()
+            hdr = struct.unpack("<QQQ", files[".header"])
+            assert hdr == (2011101701, 25, m)
+            sa = struct.unpack("<8Q", files[".kmers.header"])
+            assert sa[0] == 2012030501 and sa[7] == m and sa[5] == 4 ** 25 and sa[6] == 0
+            assert sa[1] == 23 and sa[2] == 24                      # D, quantizedD of SURVEY section 8(a13) for M ~ 10^8
+            rep = ctx.check_index({k[len(".kmers"):]: v for k, v in files.items() if k.startswith(".kmers")})
+            assert rep["select"] == 0 and rep["rank"] == 0 and rep["access"] == 0 and rep["failures"] == 0, rep
+        res.append((keys, counts, c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
