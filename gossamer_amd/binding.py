@@ -207,6 +207,18 @@ class Context:
                                                        N_end & mask, N_end >> 64))
         return self.files()
 
+    def lint(self, asymmetric=False):
+        """goss_gpu_lint on the finished graph: dict of the problem counts of lint-graph's pass 1."""
+        class LintReport(C.Structure):
+            _fields_ = [("missing_rc", C.c_uint64), ("count_mismatch", C.c_uint64), ("zero_count", C.c_uint64),
+                        ("order_violation", C.c_uint64), ("nexamples", C.c_uint32), ("pad", C.c_uint32),
+                        ("ex_index", C.c_uint64 * 32), ("ex_other", C.c_uint64 * 32), ("ex_kind", C.c_uint32 * 32)]
+        rep = LintReport()
+        self._L.goss_gpu_lint.argtypes = [C.c_void_p, C.c_int, C.POINTER(LintReport)]
+        self._check(self._L.goss_gpu_lint(self._h, 1 if asymmetric else 0, C.byref(rep)))
+        return {"missing_rc": rep.missing_rc, "count_mismatch": rep.count_mismatch, "zero_count": rep.zero_count,
+                "order_violation": rep.order_violation}
+
     def check_index(self, files, base=""):
         """goss_gpu_check_index on a SparseArray given as {suffix: bytes} (files[base + ".header"]
         ...): the context must hold the array's decoded elements (push_run + finish).  Returns a

@@ -65,3 +65,39 @@ def test_c2_full_size_properties():
         ctx.close()
     assert res[0][2] == res[1][2]
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_c4_full_size_properties():
+    """BASELINE config C4 at full size: build-graph k = 55 on 200 M x 150 bp reads (19 G windows,
+    38 G 112-bit keys, several chunks + merge).  The edge set of a graph built from reads is
+    closed under reverse complement with equal multiplicities -- checked for all 2e8 edges by the
+    device-side lint pass -- multiplicities add up to twice the number of windows, edges are
+    strictly increasing, and the emitted edge SparseArray passes its own select / rank check."""
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 250 * (1 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    n, L, G = 200_000_000, 150, 100_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    budget = int((free_b - buf.numel()) * 0.90)
+    with g.Context(55, g.MODE_GRAPH, hbm_budget=budget) as ctx:
+        ctx.synth_reads(buf.data_ptr(), n, L, G, seed=1)
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert c.key_words == 2 and c.keys == 2 * c.windows
+        assert n * 95 * 0.98 < c.windows <= n * 95
+        kp, cp, m = ctx.result_ptrs()
+        assert m == c.distinct and m % 2 == 0          # edges come in reverse-complement pairs (a palindromic 56-mer has probability 4^-28)
+        counts = gd.device_view(cp, m, torch.int32, "cuda")
+        assert int(counts.to(torch.int64).sum().item()) == c.keys
+        rep = ctx.lint()
+        assert rep == {"missing_rc": 0, "count_mismatch": 0, "zero_count": 0, "order_violation": 0}, rep
+        files = ctx.emit()
+        assert struct.unpack("<QQQ", files[".header"]) == (2011101014, 55, 0)
+        sa = struct.unpack("<8Q", files["-edges.header"])
+        assert sa[7] == m and sa[1] == 84 and sa[2] == 88            # D = 84, qD = 88 (SURVEY section 8(a13))
+        irep = ctx.check_index({k[len("-edges"):]: v for k, v in files.items() if k.startswith("-edges")})
+        assert irep["select"] == 0 and irep["rank"] == 0 and irep["access"] == 0 and irep["failures"] == 0, irep
+        hist = files["-counts-hist.txt"].decode().split("\n")
+        assert sum(int(l.split("\t")[1]) for l in hist if l) == m
