@@ -674,14 +674,16 @@ template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
                    const uint64_t* seg_end);
 
-bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, Key1* ka, uint64_t ka_slots,
-                         Key1* kb, uint64_t kb_slots)
+template <class K>
+bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, K* ka, uint64_t ka_slots,
+                         K* kb, uint64_t kb_slots)
 {
+    constexpr bool kOne = std::is_same<K, Key1>::value;          // one-word keys
     const uint32_t keybits = 2 * c->len;
-    if (!c->fused || c->words != 1 || c->path != 0 || !c->lookback || c->ordered_tiles ||
+    if (!c->fused || c->path != 0 || !c->lookback || c->ordered_tiles ||
         c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
         return false;
-    constexpr int kTile = SortCfg<Key1, false>::kTile;
+    constexpr int kTile = SortCfg<K, false>::kTile;
     uint64_t mark = c->arena.mark();
     struct Release { goss_gpu_ctx* c; uint64_t m; ~Release() { c->arena.release(m); } } release{c, mark};
     auto decline = [&](const char* why) {
@@ -701,13 +703,14 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     //    kernel.  The two-level form needs the joint histogram of two digits (65 536 bins), hence
     //    a larger sample: 1/64 of the chunk but at least 160 M window starts; a chunk of up to 640 M
     //    window starts is sampled whole (exact sizes, +4 % extraction work at most).
-    const bool want_msd = c->fused_msd;
+    const bool want_msd = c->fused_msd && kOne;
     uint64_t sample_starts = nstarts <= (16u << 20) ? nstarts : (4u << 20);
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
     const bool graph_mode = c->mode == GOSS_MODE_GRAPH;
-    const uint64_t kPlainSuper = 8ULL * kTB * (graph_mode ? 8 : 16);
+    // window starts per super-tile of the plain kernels: extract1_kernel<0,16,8> / <1,8,8>, extract2_kernel<0,8,8> / <1,4,8>
+    const uint64_t kPlainSuper = 8ULL * kTB * (kOne ? (graph_mode ? 8 : 16) : (graph_mode ? 4 : 8));
     // a slice is ONE super-tile (~217 reads of 150 bp): thousands of slices follow a drifting
     // k-mer distribution (sorted inputs) far better than a few long ones
     const uint64_t nslices = sample_starts >= nstarts ? 1 : std::max<uint64_t>(64, sample_starts / kPlainSuper);
@@ -719,7 +722,20 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     {
         const uintptr_t addr0 = (uintptr_t)d_bases;
         const uint32_t mis0 = (uint32_t)(addr0 & 15u);
-        if (nslices == 1) extract_dispatch<Key1>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
+        if (nslices == 1) extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
+        else if constexpr (!kOne)
+        {
+            const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
+            if (graph_mode)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<1, 4, 8>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, nsuper, slice_tiles,
+                                   slice_stride);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<0, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, nsuper, slice_tiles,
+                                   slice_stride);
+        }
         else
         {
             const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
@@ -755,13 +771,13 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     lap("sample extracted");
     const bool exact = nslices == 1;                                   // the sample is the chunk
     const uint64_t s4 = std::min<uint64_t>(ns, 4u << 20);
-    const uint64_t d_s = count_distinct_sample<Key1>(c, ka, s4);
+    const uint64_t d_s = count_distinct_sample<K>(c, ka, s4);
     const uint64_t m_est = birthday_estimate(s4, d_s);
     lap("distinct keys estimated");
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
-    const uint64_t limit = SegCfg<Key1>::kLimit;
+    const uint64_t limit = SegCfg<K>::kLimit;
     uint32_t segbits = kSegBits;
     while (segbits < (uint32_t)kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;
     if ((m_est >> segbits) > limit || segbits + 8 > keybits) return decline("too many distinct keys per segment");
@@ -778,10 +794,10 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         // order the sample by its top 16 bits (kept out of the per-kernel timing) and read the
         // segment bounds
         c->mute_timing = true;
-        const bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, ns, 2, shift);
+        const bool in_b = radix_sort<K, false>(c, ka, kb, nullptr, nullptr, ns, 2, shift);
         uint64_t* soff = (uint64_t*)c->arena.temp(65537 * 8);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<Key1>), dim3(65536 / 256 + 1), dim3(256), 0, c->stream,
-                           (const Key1*)(in_b ? kb : ka), ns, shift, 65536u, soff);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(65536 / 256 + 1), dim3(256), 0, c->stream,
+                           (const K*)(in_b ? kb : ka), ns, shift, 65536u, soff);
         c->mute_timing = false;
         std::vector<uint64_t> ho(65537);
         HIP_TRY(hipMemcpyAsync(ho.data(), soff, 65537 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -794,7 +810,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         unsigned long long* shist = (unsigned long long*)c->arena.temp(256 * 8);
         HIP_TRY(hipMemsetAsync(shist, 0, 256 * 8, c->stream));
         c->mute_timing = true;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<Key1>), dim3(256), dim3(kTB), 0, c->stream, (const Key1*)ka, ns, shift, 1u, shist);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(global_hist_kernel<K>), dim3(256), dim3(kTB), 0, c->stream, (const K*)ka, ns, shift, 1u, shist);
         c->mute_timing = false;
         HIP_TRY(hipMemcpyAsync(hh.data(), shist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -865,11 +881,17 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
 #define GOSS_FUSED_G 1
 #endif
         const bool graph = c->mode == GOSS_MODE_GRAPH;
-        const uint64_t kSuper = (uint64_t)GOSS_FUSED_G * kTB * (graph ? 8 : 16);
+#ifndef GOSS_FUSED_NKEYS2
+#define GOSS_FUSED_NKEYS2 16
+#endif
+        const uint64_t kSuper = kOne ? (uint64_t)GOSS_FUSED_G * kTB * (graph ? 8 : 16)
+                                     : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, GOSS_FUSED_G == 1 ? 1024 : 512);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);
         const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
+        if constexpr (kOne)
+        {
 #define GOSS_LAUNCH_EP3(MODE, NB, NH)                                                                                 \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NB, GOSS_FUSED_G, NH>), dim3(grid), dim3(kTB), 0, c->stream,     \
                        aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
@@ -880,26 +902,36 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         else if (nh == 1) GOSS_LAUNCH_EP2(NB, 1);                                                                     \
         else GOSS_LAUNCH_EP2(NB, 2);                                                                                  \
     } while (0)
-        if (graph)
-        {
-            // graph mode does not hash: one instantiation serves every key width
-            if (nh == 0) GOSS_LAUNCH_EP3(1, 8, 0);
-            else if (nh == 1) GOSS_LAUNCH_EP3(1, 8, 1);
-            else GOSS_LAUNCH_EP3(1, 8, 2);
-        }
-        else
-            switch ((2 * c->len + 7) / 8)
+            if (graph)
             {
-                case 3: GOSS_LAUNCH_EP(3); break;
-                case 4: GOSS_LAUNCH_EP(4); break;
-                case 5: GOSS_LAUNCH_EP(5); break;
-                case 6: GOSS_LAUNCH_EP(6); break;
-                case 7: GOSS_LAUNCH_EP(7); break;
-                default: GOSS_LAUNCH_EP(8); break;
+                // graph mode does not hash: one instantiation serves every key width
+                if (nh == 0) GOSS_LAUNCH_EP3(1, 8, 0);
+                else if (nh == 1) GOSS_LAUNCH_EP3(1, 8, 1);
+                else GOSS_LAUNCH_EP3(1, 8, 2);
             }
+            else
+                switch ((2 * c->len + 7) / 8)
+                {
+                    case 3: GOSS_LAUNCH_EP(3); break;
+                    case 4: GOSS_LAUNCH_EP(4); break;
+                    case 5: GOSS_LAUNCH_EP(5); break;
+                    case 6: GOSS_LAUNCH_EP(6); break;
+                    case 7: GOSS_LAUNCH_EP(7); break;
+                    default: GOSS_LAUNCH_EP(8); break;
+                }
 #undef GOSS_LAUNCH_EP
 #undef GOSS_LAUNCH_EP2
 #undef GOSS_LAUNCH_EP3
+        }
+        else
+        {
+#define GOSS_LAUNCH_E2P(MODE, NH)                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
+                       navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
+            if (graph) { if (nh == 1) GOSS_LAUNCH_E2P(1, 1); else GOSS_LAUNCH_E2P(1, 2); }
+            else { if (nh == 1) GOSS_LAUNCH_E2P(0, 1); else GOSS_LAUNCH_E2P(0, 2); }
+#undef GOSS_LAUNCH_E2P
+        }
         t.stop();
     }
     std::vector<unsigned long long> hpc(sizeof(PartCounters) / 8);
@@ -928,6 +960,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     Run r{nullptr, nullptr, 0};
     if (msd)
     {
+      if constexpr (kOne)
+      {
         // 4a. second level: keys of region b go to sub-region (b, low digit) by atomic cursors
         SubTable* dsub = (SubTable*)c->arena.temp(sizeof(SubTable));
         unsigned long long* cur2 = (unsigned long long*)c->arena.temp(65536ULL * kSubCursorStride * 8);
@@ -952,6 +986,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         const int rc = segment_reduce<Key1>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
         c->fused_msd_chunks++;
+      }
     }
     else
     {
@@ -963,7 +998,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
             hipLaunchKernelGGL(scan_rows256_kernel, dim3(2), dim3(kTB), 0, c->stream, pc->hist);
             t.stop();
         }
-        Key1* src = ka; Key1* dst = kb;
+        K* src = ka; K* dst = kb;
         for (uint32_t di = 1; di < npass; ++di)
         {
             const uint32_t d = shift + 8 * di;
@@ -973,13 +1008,13 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
             {
                 PhaseTimer t(c, GOSS_T_SCATTER, n);
                 if (gapped)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)nt), dim3(kTB), 0,
-                                       c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                       c->stream, (const K*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
                                        (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
                                        (unsigned long long*)nullptr, (const GapTable*)dgt, (const SubTable*)nullptr);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, false>), dim3((uint32_t)nt), dim3(kTB), 0,
-                                       c->stream, (const Key1*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, false>), dim3((uint32_t)nt), dim3(kTB), 0,
+                                       c->stream, (const K*)src, (const uint32_t*)nullptr, dst, (uint32_t*)nullptr, n, d, shift,
                                        (const unsigned long long*)(pc->hist + (di - 1) * 256), status, ctl,
                                        (unsigned long long*)nullptr, (const GapTable*)nullptr, (const SubTable*)nullptr);
                 t.stop();
@@ -997,7 +1032,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         }
         // src = partitioned keys (dense: npass >= 2), dst = spare
         c->arena.release(mark); release.m = c->arena.mark();
-        const int rc = segment_reduce<Key1>(c, src, dst, n, segbits, &r, nullptr, nullptr);
+        const int rc = segment_reduce<K>(c, src, dst, n, segbits, &r, nullptr, nullptr);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
     }
     lap("segments counted");
@@ -1020,7 +1055,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     // slots in the first buffer when the arena can spare them beyond the two buffers and the
     // partition / segment tables
     uint64_t ka_slots = cap;
-    if (std::is_same<K, Key1>::value && c->fused && nstarts >= c->fused_min)
+    if (c->fused && nstarts >= c->fused_min)
     {
         const uint64_t extra = cap / 8 + 256 * 16;
         const uint64_t need = (2 * cap + extra) * sizeof(K) + cap / 2 + (uint64_t)(1u << kSegBits) * kSegLimit * 12 + (64u << 20);
@@ -1028,10 +1063,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     }
     K* ka = (K*)c->arena.temp(ka_slots * sizeof(K));
     K* kb = (K*)c->arena.temp(cap * sizeof(K));
-    if constexpr (std::is_same<K, Key1>::value)
-    {
-        if (process_chunk_fused(c, d_bases, nstarts, navail, ka, ka_slots, kb, cap)) { c->arena.release(mark); return; }
-    }
+    if (process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, cap)) { c->arena.release(mark); return; }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     uintptr_t addr = (uintptr_t)d_bases;
     uint32_t mis = (uint32_t)(addr & 15u);

@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 template <int MODE, int P, int G>
 __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
-                                                       Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper)
+                                                       Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper,
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
 {
     constexpr int T = kTB * P;
     constexpr int NVEC = G * T / 16 + 6;
@@ -483,7 +484,9 @@ __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict
 
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
     {
-        const uint64_t tile_base = st * (uint64_t)(G * T);
+        // sampling mode (slice_tiles != 0): as in extract1_kernel
+        const uint64_t tile_base = slice_tiles ? (st / slice_tiles) * slice_stride + (st % slice_tiles) * (uint64_t)(G * T)
+                                               : st * (uint64_t)(G * T);
         // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
         for (uint32_t v = tid; v < NVEC; v += kTB)
         {
@@ -852,6 +855,190 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
     if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     // valid windows of this workgroup
+    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
+    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
+}
+
+// The same fusion for two-word keys (32 <= len <= 63): windows out of a 192-bit register buffer
+// (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`.
+// Only the one-level form uses it (two-word keys need more than two partition digits at the
+// sizes where fusing pays).
+template <int MODE, int NH, int NKEYS>
+__global__ __launch_bounds__(kTB) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                            uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                            Key2* __restrict__ out, PartCounters* __restrict__ pc,
+                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper)
+{
+    constexpr int S = MODE == 1 ? 2 : 1;
+    constexpr int P = NKEYS / S;                 // windows per thread; NKEYS keys per thread
+    constexpr int T = kTB * P;
+    constexpr int NVEC = T / 16 + 6;
+    constexpr int NK = P * S;
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key2 sorted[T * S];
+    __shared__ uint32_t dh[256];
+    __shared__ uint64_t gbase[256];
+    __shared__ uint32_t lh[NH ? 256 * NH : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ uint32_t sh_ovf;
+
+    const uint32_t tid = threadIdx.x;
+    if (NH > 0) lh[tid] = 0;
+    if (NH > 1) lh[tid + 256] = 0;
+    dh[tid] = 0;
+    if (tid == 0) sh_ovf = 0;
+    const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t bits = 2 * len;                                       // 64..126
+    const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
+    const uint64_t lmask = (1ULL << len) - 1;
+    unsigned long long nvalid = 0;
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        const uint64_t tile_base = st * (uint64_t)T;
+        for (uint32_t v = tid; v < NVEC; v += kTB)
+        {
+            uint64_t byte0 = tile_base + (uint64_t)v * 16;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            if (byte0 + 16 <= navail + mis)
+            {
+                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            }
+            else if (byte0 < navail + mis)
+            {
+                for (int j = 0; j < 16; ++j)
+                {
+                    uint64_t b = byte0 + j;
+                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+            }
+            uint32_t codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                uint32_t l = w[i] | 0x20202020u;
+                uint32_t x = (l >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                uint32_t b1 = bad >> 7;
+                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                codes |= c8 << (8 * i);
+                bads |= b4 << (4 * i);
+            }
+            pk[v] = codes;
+            iv[v] = bads;
+        }
+        __syncthreads();
+
+        Key2 kreg[NK];
+        uint16_t rk[NK];
+        uint32_t vm = 0;
+        {
+            const uint32_t q0 = tid * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)tid * P;
+            const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
+            const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t t = sh + i;
+                const uint64_t win = t ? ((inv_lo >> t) | (inv_hi << (64 - t))) : inv_lo;
+                bool ok = (win & lmask) == 0 && (p0 + i < nstarts);
+                vm |= ok ? (1u << i) : 0u;
+            }
+            nvalid += __popc(vm);
+            if (vm)
+            {
+                const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
+                const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
+                const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
+                Key2 f{0, 0};
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                {
+                    const uint32_t t2 = 2 * (sh + i);
+                    Key2 e;
+                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
+                    if (i == 0)
+                    {
+                        const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
+                        const uint32_t sft = 128 - bits;
+                        if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                        else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                    }
+                    else
+                    {
+                        const uint32_t pos = 2 * (sh + i + len - 1);
+                        const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
+                        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+                        f.lo = (f.lo << 2) | nb;
+                    }
+                    if ((vm >> i) & 1u)
+                    {
+                        const Key2 rck{~e.lo, (~e.hi) & mask_hi};
+                        if (MODE == 0)
+                        {
+                            const Key2 k = canonical(f, rck);
+                            kreg[i] = k;
+                            rk[i] = (uint16_t)atomicAdd(&dh[key_digit(k, shift)], 1u);
+                        }
+                        else
+                        {
+                            kreg[2 * i] = f;
+                            rk[2 * i] = (uint16_t)atomicAdd(&dh[key_digit(f, shift)], 1u);
+                            kreg[2 * i + 1] = rck;
+                            rk[2 * i + 1] = (uint16_t)atomicAdd(&dh[key_digit(rck, shift)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        uint32_t total;
+        {
+            const uint32_t cnt = dh[tid];
+            const uint32_t start = block_excl_scan<uint32_t>(cnt, sh_scan, &total);
+            dh[tid] = start;
+            unsigned long long at = cnt ? atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)cnt) : 0ULL;
+            gbase[tid] = my_start + at - start;
+            if (cnt && at + cnt > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            if ((vm >> i) & 1u)
+            {
+#pragma unroll
+                for (int q = 0; q < S; ++q)
+                {
+                    const Key2 k = kreg[i * S + q];
+                    sorted[dh[key_digit(k, shift)] + rk[i * S + q]] = k;
+                }
+            }
+        __syncthreads();
+        dh[tid] = 0;
+        if (!sh_ovf)
+        {
+            for (uint32_t i = tid; i < total; i += kTB)
+            {
+                const Key2 k = sorted[i];
+                out[gbase[key_digit(k, shift)] + i] = k;
+                if (NH > 0) atomicAdd(&lh[key_digit(k, shift + 8)], 1u);
+                if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
+    if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
     if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
 }
