@@ -703,7 +703,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     //    kernel.  The two-level form needs the joint histogram of two digits (65 536 bins), hence
     //    a larger sample: 1/64 of the chunk but at least 160 M window starts; a chunk of up to 640 M
     //    window starts is sampled whole (exact sizes, +4 % extraction work at most).
-    const bool want_msd = c->fused_msd && kOne;
+    const bool want_msd = c->fused_msd;
     uint64_t sample_starts = nstarts <= (16u << 20) ? nstarts : (4u << 20);
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
@@ -928,8 +928,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
 #define GOSS_LAUNCH_E2P(MODE, NH)                                                                                     \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
                        navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
-            if (graph) { if (nh == 1) GOSS_LAUNCH_E2P(1, 1); else GOSS_LAUNCH_E2P(1, 2); }
-            else { if (nh == 1) GOSS_LAUNCH_E2P(0, 1); else GOSS_LAUNCH_E2P(0, 2); }
+            if (graph) { if (nh == 0) GOSS_LAUNCH_E2P(1, 0); else if (nh == 1) GOSS_LAUNCH_E2P(1, 1); else GOSS_LAUNCH_E2P(1, 2); }
+            else { if (nh == 0) GOSS_LAUNCH_E2P(0, 0); else if (nh == 1) GOSS_LAUNCH_E2P(0, 1); else GOSS_LAUNCH_E2P(0, 2); }
 #undef GOSS_LAUNCH_E2P
         }
         t.stop();
@@ -960,8 +960,6 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     Run r{nullptr, nullptr, 0};
     if (msd)
     {
-      if constexpr (kOne)
-      {
         // 4a. second level: keys of region b go to sub-region (b, low digit) by atomic cursors
         SubTable* dsub = (SubTable*)c->arena.temp(sizeof(SubTable));
         unsigned long long* cur2 = (unsigned long long*)c->arena.temp(65536ULL * kSubCursorStride * 8);
@@ -971,8 +969,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         HIP_TRY(hipMemsetAsync(cur2, 0, 65536ULL * kSubCursorStride * 8, c->stream));
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<Key1, false, false, true>), dim3((uint32_t)tiles), dim3(kTB), 0,
-                               c->stream, (const Key1*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)tiles), dim3(kTB), 0,
+                               c->stream, (const K*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, ctl, cur2,
                                (const GapTable*)dgt, (const SubTable*)dsub);
             t.stop();
@@ -983,10 +981,9 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
         lap("second level");
-        const int rc = segment_reduce<Key1>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
+        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
         c->fused_msd_chunks++;
-      }
     }
     else
     {

@@ -206,8 +206,8 @@ def test_extreme_skew_one_kmer_five_billion_times():
 
 @pytest.mark.parametrize("k,mode,form", [(13, "kmer", "msd"), (16, "kmer", "lsd"), (25, "kmer", "msd"), (31, "kmer", "lsd"),
                                          (12, "graph", "msd"), (24, "graph", "lsd"), (30, "graph", "msd"),
-                                         (32, "kmer", "two-word"), (45, "kmer", "two-word"), (63, "kmer", "two-word"),
-                                         (31, "graph", "two-word"), (55, "graph", "two-word"), (62, "graph", "two-word")])
+                                         (32, "kmer", "msd"), (45, "kmer", "lsd"), (63, "kmer", "msd"),
+                                         (31, "graph", "lsd"), (55, "graph", "msd"), (62, "graph", "lsd")])
 def test_fused_kernels_on_ragged_reads(oracle, k, mode, form):
     """The fused kernels on reads that are nothing like the synthetic set: lengths 20..180 (some
     shorter than k), 2 % non-ACGT bytes of several kinds, lower case, heavy duplication.
