@@ -97,6 +97,8 @@ struct goss_gpu_ctx {
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
+    bool seg_merge = true;              // GOSS_GPU_NO_SEG_MERGE=1: merge runs by sorting their concatenation
+    uint32_t seg_merges = 0;            // merges done by segments
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
@@ -1105,9 +1107,75 @@ void merge_runs(goss_gpu_ctx* c)
         off += r.m;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> run_off;
+    {
+        uint64_t o = 0;
+        for (auto& r : c->runs) { run_off.push_back(o); o += r.m; }
+        run_off.push_back(o);
+    }
+    const uint32_t nruns = (uint32_t)c->runs.size();
     // the old runs' permanent storage is dead now: rewind the permanent end to the first run
     c->arena.lo = (uint64_t)((uint8_t*)c->runs.front().keys - c->arena.base);
     c->runs.clear();
+
+    // Merge by segments (seg_merge_kernel): every entry read once, written once.  Needs every
+    // segment's entries of all runs to fit kMergeCap; else the concatenation is sorted again.
+    if (c->seg_merge && nruns <= (uint32_t)kMergeRuns && total >= 1024)
+    {
+        const uint32_t keybits = 2 * c->len;
+        uint32_t segbits = 8;
+        while (segbits < 26 && segbits + 1 <= keybits && (total >> segbits) > (uint64_t)kMergeCap / 2) ++segbits;
+        for (int attempt = 0; attempt < 3 && segbits <= 26 && segbits <= keybits; ++attempt, segbits += 2)
+        {
+            const uint32_t nseg = 1u << segbits, shift = keybits - segbits;
+            uint64_t m2 = c->arena.mark();
+            const uint64_t need = (uint64_t)nruns * (nseg + 1) * 8 + (uint64_t)nseg * 32 + (1u << 20);
+            if (c->arena.avail() < need) break;
+            uint64_t* bounds = (uint64_t*)c->arena.temp((uint64_t)nruns * (nseg + 1) * 8);
+            uint64_t* d_off = (uint64_t*)c->arena.temp((nruns + 1) * 8);
+            unsigned long long* d_max = (unsigned long long*)c->arena.temp(16);
+            HIP_TRY(hipMemcpyAsync(d_off, run_off.data(), (nruns + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemsetAsync(d_max, 0, 16, c->stream));
+            PhaseTimer t(c, GOSS_T_REDUCE, total);
+            for (uint32_t r = 0; r < nruns; ++r)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
+                                   (const K*)(ka + run_off[r]), run_off[r + 1] - run_off[r], shift, nseg,
+                                   bounds + (uint64_t)r * (nseg + 1));
+            hipLaunchKernelGGL(seg_totals_kernel, dim3(nseg / 256 + 1), dim3(256), 0, c->stream, (const uint64_t*)bounds, nruns, nseg, d_max);
+            unsigned long long* hmax = (unsigned long long*)c->h_pinned;
+            HIP_TRY(hipMemcpyAsync(hmax, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (hmax[0] > (unsigned long long)kMergeCap) { t.stop(); c->arena.release(m2); continue; }
+            uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
+            uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+            uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+            SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
+            SegOut hso{};
+            hso.stage_cap = total;
+            HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_merge_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream, (const K*)ka, (const uint32_t*)va,
+                               (const uint64_t*)d_off, (const uint64_t*)bounds, nruns, nseg, so, seg_pos, seg_cnt, kb, vb, c->d_flags);
+            SegOut* h = (SegOut*)c->h_pinned;
+            HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (h->overflow) { t.stop(); c->arena.release(m2); break; }
+            const uint64_t m = h->cursor;
+            HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nseg * 8, hipMemcpyDeviceToDevice, c->stream));
+            exclusive_scan_u64(c, seg_dst, nseg);
+            Run r{nullptr, nullptr, m};
+            r.keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
+            r.counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream,
+                               (const K*)kb, (const uint32_t*)vb, (const uint64_t*)seg_pos,
+                               (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)r.keys, r.counts);
+            t.stop();
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->runs.push_back(r);
+            c->seg_merges++;
+            c->arena.release(mark);
+            return;
+        }
+    }
     bool in_b = radix_sort<K, true>(c, ka, kb, va, vb, total, key_digits(c));
     PhaseTimer t(c, GOSS_T_REDUCE, total);
     Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb);
@@ -1576,6 +1644,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }
@@ -2021,6 +2090,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
+    else if (n == "seg_merges") *value = c->seg_merges;
     else if (n == "segment_retries") *value = c->segment_retries;
     else if (n == "lookback_failures") *value = c->lookback_failures;
     else if (n == "runs") *value = c->runs.size();

@@ -2263,6 +2263,141 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Merge of sorted (key,count) runs by segments
+// --------------------------------------------------------------------------------------
+//
+// The runs of the chunks (or of the ranks of a multi-GPU exchange, or of the inputs of merge-*)
+// are each sorted and distinct.  Instead of sorting their concatenation again (7 to 14 radix
+// passes), the key space is cut into segments small enough for LDS: the bounds of every segment
+// inside every run come from binary searches (seg_bounds_kernel), and one workgroup per segment
+// loads its at most kMergeCap entries from all runs, orders them with a bitonic network, adds up
+// the counts of equal keys and appends the result to a staging area -- every entry is read once
+// and written once.
+constexpr int kMergeCap = 2048;
+constexpr int kMergeRuns = 64;
+
+// total[s] = sum over runs of the segment's length; *maxv = largest total.
+__global__ void seg_totals_kernel(const uint64_t* __restrict__ bounds, uint32_t nruns, uint32_t nseg,
+                                  unsigned long long* __restrict__ maxv)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    uint64_t t = 0;
+    for (uint32_t r = 0; r < nruns; ++r)
+    {
+        const uint64_t* b = bounds + (uint64_t)r * (nseg + 1);
+        t += b[s + 1] - b[s];
+    }
+    atomicMax(maxv, (unsigned long long)t);
+}
+
+template <class K> __device__ inline K key_max();
+template <> __device__ inline Key1 key_max<Key1>() { return Key1{~0ULL}; }
+template <> __device__ inline Key2 key_max<Key2>() { return Key2{~0ULL, ~0ULL}; }
+
+template <class K>
+__global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                        const uint64_t* __restrict__ run_off, const uint64_t* __restrict__ bounds,
+                                                        uint32_t nruns, uint32_t nseg, SegOut* __restrict__ so,
+                                                        uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                        K* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                        uint32_t* __restrict__ count_overflow)
+{
+    __shared__ K lk[kMergeCap];
+    __shared__ uint32_t lc[kMergeCap];
+    __shared__ uint64_t rsrc[kMergeRuns];        // first source index of the segment in run r
+    __shared__ uint32_t rpre[kMergeRuns + 1];    // entries of runs < r
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0)
+    {
+        uint32_t n0 = 0;
+        for (uint32_t r = 0; r < nruns; ++r)
+        {
+            const uint64_t* b = bounds + (uint64_t)r * (nseg + 1);
+            rsrc[r] = run_off[r] + b[s];
+            rpre[r] = n0;
+            n0 += (uint32_t)(b[s + 1] - b[s]);       // the host checked total <= kMergeCap
+        }
+        rpre[nruns] = n0;
+    }
+    __syncthreads();
+    const uint32_t n = rpre[nruns];
+    if (n == 0)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    uint32_t nsort = 64;
+    while (nsort < n) nsort <<= 1;
+    for (uint32_t i = tid; i < nsort; i += kTB)
+    {
+        if (i < n)
+        {
+            uint32_t r = 0;
+            while (i >= rpre[r + 1]) ++r;
+            const uint64_t src = rsrc[r] + (i - rpre[r]);
+            lk[i] = keys[src];
+            lc[i] = vals[src];
+        }
+        else { lk[i] = key_max<K>(); lc[i] = 0; }
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+    {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+        {
+            for (uint32_t t = tid; t < nsort / 2; t += kTB)
+            {
+                const uint32_t i = 2 * t - (t & (j - 1));
+                const uint32_t p = i + j;
+                const bool up = (i & k2) == 0;
+                const K a = lk[i], b = lk[p];
+                if ((b < a) == up)
+                {
+                    lk[i] = b; lk[p] = a;
+                    const uint32_t ca = lc[i]; lc[i] = lc[p]; lc[p] = ca;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // distinct keys of the segment, then their places in the staging area
+    uint32_t heads = 0;
+    for (uint32_t i = tid; i < n; i += kTB) heads += (i == 0 || lk[i] != lk[i - 1]) ? 1u : 0u;
+    uint32_t d;
+    block_excl_scan<uint32_t>(heads, sh_scan, &d);
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
+    uint32_t done = 0;                               // heads in the chunks before this one
+    for (uint32_t c0 = 0; c0 < n; c0 += kTB)
+    {
+        const uint32_t i = c0 + tid;
+        const bool head = i < n && (i == 0 || lk[i] != lk[i - 1]);
+        uint32_t tot;
+        const uint32_t before = block_excl_scan<uint32_t>(head ? 1u : 0u, sh_scan, &tot);
+        if (head)
+        {
+            uint64_t sum = 0;
+            for (uint32_t j = i; j < n && lk[j] == lk[i]; ++j) sum += lc[j];
+            if (sum > 0xFFFFFFFFULL) { atomicOr(count_overflow, 1u); sum = 0xFFFFFFFFULL; }
+            stage_keys[ob + done + before] = lk[i];
+            stage_counts[ob + done + before] = (uint32_t)sum;
+        }
+        done += tot;
+    }
+}
+
 // Restore segment order: out[seg_dst[s] + i] = stage[seg_pos[s] + i].
 template <class K>
 __global__ __launch_bounds__(kTB) void seg_gather_kernel(const K* __restrict__ stage_keys, const uint32_t* __restrict__ stage_counts,
