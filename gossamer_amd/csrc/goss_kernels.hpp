@@ -2330,40 +2330,49 @@ __global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ ke
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    uint32_t nsort = 64;
-    while (nsort < n) nsort <<= 1;
-    for (uint32_t i = tid; i < nsort; i += kTB)
+    // load: entry i of the segment's concatenation comes from run r(i)
+    for (uint32_t i = tid; i < n; i += kTB)
     {
+        uint32_t r = 0;
+        while (i >= rpre[r + 1]) ++r;
+        const uint64_t src = rsrc[r] + (i - rpre[r]);
+        lk[i] = keys[src];
+        lc[i] = vals[src];
+    }
+    __syncthreads();
+    // merge by ranks: every sub-run is sorted, so the final place of an entry is its index in
+    // its own run plus, for every other run, the number of that run's entries that go before it
+    // (ties go to the lower run) -- binary searches in LDS, no barriers in between
+    constexpr int kPerT = kMergeCap / kTB;
+    K mk[kPerT];
+    uint32_t mc[kPerT], mp[kPerT];
+#pragma unroll
+    for (int j = 0; j < kPerT; ++j)
+    {
+        const uint32_t i = tid + j * kTB;
         if (i < n)
         {
             uint32_t r = 0;
             while (i >= rpre[r + 1]) ++r;
-            const uint64_t src = rsrc[r] + (i - rpre[r]);
-            lk[i] = keys[src];
-            lc[i] = vals[src];
+            const K k = lk[i];
+            uint32_t pos = i - rpre[r];
+            for (uint32_t q = 0; q < nruns; ++q)
+            {
+                if (q == r) continue;
+                uint32_t lo = rpre[q], hi = rpre[q + 1];
+                const uint32_t base = lo;
+                if (q < r) { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (lk[m] < k || lk[m] == k) lo = m + 1; else hi = m; } }
+                else       { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (lk[m] < k) lo = m + 1; else hi = m; } }
+                pos += lo - base;
+            }
+            mk[j] = k; mc[j] = lc[i]; mp[j] = pos;
         }
-        else { lk[i] = key_max<K>(); lc[i] = 0; }
     }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
-    {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
-        {
-            for (uint32_t t = tid; t < nsort / 2; t += kTB)
-            {
-                const uint32_t i = 2 * t - (t & (j - 1));
-                const uint32_t p = i + j;
-                const bool up = (i & k2) == 0;
-                const K a = lk[i], b = lk[p];
-                if ((b < a) == up)
-                {
-                    lk[i] = b; lk[p] = a;
-                    const uint32_t ca = lc[i]; lc[i] = lc[p]; lc[p] = ca;
-                }
-            }
-            __syncthreads();
-        }
-    }
+#pragma unroll
+    for (int j = 0; j < kPerT; ++j)
+        if (tid + j * kTB < n) { lk[mp[j]] = mk[j]; lc[mp[j]] = mc[j]; }
+    __syncthreads();
     // distinct keys of the segment, then their places in the staging area
     uint32_t heads = 0;
     for (uint32_t i = tid; i < n; i += kTB) heads += (i == 0 || lk[i] != lk[i - 1]) ? 1u : 0u;
