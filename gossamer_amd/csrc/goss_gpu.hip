@@ -431,14 +431,28 @@ void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
     if (c->mode == GOSS_MODE_KMER_SET) launch_extract1<0, 16, 8>(c, aligned, mis, nstarts, navail, out);
     else launch_extract1<1, 8, 8>(c, aligned, mis, nstarts, navail, out);
 }
+// significant bytes of a two-word key's high word, rounded up to the instantiated classes 2/4/6/8
+inline int key2_nbh(const goss_gpu_ctx* c) { const int nb = (int)(2 * c->len + 7) / 8 - 8; return nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 6 ? 6 : 8; }
+
 template <int MODE, int P, int G>
-void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
+void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out,
+                     uint64_t slice_tiles = 0, uint64_t slice_stride = 0, uint64_t nsuper_override = 0)
 {
     constexpr int T = kTB * P * G;
-    const uint64_t nsuper = (nstarts + T - 1) / T;
+    const uint64_t nsuper = nsuper_override ? nsuper_override : (nstarts + T - 1) / T;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper ? nsuper : 1, 1024 * 2);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, navail,
-                       c->len, out, c->d_ctr, nsuper);
+#define GOSS_LAUNCH_E2(NBH)                                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G, NBH>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
+                       navail, c->len, out, c->d_ctr, nsuper, slice_tiles, slice_stride)
+    if (MODE == 1) { GOSS_LAUNCH_E2(8); return; }             // graph mode does not hash
+    switch (key2_nbh(c))
+    {
+        case 2: GOSS_LAUNCH_E2(2); break;
+        case 4: GOSS_LAUNCH_E2(4); break;
+        case 6: GOSS_LAUNCH_E2(6); break;
+        default: GOSS_LAUNCH_E2(8); break;
+    }
+#undef GOSS_LAUNCH_E2
 }
 template <>
 void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
@@ -729,14 +743,9 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         {
             const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
-            if (graph_mode)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<1, 4, 8>), dim3(grid), dim3(kTB), 0, c->stream,
-                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, nsuper, slice_tiles,
-                                   slice_stride);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<0, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
-                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, nsuper, slice_tiles,
-                                   slice_stride);
+            (void)grid;
+            if (graph_mode) launch_extract2<1, 4, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
+            else launch_extract2<0, 8, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
         }
         else
         {
@@ -927,11 +936,21 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         }
         else
         {
-#define GOSS_LAUNCH_E2P(MODE, NH)                                                                                     \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
-                       navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
-            if (graph) { if (nh == 0) GOSS_LAUNCH_E2P(1, 0); else if (nh == 1) GOSS_LAUNCH_E2P(1, 1); else GOSS_LAUNCH_E2P(1, 2); }
-            else { if (nh == 0) GOSS_LAUNCH_E2P(0, 0); else if (nh == 1) GOSS_LAUNCH_E2P(0, 1); else GOSS_LAUNCH_E2P(0, 2); }
+#define GOSS_LAUNCH_E2P(MODE, NH, NBH)                                                                                \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
+                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
+#define GOSS_LAUNCH_E2N(MODE, NBH)                                                                                    \
+    do { if (nh == 0) GOSS_LAUNCH_E2P(MODE, 0, NBH); else if (nh == 1) GOSS_LAUNCH_E2P(MODE, 1, NBH); else GOSS_LAUNCH_E2P(MODE, 2, NBH); } while (0)
+            if (graph) GOSS_LAUNCH_E2N(1, 8);
+            else
+                switch (key2_nbh(c))
+                {
+                    case 2: GOSS_LAUNCH_E2N(0, 2); break;
+                    case 4: GOSS_LAUNCH_E2N(0, 4); break;
+                    case 6: GOSS_LAUNCH_E2N(0, 6); break;
+                    default: GOSS_LAUNCH_E2N(0, 8); break;
+                }
+#undef GOSS_LAUNCH_E2N
 #undef GOSS_LAUNCH_E2P
         }
         t.stop();

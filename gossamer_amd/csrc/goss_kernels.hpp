@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 // K2, two-word keys (32 <= len <= 63): the same windows-out-of-registers scheme with a 192-bit
 // buffer of 2-bit codes per thread (96 bases >= 15 + P - 1 + 63)
 // --------------------------------------------------------------------------------------
-template <int MODE, int P, int G>
+template <int MODE, int P, int G, int NBH = 8>
 __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper,
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict
                     if ((vm >> i) & 1u)
                     {
                         const Key2 rk{~e.lo, (~e.hi) & mask_hi};
-                        if (MODE == 0) stage[s++] = canonical(f, rk);
+                        if (MODE == 0) stage[s++] = canonical_tail<NBH>(f, rk);
                         else { stage[s++] = f; stage[s++] = rk; }
                     }
                 }
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
 // (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`.
 // Only the one-level form uses it (two-word keys need more than two partition digits at the
 // sizes where fusing pays).
-template <int MODE, int NH, int NKEYS>
+template <int MODE, int NH, int NKEYS, int NBH = 8>
 __global__ __launch_bounds__(kTB) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key2* __restrict__ out, PartCounters* __restrict__ pc,
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(kTB) void extract2_part_kernel(const uint8_t* __res
                         const Key2 rck{~e.lo, (~e.hi) & mask_hi};
                         if (MODE == 0)
                         {
-                            const Key2 k = canonical(f, rck);
+                            const Key2 k = canonical_tail<NBH>(f, rck);
                             kreg[i] = k;
                             rk[i] = (uint16_t)atomicAdd(&dh[key_digit(k, shift)], 1u);
                         }

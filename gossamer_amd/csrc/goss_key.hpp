@@ -156,6 +156,29 @@ GK_HD Key1 canonical_short(const Key1& x, const Key1& rc)
     return x;
 }
 
+// Two-word keys whose high word has at most NBH significant bytes (NBH = 2, 4, 6 or 8): the
+// zero bytes above them fold into one multiplication by prime^(8 - NBH).
+template <int NBH>
+GK_HD uint64_t key_hash_tail(const Key2& k)
+{
+    uint64_t h = fnv_word(k.lo, kFnvSeed);
+#pragma unroll
+    for (int i = 0; i < NBH; ++i)
+    {
+        h ^= (k.hi >> (8 * i)) & 0xFFULL;
+        h = fnv_mul(h);
+    }
+    return NBH < 8 ? h * fnv_pow(8 - NBH) : h;
+}
+template <int NBH>
+GK_HD Key2 canonical_tail(const Key2& x, const Key2& rc)
+{
+    uint64_t h0 = key_hash_tail<NBH>(x), h1 = key_hash_tail<NBH>(rc);
+    if (h0 > h1) return rc;
+    if (h0 == h1 && rc < x) return rc;
+    return x;
+}
+
 // canonical(x) given rc = revcomp(x)
 template <class K>
 GK_HD K canonical(const K& x, const K& rc)
