@@ -22,6 +22,7 @@ SYMBOLS = [
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
+    "goss_gpu_set_budget_limit",
 ]
 
 
@@ -156,6 +157,11 @@ class Context:
 
     def reset(self):
         self._check(self._L.goss_gpu_reset(self._h))
+
+    def set_budget_limit(self, max_bytes):
+        """Let the arena grow up to max_bytes when a chunk or a merge needs it (goss_gpu_set_budget_limit)."""
+        self._L.goss_gpu_set_budget_limit.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_set_budget_limit(self._h, max_bytes))
 
     def stat(self, name):
         """A diagnostic counter of the context (goss_gpu_stat)."""

@@ -96,6 +96,8 @@ struct goss_gpu_ctx {
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
+    uint64_t budget_limit = 0;          // the arena may grow up to this many bytes (goss_gpu_set_budget_limit; 0 = fixed)
+    uint32_t arena_grows = 0;
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
     bool seg_merge = true;              // GOSS_GPU_NO_SEG_MERGE=1: merge runs by sorting their concatenation
     uint32_t seg_merges = 0;            // merges done by segments
@@ -195,6 +197,47 @@ void ensure_arena(goss_gpu_ctx* c)
     c->arena.lo = 0;
     c->arena.hi = budget;
     c->budget = budget;
+}
+
+// Grow the arena so that at least `want_avail` bytes are free (or double it when want_avail is 0),
+// up to budget_limit (0 = the budget is fixed): a new mapping, the permanent part and a live
+// staging buffer copied over, every pointer into the arena rebased.  Only legal where the staging
+// buffer is the only live temporary (start of a chunk, start of a merge).  False = not possible.
+bool grow_arena(goss_gpu_ctx* c, uint64_t want_avail)
+{
+    Arena& a = c->arena;
+    if (!a.base || c->budget_limit <= a.size) return false;
+    const uint64_t top = a.size - a.hi;                    // live temporaries at the top
+    if (top != 0 && !(c->stage && (uint64_t)(c->stage - a.base) == a.hi)) return false;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t target = std::max<uint64_t>(a.size * 2, a.lo + top + want_avail + (1ULL << 30));
+    target = std::min<uint64_t>(target, c->budget_limit);
+    target = std::min<uint64_t>(target, (uint64_t)((double)free_b * 0.95));        // the old mapping is still there
+    if (target < a.size + (1ULL << 30) || (want_avail && target < a.lo + top + want_avail)) return false;
+    void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipMalloc(&p, target) != hipSuccess) { (void)hipGetLastError(); return false; }
+    c->arena_ms += (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    uint8_t* nb = (uint8_t*)p;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (a.lo) HIP_TRY(hipMemcpyAsync(nb, a.base, a.lo, hipMemcpyDeviceToDevice, c->stream));
+    if (top) HIP_TRY(hipMemcpyAsync(nb + target - top, a.base + a.hi, top, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    auto rebase = [&](auto*& ptr) {
+        if (!ptr) return;
+        uint8_t* q = (uint8_t*)ptr;
+        if (q >= a.base && q < a.base + a.size) ptr = (std::remove_reference_t<decltype(ptr)>)(nb + (q - a.base));
+    };
+    for (auto& r : c->runs) { rebase(r.keys); rebase(r.counts); }
+    rebase(c->res_keys); rebase(c->res_counts);
+    if (c->stage) c->stage = nb + target - top + (c->stage - (a.base + a.hi));
+    (void)hipFree(a.base);
+    a.base = nb; a.hi = target - top; a.size = target;
+    c->budget = target;
+    c->arena_grows++;
+    if (c->debug) std::fprintf(stderr, "libgossgpu: arena grown to %llu GB\n", (unsigned long long)(target >> 30));
+    return true;
 }
 
 // ---- device-wide exclusive scan (in place) -------------------------------------------
@@ -1113,6 +1156,11 @@ void merge_runs(goss_gpu_ctx* c)
     if (c->runs.size() <= 1) return;
     uint64_t total = 0;
     for (auto& r : c->runs) total += r.m;
+    {
+        // two copies of all entries + segment tables; low-duplication inputs do not shrink
+        const uint64_t need = 2 * total * (sizeof(K) + 4) + (512ULL << 20);
+        if (c->arena.avail() < need) grow_arena(c, need);
+    }
     uint64_t mark = c->arena.mark();
     K* ka = (K*)c->arena.temp(total * sizeof(K));
     K* kb = (K*)c->arena.temp(total * sizeof(K));
@@ -1239,6 +1287,12 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
     const uint64_t nstarts_total = nbytes - c->len + 1;
     uint64_t done = 0;
     uint64_t limit = 0;                 // chunk size cap after an out-of-memory retry
+    // the bases may live in the context's own staging buffer, which moves when the arena grows
+    const uint8_t* stage0 = c->stage;
+    auto follow_stage = [&]() {
+        if (stage0 && c->stage != stage0 && d >= stage0 && d < stage0 + c->stage_cap + 16) d = c->stage + (d - stage0);
+        stage0 = c->stage;
+    };
     while (done < nstarts_total)
     {
         const bool optimistic = use_segment_path<K>(c);
@@ -1247,7 +1301,8 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         if (capn < 4096)
         {
             // try to make room by merging what we have
-            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c, false); }
+            if (c->runs.size() > 1) { merge_runs<K>(c); follow_stage(); capn = chunk_capacity(c, false); }
+            if (capn < 4096 && grow_arena(c, 0)) { follow_stage(); capn = chunk_capacity(c, false); }
             if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
         }
         if (limit && capn > limit) capn = limit;
@@ -1262,10 +1317,11 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         catch (const StatusError& e)
         {
             if (e.status != GOSS_ERR_OOM || ns <= 8192) throw;
-            // undo the partial chunk and retry it in halves
+            // undo the partial chunk; retry it in a larger arena if the budget may grow, else in halves
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->arena.lo = lo0; c->arena.hi = hi0;
             c->runs.resize(runs0);
+            if (grow_arena(c, 0)) { follow_stage(); continue; }
             limit = (ns / 2) & ~4095ULL;
             continue;
         }
@@ -1273,7 +1329,13 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         // keep the accumulated runs from eating the budget
         uint64_t run_bytes = 0;
         for (auto& r : c->runs) run_bytes += r.m * (c->words * 8 + 4);
-        if (c->runs.size() > 1 && run_bytes > c->arena.size / 4) merge_runs<K>(c);
+        if (c->runs.size() > 1 && run_bytes > c->arena.size / 4)
+        {
+            // merging needs two more copies of the runs: possible now, or after growing; else the
+            // runs wait for finish (which can grow the arena once the staging buffer is gone)
+            if (c->arena.avail() >= 2 * run_bytes + (512ULL << 20) || grow_arena(c, 2 * run_bytes + (512ULL << 20))) merge_runs<K>(c);
+            follow_stage();
+        }
     }
 }
 
@@ -1815,6 +1877,11 @@ int goss_gpu_emit(goss_gpu_ctx* c)
     if (!c->finished || c->emitted) { c->last_error = "emit needs exactly one finish before it"; return GOSS_ERR_STATE; }
     int rc = guarded(c, [&]() {
         c->files.clear();
+        {
+            // file images: low bits (up to 16 B), bitmap, DenseSelect blocks, counts per element
+            const uint64_t need = c->M * 40 + (256ULL << 20);
+            if (c->arena.avail() < need) grow_arena(c, need);
+        }
         if (c->words == 1) emit_object<Key1>(c); else emit_object<Key2>(c);
         HIP_TRY(hipStreamSynchronize(c->stream));
     });
@@ -1929,6 +1996,7 @@ int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t
     return guarded(c, [&]() {
         ensure_arena(c);
         const uint64_t ksz = c->words * 8;
+        if (c->arena.avail() < m * (ksz + 4) + (64u << 20)) grow_arena(c, m * (ksz + 4) + (64u << 20));
         Run r{nullptr, nullptr, m};
         r.keys = c->arena.perm(m * ksz);
         r.counts = (uint32_t*)c->arena.perm(m * 4);
@@ -1952,6 +2020,7 @@ int goss_gpu_push_run_host(goss_gpu_ctx* c, const uint64_t* keys, const uint32_t
         ensure_arena(c);
         flush_staging(c);
         const uint64_t ksz = c->words * 8;
+        if (c->arena.avail() < m * (ksz + 4) + (64u << 20)) grow_arena(c, m * (ksz + 4) + (64u << 20));
         Run r{nullptr, nullptr, m};
         r.keys = c->arena.perm(m * ksz);
         r.counts = (uint32_t*)c->arena.perm(m * 4);
@@ -1971,6 +2040,11 @@ int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
         ensure_arena(c);
         flush_staging(c);
         const uint64_t m = s->count, ksz = c->words * 8;
+        {
+            uint64_t need = m * (ksz + 4) + s->high_words * 16 + (64u << 20);
+            for (uint32_t i = 0; i < s->ncols; ++i) need += m * s->col_bytes[i] + 256;
+            if (c->arena.avail() < need) grow_arena(c, need);
+        }
         Run r{nullptr, nullptr, m};
         r.keys = c->arena.perm(m * ksz);
         r.counts = (uint32_t*)c->arena.perm(m * 4);
@@ -2102,6 +2176,13 @@ int goss_gpu_check_index(goss_gpu_ctx* c, const goss_gpu_sparse_files* f, goss_g
     });
 }
 
+int goss_gpu_set_budget_limit(goss_gpu_ctx* c, uint64_t max_bytes)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    c->budget_limit = max_bytes;
+    return GOSS_OK;
+}
+
 int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
 {
     if (!c || !name || !value) return GOSS_ERR_INVALID_ARG;
@@ -2114,6 +2195,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "lookback_failures") *value = c->lookback_failures;
     else if (n == "runs") *value = c->runs.size();
     else if (n == "arena_ms") *value = c->arena_ms;
+    else if (n == "arena_grows") *value = c->arena_grows;
     else if (n == "arena_bytes") *value = c->arena.size;
     else return GOSS_ERR_INVALID_ARG;
     return GOSS_OK;

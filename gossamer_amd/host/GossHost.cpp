@@ -561,6 +561,9 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     }
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
+    // a budget the user did not ask for is a starting size: inputs with little duplication (a
+    // genome in FASTA: every k-mer once) need room for runs that do not shrink
+    if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
 
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));

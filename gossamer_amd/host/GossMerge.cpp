@@ -272,6 +272,7 @@ void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, graph ? GOSS_MODE_GRAPH : GOSS_MODE_KMER_SET, budget, nullptr),
             "creating the GPU context");
+    if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     const size_t words = (2 * (K + (graph ? 1 : 0)) <= 62) ? 1 : 2;
 
     std::deque<Item> todo;
@@ -395,6 +396,7 @@ void GossCmdIntersectKmerSets::operator()(const GossCmdContext& pCxt)
     if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    if (pCxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     log(info, "counting k-mers");
     uint32_t sets = 0;
     for (size_t i = 0; i < mIns.size(); ++i)
@@ -431,6 +433,7 @@ void GossCmdSubtractKmerSet::operator()(const GossCmdContext& pCxt)
     if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    if (pCxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     log(info, "calculating difference");
     pushObject(g, mIns[0], false, 1);
     pushObject(g, mIns[1], false, 2);
@@ -461,6 +464,7 @@ void GossCmdMergeAndAnnotateKmerSets::operator()(const GossCmdContext& pCxt)
     if (K > 63 || K == 0) throw Error::General("unable to build a graph with k=" + num(K));
     GpuCtx g;
     g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)K, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    if (pCxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     log(info, "counting kmers.");
     pushObject(g, mLhs, false, 1);
     pushObject(g, mRhs, false, 2);
@@ -496,6 +500,7 @@ void loadObject(const GossCmdContext& cxt, GpuCtx& g, const std::string& name, b
     const uint64_t budget = cxt.hbmBudget ? cxt.hbmBudget : bytes + (4ULL << 30);
     g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)o.K, graph ? GOSS_MODE_GRAPH : GOSS_MODE_KMER_SET, budget, nullptr),
             "creating the GPU context");
+    if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     pushObject(g, name, graph);
     goss_gpu_counts counts;
     g.check(goss_gpu_finish(g.h, &counts), "decoding");
@@ -626,6 +631,7 @@ void GossCmdRestoreGraph::operator()(const GossCmdContext& pCxt)
     GpuCtx g;
     const uint64_t budget = pCxt.hbmBudget ? pCxt.hbmBudget : counts.size() * 64 + (4ULL << 30);
     g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)k, GOSS_MODE_GRAPH, budget, nullptr), "creating the GPU context");
+    if (pCxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
     g.check(goss_gpu_push_run_host(g.h, keys.data(), counts.data(), counts.size()), "loading the edges");
     goss_gpu_counts gc;
     g.check(goss_gpu_finish(g.h, &gc), "loading the edges");

@@ -234,6 +234,14 @@ typedef struct {
 int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, goss_gpu_index_report* out);
 
 /*
+ * Let the context's HBM arena grow beyond hbm_budget, up to max_bytes (0 = fixed, the default):
+ * mapping HBM costs time, so a caller may start small and let inputs with little duplication --
+ * whose sorted runs do not shrink (the case the reference spills to disk for, AsyncMerge.tcc) --
+ * enlarge it when a chunk or a merge needs the room.
+ */
+int goss_gpu_set_budget_limit(goss_gpu_ctx* ctx, uint64_t max_bytes);
+
+/*
  * Diagnostic counters of the context, by name: "fused_chunks" (chunks counted by the extraction
  * that partitions), "fused_overflows" (chunks redone unfused because a bucket region was too
  * small), "segment_retries", "lookback_failures", "runs".

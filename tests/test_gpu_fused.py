@@ -243,3 +243,41 @@ def test_fused_kernels_on_ragged_reads(oracle, k, mode, form):
     assert st["fused_msd_chunks"] == (1 if form == "msd" else 0)
     assert c.windows == nwin
     _same(got, _suffix_map(exp, "o"))
+
+
+def test_arena_grows_for_inputs_without_duplication():
+    """60 M random bases (every 25-mer once): the sorted runs do not shrink, so a 1 GB arena cannot
+    hold the merge; with a budget limit the context maps a larger arena, moves its runs and its
+    staging buffer over, and ends with the same result as a context that had room from the start."""
+    import numpy as np
+    import torch
+    from gossamer_amd import dist as gd
+    rng = np.random.default_rng(16)
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 60_000_000)].tobytes() + b"\n"
+    res = []
+    for budget, limit in ((1 << 30, 24 << 30), (16 << 30, 0)):
+        with g.Context(25, g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+            if limit:
+                ctx.set_budget_limit(limit)
+            for i in range(0, len(reads), 8 << 20):                # host pushes through the staging buffer
+                ctx.push_host(reads[i:i + (8 << 20)])
+            c = ctx.finish()
+            grows = ctx.stat("arena_grows")
+            assert (grows >= 1) == bool(limit)
+            kp, cp, m = ctx.result_ptrs()
+            keys = gd.device_view(kp, m, torch.int64, "cuda").clone()
+            files = ctx.emit()
+            res.append((keys, c.windows, c.distinct, files))
+    assert res[0][1] != 0
+    # pushes of 8 MB cut windows at their borders (windows never span two pushes): both contexts
+    # were fed the same pieces, so everything must agree
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][3] == res[1][3]
+    # without a limit the small arena must fail loudly, not silently drop data
+    with g.Context(25, g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
+        with pytest.raises(g.GossGpuError):
+            for i in range(0, len(reads), 8 << 20):
+                ctx.push_host(reads[i:i + (8 << 20)])
+            ctx.finish()
+            ctx.emit()
