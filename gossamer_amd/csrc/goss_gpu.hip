@@ -96,6 +96,8 @@ struct goss_gpu_ctx {
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
+    uint64_t dump_lo = 0;               // permanent top before the current dump piece
+    bool dump_live = false;
     uint64_t budget_limit = 0;          // the arena may grow up to this many bytes (goss_gpu_set_budget_limit; 0 = fixed)
     uint32_t arena_grows = 0;
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
@@ -1984,6 +1986,7 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;
         c->arena.lo = 0; c->arena.hi = c->arena.size;
         c->stage = nullptr; c->stage_fill = 0;
+        c->dump_live = false;
         HIP_TRY(hipMemsetAsync(c->d_flags, 0, 16, c->stream));
     });
 }
@@ -2201,22 +2204,30 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     return GOSS_OK;
 }
 
-int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
+int goss_gpu_emit_dump_range(goss_gpu_ctx* c, uint64_t flags, uint64_t first, uint64_t count)
 {
     if (!c) return GOSS_ERR_INVALID_ARG;
     if (!c->finished) { c->last_error = "dump before finish"; return GOSS_ERR_STATE; }
+    if (first > c->M || count > c->M - first) return GOSS_ERR_INVALID_ARG;
     return guarded(c, [&]() {
         c->files.clear();
-        PhaseTimer t(c, GOSS_T_EMIT, c->M);
-        const uint64_t m = c->M;
+        // the previous piece's text is dead: give its room back (nothing else was allocated since)
+        if (c->dump_live) { c->arena.lo = c->dump_lo; c->dump_live = false; }
+        PhaseTimer t(c, GOSS_T_EMIT, count);
+        const uint64_t m = count;
         const uint32_t len = c->len;
         // "#<version>\nK\tcount\n" (GossCmdDumpKmerSet.cc:44-45) / "#<version>\nK\tcount\tflags\n"
-        // (GossCmdDumpGraph.cc:50-51)
+        // (GossCmdDumpGraph.cc:50-51): in front of the first piece only
         char head[128];
-        int hl = c->mode == GOSS_MODE_KMER_SET
-                     ? std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\n", 2011101701ULL, c->k, (unsigned long long)m)
-                     : std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\t%llu\n", 2011101014ULL, c->k, (unsigned long long)m,
+        int hl = 0;
+        if (first == 0)
+            hl = c->mode == GOSS_MODE_KMER_SET
+                     ? std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\n", 2011101701ULL, c->k, (unsigned long long)c->M)
+                     : std::snprintf(head, sizeof head, "#%llu\n%u\t%llu\t%llu\n", 2011101014ULL, c->k, (unsigned long long)c->M,
                                      (unsigned long long)flags);
+        const uint64_t ksz = c->words * 8;
+        const uint8_t* keys = (const uint8_t*)c->res_keys + first * ksz;
+        const uint32_t* counts = c->res_counts + first;
         uint64_t body = 0;
         uint64_t mark = c->arena.mark();
         uint64_t* offs = nullptr;
@@ -2224,8 +2235,7 @@ int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
         else if (m)
         {
             offs = (uint64_t*)c->arena.temp((m + 1) * 8);
-            hipLaunchKernelGGL(dump_line_len_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
-                               (const uint32_t*)c->res_counts, m, len, offs);
+            hipLaunchKernelGGL(dump_line_len_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, len, offs);
             HIP_TRY(hipMemsetAsync(offs + m, 0, 8, c->stream));
             exclusive_scan_u64(c, offs, m + 1);
             uint64_t* h = (uint64_t*)c->h_pinned;
@@ -2233,8 +2243,10 @@ int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
             HIP_TRY(hipStreamSynchronize(c->stream));
             body = h[0];
         }
+        c->dump_lo = c->arena.lo;
         uint8_t* text = (uint8_t*)c->arena.perm(hl + body + 16);
-        HIP_TRY(hipMemcpyAsync(text, head, hl, hipMemcpyHostToDevice, c->stream));
+        c->dump_live = true;
+        if (hl) HIP_TRY(hipMemcpyAsync(text, head, hl, hipMemcpyHostToDevice, c->stream));
         if (m)
         {
             if (c->mode == GOSS_MODE_KMER_SET)
@@ -2242,17 +2254,17 @@ int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
                 const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_for(body, 256), 256 * 64);
                 if (c->words == 1)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_kmers_kernel<Key1>), dim3(grid), dim3(256), 0, c->stream,
-                                       (const Key1*)c->res_keys, m, len, text + hl);
+                                       (const Key1*)keys, m, len, text + hl);
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_kmers_kernel<Key2>), dim3(grid), dim3(256), 0, c->stream,
-                                       (const Key2*)c->res_keys, m, len, text + hl);
+                                       (const Key2*)keys, m, len, text + hl);
             }
             else if (c->words == 1)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_edges_kernel<Key1>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
-                                   (const Key1*)c->res_keys, (const uint32_t*)c->res_counts, (const uint64_t*)offs, m, len, text + hl);
+                                   (const Key1*)keys, counts, (const uint64_t*)offs, m, len, text + hl);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(dump_edges_kernel<Key2>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
-                                   (const Key2*)c->res_keys, (const uint32_t*)c->res_counts, (const uint64_t*)offs, m, len, text + hl);
+                                   (const Key2*)keys, counts, (const uint64_t*)offs, m, len, text + hl);
         }
         t.stop();
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2260,6 +2272,12 @@ int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
         OutFile f; f.suffix = ".dump"; f.size = hl + body; f.dev = text;
         c->files.push_back(std::move(f));
     });
+}
+
+int goss_gpu_emit_dump(goss_gpu_ctx* c, uint64_t flags)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    return goss_gpu_emit_dump_range(c, flags, 0, c->M);
 }
 
 int goss_gpu_lint(goss_gpu_ctx* c, int asymmetric, goss_gpu_lint_report* out)

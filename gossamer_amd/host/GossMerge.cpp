@@ -506,20 +506,27 @@ void loadObject(const GossCmdContext& cxt, GpuCtx& g, const std::string& name, b
     g.check(goss_gpu_finish(g.h, &counts), "decoding");
 }
 
-// FileFactory::out(name): "-" is standard output (PhysicalFileFactory.cc:279-298).
-void writeText(GpuCtx& g, const std::string& out)
+// FileFactory::out(name): "-" is standard output (PhysicalFileFactory.cc:279-298).  The text is
+// formatted on the device 32 M elements at a time (about 1 GB) and written as it comes.
+void writeText(GpuCtx& g, const std::string& out, uint64_t flags)
 {
     FILE* fp = out == "-" ? stdout : fopen(out.c_str(), "wb");
     if (!fp) throw Error::Errno(out, errno);
-    uint64_t size = 0; char suffix[32];
-    g.check(goss_gpu_file_info(g.h, 0, suffix, sizeof suffix, &size), "listing output files");
-    const uint64_t piece = 64u << 20;
-    std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
-    for (uint64_t off = 0; off < size; off += piece)
+    uint64_t m = 0;
+    g.check(goss_gpu_result(g.h, nullptr, nullptr, &m), "counting");
+    const uint64_t step = 32u << 20, piece = 64u << 20;
+    std::vector<char> buf((size_t)piece);
+    for (uint64_t first = 0; first == 0 || first < m; first += step)
     {
-        uint64_t n = std::min(piece, size - off);
-        g.check(goss_gpu_file_read(g.h, 0, off, buf.data(), n), "reading device file");
-        if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { if (fp != stdout) fclose(fp); throw Error::Write(out); }
+        g.check(goss_gpu_emit_dump_range(g.h, flags, first, std::min(step, m - first)), "formatting");
+        uint64_t size = 0; char suffix[32];
+        g.check(goss_gpu_file_info(g.h, 0, suffix, sizeof suffix, &size), "listing output files");
+        for (uint64_t off = 0; off < size; off += piece)
+        {
+            uint64_t n = std::min(piece, size - off);
+            g.check(goss_gpu_file_read(g.h, 0, off, buf.data(), n), "reading device file");
+            if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { if (fp != stdout) fclose(fp); throw Error::Write(out); }
+        }
     }
     if (fp == stdout) fflush(stdout);
     else if (fclose(fp) != 0) throw Error::Write(out);
@@ -545,8 +552,7 @@ void GossCmdDumpKmerSet::operator()(const GossCmdContext& pCxt)
     auto t0 = std::chrono::steady_clock::now();
     GpuCtx g; ObjectInfo o;
     loadObject(pCxt, g, mIn, false, o);
-    g.check(goss_gpu_emit_dump(g.h, 0), "formatting");
-    writeText(g, mOut);
+    writeText(g, mOut, 0);
     pCxt.log(info, elapsed(t0));
 }
 
@@ -555,8 +561,7 @@ void GossCmdDumpGraph::operator()(const GossCmdContext& pCxt)
 {
     GpuCtx g; ObjectInfo o;
     loadObject(pCxt, g, mIn, true, o);
-    g.check(goss_gpu_emit_dump(g.h, o.asymmetric ? 1 : 0), "formatting");
-    writeText(g, mOut);
+    writeText(g, mOut, o.asymmetric ? 1 : 0);
 }
 
 // GossCmdRestoreGraph::operator() (GossCmdRestoreGraph.cc:72-135): "#version" line, then

@@ -255,6 +255,10 @@ int goss_gpu_stat(goss_gpu_ctx* ctx, const char* name, uint64_t* value);
  * (GossCmdDumpGraph.cc:31-61).  Replaces the file list; read it with goss_gpu_file_read.
  */
 int goss_gpu_emit_dump(goss_gpu_ctx* ctx, uint64_t flags);
+/* The same for elements [first, first + count) only (the header lines go in front of the piece
+ * that starts at 0): the text of a large object is produced and written piece by piece; each call
+ * releases the previous piece. */
+int goss_gpu_emit_dump_range(goss_gpu_ctx* ctx, uint64_t flags, uint64_t first, uint64_t count);
 
 /*
  * After finish, graph mode: the checks of lint-graph's first pass (GossCmdLintGraph.cc:131-199)
