@@ -59,3 +59,33 @@ def test_c5_set_algebra_properties(tmp_path):
     run(["dump-kmer-set", "-G", P("u"), "-o", P("u.txt")])
     run(["dump-kmer-set", "-G", P("u3"), "-o", P("u3.txt")])
     assert (tmp_path / "u.txt").read_bytes() == (tmp_path / "u3.txt").read_bytes()
+
+
+def test_batchwise_build_then_merge_equals_one_build(tmp_path):
+    """The reference's scale-out workflow (docs/goss.md: build graphs of batches, merge them): the
+    merged graph must hold the same edges and multiplicities as one build over all reads (compared
+    through dump-graph: the merged object's SparseArray is sized with the sum of the inputs' counts,
+    so its files differ while its content may not), and it must pass lint-graph."""
+    n, L, G = 400_000, 150, 3_000_000
+    whole = g.synth_reads_host(2 * n, L, G, seed=33)
+    half = len(whole) // 2
+    (tmp_path / "all.txt").write_bytes(whole)
+    (tmp_path / "a.txt").write_bytes(whole[:half])
+    (tmp_path / "b.txt").write_bytes(whole[half:])
+
+    def run(args):
+        p = subprocess.run([GOSS] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        return p
+
+    P = lambda s: str(tmp_path / s)
+    for k in (27, 55):
+        for name in ("all", "a", "b"):
+            run(["build-graph", "-k", str(k), "--line-in", P(name + ".txt"), "-O", P("%s%d" % (name, k))])
+        run(["merge-graphs", "-G", P("a%d" % k), "-G", P("b%d" % k), "-O", P("m%d" % k)])
+        run(["dump-graph", "-G", P("all%d" % k), "-o", P("all%d.txt" % k)])
+        run(["dump-graph", "-G", P("m%d" % k), "-o", P("m%d.txt" % k)])
+        assert (tmp_path / ("all%d.txt" % k)).read_bytes() == (tmp_path / ("m%d.txt" % k)).read_bytes()
+        assert (tmp_path / ("all%d-counts-hist.txt" % k)).read_bytes() == (tmp_path / ("m%d-counts-hist.txt" % k)).read_bytes()
+        p = run(["lint-graph", "-G", P("m%d" % k)])
+        assert b"warning" not in p.stderr
