@@ -591,8 +591,60 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     // same order as the reference: line, fasta, fastq (GossCmdBuildKmerSet.cc:118-141)
     for (auto& f : lines) { log(info, "parsing sequences from " + f); reads += parseLines(f, sink); }
     for (auto& f : fastas) { log(info, "parsing sequences from " + f); reads += parseFasta(f, sink); }
+    // Compressed FASTQ cannot be cut into chunks (one inflate stream per file), but several such
+    // files -- lanes, read pairs -- can be inflated and framed side by side: one worker per file,
+    // each with its own batch, pushes serialised.  The k-mer multiset does not depend on the
+    // order in which reads arrive, so the output is the reference's.
+    std::vector<std::string> gzFiles;
+    for (auto& f : fastqs) if (endsWith(f, ".gz")) gzFiles.push_back(f);
+    if (gzFiles.size() > 1 && threads > 1)
+    {
+        flush();
+        std::mutex pushMutex, errMutex;
+        std::unique_ptr<Error> firstError;
+        std::atomic<size_t> nextFile{0};
+        std::atomic<uint64_t> gzReads{0};
+        auto worker = [&]() {
+            std::vector<char> mine;
+            mine.reserve(cxt.batchBytes / 4 + (1u << 20));
+            auto mflush = [&]() {
+                if (mine.empty()) return;
+                std::lock_guard<std::mutex> lk(pushMutex);
+                timedPush(mine.data(), mine.size());
+                mine.clear();
+            };
+            for (;;)
+            {
+                const size_t i = nextFile.fetch_add(1);
+                if (i >= gzFiles.size()) break;
+                try
+                {
+                    ReadSink s = [&](const char* seq, size_t len) {
+                        mine.insert(mine.end(), seq, seq + len);
+                        mine.push_back('\n');
+                        if (mine.size() >= cxt.batchBytes / 4) mflush();
+                    };
+                    gzReads += parseFastq(gzFiles[i], s);
+                    mflush();
+                }
+                catch (const Error& e)
+                {
+                    std::lock_guard<std::mutex> lk(errMutex);
+                    if (!firstError) firstError.reset(new Error(e));
+                }
+            }
+        };
+        for (auto& f : gzFiles) log(info, "parsing sequences from " + f);
+        std::vector<std::thread> pool;
+        const size_t nw = std::min<size_t>(gzFiles.size(), (size_t)std::min<uint64_t>(threads, 64));
+        for (size_t w = 0; w < nw; ++w) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+        if (firstError) throw *firstError;
+        reads += gzReads;
+    }
     for (auto& f : fastqs)
     {
+        if (gzFiles.size() > 1 && threads > 1 && endsWith(f, ".gz")) continue;      // done above
         log(info, "parsing sequences from " + f);
         flush();
         uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned);

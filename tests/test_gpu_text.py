@@ -112,3 +112,38 @@ def test_dump_restore_lint(oracle, tmp_path):
     assert p.returncode == 1 and "mandatory option graph-in was not given." in p.stderr.decode()
     p = run(["restore-graph", "-O", str(tmp_path / "bad")], input=b"#v\n25\t1\t0\nACGT\t1\n")
     assert p.returncode == 1 and "sequence ACGT has wrong length" in p.stderr.decode()
+
+
+def test_several_gz_inputs_side_by_side(oracle, tmp_path):
+    """Compressed FASTQ files are inflated and framed by one worker each (-T > 1): the objects must
+    be the ones a serial pass over the same files gives, and a framing error in one of them must
+    still surface as the reference's message."""
+    import gzip
+    rng = random.Random(53)
+    genome = "".join(rng.choice("ACGT") for _ in range(5000))
+    inputs = []
+    args = []
+    for i in range(4):
+        reads = [genome[s:s + 100] for s in (rng.randrange(0, 4900) for _ in range(800))]
+        fq = "".join("@r%d\n%s\n+\n%s\n" % (j, r, "I" * len(r)) for j, r in enumerate(reads))
+        name = "p%d.fq.gz" % i if i < 3 else "p3.fq"
+        if i < 3:
+            with gzip.open(tmp_path / name, "wb") as f:
+                f.write(fq.encode())
+        else:
+            (tmp_path / name).write_text(fq)
+        inputs.append((oracle.FASTQ, name, fq))
+        args += ["-i", str(tmp_path / name)]
+    for cmd, k, build, base in (("build-kmer-set", 25, oracle.build_kmer_set, "ks"), ("build-graph", 31, oracle.build_graph, "gr")):
+        exp, nwin = build(inputs, k, out=base)
+        p = run([cmd, "-k", str(k), "-T", "4", "-O", str(tmp_path / base)] + args)
+        assert p.returncode == 0, p.stderr.decode()
+        got = disk(tmp_path, base)
+        assert sorted(got) == sorted(exp)
+        for name in exp:
+            assert got[name] == exp[name], (cmd, name)
+    with gzip.open(tmp_path / "bad.fq.gz", "wb") as f:
+        f.write(b"@r0\nACGT\n+\nIII\n")                       # quality shorter than the sequence
+    p = run(["build-kmer-set", "-k", "25", "-T", "4", "-O", str(tmp_path / "x"), "-i", str(tmp_path / "p0.fq.gz"),
+             "-i", str(tmp_path / "bad.fq.gz")])
+    assert p.returncode == 1 and "bad.fq.gz" in p.stderr.decode()
