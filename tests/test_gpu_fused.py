@@ -281,3 +281,31 @@ def test_arena_grows_for_inputs_without_duplication():
                 ctx.push_host(reads[i:i + (8 << 20)])
             ctx.finish()
             ctx.emit()
+
+
+@pytest.mark.parametrize("k,mode", [(25, "kmer"), (27, "graph"), (45, "kmer")])
+def test_fused_path_misaligned_device_buffer(k, mode):
+    """push_bases_device with a pointer that is not 16-byte aligned (the kernels load 16-byte
+    vectors from the aligned address below it): same result as the aligned copy."""
+    import torch
+    from gossamer_amd import dist as gd
+    reads = g.synth_reads_host(300000, 150, 1500000, seed=17)
+    base = torch.frombuffer(bytearray(b"\n" * 16 + reads), dtype=torch.uint8).cuda()
+    res = []
+    for off in (16, 3, 9):
+        view = base[off:]
+        if off != 16:
+            view = base[off: off + len(reads)]
+            view.copy_(base[16: 16 + len(reads)].clone())
+        m = g.MODE_GRAPH if mode == "graph" else g.MODE_KMER_SET
+        with g.Context(k, m, hbm_budget=12 << 30) as ctx:
+            ctx.push_device(view.data_ptr(), len(reads))
+            c = ctx.finish()
+            assert ctx.stat("fused_chunks") == 1
+            kp, cp, n = ctx.result_ptrs()
+            w = c.key_words
+            res.append((gd.device_view(kp, n * w, torch.int64, "cuda").clone(), gd.device_view(cp, n, torch.int32, "cuda").clone(), c.windows))
+        base[16: 16 + len(reads)].copy_(torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda())
+    for other in res[1:]:
+        assert other[2] == res[0][2]
+        assert torch.equal(other[0], res[0][0]) and torch.equal(other[1], res[0][1])
