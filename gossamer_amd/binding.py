@@ -108,6 +108,16 @@ def synth_reads_host(nreads, read_len, genome_len, seed=1, first_read=0):
     return buf.raw
 
 
+def _torch_ready():
+    """The library runs on its own HIP stream.  Device buffers handed to it by pointer usually come
+    from torch, whose kernels are asynchronous on torch's stream: wait for them (C callers of the
+    ABI order their own streams; this wrapper does it for the Python tests and bench.py)."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+
+
 class Context:
     """One counting context on one GPU (include/goss_gpu.h)."""
 
@@ -146,9 +156,11 @@ class Context:
         self._check(self._L.goss_gpu_push_bases_host(self._h, data, len(data)))
 
     def push_device(self, ptr, nbytes):
+        _torch_ready()
         self._check(self._L.goss_gpu_push_bases_device(self._h, C.c_void_p(ptr), nbytes))
 
     def push_run(self, keys_ptr, counts_ptr, m):
+        _torch_ready()
         self._check(self._L.goss_gpu_push_run_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
 
     def set_path(self, path):
@@ -209,6 +221,7 @@ class Context:
         if N_end is None:
             N_end = N
         mask = (1 << 64) - 1
+        _torch_ready()
         self._check(self._L.goss_gpu_emit_sparse_array(self._h, C.c_void_p(dev_ptr), key_words, n, N & mask, N >> 64, M,
                                                        N_end & mask, N_end >> 64))
         return self.files()

@@ -1874,7 +1874,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     volatile uint32_t* vovf = &ovf;
     // kSegUnroll independent coalesced loads are issued before the first insert so that
     // enough bytes are in flight per CU to cover the HBM latency
-    constexpr int kSegUnroll = 8;
+#ifndef GOSS_SEG_UNROLL
+#define GOSS_SEG_UNROLL 16
+#endif
+    constexpr int kSegUnroll = GOSS_SEG_UNROLL;
     unsigned long long nxt[kSegUnroll];
 #pragma unroll
     for (int u = 0; u < kSegUnroll; ++u)

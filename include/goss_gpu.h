@@ -74,7 +74,9 @@ void goss_gpu_destroy(goss_gpu_ctx* ctx);
  * (GossRead.hh:57-114, GossReadBaseString.hh:52-188) and the insert loop
  * (GossCmdBuildKmerSet.tcc:246-256 + BackyardHash::insert BackyardHash.cc:115-242).
  * _host: bytes in host memory (pinned memory makes the copy asynchronous);
- * _device: bytes already resident in HBM on the context's device (not modified).
+ * _device: bytes already resident in HBM on the context's device (not modified).  The context
+ *          works on its own stream and does not wait for any other: whatever produced the bytes
+ *          (a copy, a kernel on another stream) must have completed before the call.
  */
 int goss_gpu_push_bases_host(goss_gpu_ctx* ctx, const char* bases, uint64_t nbytes);
 int goss_gpu_push_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes);

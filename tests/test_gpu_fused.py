@@ -297,6 +297,7 @@ def test_fused_path_misaligned_device_buffer(k, mode):
         if off != 16:
             view = base[off: off + len(reads)]
             view.copy_(base[16: 16 + len(reads)].clone())
+        torch.cuda.synchronize()          # the context runs on its own stream: the bytes must be there
         m = g.MODE_GRAPH if mode == "graph" else g.MODE_KMER_SET
         with g.Context(k, m, hbm_budget=12 << 30) as ctx:
             ctx.push_device(view.data_ptr(), len(reads))
