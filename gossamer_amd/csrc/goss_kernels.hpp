@@ -2122,7 +2122,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     volatile uint32_t* vst = st;
     volatile unsigned long long* vlo = tlo;
     volatile unsigned long long* vhi = thi;
-    constexpr int kU = 4;
+#ifndef GOSS_SEG_UNROLL2
+#define GOSS_SEG_UNROLL2 4
+#endif
+    constexpr int kU = GOSS_SEG_UNROLL2;
     // software pipeline: the next batch's loads are in flight while this one is inserted
     // (hi = all ones marks "no key": 2*len <= 126 bits)
     Key2 nxt[kU];
