@@ -101,6 +101,7 @@ struct goss_gpu_ctx {
     uint64_t budget_limit = 0;          // the arena may grow up to this many bytes (goss_gpu_set_budget_limit; 0 = fixed)
     uint32_t arena_grows = 0;
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
+    uint32_t fused_grid = 0;            // GOSS_GPU_FUSED_GRID: workgroups of the fused extraction kernel (0 = 1024)
     bool seg_merge = true;              // GOSS_GPU_NO_SEG_MERGE=1: merge runs by sorting their concatenation
     uint32_t seg_merges = 0;            // merges done by segments
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
@@ -943,7 +944,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
         const uint64_t kSuper = kOne ? (uint64_t)GOSS_FUSED_G * kTB * (graph ? 8 : 16)
                                      : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);
+        if (c->fused_grid) grid = std::min(grid, c->fused_grid);      // experiments: leave room for a second context's kernels
         const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         if constexpr (kOne)
@@ -1727,6 +1729,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
+    { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
