@@ -911,11 +911,11 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     for (int d = 0; d < 256; ++d)
     {
         const double h = (double)hh[d];
-        base[d] = (h + 5.0 * std::sqrt(h + 1.0) + 16.0) * scale + 1024.0;
+        base[d] = exact ? h + 64.0 : (h + 5.0 * std::sqrt(h + 1.0) + 16.0) * scale + 1024.0;    // exact counts need no slack
         base_sum += base[d];
     }
     double slack = std::min(1.25, ((double)ka_slots - 256.0 * 16.0) / base_sum);
-    if (slack < 1.02) return decline("bucket regions do not fit the key buffer");
+    if (slack < (exact ? 1.0 : 1.02)) return decline("bucket regions do not fit the key buffer");
     slack *= c->fused_capscale;
     uint64_t at = 0;
     for (int d = 0; d < 256; ++d)

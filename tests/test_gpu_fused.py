@@ -310,3 +310,47 @@ def test_fused_path_misaligned_device_buffer(k, mode):
     for other in res[1:]:
         assert other[2] == res[0][2]
         assert torch.equal(other[0], res[0][0]) and torch.equal(other[1], res[0][1])
+
+
+@pytest.mark.parametrize("mode", ["kmer", "graph"])
+def test_fused_path_many_k(oracle, mode):
+    """The fused kernels over the key widths they serve (24..126 bits): keys and counts against the
+    oracle, small input forced down the fused path."""
+    import random
+    rng = random.Random(4242)
+    genome = "".join(rng.choice("ACGT") for _ in range(20000))
+    reads = []
+    for _ in range(30000):
+        L = rng.randint(70, 150)
+        p = rng.randint(0, len(genome) - L)
+        r = genome[p:p + L]
+        if rng.random() < 0.05:
+            q = rng.randrange(L)
+            r = r[:q] + "N" + r[q + 1:]
+        reads.append(r)
+    txt = "\n".join(reads) + "\n"
+    old = os.environ.get("GOSS_GPU_FUSED_MIN")
+    os.environ["GOSS_GPU_FUSED_MIN"] = "0"
+    try:
+        top = 63 if mode == "kmer" else 62
+        ks_to_try = sorted(set(list(range(12, top + 1, 3)) + [30, 31, 32, 33, top]))
+        for k in ks_to_try:
+            length = k if mode == "kmer" else k + 1
+            keys, nreads, nwin = oracle.collect([(oracle.LINE, "r", txt)], length, 0 if mode == "kmer" else 1)
+            exp = {}
+            for x in keys:
+                exp[x] = exp.get(x, 0) + 1
+            ek = sorted(exp)
+            with g.Context(k, g.MODE_KMER_SET if mode == "kmer" else g.MODE_GRAPH, hbm_budget=2 << 30) as ctx:
+                ctx.push_host(txt)
+                c = ctx.finish()
+                assert ctx.stat("fused_chunks") == 1, k
+                gk, gc = ctx.result()
+            assert c.windows == nwin, k
+            assert gk == ek, k
+            assert [int(x) for x in gc] == [exp[x] for x in ek], k
+    finally:
+        if old is None:
+            del os.environ["GOSS_GPU_FUSED_MIN"]
+        else:
+            os.environ["GOSS_GPU_FUSED_MIN"] = old

@@ -487,3 +487,19 @@ def test_goss_set_algebra_commands(oracle, tmp_path):
     assert p.returncode == 1 and "Exactly two input k-mer sets required!" in p.stderr.decode()
     p = run(["merge-and-annotate-kmer-sets", "-G", P[0], "-O", str(tmp_path / "bad")])
     assert p.returncode == 1 and "mandatory option graph-in must be supplied exactly twice." in p.stderr.decode()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_every_k(oracle, mode):
+    """Every kmer-size the commands accept (build-kmer-set 1..63, build-graph 1..62): keys and
+    counts against the oracle on a small ragged input -- every key width, both word counts, every
+    byte class of the hash, the 31/32 and 30/31 boundaries."""
+    rng = random.Random(77 + mode)
+    reads = make_reads(rng, 220, (3, 140), 1500, lower=True)
+    for k in range(1, 64 - mode):
+        length = k + 1 if mode == 1 else k
+        ek, ec, nwin = oracle_counts(oracle, reads, length, mode)
+        ks, cs, c = gpu_counts(reads, k, mode)
+        assert c.windows == nwin, k
+        assert ks == ek, k
+        assert cs == ec, k
