@@ -1310,6 +1310,16 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
             if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
         }
         if (limit && capn > limit) capn = limit;
+        // equal chunks rather than full ones and a small remainder: a remainder covers the
+        // genome too thinly for the segment path and would go through the full sort
+        {
+            const uint64_t left = nstarts_total - done;
+            if (left > capn)
+            {
+                const uint64_t parts = (left + capn - 1) / capn;
+                capn = std::min<uint64_t>(capn, ((left + parts - 1) / parts + 4095) & ~4095ULL);
+            }
+        }
         uint64_t ns = std::min(capn, nstarts_total - done);
         uint64_t navail = std::min(nbytes - done, ns + c->len - 1);
         const uint64_t lo0 = c->arena.lo, hi0 = c->arena.hi;
