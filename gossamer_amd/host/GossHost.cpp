@@ -13,6 +13,7 @@
 #include <cerrno>
 #include <cmath>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -355,20 +356,104 @@ struct GpuCtx {
     }
 };
 
-void writeFile(const std::string& path, const std::string& objName, GpuCtx& g, uint32_t idx, uint64_t size)
+}  // namespace
+
+// Every file of the emitted object to "<out><suffix>".  The calling thread (the context's) copies
+// 32 MB pieces from the device into a ring of page-locked buffers; a pool of writer threads pwrites
+// them, so the copies into the page cache run on several cores while the next pieces arrive.
+void writeObjectFiles(goss_gpu_ctx* h, const std::string& out)
 {
-    FILE* fp = fopen(path.c_str(), "wb");
-    if (!fp) throw Error::Write(objName);
-    const uint64_t piece = 64u << 20;
-    std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
-    for (uint64_t off = 0; off < size; off += piece)
+    auto check = [&](int rc, const char* what) {
+        if (rc == GOSS_OK) return;
+        std::string msg = std::string(what) + ": " + goss_gpu_strerror(rc);
+        const char* d = goss_gpu_last_error(h);
+        if (d && *d) msg += std::string(" (") + d + ")";
+        throw Error::General(msg + "\n");
+    };
+    constexpr size_t kPiece = 32u << 20;
+    constexpr int kBuffers = 6, kWriters = 4;
+    struct Job { int fd; uint64_t off; size_t n; int buf; };
+    std::vector<void*> bufs(kBuffers, nullptr);
+    std::vector<bool> pinned(kBuffers, false);
+    std::mutex m;
+    std::condition_variable cvJob, cvFree;
+    std::deque<Job> jobs;
+    std::vector<int> freeBufs;
+    bool done = false, failed = false;
+    for (int i = 0; i < kBuffers; ++i)
     {
-        uint64_t n = std::min(piece, size - off);
-        g.check(goss_gpu_file_read(g.h, idx, off, buf.data(), n), "reading device file");
-        if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { fclose(fp); throw Error::Write(objName); }
+        if (goss_gpu_host_alloc(&bufs[i], kPiece) == GOSS_OK) pinned[i] = true;
+        else bufs[i] = malloc(kPiece);
+        if (!bufs[i]) throw Error::General("out of host memory for the output buffers\n");
+        freeBufs.push_back(i);
     }
-    if (fclose(fp) != 0) throw Error::Write(objName);
+    auto writer = [&]() {
+        for (;;)
+        {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cvJob.wait(lk, [&] { return !jobs.empty() || done; });
+                if (jobs.empty()) return;
+                j = jobs.front(); jobs.pop_front();
+            }
+            size_t w = 0;
+            while (w < j.n)
+            {
+                ssize_t r = pwrite(j.fd, (const char*)bufs[j.buf] + w, j.n - w, (off_t)(j.off + w));
+                if (r <= 0) { std::lock_guard<std::mutex> lk(m); failed = true; break; }
+                w += (size_t)r;
+            }
+            { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(j.buf); }
+            cvFree.notify_one();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 0; i < kWriters; ++i) pool.emplace_back(writer);
+    std::vector<int> fds;
+    auto finishAll = [&]() {
+        { std::lock_guard<std::mutex> lk(m); done = true; }
+        cvJob.notify_all();
+        for (auto& t : pool) t.join();
+        for (int fd : fds) if (::close(fd) != 0) failed = true;
+        for (int i = 0; i < kBuffers; ++i) { if (pinned[i]) goss_gpu_host_free(bufs[i]); else free(bufs[i]); }
+    };
+    try
+    {
+        uint32_t nfiles = 0;
+        check(goss_gpu_file_count(h, &nfiles), "listing output files");
+        for (uint32_t i = 0; i < nfiles; ++i)
+        {
+            char suffix[256]; uint64_t size = 0;
+            check(goss_gpu_file_info(h, i, suffix, sizeof suffix, &size), "listing output files");
+            int fd = ::open((out + suffix).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            if (fd < 0) throw Error::Write(out);
+            fds.push_back(fd);
+            for (uint64_t off = 0; off < size; off += kPiece)
+            {
+                const size_t n = (size_t)std::min<uint64_t>(kPiece, size - off);
+                int b;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cvFree.wait(lk, [&] { return !freeBufs.empty(); });
+                    b = freeBufs.back(); freeBufs.pop_back();
+                }
+                check(goss_gpu_file_read(h, i, off, bufs[b], n), "reading device file");
+                { std::lock_guard<std::mutex> lk(m); jobs.push_back(Job{fd, off, n, b}); }
+                cvJob.notify_one();
+            }
+        }
+    }
+    catch (...)
+    {
+        finishAll();
+        throw;
+    }
+    finishAll();
+    if (failed) throw Error::Write(out);
 }
+
+namespace {
 
 // Bytes of file per parser work item (GOSS_PARSE_CHUNK overrides: tests use small chunks).
 size_t parseChunkBytes()
@@ -670,14 +755,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     { std::ostringstream o; o << "merged at " << secs() << "s"; log(info, o.str()); }
     log(info, "writing out graph.");
     g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
-    uint32_t nfiles = 0;
-    g.check(goss_gpu_file_count(g.h, &nfiles), "listing output files");
-    for (uint32_t i = 0; i < nfiles; ++i)
-    {
-        char suffix[256]; uint64_t size = 0;
-        g.check(goss_gpu_file_info(g.h, i, suffix, sizeof suffix, &size), "listing output files");
-        writeFile(out + suffix, out, g, i, size);
-    }
+    writeObjectFiles(g.h, out);
+    { std::ostringstream o; o << "written at " << secs() << "s"; log(info, o.str()); }
     stats.reads = reads; stats.windows = counts.windows; stats.keys = counts.keys; stats.distinct = counts.distinct;
     stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::ostringstream os;

@@ -234,6 +234,14 @@ private:
     const std::string mIn; const bool mDumpProperties; uint64_t mProblems = 0;
 };
 
+}  // namespace gosshost
+struct goss_gpu_ctx;
+namespace gosshost {
+
+// Writes every file image of the emitted object to "<out><suffix>" (the write half of the
+// reference's FileFactory for KmerSet::Builder / Graph::Builder::end()).
+void writeObjectFiles(goss_gpu_ctx* h, const std::string& out);
+
 // App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);
 

@@ -224,24 +224,7 @@ struct Item { std::string name; bool temp = false; HostRun run; uint64_t count =
 
 void writeOut(GpuCtx& g, const std::string& out)
 {
-    uint32_t nfiles = 0;
-    g.check(goss_gpu_file_count(g.h, &nfiles), "listing output files");
-    for (uint32_t i = 0; i < nfiles; ++i)
-    {
-        char suffix[256]; uint64_t size = 0;
-        g.check(goss_gpu_file_info(g.h, i, suffix, sizeof suffix, &size), "listing output files");
-        FILE* fp = fopen((out + suffix).c_str(), "wb");
-        if (!fp) throw Error::Write(out);
-        const uint64_t piece = 64u << 20;
-        std::vector<char> buf((size_t)std::min<uint64_t>(size ? size : 1, piece));
-        for (uint64_t off = 0; off < size; off += piece)
-        {
-            uint64_t n = std::min(piece, size - off);
-            g.check(goss_gpu_file_read(g.h, i, off, buf.data(), n), "reading device file");
-            if (fwrite(buf.data(), 1, (size_t)n, fp) != n) { fclose(fp); throw Error::Write(out); }
-        }
-        if (fclose(fp) != 0) throw Error::Write(out);
-    }
+    writeObjectFiles(g.h, out);
 }
 
 void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_t maxMerge, const std::string& out)

@@ -26,7 +26,7 @@ def test_c2_full_size_properties():
         pytest.skip("needs the 288 GB of an MI355X")
     n, L, G = 100_000_000, 150, 100_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
-    budget = int((free_b - buf.numel()) * 0.90)
+    budget = int((free_b - buf.numel()) * 0.94)          # bench.py's share: one chunk
     res = []
     for env in ({}, {"GOSS_GPU_NO_FUSED": "1"}):
         old = {k: os.environ.get(k) for k in env}
@@ -43,7 +43,8 @@ def test_c2_full_size_properties():
             ctx.synth_reads(buf.data_ptr(), n, L, G, seed=1)
         ctx.push_device(buf.data_ptr(), buf.numel())
         c = ctx.finish()
-        assert ctx.stat("fused_msd_chunks") == (0 if env else 1)
+        fused = ctx.stat("fused_msd_chunks")
+        assert fused == 0 if env else fused >= 1
         kp, cp, m = ctx.result_ptrs()
         keys = gd.device_view(kp, m, torch.int64, "cuda").clone()
         counts = gd.device_view(cp, m, torch.int32, "cuda").clone()
