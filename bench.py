@@ -100,8 +100,12 @@ def main():
     bases = torch.empty(nbytes, dtype=torch.uint8, device=device)
     free_b, total_b = torch.cuda.mem_get_info(device)
     # the exchange buffers of the multi-GPU path are torch tensors outside the library's arena
-    share = 0.84 if use_dist else 0.94
-    budget = int(args.hbm_budget_gb * (1 << 30)) if args.hbm_budget_gb > 0 else int(free_b * share)
+    # (received runs, this rank's range, the gathered set on rank 0: ~21 GB at 8 ranks)
+    budget = int(free_b * 0.94)
+    if use_dist:
+        budget = min(budget, free_b - (32 << 30))
+    if args.hbm_budget_gb > 0:
+        budget = int(args.hbm_budget_gb * (1 << 30))
     ctx = g.Context(k, g.MODE_GRAPH if args.graph else g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
     ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)
     torch.cuda.synchronize(device)

@@ -96,6 +96,8 @@ struct goss_gpu_ctx {
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
     uint32_t fused_overflows = 0;       // fused chunks redone because a bucket region was too small
+    uint32_t valid_sized_chunks = 0;    // chunks counted in key buffers sized from the estimated share of valid windows
+    uint32_t valid_resizes = 0;         // chunks whose estimate was too low: redone in full-size buffers
     uint64_t dump_lo = 0;               // permanent top before the current dump piece
     bool dump_live = false;
     uint64_t budget_limit = 0;          // the arena may grow up to this many bytes (goss_gpu_set_budget_limit; 0 = fixed)
@@ -109,6 +111,8 @@ struct goss_gpu_ctx {
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
+    double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
+    bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
     uint64_t budget = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -736,21 +740,28 @@ template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
                    const uint64_t* seg_end);
 
+// Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
+// key buffers were sized for fewer valid windows than the sample shows: the caller retries with
+// buffers of one key per window start).
+enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2 };
+constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
+constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
+
 template <class K>
-bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, K* ka, uint64_t ka_slots,
-                         K* kb, uint64_t kb_slots)
+int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, K* ka, uint64_t ka_slots,
+                        K* kb, uint64_t kb_slots)
 {
     constexpr bool kOne = std::is_same<K, Key1>::value;          // one-word keys
     const uint32_t keybits = 2 * c->len;
     if (!c->fused || c->path != 0 || !c->lookback || c->ordered_tiles ||
         c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
-        return false;
+        return kFusedDeclined;
     constexpr int kTile = SortCfg<K, false>::kTile;
     uint64_t mark = c->arena.mark();
     struct Release { goss_gpu_ctx* c; uint64_t m; ~Release() { c->arena.release(m); } } release{c, mark};
     auto decline = [&](const char* why) {
         if (c->debug) std::fprintf(stderr, "libgossgpu: fused path declined (%s), %llu window starts\n", why, (unsigned long long)nstarts);
-        return false;
+        return (int)kFusedDeclined;
     };
 
     const auto t_begin = std::chrono::steady_clock::now();
@@ -778,6 +789,11 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const uint64_t nslices = sample_starts >= nstarts ? 1 : std::max<uint64_t>(64, sample_starts / kPlainSuper);
     const uint64_t slice_starts = sample_starts >= nstarts ? nstarts : kPlainSuper;
     if (nslices > 1 && nstarts < 4 * nslices * slice_starts) return decline("chunk smaller than the sample");
+    // key buffers sized from the estimated share of valid windows (process_chunk): they must hold
+    // the sample whatever it contains
+    const uint64_t kps = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
+    const bool reduced = ka_slots < nstarts * kps || kb_slots < nstarts * kps;
+    if (reduced && (nslices == 1 || nslices * slice_starts * kps > std::min(ka_slots, kb_slots))) return (int)kFusedNeedFull;
     const uint64_t slice_stride = nslices > 1 ? ((nstarts - slice_starts) / (nslices - 1)) & ~15ULL : 0;
     c->mute_timing = true;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
@@ -834,6 +850,15 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
+    // buffers sized from the estimated share of valid windows must hold what the sample promises
+    {
+        if (reduced && ((double)n_exp * 1.035 + 262144.0 > (double)ka_slots || (double)n_exp * 1.02 + 6.0e6 > (double)kb_slots))
+        {
+            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: %llu keys expected, buffers of %llu / %llu slots too small\n",
+                                       (unsigned long long)n_exp, (unsigned long long)ka_slots, (unsigned long long)kb_slots);
+            return (int)kFusedNeedFull;
+        }
+    }
     const uint64_t limit = SegCfg<K>::kLimit;
     uint32_t segbits = kSegBits;
     while (segbits < (uint32_t)kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;
@@ -888,6 +913,11 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
                                        : (((uint64_t)(((h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0) * c->fused_capscale) + 15) & ~15ULL);
             hsub[0].start[i] = at; hsub[0].cap[i] = cap;
             at += cap;
+        }
+        if (at > kb_slots && reduced)
+        {
+            if (c->debug) std::fprintf(stderr, "libgossgpu: sub-regions need %llu slots of %llu\n", (unsigned long long)at, (unsigned long long)kb_slots);
+            return (int)kFusedNeedFull;
         }
         if (at > kb_slots)
         {
@@ -1009,7 +1039,8 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     if (hp->overflow) { c->fused_overflows++; return decline("a bucket region overflowed"); }
     lap("extraction + first level");
     const uint64_t n = hp->keys_out;
-    if (n == 0) return false;
+    if (n == 0) return kFusedDeclined;
+    if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");
     uint64_t tiles = 0, sum = 0;
     for (int d = 0; d < 256; ++d)
     {
@@ -1091,7 +1122,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
                 std::fprintf(stderr, "libgossgpu: radix look-back chain gave up in the fused path; redoing the chunk unfused\n");
                 c->lookback_failures++;
                 c->ordered_tiles = true;
-                return false;
+                return kFusedDeclined;
             }
             std::swap(src, dst);
         }
@@ -1105,7 +1136,7 @@ bool process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstar
     c->windows += hp->windows;
     c->keys_total += n;
     c->fused_chunks++;
-    return true;
+    return kFusedDone;
 }
 
 // Process window starts [0, nstarts) of a device-resident byte string (navail readable bytes,
@@ -1119,16 +1150,45 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     // the fused path wants room for its bucket regions (expected keys + slack): up to cap/8 more
     // slots in the first buffer when the arena can spare them beyond the two buffers and the
     // partition / segment tables
-    uint64_t ka_slots = cap;
-    if (c->fused && nstarts >= c->fused_min)
-    {
+    uint64_t ka_slots = cap, kb_slots = cap;
+    auto full_slots = [&]() {
+        ka_slots = cap; kb_slots = cap;
         const uint64_t extra = cap / 8 + 256 * 16;
         const uint64_t need = (2 * cap + extra) * sizeof(K) + cap / 2 + (uint64_t)(1u << kSegBits) * kSegLimit * 12 + (64u << 20);
         if (c->arena.avail() >= need) ka_slots = cap + extra;
+    };
+    bool reduced = false;
+    if (c->fused && nstarts >= c->fused_min)
+    {
+        // a chunk whose sample is a set of slices (not the whole chunk): buffers for the expected
+        // number of keys -- bucket regions with 6 % of slack, sub-regions with 13 %
+        if (c->valid_frac < 0.97 && nstarts > kValidSizingMin)
+        {
+            ka_slots = std::min<uint64_t>(cap, (uint64_t)((double)cap * c->valid_frac * kValidSlackA) + (1u << 20));
+            kb_slots = std::min<uint64_t>(cap, (uint64_t)((double)cap * c->valid_frac * kValidSlackB) + (8u << 20));
+            reduced = ka_slots < cap || kb_slots < cap;
+        }
+        if (!reduced) full_slots();
     }
     K* ka = (K*)c->arena.temp(ka_slots * sizeof(K));
-    K* kb = (K*)c->arena.temp(cap * sizeof(K));
-    if (process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, cap)) { c->arena.release(mark); return; }
+    K* kb = (K*)c->arena.temp(kb_slots * sizeof(K));
+    int frc = process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots);
+    if (frc == kFusedDone) { if (reduced) c->valid_sized_chunks++; c->arena.release(mark); return; }
+    if (reduced)
+    {
+        c->valid_resizes++;
+        // the unfused kernels (and a fused retry) want one slot per window start
+        c->arena.release(mark);
+        c->valid_frac = 1.0;
+        full_slots();
+        ka = (K*)c->arena.temp(ka_slots * sizeof(K));
+        kb = (K*)c->arena.temp(kb_slots * sizeof(K));
+        if (frc == kFusedNeedFull && process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots) == kFusedDone)
+        {
+            c->arena.release(mark);
+            return;
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     uintptr_t addr = (uintptr_t)d_bases;
     uint32_t mis = (uint32_t)(addr & 15u);
@@ -1271,6 +1331,7 @@ uint64_t chunk_capacity(goss_gpu_ctx* c, bool optimistic)
         if (avail <= fixed) return 0;
         avail -= fixed;
         per_key = 2.0 * ksz + 0.6;
+        if (c->valid_frac < 0.97) per_key = (kValidSlackA + kValidSlackB) * c->valid_frac * ksz + 0.6;
     }
     else
     {
@@ -1279,8 +1340,34 @@ uint64_t chunk_capacity(goss_gpu_ctx* c, bool optimistic)
     }
     uint64_t keys = (uint64_t)((double)avail * 0.95 / per_key);
     uint64_t starts = keys / S;
+    if (optimistic && c->valid_frac < 0.97 && starts <= kValidSizingMin + 4096)
+        starts = (uint64_t)((double)avail * 0.95 / (2.0 * ksz + 0.6)) / S;     // such chunks get full buffers
     starts &= ~4095ULL;
     return starts;
+}
+
+// Share of the window starts of a pushed string that begin a valid window, estimated from 64 MB of
+// evenly spread slices: a non-base removes at most `len` windows.  One point of margin; the
+// fused path checks the figure against its own sample and asks for full buffers when it was low.
+double estimate_valid_fraction(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
+{
+    constexpr uint32_t kSlice = 16384;
+    constexpr uint64_t kSlices = 4096;
+    const uint8_t* al = (const uint8_t*)(((uintptr_t)d + 15) & ~(uintptr_t)15);
+    const uint64_t skip = (uint64_t)(al - d);
+    if (nbytes < skip + 2 * kSlices * kSlice) return 1.0;
+    const uint64_t stride = ((nbytes - skip - kSlice) / (kSlices - 1)) & ~15ULL;
+    c->mute_timing = true;
+    HIP_TRY(hipMemsetAsync(c->d_ctr, 0, 16, c->stream));
+    hipLaunchKernelGGL(nonbase_sample_kernel, dim3(1024), dim3(kTB), 0, c->stream, al, kSlices, stride, kSlice,
+                       (unsigned long long*)c->d_ctr);
+    c->mute_timing = false;
+    unsigned long long* h = (unsigned long long*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, c->d_ctr, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h[1] == 0) return 1.0;
+    const double f = 1.0 - (double)h[0] / (double)h[1] * (double)c->len + 0.01;
+    return std::min(1.0, std::max(0.05, f));
 }
 
 template <class K>
@@ -1289,6 +1376,12 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
     if (nbytes < c->len) return;
     ensure_arena(c);
     const uint64_t nstarts_total = nbytes - c->len + 1;
+    c->valid_frac = 1.0;
+    if (c->size_by_valid && c->fused && c->path == 0 && nstarts_total > kValidSizingMin)
+    {
+        c->valid_frac = estimate_valid_fraction(c, d, nbytes);
+        if (c->debug) std::fprintf(stderr, "libgossgpu: valid windows per window start, estimated: %.3f\n", c->valid_frac);
+    }
     uint64_t done = 0;
     uint64_t limit = 0;                 // chunk size cap after an out-of-memory retry
     // the bases may live in the context's own staging buffer, which moves when the arena grows
@@ -1742,6 +1835,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_VALID_SIZING"); if (e && *e && *e != '0') c->size_by_valid = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }
     { const char* e = std::getenv("GOSS_GPU_DEBUG"); if (e && *e == '1') c->debug = true; }
@@ -2206,6 +2300,8 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
+    else if (n == "valid_sized_chunks") *value = c->valid_sized_chunks;
+    else if (n == "valid_resizes") *value = c->valid_resizes;
     else if (n == "seg_merges") *value = c->seg_merges;
     else if (n == "segment_retries") *value = c->segment_retries;
     else if (n == "lookback_failures") *value = c->lookback_failures;

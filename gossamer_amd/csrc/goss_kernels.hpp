@@ -126,6 +126,35 @@ struct ExtractCounters {
     unsigned long long hist[512];  // partition digit histograms (extract1_kernel)
 };
 
+// Bytes that are not one of ACGTacgt in `nslices` slices of `slice` bytes (a multiple of 16),
+// `stride` bytes apart, of a 16-byte aligned string: out[0] += such bytes, out[1] += bytes looked
+// at.  The host sizes the key buffers of a chunk from it (a non-base removes at most `len` windows).
+__global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __restrict__ aligned, uint64_t nslices,
+                                                             uint64_t stride, uint32_t slice,
+                                                             unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0, seen = 0;
+    auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+    for (uint64_t s = blockIdx.x; s < nslices; s += gridDim.x)
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(aligned + s * stride);
+        for (uint32_t v = threadIdx.x; v < slice / 16; v += kTB)
+        {
+            const uint4 q = p[v];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const uint32_t l = w[i] | 0x20202020u;
+                bad += __popc(nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u));
+            }
+            seen += 16;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_down(bad, o, 64); seen += __shfl_down(seen, o, 64); }
+    if ((threadIdx.x & 63u) == 0 && seen) { atomicAdd(&out[0], bad); atomicAdd(&out[1], seen); }
+}
+
 template <class K> struct KeyOps;
 template <> struct KeyOps<Key1> {
     static __device__ __forceinline__ Key1 zero() { return Key1{0}; }

@@ -122,6 +122,7 @@ def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit
             ctx.push_run(rk.data_ptr() + off * 8, rc.data_ptr() + off * 4, n)
         off += n
     c2 = ctx.finish()
+    del rk, rc             # the runs were copied into the library's arena
     ms, M, _ = gather_counts(c2.distinct, device, group)
     out = {"windows": windows, "M": M, "m_range": c2.distinct}
     if emit_on_root:

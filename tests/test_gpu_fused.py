@@ -138,6 +138,53 @@ def test_two_level_form_with_sampled_regions():
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
+def test_key_buffers_sized_by_valid_windows():
+    """Chunks above 640 M window starts get key buffers for the estimated number of valid windows
+    (a 64 MB sample of non-base bytes).  Plain reads: the estimate holds and the chunk is counted
+    in the smaller buffers.  Reads with long runs of N: a run removes far fewer windows than
+    25 per byte, the estimate is far too low, the fused path notices from its own sample and the
+    chunk is redone in full-size buffers.  Both must equal the result with the sizing off."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 4_600_000, 150, 5_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    for with_n_runs in (False, True):
+        res = []
+        for env in ({}, {"GOSS_GPU_NO_VALID_SIZING": "1"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        del os.environ[k]
+                    else:
+                        os.environ[k] = v
+            if not res:
+                ctx.synth_reads(buf.data_ptr(), n, L, G, seed=33)
+                if with_n_runs:
+                    # every 1 MiB block starts with 300 KiB of N
+                    blocks = buf[: (buf.numel() >> 20) << 20].view(-1, 1 << 20)
+                    blocks[:, : 300 << 10] = ord("N")
+                torch.cuda.synchronize()
+            ctx.push_device(buf.data_ptr(), buf.numel())
+            c = ctx.finish()
+            assert ctx.stat("fused_chunks") == 1
+            if env:
+                assert ctx.stat("valid_sized_chunks") == 0 and ctx.stat("valid_resizes") == 0
+            elif with_n_runs:
+                assert ctx.stat("valid_sized_chunks") == 0 and ctx.stat("valid_resizes") == 1
+            else:
+                assert ctx.stat("valid_sized_chunks") == 1 and ctx.stat("valid_resizes") == 0
+            kp, cp, m = ctx.result_ptrs()
+            res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+            ctx.close()
+        assert res[0][2] == res[1][2]
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
+
+
 def test_segment_sort_skewed_low_bits(oracle):
     """Keys of one segment that also agree on the ten bits below the segment bits overflow the
     bucket sort's insertion-sort limit: the bitonic fallback of seg_hash_reduce_kernel must give
