@@ -117,7 +117,7 @@ def main():
             c = ctx.finish()
             ctx.emit_device()
             return c.windows, c.distinct
-        r = gdist.count_distributed(ctx, bases.data_ptr(), nbytes, 2 * k, device)
+        r = gdist.count_distributed(ctx, bases.data_ptr(), nbytes, 2 * (k + 1 if args.graph else k), device)
         return r["windows"], r["M"]
 
     def barrier():

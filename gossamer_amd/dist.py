@@ -10,28 +10,61 @@ bulk data anywhere.  The reference has no distributed path
 is new design, constrained only by having to produce the reference's single-pass result.
 
 The functions below work on torch tensors and a process group only, so the same code runs
-under gloo on CPU (tests, world_size 2) and under RCCL on GPUs (bench.py).  Keys are one
-64-bit word (2*len <= 62 bits), carried in int64 tensors: their sign bit is never set, so
-signed comparisons order them correctly.
+under gloo on CPU (tests, world_size 2) and under RCCL on GPUs (bench.py).  One-word keys
+(2*len <= 62 bits) are int64 tensors of shape [m]: their sign bit is never set, so signed
+comparisons order them correctly.  Two-word keys (2*len <= 128) are int64 tensors of shape
+[m, 2] with columns (lo, hi) -- the library's Key2 layout; both words are unsigned, so they are
+compared after flipping the sign bit.
 """
 import torch
 import torch.distributed as dist
 
 
+_SIGN = -(1 << 63)
+
+
+def _as_i64(v):
+    """unsigned 64-bit value -> the int64 with the same bits"""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
 def uniform_splitters(key_bits, parts, dtype=torch.int64, device="cpu"):
-    """parts-1 interior splitters cutting [0, 2^key_bits) into equal ranges.  Hash-chosen
+    """parts-1 interior splitters cutting [0, 2^key_bits) into equal ranges: shape [parts-1] for
+    one-word keys (key_bits <= 62), [parts-1, 2] = (lo, hi) for two-word keys.  Hash-chosen
     canonical k-mers of an i.i.d. genome are uniform on the top bits (SURVEY.md section 8(e));
     sampled splitters can replace this for skewed data without changing anything else."""
     total = 1 << key_bits
-    return torch.tensor([(total * p) // parts for p in range(1, parts)], dtype=dtype, device=device)
+    cuts = [(total * p) // parts for p in range(1, parts)]
+    if key_bits <= 62:
+        return torch.tensor(cuts, dtype=dtype, device=device)
+    rows = [[_as_i64(c), _as_i64(c >> 64)] for c in cuts]
+    return torch.tensor(rows, dtype=dtype, device=device).reshape(len(rows), 2)
+
+
+def _lower_bound2(keys, lo, hi):
+    """number of two-word keys (sorted, columns lo / hi, unsigned) below (hi, lo)"""
+    khi = keys[:, 1] ^ _SIGN
+    probe = torch.tensor([hi ^ _SIGN], dtype=torch.int64, device=keys.device)
+    a = int(torch.searchsorted(khi, probe, right=False).item())
+    b = int(torch.searchsorted(khi, probe, right=True).item())
+    if a == b:
+        return a
+    klo = (keys[a:b, 0] ^ _SIGN).contiguous()
+    probe = torch.tensor([lo ^ _SIGN], dtype=torch.int64, device=keys.device)
+    return a + int(torch.searchsorted(klo, probe, right=False).item())
 
 
 def split_sizes(sorted_keys, splitters):
     """How many of this rank's sorted distinct keys fall in each range."""
-    if splitters.numel() == 0:
-        return [int(sorted_keys.numel())]
-    cuts = torch.searchsorted(sorted_keys, splitters, right=False).tolist()
-    edges = [0] + cuts + [int(sorted_keys.numel())]
+    n = int(sorted_keys.shape[0])
+    if splitters.shape[0] == 0:
+        return [n]
+    if sorted_keys.dim() == 1:
+        cuts = torch.searchsorted(sorted_keys, splitters, right=False).tolist()
+    else:
+        cuts = [_lower_bound2(sorted_keys, int(lo), int(hi)) for lo, hi in splitters.tolist()]
+    edges = [0] + cuts + [n]
     return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
 
 
@@ -46,9 +79,9 @@ def exchange_runs(keys, counts, splitters, group=None):
     recv_t = torch.empty(world, dtype=torch.int64, device=keys.device)
     dist.all_to_all_single(recv_t, send_t, group=group)
     recv = [int(x) for x in recv_t.tolist()]
-    rk = torch.empty(sum(recv), dtype=keys.dtype, device=keys.device)
+    rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
     rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
-    dist.all_to_all_single(rk, keys, recv, send, group=group)
+    dist.all_to_all_single(rk, keys, recv, send, group=group)        # splits along dim 0: whole keys
     dist.all_to_all_single(rc, counts, recv, send, group=group)
     return rk, rc, recv
 
@@ -69,9 +102,9 @@ def gather_ranges_to_root(keys, counts, ms, group=None):
     the concatenation is the globally sorted distinct key set)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    send = [int(keys.numel())] + [0] * (world - 1)
+    send = [int(keys.shape[0])] + [0] * (world - 1)
     recv = ms if rank == 0 else [0] * world
-    rk = torch.empty(sum(recv), dtype=keys.dtype, device=keys.device)
+    rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
     rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
     dist.all_to_all_single(rk, keys, recv, send, group=group)
     dist.all_to_all_single(rc, counts, recv, send, group=group)
@@ -92,26 +125,33 @@ def device_view(ptr, n, dtype, device):
     return torch.as_tensor(DevArray(ptr, n, typestr), device=device)
 
 
+def key_view(ptr, m, words, device):
+    """the library's key array: [m] int64 for one-word keys, [m, 2] (lo, hi) for two-word keys"""
+    v = device_view(ptr, m * words, torch.int64, device)
+    return v if words == 1 else v.reshape(m, 2)
+
+
 def _sync(device):
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
 
 
 def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True):
-    """The whole multi-GPU job for one-word keys on an already created Context:
+    """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
     local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
     Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
     world = dist.get_world_size(group)
     ctx.reset()
     ctx.push_device(bases_ptr, nbytes)
     c = ctx.finish()
-    if c.key_words != 1:
-        raise NotImplementedError("multi-GPU exchange is implemented for one-word keys (2*len <= 62)")
+    words = c.key_words
     windows = c.windows
     kp, cp, m = ctx.result_ptrs()
-    keys = device_view(kp, m, torch.int64, device)
+    keys = key_view(kp, m, words, device)
     counts = device_view(cp, m, torch.int32, device)
     splitters = uniform_splitters(key_bits, world, device=device)
+    if (splitters.dim() == 2) != (words == 2):
+        raise ValueError("key_bits = %d does not match the context's %d-word keys (2*len: len = k, or k+1 for graphs)" % (key_bits, words))
     rk, rc, recv = exchange_runs(keys, counts, splitters, group)
     _sync(device)          # the library runs on its own stream: finish the collectives first
     # merge the received runs: they replace the local result
@@ -119,7 +159,7 @@ def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit
     off = 0
     for n in recv:
         if n:
-            ctx.push_run(rk.data_ptr() + off * 8, rc.data_ptr() + off * 4, n)
+            ctx.push_run(rk.data_ptr() + off * 8 * words, rc.data_ptr() + off * 4, n)
         off += n
     c2 = ctx.finish()
     del rk, rc             # the runs were copied into the library's arena
@@ -127,7 +167,7 @@ def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit
     out = {"windows": windows, "M": M, "m_range": c2.distinct}
     if emit_on_root:
         kp, cp, m = ctx.result_ptrs()
-        keys = device_view(kp, m, torch.int64, device).clone()
+        keys = key_view(kp, m, words, device).clone()
         counts = device_view(cp, m, torch.int32, device).clone()
         ak, ac = gather_ranges_to_root(keys, counts, ms, group)
         _sync(device)

@@ -30,32 +30,46 @@ def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q):
         for x in keys:
             d[x] = d.get(x, 0) + 1
         ks = sorted(d)
-        kt = torch.tensor(ks, dtype=torch.int64)
+        two = 2 * k > 62                          # two-word keys travel as [m, 2] = (lo, hi)
+
+        def to_tensor(vals):
+            if not two:
+                return torch.tensor(vals, dtype=torch.int64)
+            return torch.tensor([[gd._as_i64(v), gd._as_i64(v >> 64)] for v in vals], dtype=torch.int64).reshape(len(vals), 2)
+
+        def to_ints(t):
+            if not two:
+                return [int(x) for x in t.tolist()]
+            return [((h & (2 ** 64 - 1)) << 64) | (l & (2 ** 64 - 1)) for l, h in t.tolist()]
+
+        kt = to_tensor(ks)
         ct = torch.tensor([d[x] for x in ks], dtype=torch.int32)
         splitters = gd.uniform_splitters(2 * k, world)
         rk, rc, recv = gd.exchange_runs(kt, ct, splitters)
-        assert len(recv) == world and sum(recv) == rk.numel()
+        assert len(recv) == world and sum(recv) == rk.shape[0]
         # every received key belongs to this rank's range, and each run is sorted
-        lo = 0 if rank == 0 else int(splitters[rank - 1])
-        hi = (1 << (2 * k)) if rank == world - 1 else int(splitters[rank])
-        assert all(lo <= int(x) < hi for x in rk.tolist())
+        cuts = to_ints(splitters)
+        lo = 0 if rank == 0 else cuts[rank - 1]
+        hi = (1 << (2 * k)) if rank == world - 1 else cuts[rank]
+        got = to_ints(rk)
+        assert all(lo <= x < hi for x in got)
         off = 0
         for n in recv:
-            seg = rk[off:off + n].tolist()
+            seg = got[off:off + n]
             assert seg == sorted(seg)
             off += n
         # merge the runs (sum equal keys)
         m = {}
-        for x, c in zip(rk.tolist(), rc.tolist()):
+        for x, c in zip(got, rc.tolist()):
             m[x] = m.get(x, 0) + c
         mk = sorted(m)
-        mkt = torch.tensor(mk, dtype=torch.int64)
+        mkt = to_tensor(mk)
         mct = torch.tensor([m[x] for x in mk], dtype=torch.int32)
         ms, M, offset = gd.gather_counts(len(mk), "cpu")
         assert M == len(expect_keys) and offset == sum(ms[:rank])
         ak, ac = gd.gather_ranges_to_root(mkt, mct, ms)
         if rank == 0:
-            assert ak.tolist() == expect_keys
+            assert to_ints(ak) == expect_keys
             assert ac.tolist() == expect_counts
         else:
             assert ak.numel() == 0
@@ -67,11 +81,11 @@ def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q):
         dist.destroy_process_group()
 
 
-def test_range_partition_exchange_world2():
+@pytest.mark.parametrize("k", [13, 40])
+def test_range_partition_exchange_world2(k):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
     rng = random.Random(31)
-    k = 13
     genome = "".join(rng.choice("ACGT") for _ in range(3000))
     reads = [genome[p:p + 60] for p in (rng.randrange(0, 2940) for _ in range(400))]
     shards = ["\n".join(reads[:200]) + "\n", "\n".join(reads[200:]) + "\n"]
@@ -103,3 +117,25 @@ def test_uniform_splitters_and_split_sizes():
     assert gd.split_sizes(keys, s) == [3, 1, 0, 0, 1, 0, 0, 1]
     assert gd.split_sizes(keys, gd.uniform_splitters(50, 1)) == [6]
     assert gd.split_sizes(torch.empty(0, dtype=torch.int64), s) == [0] * 8
+
+
+def test_two_word_splitters_and_split_sizes():
+    """Two-word keys are (lo, hi) pairs of unsigned words: the order must survive the int64
+    container (sign bits flipped for the comparison), also for the longest keys (128 bits)."""
+    sys.path.insert(0, ROOT)
+    from gossamer_amd import dist as gd
+    rng = random.Random(5)
+    for bits in (64, 80, 112, 128):
+        for parts in (1, 2, 8):
+            s = gd.uniform_splitters(bits, parts)
+            assert tuple(s.shape) == (parts - 1, 2)
+            cuts = [((h & (2 ** 64 - 1)) << 64) | (l & (2 ** 64 - 1)) for l, h in s.tolist()]
+            assert cuts == [(1 << bits) * p // parts for p in range(1, parts)]
+            vals = sorted(set([0, (1 << bits) - 1] + cuts + [c - 1 for c in cuts if c] +
+                              [rng.randrange(1 << bits) for _ in range(200)] +
+                              [(rng.randrange(1 << (bits - 64)) << 64) | v for v in (0, 2 ** 63, 2 ** 64 - 1) for _ in range(5)]))
+            t = torch.tensor([[gd._as_i64(v), gd._as_i64(v >> 64)] for v in vals], dtype=torch.int64).reshape(len(vals), 2)
+            edges = [0] + cuts + [1 << bits]
+            want = [sum(1 for v in vals if edges[i] <= v < edges[i + 1]) for i in range(parts)]
+            assert gd.split_sizes(t, s) == want, (bits, parts)
+    assert gd.split_sizes(torch.empty((0, 2), dtype=torch.int64), gd.uniform_splitters(100, 4)) == [0] * 4

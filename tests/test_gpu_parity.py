@@ -330,30 +330,42 @@ def test_large_scale_properties():
     assert res[0][2] <= n * (L - 25 + 1) and res[0][2] > n * (L - 25 + 1) * 0.99
 
 
-def test_distributed_path_world1(oracle):
+@pytest.fixture(scope="module")
+def nccl_world1():
+    """one RCCL process group for the whole module (setting one up takes tens of seconds)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,graph", [(25, False), (40, False), (27, True), (55, True)])
+def test_distributed_path_world1(oracle, nccl_world1, k, graph):
     """The multi-GPU code path (exchange over RCCL, merge of received runs, gather to rank 0,
-    emit) with a single rank: must give exactly the single-GPU files."""
+    emit) with a single rank: must give exactly the single-GPU files -- k-mer sets and graphs,
+    one- and two-word keys."""
     import os
     import torch
     import torch.distributed as dist
     from gossamer_amd import dist as gd
     reads = g.synth_reads_host(20000, 150, 100000, seed=9)
-    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
-    exp = _suffix_map(exp, "ks")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
-        with g.Context(25, g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
-            r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 50, torch.device("cuda", 0))
-            got = ctx.files()
-        assert r["windows"] == nwin
-        assert sorted(got) == sorted(exp)
-        for name in exp:
-            assert got[name] == exp[name], name
-    finally:
-        dist.destroy_process_group()
+    if graph:
+        exp, nwin = oracle.build_graph([(oracle.LINE, "reads", reads)], k, out="ob")
+    else:
+        exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], k, out="ob")
+    exp = _suffix_map(exp, "ob")
+    buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
+    with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
+        r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0))
+        got = ctx.files()
+    assert r["windows"] == nwin
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
 
 
 def test_goss_merge_commands(oracle, tmp_path):
