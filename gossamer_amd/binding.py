@@ -209,6 +209,12 @@ class Context:
             ks = [int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64) for i in range(m)]
         return ks, cnts
 
+    def select_counts(self, lo, hi):
+        """Between finish and emit: keep the result items whose count lies in [lo, hi]
+        (goss_gpu_select_counts: the set algebra of intersect-kmer-sets / subtract-kmer-set)."""
+        self._L.goss_gpu_select_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        self._check(self._L.goss_gpu_select_counts(self._h, lo, hi))
+
     def emit_device(self):
         """Build the on-disk arrays in HBM without copying them to the host."""
         self._check(self._L.goss_gpu_emit(self._h))

@@ -136,10 +136,9 @@ def _sync(device):
         torch.cuda.synchronize(device)
 
 
-def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True):
-    """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
-    local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
-    Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
+def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None):
+    """local count -> exchange -> merge of the received runs: this rank's range of the global
+    result stays in the Context.  Returns (this rank's windows, key words)."""
     world = dist.get_world_size(group)
     ctx.reset()
     ctx.push_device(bases_ptr, nbytes)
@@ -161,19 +160,80 @@ def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit
         if n:
             ctx.push_run(rk.data_ptr() + off * 8 * words, rc.data_ptr() + off * 4, n)
         off += n
-    c2 = ctx.finish()
+    ctx.finish()
     del rk, rc             # the runs were copied into the library's arena
-    ms, M, _ = gather_counts(c2.distinct, device, group)
-    out = {"windows": windows, "M": M, "m_range": c2.distinct}
-    if emit_on_root:
-        kp, cp, m = ctx.result_ptrs()
-        keys = key_view(kp, m, words, device).clone()
-        counts = device_view(cp, m, torch.int32, device).clone()
-        ak, ac = gather_ranges_to_root(keys, counts, ms, group)
-        _sync(device)
-        if dist.get_rank(group) == 0:
-            ctx.reset()
+    return windows, words
+
+
+def _range_tensors(ctx, words, device):
+    kp, cp, m = ctx.result_ptrs()
+    return key_view(kp, m, words, device).clone(), device_view(cp, m, torch.int32, device).clone()
+
+
+def _assemble_on_root(ctx, keys, counts, ms, M, device, group):
+    """ranges -> rank 0 -> one run -> on-disk arrays (in HBM) on rank 0"""
+    ak, ac = gather_ranges_to_root(keys, counts, ms, group)
+    _sync(device)
+    if dist.get_rank(group) == 0:
+        ctx.reset()
+        if M:
             ctx.push_run(ak.data_ptr(), ac.data_ptr(), M)
-            ctx.finish()
-            ctx.emit_device()
+        ctx.finish()
+        ctx.emit_device()
+
+
+def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True):
+    """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
+    local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
+    Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
+    windows, words = count_range(ctx, bases_ptr, nbytes, key_bits, device, group)
+    m_range = ctx.counts.distinct
+    ms, M, _ = gather_counts(m_range, device, group)
+    out = {"windows": windows, "M": M, "m_range": m_range}
+    if emit_on_root:
+        keys, counts = _range_tensors(ctx, words, device)
+        _assemble_on_root(ctx, keys, counts, ms, M, device, group)
     return out
+
+
+def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_on_root=True):
+    """BASELINE config C5 across ranks: every input (bases_ptr, nbytes) is this rank's share of the
+    reads of one k-mer set.  The sets are counted and range-partitioned one after the other with
+    the same splitters, so the set operation needs no further exchange: each rank combines its
+    ranges (goss_gpu_select_counts on weighted runs, as the single-GPU commands do), rank 0
+    assembles the result.  op = "intersect" (all sets; globally empty ones are skipped, as
+    GossCmdIntersectKmerSets.cc:29-79 does) or "subtract" (first minus second,
+    GossCmdSubtractKmerSet.cc:47-66).  Returns dict(sizes=<global size of every input>, M=<result>)."""
+    if op not in ("intersect", "subtract") or (op == "subtract" and len(inputs) != 2):
+        raise ValueError("op must be 'intersect' or 'subtract' (exactly two sets)")
+    ranges, sizes, words = [], [], 1
+    for ptr, nbytes in inputs:
+        _, words = count_range(ctx, ptr, nbytes, key_bits, device, group)
+        ranges.append(_range_tensors(ctx, words, device))
+        sizes.append(gather_counts(ranges[-1][0].shape[0], device, group)[1])
+    ctx.reset()
+    if op == "intersect":
+        use = [i for i, n in enumerate(sizes) if n]
+        weights = {i: 1 for i in use}
+        keep = max(len(use), 1)
+    else:
+        use = [0, 1]
+        weights = {0: 1, 1: 2}
+        keep = 1
+    held = []
+    for i in use:
+        keys, _ = ranges[i]
+        if keys.shape[0]:
+            w = torch.full((keys.shape[0],), weights[i], dtype=torch.int32, device=device)
+            held.append(w)
+            ctx.push_run(keys.data_ptr(), w.data_ptr(), keys.shape[0])
+    _sync(device)
+    ctx.finish()
+    ctx.select_counts(keep, keep)
+    kp, cp, m = ctx.result_ptrs()
+    ms, M, _ = gather_counts(m, device, group)
+    if emit_on_root:
+        keys = key_view(kp, m, words, device).clone()
+        counts = torch.ones(m, dtype=torch.int32, device=device)
+        _assemble_on_root(ctx, keys, counts, ms, M, device, group)
+    return {"sizes": sizes, "M": M}

@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Integer / byte work: the bar is bit-exact."""
 import random
+import struct
 
 import pytest
 
@@ -366,6 +367,41 @@ def test_distributed_path_world1(oracle, nccl_world1, k, graph):
     assert sorted(got) == sorted(exp)
     for name in exp:
         assert got[name] == exp[name], name
+
+
+@pytest.mark.parametrize("k", [25, 45])
+def test_distributed_set_algebra_world1(oracle, nccl_world1, k):
+    """BASELINE config C5 through the multi-GPU code path with one rank: two (three) k-mer sets
+    counted and range-partitioned, intersected / subtracted range by range, assembled on rank 0 --
+    files equal to the oracle's restatement of intersect-kmer-sets / subtract-kmer-set."""
+    import torch
+    from gossamer_amd import dist as gd
+    dev = torch.device("cuda", 0)
+    texts = [g.synth_reads_host(6000, 150, 400000, seed=71, first_read=f) for f in (0, 3000)] + [b"ACGTACGT\n"]
+    files, names = {}, []
+    for i, t in enumerate(texts):
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "reads", t)], k, out="s%d" % i)
+        files.update(f)
+        names.append("s%d" % i)
+    bufs = [torch.frombuffer(bytearray(t), dtype=torch.uint8).cuda() for t in texts]
+    ins = [(b.data_ptr(), b.numel()) for b in bufs]
+    with g.Context(k, g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
+        # all inputs empty: undefined in the reference (the oracle refuses); here the empty set
+        r = gd.set_algebra_distributed(ctx, [ins[2]], 2 * k, "intersect", dev)
+        assert r["M"] == 0 and r["sizes"] == [0] and struct.unpack("<QQQ", ctx.files()[".header"])[2] == 0
+        for sel, op in (((0, 1), "intersect"), ((0, 2, 1), "intersect"), ((0, 1), "subtract"),
+                        ((1, 0), "subtract"), ((0, 2), "subtract"), ((2, 0), "subtract"), ((0, 0), "subtract")):
+            if op == "intersect":
+                exp = oracle.intersect_kmer_sets(files, [names[j] for j in sel], "out")
+            else:
+                exp = oracle.subtract_kmer_set(files, names[sel[0]], names[sel[1]], "out")
+            r = gd.set_algebra_distributed(ctx, [ins[j] for j in sel], 2 * k, op, dev)
+            got = ctx.files()
+            exp = _suffix_map(exp, "out")
+            assert sorted(got) == sorted(exp), (sel, op)
+            for name in exp:
+                assert got[name] == exp[name], (sel, op, name)
+            assert r["M"] == struct.unpack("<QQQ", got[".header"])[2]
 
 
 def test_goss_merge_commands(oracle, tmp_path):
