@@ -21,7 +21,7 @@ SYMBOLS = [
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
-    "goss_gpu_select_counts", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
+    "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range",
 ]
 
@@ -214,6 +214,11 @@ class Context:
         (goss_gpu_select_counts: the set algebra of intersect-kmer-sets / subtract-kmer-set)."""
         self._L.goss_gpu_select_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         self._check(self._L.goss_gpu_select_counts(self._h, lo, hi))
+
+    def select_normal(self):
+        """Between finish and emit: keep the items that are their own canonical form (goss_gpu_select_normal)."""
+        self._L.goss_gpu_select_normal.argtypes = [C.c_void_p]
+        self._check(self._L.goss_gpu_select_normal(self._h))
 
     def emit_device(self):
         """Build the on-disk arrays in HBM without copying them to the host."""

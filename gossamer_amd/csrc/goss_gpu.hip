@@ -2225,6 +2225,32 @@ int goss_gpu_select_counts(goss_gpu_ctx* c, uint32_t lo, uint32_t hi)
     });
 }
 
+int goss_gpu_select_normal(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished || c->emitted) { c->last_error = "select_normal belongs between finish and emit"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        PhaseTimer t(c, GOSS_T_REDUCE, c->M);
+        if (c->M)
+        {
+            const uint32_t grid = (uint32_t)((c->M + kTB - 1) / kTB);
+            if (c->words == 1)
+            {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key1>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const Key1*)c->res_keys, c->M, c->len, c->res_counts);
+                select_counts<Key1>(c, 1, 1);
+            }
+            else
+            {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key2>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const Key2*)c->res_keys, c->M, c->len, c->res_counts);
+                select_counts<Key2>(c, 1, 1);
+            }
+        }
+        t.stop();
+    });
+}
+
 // DenseSelect::DenseSelect (DenseArray.cc:36-91): header checks, then the device view of the file
 static RdDenseSelect open_dense_select(goss_gpu_ctx* c, const void* host, uint64_t size, int invert)
 {

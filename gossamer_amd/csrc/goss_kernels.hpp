@@ -1631,6 +1631,20 @@ __global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m,
     counts[j] = (uint32_t)s;
 }
 
+// graph-to-kmer-set (GossCmdGraphToKmerSet.cc:40-55): an edge stays when it is its own canonical
+// form -- Gossamer::edge_type::isNormal, RankSelect.hh:117-124, the same hash order and tie rule
+// as normalize.  Writes 1 / 0 over the item's count; the count filter below does the rest.
+template <class K>
+__global__ __launch_bounds__(kTB) void mark_normal_kernel(const K* __restrict__ keys, uint64_t n, uint32_t len,
+                                                          uint32_t* __restrict__ counts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const K x = keys[i];
+    const K rc = revcomp(x, len);
+    counts[i] = canonical<K>(x, rc) == x ? 1u : 0u;
+}
+
 // Selection by count: keeps the (key,count) items with lo <= count <= hi, order preserved.
 // The set algebra of intersect-kmer-sets / subtract-kmer-set is a merge of weighted runs
 // followed by this filter (GossCmdIntersectKmerSets.cc:29-79, GossCmdSubtractKmerSet.cc:47-66).

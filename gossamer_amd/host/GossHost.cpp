@@ -1005,7 +1005,8 @@ void printHelp(const std::string& cmdName, const OptTable* t)
               << "  merge-and-annotate-kmer-sets  Decorate a graph with an assignment of kmers to graphs.\n"
               << "  merge-graphs     create a new graph by merging zero or more existing graphs\n"
               << "  merge-kmer-sets  create a new graph by merging zero or more existing graphs\n"
-              << "  subtract-kmer-set  subtract the second k-mer set from the first\n";
+              << "  subtract-kmer-set  subtract the second k-mer set from the first\n"
+              << "  graph-to-kmer-set  generate a graph's k-mer set\n";
     if (t)
     {
         std::cerr << "\n" << cmdName << "\n" << t->describe() << std::endl;
@@ -1031,9 +1032,10 @@ int gossMain(int argc, char* argv[])
         const bool isMerge = cmdName == "merge-kmer-sets" || cmdName == "merge-graphs";
         const bool isIntersect = cmdName == "intersect-kmer-sets", isSubtract = cmdName == "subtract-kmer-set";
         const bool isAnnotate = cmdName == "merge-and-annotate-kmer-sets";
+        const bool isToKmerSet = cmdName == "graph-to-kmer-set";
         const bool isDump = cmdName == "dump-kmer-set" || cmdName == "dump-graph";
         const bool isRestore = cmdName == "restore-graph", isLint = cmdName == "lint-graph";
-        if (isMerge || isIntersect || isSubtract || isAnnotate || isDump || isRestore || isLint)
+        if (isMerge || isIntersect || isSubtract || isAnnotate || isDump || isRestore || isLint || isToKmerSet)
         {
             // GossCmdFactoryDumpKmerSet/DumpGraph::create (GossCmdDumpKmerSet.cc:58-73,
             // GossCmdDumpGraph.cc:64-79), GossCmdFactoryRestoreGraph::create (GossCmdRestoreGraph.cc:138-152),
@@ -1103,6 +1105,16 @@ int gossMain(int argc, char* argv[])
                 if (opts.count("input-file")) textName = opts.str("input-file");
                 chk.mandatoryOut("graph-out", outName);
             }
+            else if (isToKmerSet)
+            {
+                // GossCmdFactoryGraphToKmerSet::create (GossCmdGraphToKmerSet.cc:62-77)
+                if (!opts.count("graph-in")) { chk.errors += "mandatory option graph-in was not given.\n"; chk.suggestUsage = true; }
+                else if (opts.strs("graph-in").size() != 1)
+                { chk.errors += "mandatory option graph-in must be supplied exactly once.\n"; chk.suggestUsage = true; }
+                else ins = opts.strs("graph-in");
+                if (!opts.count("graph-out")) { chk.errors += "mandatory option graph-out was not given.\n"; chk.suggestUsage = true; }
+                else outName = opts.str("graph-out");
+            }
             else if (isAnnotate)
             {
                 if (!opts.count("graph-in")) { chk.errors += "mandatory option graph-in was not given.\n"; chk.suggestUsage = true; }
@@ -1138,6 +1150,7 @@ int gossMain(int argc, char* argv[])
                 else if (cmdName == "dump-graph") { GossCmdDumpGraph cmd(ins[0], textName); cmd(cxt); }
                 else if (isRestore) { GossCmdRestoreGraph cmd(textName, outName); cmd(cxt); }
                 else if (isLint) { GossCmdLintGraph cmd(ins[0], opts.count("dump-properties") != 0); cmd(cxt); }
+                else if (isToKmerSet) { GossCmdGraphToKmerSet cmd(ins[0], outName); cmd(cxt); }
                 else { GossCmdMergeAndAnnotateKmerSets cmd(ins[0], ins[1], outName); cmd(cxt); }
             }
             catch (Error& e) { e.cmd = cmdName; throw; }

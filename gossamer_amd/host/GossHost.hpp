@@ -190,6 +190,16 @@ private:
     const strings mIns; const std::string mOut;
 };
 
+// GossCmdGraphToKmerSet (GossCmdGraphToKmerSet.{hh,cc}): the normal-form edges of a graph as a
+// k-mer set of k = K + 1.
+class GossCmdGraphToKmerSet {
+public:
+    GossCmdGraphToKmerSet(const std::string& pIn, const std::string& pOut) : mIn(pIn), mOut(pOut) {}
+    void operator()(const GossCmdContext& pCxt);
+private:
+    const std::string mIn, mOut;
+};
+
 class GossCmdMergeAndAnnotateKmerSets {
 public:
     GossCmdMergeAndAnnotateKmerSets(const std::string& pLhs, const std::string& pRhs, const std::string& pOut)

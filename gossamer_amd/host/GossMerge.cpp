@@ -432,6 +432,41 @@ void GossCmdSubtractKmerSet::operator()(const GossCmdContext& pCxt)
     log(info, elapsed(t0));
 }
 
+// GossCmdGraphToKmerSet::operator() (GossCmdGraphToKmerSet.cc:30-59): every edge that is its own
+// normal form goes into a KmerSet::Builder(K + 1, out, fac, <edge count of the graph>).
+void GossCmdGraphToKmerSet::operator()(const GossCmdContext& pCxt)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    Logger& log = pCxt.log;
+    const ObjectInfo gi = objectInfo(mIn, true);
+    const uint64_t rho = gi.K + 1;
+    if (rho > 63) throw Error::General("unable to build a k-mer set with k=" + num(rho));
+    SparseFiles s;
+    openSparse(mIn + "-edges", s);
+    const uint64_t budget = pCxt.hbmBudget ? pCxt.hbmBudget : s.count * 24 * 6 + s.high.n + (4ULL << 30);
+    GpuCtx g;
+    g.check(goss_gpu_create(&g.h, pCxt.device, (uint32_t)rho, GOSS_MODE_KMER_SET, budget, nullptr), "creating the GPU context");
+    if (pCxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
+    log(info, "building (k+1)-mer set");
+    goss_gpu_sparse_run r{};
+    r.D = s.D; r.count = s.count;
+    r.high_bits = (const uint64_t*)s.high.p; r.high_words = s.high.n / 8;
+    r.ncols = (uint32_t)s.cols.size();
+    for (size_t i = 0; i < s.cols.size(); ++i)
+    {
+        r.col[i] = s.colFiles[i].p; r.col_bytes[i] = s.cols[i].bytes; r.col_shift[i] = s.cols[i].shift;
+    }
+    r.counts = nullptr;
+    r.weight = 1;
+    g.check(goss_gpu_push_run_sparse(g.h, &r), "reading the graph's edges");
+    goss_gpu_counts counts;
+    g.check(goss_gpu_finish(g.h, &counts), "reading the graph's edges");
+    g.check(goss_gpu_select_normal(g.h), "selecting the normal edges");
+    g.check(goss_gpu_emit_estimate(g.h, gi.count), "building the on-disk arrays");
+    writeOut(g, mOut);
+    log(info, elapsed(t0));
+}
+
 // GossCmdMergeAndAnnotateKmerSets::operator() (GossCmdMergeAndAnnotateKmerSets.cc:30-206): the
 // union of two k-mer sets built with the exact count, plus one membership bitmap per side.
 void GossCmdMergeAndAnnotateKmerSets::operator()(const GossCmdContext& pCxt)

@@ -203,6 +203,14 @@ int goss_gpu_emit_estimate(goss_gpu_ctx* ctx, uint64_t m_estimate);
 int goss_gpu_select_counts(goss_gpu_ctx* ctx, uint32_t lo, uint32_t hi);
 
 /*
+ * Between finish and emit: keep only the result items that are their own canonical form
+ * (edge_type::isNormal, RankSelect.hh:117-124); their counts become 1.  With the edges of a graph
+ * pushed into a k-mer-set context of k = K + 1 and goss_gpu_emit_estimate(<edge count>) this is
+ * graph-to-kmer-set (GossCmdGraphToKmerSet.cc:30-59).
+ */
+int goss_gpu_select_normal(goss_gpu_ctx* ctx);
+
+/*
  * After emit: append a file `suffix` holding one bit per result item, set where
  * (count & mask) != 0, in WordyBitVector layout -- the <out>.lhs-bits / <out>.rhs-bits
  * annotation of GossCmdMergeAndAnnotateKmerSets.cc:126-201 when the two sets were pushed with

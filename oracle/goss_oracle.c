@@ -1740,6 +1740,30 @@ int go_subtract_kmer_set(const go_fs* in, const char* lhs, const char* rhs, go_f
     return rc ? -1 : 0;
 }
 
+/* GossCmdGraphToKmerSet.cc:30-59: the edges ((K+1)-mers) of a graph that are their own normal
+ * form (edge_type::isNormal, RankSelect.hh:117-124: h(x) < h(rc), or equal hashes and rc >= x),
+ * as a KmerSet of k = K + 1 built with the graph's edge count as the size estimate (:45). */
+int go_graph_to_kmer_set(const go_fs* in, const char* graph, go_fs* outfs, const char* out_name, char* err, size_t errcap)
+{
+    uint64_t K = 0, z = 0;
+    merge_item a = {0};
+    if (merge_load(in, graph, 1, &K, &z, &a, err, errcap)) return -1;
+    const unsigned rho = (unsigned)K + 1;
+    go_key* keys = (go_key*)malloc((a.n ? a.n : 1) * sizeof(go_key));
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < a.n; ++i)
+    {
+        const go_key x = a.k[i], rc = go_revcomp(x, rho);
+        const uint64_t h0 = go_hash(x), h1 = go_hash(rc);
+        if (h0 < h1 || (h0 == h1 && k2u(rc) >= k2u(x))) keys[m++] = x;
+    }
+    int rc = go_write_kmer_set(outfs, out_name, rho, keys, m, z);
+    if (rc) snprintf(err, errcap, "write error");
+    free(keys);
+    merge_item_free(&a);
+    return rc ? -1 : 0;
+}
+
 /* GossCmdMergeAndAnnotateKmerSets.cc:30-206: union of two k-mer sets built with the exact count,
  * plus <out>.lhs-bits / <out>.rhs-bits (WordyBitVector, one bit per k-mer of the union).
  * stats = { lhs count, rhs count, common } (the line printed on stdout, :204). */

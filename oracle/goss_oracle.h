@@ -125,6 +125,8 @@ int go_intersect_kmer_sets(const go_fs* in, const char* const* names, size_t nin
                            char* err, size_t errcap);
 int go_subtract_kmer_set(const go_fs* in, const char* lhs, const char* rhs, go_fs* out, const char* out_name,
                          char* err, size_t errcap);
+/* GossCmdGraphToKmerSet.cc:30-59 */
+int go_graph_to_kmer_set(const go_fs* in, const char* graph, go_fs* outfs, const char* out_name, char* err, size_t errcap);
 int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_fs* out, const char* out_name,
                           uint64_t stats[3], char* err, size_t errcap);
 

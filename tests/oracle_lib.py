@@ -411,6 +411,17 @@ def subtract_kmer_set(files, lhs, rhs, out):
     return dst.files()
 
 
+def graph_to_kmer_set(files, graph, out):
+    L = lib()
+    L.go_graph_to_kmer_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    src = FileSet.from_files(files)
+    dst = FileSet()
+    err = C.create_string_buffer(1024)
+    if L.go_graph_to_kmer_set(src.handle, graph.encode(), dst.handle, out.encode(), err, 1024):
+        raise OracleError(err.value.decode())
+    return dst.files()
+
+
 def merge_and_annotate(files, lhs, rhs, out):
     """Returns (files, (lhs count, rhs count, common))."""
     L = lib()

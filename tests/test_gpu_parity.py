@@ -466,6 +466,44 @@ def test_goss_merge_commands(oracle, tmp_path):
     assert p.returncode == 1 and "must have the same kmer-size" in p.stderr.decode()
 
 
+def test_goss_graph_to_kmer_set(oracle, tmp_path):
+    """goss graph-to-kmer-set (GossCmdGraphToKmerSet.cc:30-59): graphs built by the product, their
+    normal edges selected on the device and written as a k-mer set of k + 1 sized with the edge
+    count -- every file equal to the oracle's, for one-word edges, edges that need two words as
+    k-mers of k + 1 = 32, and two-word edges."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    goss = os.path.join(root, "gossamer_amd", "goss")
+    rng = random.Random(47)
+    reads = make_reads(rng, 600, (60, 150), 30000)
+    reads.append("ACGT" * 30)
+    (tmp_path / "r.txt").write_text("\n".join(reads) + "\n")
+
+    def run(args):
+        return subprocess.run([goss] + args + ["--hbm-budget", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+    def disk(base):
+        return {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
+
+    for k in (27, 31, 55):
+        g_name, s_name = "g%d" % k, "s%d" % k
+        p = run(["build-graph", "-k", str(k), "--line-in", str(tmp_path / "r.txt"), "-O", str(tmp_path / g_name)])
+        assert p.returncode == 0, p.stderr.decode()
+        exp = oracle.graph_to_kmer_set(disk(g_name), g_name, s_name)
+        p = run(["graph-to-kmer-set", "-G", str(tmp_path / g_name), "-O", str(tmp_path / s_name), "-v"])
+        assert p.returncode == 0, p.stderr.decode()
+        assert "building (k+1)-mer set" in p.stderr.decode()
+        got = disk(s_name)
+        assert sorted(got) == sorted(exp), k
+        for name in exp:
+            assert got[name] == exp[name], (k, name)
+    p = run(["graph-to-kmer-set", "-O", str(tmp_path / "bad")])
+    assert p.returncode == 1 and "mandatory option graph-in was not given." in p.stderr.decode()
+    p = run(["graph-to-kmer-set", "-G", str(tmp_path / "nope"), "-O", str(tmp_path / "bad")])
+    assert p.returncode == 1
+
+
 def test_goss_set_algebra_commands(oracle, tmp_path):
     """goss intersect-kmer-sets / subtract-kmer-set / merge-and-annotate-kmer-sets on sets built by
     the product, every output file compared with the oracle's restatement of the reference loops

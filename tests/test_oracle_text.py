@@ -48,3 +48,26 @@ def test_dump_and_restore(oracle):
         oracle.restore_graph(b"#x\n3\t1\t0\nACNT\t1\n", "gr")
     with pytest.raises(oracle.OracleError, match="unexpected end of file"):
         oracle.restore_graph(b"#x\n21\t1", "gr")
+
+
+@pytest.mark.parametrize("k", [21, 31, 40])
+def test_graph_to_kmer_set_against_first_principles(oracle, k):
+    """A graph built from reads holds every (k+1)-mer and its reverse complement, so its normal
+    edges are exactly the canonical (k+1)-mers of the reads: graph-to-kmer-set of the graph must
+    hold the same k-mers as build-kmer-set with k+1 (the objects differ only in the SparseArray
+    size estimate: the graph's edge count against the exact count)."""
+    rng = random.Random(77)
+    genome = "".join(rng.choice("ACGT") for _ in range(3000))
+    reads = [genome[s:s + 90] for s in (rng.randrange(0, 2910) for _ in range(300))]
+    reads.append("ACGT" * 20)                    # palindromic (k+1)-mers: their own reverse complement
+    txt = "\n".join(reads) + "\n"
+    gr, _ = oracle.build_graph([(oracle.LINE, "r", txt)], k, out="gr")
+    ks = oracle.graph_to_kmer_set(gr, "gr", "ks")
+    direct, _ = oracle.build_kmer_set([(oracle.LINE, "r", txt)], k + 1, out="ks")
+    assert oracle.dump(ks, "ks", 0) == oracle.dump(direct, "ks", 0)
+    assert ks["ks.header"] == direct["ks.header"]
+    # the estimate is the number of edges, about twice the number of k-mers kept
+    import struct
+    n_edges = struct.unpack("<8Q", gr["gr-edges.header"])[7]
+    n_kept = struct.unpack("<QQQ", ks["ks.header"])[2]
+    assert n_kept <= n_edges <= 2 * n_kept
