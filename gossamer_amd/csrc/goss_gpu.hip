@@ -111,6 +111,8 @@ struct goss_gpu_ctx {
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
+    bool big_table = true;              // GOSS_GPU_NO_BIG_TABLE=1: never count 16-bit segments in the 8192-slot table
+    uint32_t big_table_chunks = 0;      // chunks counted that way
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
     uint64_t budget = 0;
@@ -533,13 +535,17 @@ template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; 
 template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
 
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits, bool big)
 {
-    hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
-                       rem_bits);
+    if (big)
+        hipLaunchKernelGGL(seg_hash_reduce_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so, seg_pos,
+                           seg_cnt, sk, sc, rem_bits);
+    else
+        hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
+                           rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, bool)
 {
     hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
 }
@@ -610,7 +616,7 @@ uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
 // permuted, in ka or kb (*in_b_out).
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg = nullptr,
-                   const uint64_t* seg_end = nullptr);
+                   const uint64_t* seg_end = nullptr, bool big = false);
 
 template <class K>
 int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, bool* in_b_out, Run* out)
@@ -636,7 +642,7 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
 // the bounds are found by binary search in the dense, partitioned array.
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
-                   const uint64_t* seg_end)
+                   const uint64_t* seg_end, bool big)
 {
     const uint32_t keybits = 2 * c->len;
     const uint32_t shift = keybits - segbits;
@@ -661,7 +667,7 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
                            (const K*)part, n, shift, nseg, seg_off);
         seg_beg = seg_off; seg_end = seg_off + 1;
     }
-    launch_seg_hash(c, nseg, (const K*)part, seg_beg, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift);
+    launch_seg_hash(c, nseg, (const K*)part, seg_beg, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift, big);
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -738,7 +744,7 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
 // of the input (the whole chunk when it is small), with 5 / 6 standard deviations of slack.
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
-                   const uint64_t* seg_end);
+                   const uint64_t* seg_end, bool big);
 
 // Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
@@ -862,7 +868,16 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const uint64_t limit = SegCfg<K>::kLimit;
     uint32_t segbits = kSegBits;
     while (segbits < (uint32_t)kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;
-    if ((m_est >> segbits) > limit || segbits + 8 > keybits) return decline("too many distinct keys per segment");
+    // one-word keys: between 3/4 of the small table and 3/4 of the big one per 16-bit segment, the
+    // two-level form with the big counting table saves the third partition digit
+    bool big_table = false;
+    if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && (m_est >> kSegBits) <= (uint64_t)kSegBigLimit * 3 / 4)
+    {
+        segbits = kSegBits;
+        big_table = true;
+    }
+    if ((m_est >> segbits) > (big_table ? (uint64_t)kSegBigLimit : limit) || segbits + 8 > keybits)
+        return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
     const uint32_t npass = (segbits + 7) / 8;
 
@@ -923,6 +938,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             if (c->debug) std::fprintf(stderr, "libgossgpu: sub-regions need %llu slots of %llu: one-level form\n",
                                        (unsigned long long)at, (unsigned long long)kb_slots);
+            if (big_table) return decline("sub-regions do not fit and the big table needs them");
             msd = false;
             // the one-level form partitions on the LOW digit: its marginal histogram
             std::fill(hh.begin(), hh.end(), 0ULL);
@@ -1080,9 +1096,15 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
         lap("second level");
-        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end);
-        if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
+        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end, big_table);
+        if (rc != 0)
+        {
+            c->segment_retries++;
+            if (big_table) c->big_table = false;           // this input is too skewed for it: three digits from now on
+            return decline("a segment table overflowed");
+        }
         c->fused_msd_chunks++;
+        if (big_table) c->big_table_chunks++;
     }
     else
     {
@@ -1128,7 +1150,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         }
         // src = partitioned keys (dense: npass >= 2), dst = spare
         c->arena.release(mark); release.m = c->arena.mark();
-        const int rc = segment_reduce<K>(c, src, dst, n, segbits, &r, nullptr, nullptr);
+        const int rc = segment_reduce<K>(c, src, dst, n, segbits, &r, nullptr, nullptr, false);
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
     }
     lap("segments counted");
@@ -1835,6 +1857,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_VALID_SIZING"); if (e && *e && *e != '0') c->size_by_valid = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }
@@ -2326,6 +2349,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
+    else if (n == "big_table_chunks") *value = c->big_table_chunks;
     else if (n == "valid_sized_chunks") *value = c->valid_sized_chunks;
     else if (n == "valid_resizes") *value = c->valid_resizes;
     else if (n == "seg_merges") *value = c->seg_merges;

@@ -55,6 +55,26 @@ __device__ __forceinline__ T block_excl_scan(T v, T* sh, T* total)
     return base + inc - v;
 }
 
+// The same for a workgroup of NW waves.
+template <class T, int NW>
+__device__ __forceinline__ T block_excl_scan_n(T v, T* sh, T* total)
+{
+    T inc = wave_incl_scan(v);
+    if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+    {
+        T s = sh[w];
+        if ((int)(threadIdx.x >> 6) > w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
 // --------------------------------------------------------------------------------------
 // device-wide exclusive scan of a u64 array (in place): reduce / scan partials / apply
 // --------------------------------------------------------------------------------------
@@ -1884,14 +1904,19 @@ struct SegOut {
     unsigned long long stage_cap;  // entries the staging area can take
 };
 
-__global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
-                                                              const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
-                                                              uint64_t* __restrict__ seg_cnt,
-                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                              uint32_t rem_bits)
+// NT threads per workgroup, a table of SLOTS slots (a power of two) taking SLOTS * 3 / 4 distinct keys.
+template <int NT, int SLOTS>
+__device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                     const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                     uint64_t* __restrict__ seg_cnt,
+                                                     Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                     uint32_t rem_bits)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long tab[kSegSlots];
-    __shared__ uint32_t cnt[kSegSlots];
+    constexpr int kLimit = SLOTS / 4 * 3;
+    constexpr int kBucketBits = SLOTS == 4096 ? 11 : SLOTS == 8192 ? 12 : SLOTS == 2048 ? 10 : -1;   // log2(SLOTS / 2)
+    static_assert(kBucketBits > 0 && SLOTS % NT == 0, "table size");
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS];
+    __shared__ uint32_t cnt[SLOTS];
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
@@ -1910,7 +1935,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
         return;
     }
     constexpr unsigned long long kEmpty = ~0ULL;
-    for (uint32_t i = tid; i < kSegSlots; i += kTB) { tab[i] = kEmpty; cnt[i] = 0; }
+    for (uint32_t i = tid; i < SLOTS; i += NT) { tab[i] = kEmpty; cnt[i] = 0; }
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
@@ -1925,10 +1950,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 #pragma unroll
     for (int u = 0; u < kSegUnroll; ++u)
     {
-        uint64_t i = b + (uint64_t)u * kTB + tid;
+        uint64_t i = b + (uint64_t)u * NT + tid;
         nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
     }
-    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kSegUnroll)
+    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kSegUnroll)
     {
         unsigned long long kv[kSegUnroll];
 #pragma unroll
@@ -1937,7 +1962,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
-            uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * kTB + tid;
+            uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * NT + tid;
             nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
         }
         // The table is probed in buckets of two adjacent slots (one 16-byte LDS read): at a load
@@ -1950,7 +1975,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
-            bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - 11));
+            bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - kBucketBits));
             const unsigned long long s0 = vt2[bkt[u]].x, s1 = vt2[bkt[u]].y;
             if (kv[u] != kEmpty)
             {
@@ -1960,7 +1985,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                 {
                     pend |= 1u << u;
                     // a full home bucket cannot take the key: start at the next one
-                    if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (kSegSlots / 2 - 1);
+                    if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (SLOTS / 2 - 1);
                 }
             }
         }
@@ -1993,13 +2018,13 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                     if (old == kEmpty)
                     {
                         uint32_t nd = atomicAdd(&ndist, 1u);
-                        if (nd + 1 > kSegLimit) *vovf = 1;
+                        if (nd + 1 > kLimit) *vovf = 1;
                         hit = slot;
                     }
                     else if (old == key) hit = slot;
                     // else: somebody else took the slot; look at this bucket again
                 }
-                else bk = (bk + 1) & (kSegSlots / 2 - 1);
+                else bk = (bk + 1) & (SLOTS / 2 - 1);
                 if (hit != ~0u) { atomicAdd(&cnt[hit], 1u); key = kEmpty; }
             }
             if (*vovf) break;
@@ -2016,13 +2041,13 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     // Order the occupied slots.  Every thread takes its 16 slots into registers (all reads happen
     // before any write), then the entries are bucket-sorted in place on the 10 bits below the
     // segment bits: rank inside the bucket by an LDS atomic, exclusive scan of the 1024 bucket
-    // sizes, scatter, and an insertion sort of every bucket (1.5 keys on average at kSegLimit/2).
+    // sizes, scatter, and an insertion sort of every bucket (1.5 keys on average at kLimit/2).
     // Five barriers instead of the 66 of a bitonic network over 2048 slots; a bucket with more
     // than 24 keys (skewed low bits) falls back to the bitonic sort of the compacted entries.
-    constexpr int kPer = kSegSlots / kTB;
-    constexpr int kBins = 1024, kBinsPer = kBins / kTB;
+    constexpr int kPer = SLOTS / NT;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kBucketBits - 1;
     __shared__ uint32_t bins[kBins];
-    __shared__ uint32_t sh_scan2[kWaves + 1];
+    __shared__ uint32_t sh_scan2[NT / 64 + 1];
     __shared__ uint32_t big;
     unsigned long long ck[kPer];
     uint32_t cc[kPer];
@@ -2032,10 +2057,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
         ck[j] = tab[tid * kPer + j];
         cc[j] = cnt[tid * kPer + j];
     }
-    for (uint32_t i = tid; i < kBins; i += kTB) bins[i] = 0;
+    for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
     if (tid == 0) big = 0;
     __syncthreads();
-    const uint32_t bsh = rem_bits > 10 ? rem_bits - 10 : 0;
+    const uint32_t bsh = rem_bits > (uint32_t)kBinBits ? rem_bits - kBinBits : 0;
     uint32_t rnk[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
@@ -2045,7 +2070,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
 #pragma unroll
     for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
     uint32_t tot_occ;
-    uint32_t at = block_excl_scan<uint32_t>(mine, sh_scan2, &tot_occ);
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
     volatile uint32_t* vbig = &big;
 #pragma unroll
     for (int q = 0; q < kBinsPer; ++q)
@@ -2084,14 +2109,14 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     {
         uint32_t nsort = 512;
         while (nsort < tot_occ) nsort <<= 1;
-        for (uint32_t i = tot_occ + tid; i < nsort; i += kTB) tab[i] = kEmpty;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += NT) tab[i] = kEmpty;
         __syncthreads();
         // bitonic sort of the first nsort (key,count) slots by key; empty slots (all ones) sort last
         for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
         {
             for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
             {
-                for (uint32_t t = tid; t < nsort / 2; t += kTB)
+                for (uint32_t t = tid; t < nsort / 2; t += NT)
                 {
                     uint32_t i = 2 * t - (t & (j - 1));       // element with bit j clear
                     uint32_t p = i + j;
@@ -2118,11 +2143,36 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
     __syncthreads();
     const uint64_t ob = sh_base;
     if (ob == ~0ULL) return;
-    for (uint32_t i = tid; i < d; i += kTB)
+    for (uint32_t i = tid; i < d; i += NT)
     {
         stage_keys[ob + i].lo = tab[i];
         stage_counts[ob + i] = cnt[i];
     }
+}
+
+
+__global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                              const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                              uint64_t* __restrict__ seg_cnt,
+                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                              uint32_t rem_bits)
+{
+    seg_hash_reduce_body<kTB, kSegSlots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+}
+
+// The same with one 1024-thread workgroup per CU and a table of 8192 slots (100 KB of LDS): segments
+// of up to 6144 distinct keys, i.e. 65 536 segments still do where the table above would need a
+// third partition digit (1.5e8 to 3e8 distinct keys in a chunk).
+constexpr int kSegBigThreads = 1024;
+constexpr int kSegBigSlots = 8192;
+constexpr int kSegBigLimit = kSegBigSlots / 4 * 3;
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_big_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                             const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                             uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                             Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                             uint32_t rem_bits)
+{
+    seg_hash_reduce_body<kSegBigThreads, kSegBigSlots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
 }
 
 // Two-word keys.  LDS has no 128-bit compare-and-swap, so a slot is claimed through its state
