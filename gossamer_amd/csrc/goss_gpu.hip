@@ -112,6 +112,8 @@ struct goss_gpu_ctx {
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
     bool big_table = true;              // GOSS_GPU_NO_BIG_TABLE=1: never count 16-bit segments in the 8192-slot table
+    int big_rounds_max = 2;             // GOSS_GPU_BIG_ROUNDS=<r>: at most 2^r workgroups share a segment of that form
+    int big_rounds_min = 0;             // GOSS_GPU_BIG_ROUNDS_MIN=<r>: at least 2^r (tests)
     uint32_t big_table_chunks = 0;      // chunks counted that way
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
@@ -535,17 +537,21 @@ template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; 
 template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
 
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits, bool big)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
-    if (big)
-        hipLaunchKernelGGL(seg_hash_reduce_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so, seg_pos,
-                           seg_cnt, sk, sc, rem_bits);
+    // big: 0 = the 4096-slot table; 1 + r = the 8192-slot table, every segment shared by 2^r workgroups
+    if (big > 1)
+        hipLaunchKernelGGL(seg_hash_reduce_shared_kernel, dim3(nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
+                           so, seg_pos, seg_cnt, sk, sc, rem_bits, (uint32_t)(big - 1));
+    else if (big)
+        hipLaunchKernelGGL(seg_hash_reduce_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
+                           so, seg_pos, seg_cnt, sk, sc, rem_bits, 0u);
     else
         hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
                            rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, bool)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, int)
 {
     hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
 }
@@ -616,7 +622,7 @@ uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
 // permuted, in ka or kb (*in_b_out).
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg = nullptr,
-                   const uint64_t* seg_end = nullptr, bool big = false);
+                   const uint64_t* seg_end = nullptr, int big = 0);
 
 template <class K>
 int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, bool* in_b_out, Run* out)
@@ -642,17 +648,18 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
 // the bounds are found by binary search in the dense, partitioned array.
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
-                   const uint64_t* seg_end, bool big)
+                   const uint64_t* seg_end, int big)
 {
     const uint32_t keybits = 2 * c->len;
     const uint32_t shift = keybits - segbits;
     const uint32_t nseg = 1u << segbits;
+    const uint32_t nunit = big > 1 ? nseg << (big - 1) : nseg;      // (segment, round) units of the staging area
     uint64_t mark = c->arena.mark();
     PhaseTimer t(c, GOSS_T_REDUCE, n);
     uint64_t* seg_off = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
-    uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
-    uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
-    uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+    uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nunit * 8);
+    uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nunit + 1) * 8);
+    uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nunit + 1) * 8);
     SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
     // staged (key,count) pairs share the spare key buffer: cap entries of keys, then the counts
     const uint64_t cap = n * sizeof(K) / (sizeof(K) + 4);
@@ -679,12 +686,12 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
         return why;
     }
     const uint64_t m = h->cursor;
-    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nseg * 8, hipMemcpyDeviceToDevice, c->stream));
-    exclusive_scan_u64(c, seg_dst, nseg);
+    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nunit * 8, hipMemcpyDeviceToDevice, c->stream));
+    exclusive_scan_u64(c, seg_dst, nunit);
     out->m = m;
     out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
     out->counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nunit), dim3(kTB), 0, c->stream,
                        (const K*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
                        (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)out->keys, out->counts);
     t.stop();
@@ -744,7 +751,7 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
 // of the input (the whole chunk when it is small), with 5 / 6 standard deviations of slack.
 template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
-                   const uint64_t* seg_end, bool big);
+                   const uint64_t* seg_end, int big);
 
 // Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
@@ -870,13 +877,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     while (segbits < (uint32_t)kSegBitsMax && (m_est >> segbits) > limit * 3 / 4) segbits += 4;
     // one-word keys: between 3/4 of the small table and 3/4 of the big one per 16-bit segment, the
     // two-level form with the big counting table saves the third partition digit
-    bool big_table = false;
-    if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && (m_est >> kSegBits) <= (uint64_t)kSegBigLimit * 3 / 4)
-    {
-        segbits = kSegBits;
-        big_table = true;
-    }
-    if ((m_est >> segbits) > (big_table ? (uint64_t)kSegBigLimit : limit) || segbits + 8 > keybits)
+    // (up to 4 workgroups sharing a segment, each counting the keys of one value of the next bits)
+    int big_table = 0;
+    if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && keybits >= (uint32_t)kSegBits + 8 + 2)
+        for (int r = std::max(0, c->big_rounds_min); r <= c->big_rounds_max; ++r)
+            if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
+    if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
     const uint32_t npass = (segbits + 7) / 8;
@@ -1858,6 +1864,8 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
+    { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }
+    { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS_MIN"); if (e && *e) c->big_rounds_min = std::min(3, std::max(0, std::atoi(e))); }
     { const char* e = std::getenv("GOSS_GPU_NO_VALID_SIZING"); if (e && *e && *e != '0') c->size_by_valid = false; }
     { const char* e = std::getenv("GOSS_GPU_FUSED_MIN"); if (e && *e) c->fused_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_FUSED_CAPSCALE"); if (e && *e) c->fused_capscale = std::atof(e); }

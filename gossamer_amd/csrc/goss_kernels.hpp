@@ -1905,13 +1905,17 @@ struct SegOut {
 };
 
 // NT threads per workgroup, a table of SLOTS slots (a power of two) taking SLOTS * 3 / 4 distinct keys.
-template <int NT, int SLOTS>
+template <int NT, int SLOTS, bool FILTER = false>
 __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                      const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                      uint64_t* __restrict__ seg_cnt,
                                                      Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                     uint32_t rem_bits)
+                                                     uint32_t rem_bits_all, uint32_t round_bits)
 {
+    // round_bits > 0: workgroup v = (segment, r) streams the whole segment but counts only the keys
+    // whose next round_bits bits equal r -- 2^round_bits workgroups share the reading of a segment
+    // that holds more distinct keys than one table takes; (segment, r) pairs are the units of the
+    // staging area and of the gather, in key order
     constexpr int kLimit = SLOTS / 4 * 3;
     constexpr int kBucketBits = SLOTS == 4096 ? 11 : SLOTS == 8192 ? 12 : SLOTS == 2048 ? 10 : -1;   // log2(SLOTS / 2)
     static_assert(kBucketBits > 0 && SLOTS % NT == 0, "table size");
@@ -1920,8 +1924,10 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const uint64_t b = seg_off[s], e = seg_end[s];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;          // unit (segment, round)
+    const uint32_t sseg = s >> round_bits, rnd = s & ((1u << round_bits) - 1u);
+    const uint32_t rem_bits = rem_bits_all - round_bits;       // key bits below the unit's prefix
+    const uint64_t b = seg_off[sseg], e = seg_end[sseg];
     if (b == e)
     {
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
@@ -1935,6 +1941,9 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
         return;
     }
     constexpr unsigned long long kEmpty = ~0ULL;
+    auto mine_only = [&](unsigned long long x) {
+        return (round_bits && (((uint32_t)(x >> rem_bits)) & ((1u << round_bits) - 1u)) != rnd) ? kEmpty : x;
+    };
     for (uint32_t i = tid; i < SLOTS; i += NT) { tab[i] = kEmpty; cnt[i] = 0; }
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
@@ -1957,7 +1966,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     {
         unsigned long long kv[kSegUnroll];
 #pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u) kv[u] = nxt[u];
+        for (int u = 0; u < kSegUnroll; ++u) kv[u] = mine_only(nxt[u]);
         // software pipeline: the next batch's loads are in flight while this one is inserted
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
@@ -1975,6 +1984,9 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
+            // FILTER (a segment shared by several workgroups): most keys of the batch belong to
+            // another workgroup -- no hash, no LDS read for them
+            if (FILTER && kv[u] == kEmpty) { bkt[u] = 0; continue; }
             bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - kBucketBits));
             const unsigned long long s0 = vt2[bkt[u]].x, s1 = vt2[bkt[u]].y;
             if (kv[u] != kEmpty)
@@ -2157,7 +2169,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce_kernel(const Key1* __rest
                                                               Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
                                                               uint32_t rem_bits)
 {
-    seg_hash_reduce_body<kTB, kSegSlots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+    seg_hash_reduce_body<kTB, kSegSlots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, 0u);
 }
 
 // The same with one 1024-thread workgroup per CU and a table of 8192 slots (100 KB of LDS): segments
@@ -2170,9 +2182,22 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_big_kernel(con
                                                                              const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                              uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
                                                                              Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                                             uint32_t rem_bits)
+                                                                             uint32_t rem_bits, uint32_t round_bits)
 {
-    seg_hash_reduce_body<kSegBigThreads, kSegBigSlots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+    (void)round_bits;
+    seg_hash_reduce_body<kSegBigThreads, kSegBigSlots, false>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, 0u);
+}
+
+// 2^round_bits workgroups per segment, each counting the keys of one value of the next round_bits
+// key bits: 16-bit segments of up to 4 x 4600 distinct keys (1.2e9 distinct keys in a chunk) without
+// a third partition digit, at the price of streaming every key 2^round_bits times.
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_shared_kernel(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                                const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                                uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                                Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                                uint32_t rem_bits, uint32_t round_bits)
+{
+    seg_hash_reduce_body<kSegBigThreads, kSegBigSlots, true>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, round_bits);
 }
 
 // Two-word keys.  LDS has no 128-bit compare-and-swap, so a slot is claimed through its state

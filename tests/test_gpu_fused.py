@@ -194,7 +194,8 @@ def test_big_counting_table_two_level_form():
     n, L, G = 4_600_000, 150, 170_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
-    for env in ({}, {"GOSS_GPU_NO_BIG_TABLE": "1"}):
+    # (and with 2 / 4 workgroups sharing every segment, each counting one value of the next 1 / 2 key bits)
+    for env in ({}, {"GOSS_GPU_NO_BIG_TABLE": "1"}, {"GOSS_GPU_BIG_ROUNDS_MIN": "1"}, {"GOSS_GPU_BIG_ROUNDS_MIN": "2"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -211,14 +212,16 @@ def test_big_counting_table_two_level_form():
         ctx.push_device(buf.data_ptr(), buf.numel())
         c = ctx.finish()
         assert ctx.stat("fused_chunks") == 1 and ctx.stat("segment_retries") == 0
-        assert ctx.stat("big_table_chunks") == (0 if env else 1)
-        assert ctx.stat("fused_msd_chunks") == (0 if env else 1)
+        plain = "GOSS_GPU_NO_BIG_TABLE" in env
+        assert ctx.stat("big_table_chunks") == (0 if plain else 1)
+        assert ctx.stat("fused_msd_chunks") == (0 if plain else 1)
         kp, cp, m = ctx.result_ptrs()
         assert 150_000_000 < m < 170_000_000
         res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
         ctx.close()
-    assert res[0][2] == res[1][2]
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert res[0][2] == other[2]
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
     assert bool((res[0][0][1:] > res[0][0][:-1]).all().item())
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
