@@ -15,6 +15,11 @@ namespace goss {
 constexpr int kTB = 256;           // threads per workgroup
 constexpr int kWaves = kTB / 64;
 
+// Volatile views of __shared__ arrays keep their address space: through a generic volatile
+// pointer the compiler emits FLAT loads and stores instead of ds_read / ds_write.
+typedef volatile __attribute__((address_space(3))) uint32_t* lds_vu32;
+typedef volatile __attribute__((address_space(3))) unsigned long long* lds_vu64;
+
 // --------------------------------------------------------------------------------------
 // wave / block primitives
 // --------------------------------------------------------------------------------------
@@ -1194,7 +1199,7 @@ __global__ __launch_bounds__(kTB) void radix_scatter_kernel(const K* __restrict_
         uint64_t peers = match_digit(d, valid);
         uint32_t before = __popcll(peers & lt_mask);
         uint32_t base = 0;
-        volatile uint32_t* wh = wave_hist[w];
+        lds_vu32 wh = (lds_vu32)wave_hist[w];
         if (valid) base = wh[d];
         // all reads of this round happen before the leader's update (same wave, in order)
         __builtin_amdgcn_wave_barrier();
@@ -1400,7 +1405,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
             uint64_t peers = match_digit(d, valid);
             uint32_t before = __popcll(peers & lt_mask);
             uint32_t base = 0;
-            volatile uint32_t* wh = wave_hist[w];
+            lds_vu32 wh = (lds_vu32)wave_hist[w];
             if (valid) base = wh[d];
             __builtin_amdgcn_wave_barrier();
             if (valid && before == 0) wh[d] = base + __popcll(peers);
@@ -1948,7 +1953,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
-    volatile uint32_t* vovf = &ovf;
+    lds_vu32 vovf = (lds_vu32)&ovf;
     // kSegUnroll independent coalesced loads are issued before the first insert so that
     // enough bytes are in flight per CU to cover the HBM latency
 #ifndef GOSS_SEG_UNROLL
@@ -1978,7 +1983,11 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
         // of ~0.4 a present key is almost always in its home bucket.
         // fast path: home buckets of all keys of the batch at once (independent LDS reads); a
         // key that is already there only needs its count bumped
-        const volatile ulonglong2* vt2 = reinterpret_cast<const volatile ulonglong2*>(tab);
+        // (an LDS-typed pointer to a 16-byte vector: one ds_read_b128; through a generic volatile
+        // pointer the compiler emits two 8-byte FLAT loads)
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+        typedef const volatile __attribute__((address_space(3))) ull2* lds_bucket_ptr;
+        const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
         uint32_t bkt[kSegUnroll];
         uint32_t pend = 0;
 #pragma unroll
@@ -1988,7 +1997,8 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
             // another workgroup -- no hash, no LDS read for them
             if (FILTER && kv[u] == kEmpty) { bkt[u] = 0; continue; }
             bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - kBucketBits));
-            const unsigned long long s0 = vt2[bkt[u]].x, s1 = vt2[bkt[u]].y;
+            const ull2 q01 = vt2[bkt[u]];
+            const unsigned long long s0 = q01.x, s1 = q01.y;
             if (kv[u] != kEmpty)
             {
                 if (s0 == kv[u]) atomicAdd(&cnt[2 * bkt[u]], 1u);
@@ -2019,7 +2029,8 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
             if (!__ballot(key != kEmpty)) break;
             if (key != kEmpty)
             {
-                const unsigned long long s0 = vt2[bk].x, s1 = vt2[bk].y;
+                const ull2 q01 = vt2[bk];
+                const unsigned long long s0 = q01.x, s1 = q01.y;
                 uint32_t hit = ~0u;                       // slot that holds (or now holds) the key
                 if (s0 == key) hit = 2 * bk;
                 else if (s1 == key) hit = 2 * bk + 1;
@@ -2083,7 +2094,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
     uint32_t tot_occ;
     uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
-    volatile uint32_t* vbig = &big;
+    lds_vu32 vbig = (lds_vu32)&big;
 #pragma unroll
     for (int q = 0; q < kBinsPer; ++q)
     {
@@ -2236,10 +2247,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
-    volatile uint32_t* vovf = &ovf;
-    volatile uint32_t* vst = st;
-    volatile unsigned long long* vlo = tlo;
-    volatile unsigned long long* vhi = thi;
+    lds_vu32 vovf = (lds_vu32)&ovf;
+    lds_vu32 vst = (lds_vu32)st;
+    lds_vu64 vlo = (lds_vu64)tlo;
+    lds_vu64 vhi = (lds_vu64)thi;
 #ifndef GOSS_SEG_UNROLL2
 #define GOSS_SEG_UNROLL2 4
 #endif
