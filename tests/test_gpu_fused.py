@@ -185,15 +185,16 @@ def test_key_buffers_sized_by_valid_windows():
         assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
-@pytest.mark.parametrize("n", [4_600_000, 4_200_000])
-def test_big_counting_table_two_level_form(n):
+def test_big_counting_table_two_level_form():
     """1.6e8 distinct k-mers in one chunk: more than 65 536 segments hold in the 4096-slot table
     (3/4 of 3072 each), fewer than the 8192-slot table of seg_hash_reduce_big_kernel takes -- the
     two-level form with the big table must give the keys and counts of the three-digit form.
-    4.6 M reads: regions sized from a sample; 4.2 M reads (634 M window starts): from the whole chunk."""
+    (The library estimates the key population, 1.72e8, from the repeats in a 4 M-key sample; repeats
+    come in clusters of overlapping reads, so the estimate scatters by ~3 %: the genome size sits
+    12 % inside both limits, 65 536 x 2304 and a third of the 5.8e8 keys.)"""
     import torch
     from gossamer_amd import dist as gd
-    L, G = 150, 170_000_000
+    n, L, G = 4_600_000, 150, 172_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
     # (and with 2 / 4 workgroups sharing every segment, each counting one value of the next 1 / 2 key bits)
@@ -218,7 +219,7 @@ def test_big_counting_table_two_level_form(n):
         assert ctx.stat("big_table_chunks") == (0 if plain else 1)
         assert ctx.stat("fused_msd_chunks") == (0 if plain else 1)
         kp, cp, m = ctx.result_ptrs()
-        assert 150_000_000 < m < 170_000_000
+        assert 150_000_000 < m < 172_000_000
         res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
         ctx.close()
     for other in res[1:]:
