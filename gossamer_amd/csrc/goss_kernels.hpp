@@ -1990,24 +1990,51 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
         const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
         uint32_t bkt[kSegUnroll];
         uint32_t pend = 0;
+        // The probes of half a batch are issued together (plain LDS loads: a stale miss only sends
+        // the key to the slow path, which reads the bucket again through the volatile view; keys are
+        // never removed, so there is no stale hit) and then consumed -- as volatile loads the
+        // compiler kept them in program order, one LDS round trip per key.
+        typedef const __attribute__((address_space(3))) ull2* lds_bucket_plain;
+        const lds_bucket_plain pt2 = (lds_bucket_plain)tab;
+        constexpr int kHalf = kSegUnroll / 2;
 #pragma unroll
-        for (int u = 0; u < kSegUnroll; ++u)
+        for (int h = 0; h < 2; ++h)
         {
-            // FILTER (a segment shared by several workgroups): most keys of the batch belong to
-            // another workgroup -- no hash, no LDS read for them
-            if (FILTER && kv[u] == kEmpty) { bkt[u] = 0; continue; }
-            bkt[u] = (uint32_t)((kv[u] * 0x9E3779B97F4A7C15ULL) >> (64 - kBucketBits));
-            const ull2 q01 = vt2[bkt[u]];
-            const unsigned long long s0 = q01.x, s1 = q01.y;
-            if (kv[u] != kEmpty)
+            ull2 q[kHalf];
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j)
             {
-                if (s0 == kv[u]) atomicAdd(&cnt[2 * bkt[u]], 1u);
-                else if (s1 == kv[u]) atomicAdd(&cnt[2 * bkt[u] + 1], 1u);
-                else
+                const int u = h * kHalf + j;
+                // one 32-bit multiply (a 64-bit one is three quarter-rate instructions): the high
+                // word, rotated, folded into the low one, times the golden ratio
+                const uint32_t klo = (uint32_t)kv[u], khi = (uint32_t)(kv[u] >> 32);
+                bkt[u] = ((klo ^ __builtin_rotateleft32(khi, 15)) * 0x9E3779B1u) >> (32 - kBucketBits);
+                q[j] = pt2[bkt[u]];
+            }
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j)
+            {
+                const int u = h * kHalf + j;
+                const unsigned long long s0 = q[j].x, s1 = q[j].y;
+                if (FILTER)
                 {
-                    pend |= 1u << u;
-                    // a full home bucket cannot take the key: start at the next one
-                    if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (SLOTS / 2 - 1);
+                    // most keys belong to another workgroup: one predicated atomic for a hit, one
+                    // bit for a miss (the slow path reads the home bucket again) -- measured faster
+                    // here, slower where every key is live
+                    const bool live = kv[u] != kEmpty, h0 = s0 == kv[u], h1 = s1 == kv[u];
+                    if (live && (h0 || h1)) atomicAdd(&cnt[2 * bkt[u] + (h1 ? 1u : 0u)], 1u);
+                    pend |= (live && !(h0 || h1)) ? (1u << u) : 0u;
+                }
+                else if (kv[u] != kEmpty)
+                {
+                    if (s0 == kv[u]) atomicAdd(&cnt[2 * bkt[u]], 1u);
+                    else if (s1 == kv[u]) atomicAdd(&cnt[2 * bkt[u] + 1], 1u);
+                    else
+                    {
+                        pend |= 1u << u;
+                        // a full home bucket cannot take the key: start at the next one
+                        if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (SLOTS / 2 - 1);
+                    }
                 }
             }
         }
