@@ -2307,11 +2307,36 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
 #pragma unroll
         for (int u = 0; u < kU; ++u)
         {
+            slots[u] = 0;
             if (kv[u].hi != ~0ULL)
             {
                 uint64_t h = (kv[u].lo ^ (kv[u].hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
                 slots[u] = (uint32_t)(h >> (64 - 11));
-                pend |= 1u << u;
+            }
+        }
+        // fast path: the home slots of the whole batch are read together (plain LDS loads, the
+        // states before the keys: a slot whose state shows a count was published with its key, and
+        // keys never change afterwards); a key found there only needs its count bumped.  Everything
+        // else -- empty, locked, another key, or a state that was not there yet -- goes through the
+        // state machine below, which reads through the volatile views.
+        {
+            typedef const __attribute__((address_space(3))) uint32_t* lds_u32_plain;
+            typedef const __attribute__((address_space(3))) unsigned long long* lds_u64_plain;
+            const lds_u32_plain pst = (lds_u32_plain)st;
+            const lds_u64_plain plo = (lds_u64_plain)tlo, phi = (lds_u64_plain)thi;
+            uint32_t fs[kU];
+            unsigned long long fl[kU], fh[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) fs[u] = pst[slots[u]];
+            asm volatile("" ::: "memory");           // the compiler keeps the states ahead of the keys; the LDS runs a wave's operations in order
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { fl[u] = plo[slots[u]]; fh[u] = phi[slots[u]]; }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+            {
+                if (kv[u].hi == ~0ULL) continue;
+                if (fs[u] != 0u && fs[u] != kSegLock && fl[u] == kv[u].lo && fh[u] == kv[u].hi) atomicAdd(&st[slots[u]], 1u);
+                else pend |= 1u << u;
             }
         }
         Key2 key{0, 0};
