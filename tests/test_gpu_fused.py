@@ -185,6 +185,43 @@ def test_key_buffers_sized_by_valid_windows():
         assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
+def test_valid_window_estimate_too_low_and_no_room_for_full_buffers():
+    """Runs of N make the estimate of the valid windows far too low; the arena (9 GB) holds the
+    small buffers of one big chunk but not full-size ones: the chunk must be redone in pieces --
+    same keys and counts as with a roomy arena and the sizing off."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 4_600_000, 150, 5_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for env, budget in (({}, 9 << 30), ({"GOSS_GPU_NO_VALID_SIZING": "1"}, 24 << 30)):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=budget)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=34)
+            blocks = buf[: (buf.numel() >> 20) << 20].view(-1, 1 << 20)
+            blocks[:, : 300 << 10] = ord("N")
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        if not env:
+            assert ctx.stat("valid_resizes") >= 1 and ctx.stat("valid_sized_chunks") == 0
+        kp, cp, m = ctx.result_ptrs()
+        res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
+
+
 def test_big_counting_table_two_level_form():
     """1.6e8 distinct k-mers in one chunk: more than 65 536 segments hold in the 4096-slot table
     (3/4 of 3072 each), fewer than the 8192-slot table of seg_hash_reduce_big_kernel takes -- the
