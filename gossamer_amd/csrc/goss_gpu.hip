@@ -551,9 +551,13 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, co
                            rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, int)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, int big)
 {
-    hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
+    if (big)
+        hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so, seg_pos,
+                           seg_cnt, sk, sc);
+    else
+        hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
 }
 
 // Number of distinct keys in the chunk, estimated from its first keys (reads arrive in no
@@ -882,6 +886,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && keybits >= (uint32_t)kSegBits + 8 + 2)
         for (int r = std::max(0, c->big_rounds_min); r <= c->big_rounds_max; ++r)
             if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
+    // two-word keys: the 4096-slot table, one workgroup per segment only
+    if (!kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && (m_est >> kSegBits) <= (uint64_t)kSegBigLimit2 * 3 / 4)
+    {
+        segbits = kSegBits;
+        big_table = 1;
+    }
     if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;

@@ -2245,14 +2245,18 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_shared_kernel(
 // by which time the owner (which needs no other lane to make progress) has published.
 constexpr uint32_t kSegLock = 0x80000000u;
 
-__global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
-                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
-                                                               uint64_t* __restrict__ seg_cnt,
-                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+template <int NT, int SLOTS>
+__device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                      const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                      uint64_t* __restrict__ seg_cnt,
+                                                      Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
 {
-    __shared__ unsigned long long tlo[kSegSlots2];
-    __shared__ unsigned long long thi[kSegSlots2];
-    __shared__ uint32_t st[kSegSlots2];
+    constexpr int kLimit = SLOTS / 4 * 3;
+    constexpr int kSlotBits = SLOTS == 2048 ? 11 : SLOTS == 4096 ? 12 : -1;
+    static_assert(kSlotBits > 0 && SLOTS % NT == 0, "table size");
+    __shared__ unsigned long long tlo[SLOTS];
+    __shared__ unsigned long long thi[SLOTS];
+    __shared__ uint32_t st[SLOTS];
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
@@ -2270,7 +2274,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
         if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    for (uint32_t i = tid; i < kSegSlots2; i += kTB) st[i] = 0;
+    for (uint32_t i = tid; i < SLOTS; i += NT) st[i] = 0;
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
@@ -2288,10 +2292,10 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
 #pragma unroll
     for (int u = 0; u < kU; ++u)
     {
-        uint64_t i = b + (uint64_t)u * kTB + tid;
+        uint64_t i = b + (uint64_t)u * NT + tid;
         nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
     }
-    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kTB * kU)
+    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kU)
     {
         Key2 kv[kU];
         uint32_t slots[kU];
@@ -2301,7 +2305,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
 #pragma unroll
         for (int u = 0; u < kU; ++u)
         {
-            uint64_t i = i0 + (uint64_t)(kU + u) * kTB + tid;
+            uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
             nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
         }
 #pragma unroll
@@ -2311,7 +2315,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
             if (kv[u].hi != ~0ULL)
             {
                 uint64_t h = (kv[u].lo ^ (kv[u].hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
-                slots[u] = (uint32_t)(h >> (64 - 11));
+                slots[u] = (uint32_t)(h >> (64 - kSlotBits));
             }
         }
         // fast path: the home slots of the whole batch are read together (plain LDS loads, the
@@ -2366,7 +2370,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
                         vhi[slot] = key.hi;
                         vst[slot] = 1u;                      // publish (LDS ops of a lane are in order)
                         uint32_t nd = atomicAdd(&ndist, 1u);
-                        if (nd + 1 > kSegLimit2) *vovf = 1;
+                        if (nd + 1 > kLimit) *vovf = 1;
                         have = false;
                     }
                     // else: look at this slot again next iteration
@@ -2374,7 +2378,7 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
                 else if (state != kSegLock)
                 {
                     if (vlo[slot] == key.lo && vhi[slot] == key.hi) { atomicAdd(&st[slot], 1u); have = false; }
-                    else slot = (slot + 1) & (kSegSlots2 - 1);
+                    else slot = (slot + 1) & (SLOTS - 1);
                 }
             }
             if (*vovf) break;
@@ -2391,8 +2395,8 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     // all write) and sort only the next power of two above the number of distinct keys: a segment
     // of a high-coverage input holds far fewer keys than the table has slots.  Empty slots sort
     // last: hi = all ones is never a key (2*len <= 126 bits).
-    constexpr int kPer2 = kSegSlots2 / kTB;
-    __shared__ uint32_t sh_scan2[kWaves + 1];
+    constexpr int kPer2 = SLOTS / NT;
+    __shared__ uint32_t sh_scan2[NT / 64 + 1];
     unsigned long long cl[kPer2], ch[kPer2];
     uint32_t cs[kPer2];
     uint32_t mine = 0;
@@ -2403,20 +2407,20 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
         mine += cs[j] != 0 ? 1u : 0u;
     }
     uint32_t tot_occ;
-    uint32_t at = block_excl_scan<uint32_t>(mine, sh_scan2, &tot_occ);      // syncs: every slot has been read
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);      // syncs: every slot has been read
     uint32_t nsort = 64;
     while (nsort < tot_occ) nsort <<= 1;
 #pragma unroll
     for (int j = 0; j < kPer2; ++j)
         if (cs[j] != 0) { tlo[at] = cl[j]; thi[at] = ch[j]; st[at] = cs[j]; ++at; }
     __syncthreads();
-    for (uint32_t i = tot_occ + tid; i < nsort; i += kTB) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
+    for (uint32_t i = tot_occ + tid; i < nsort; i += NT) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
     __syncthreads();
     for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
     {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
         {
-            for (uint32_t t = tid; t < nsort / 2; t += kTB)
+            for (uint32_t t = tid; t < nsort / 2; t += NT)
             {
                 uint32_t i = 2 * t - (t & (j - 1));
                 uint32_t p = i + j;
@@ -2443,11 +2447,31 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
     __syncthreads();
     const uint64_t ob = sh_base;
     if (ob == ~0ULL) return;
-    for (uint32_t i = tid; i < d; i += kTB)
+    for (uint32_t i = tid; i < d; i += NT)
     {
         stage_keys[ob + i] = Key2{tlo[i], thi[i]};
         stage_counts[ob + i] = st[i];
     }
+}
+
+__global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                               uint64_t* __restrict__ seg_cnt,
+                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+{
+    seg_hash_reduce2_body<kTB, kSegSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+}
+
+// One 1024-thread workgroup per CU and 4096 slots (80 KB of LDS): 16-bit segments of up to 2 300
+// distinct two-word keys keep the two-level form (see seg_hash_reduce_big_kernel).
+constexpr int kSegBigSlots2 = 4096;
+constexpr int kSegBigLimit2 = kSegBigSlots2 / 4 * 3;
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce2_big_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                              const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                              uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                              Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+{
+    seg_hash_reduce2_body<kSegBigThreads, kSegBigSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts);
 }
 
 // --------------------------------------------------------------------------------------
