@@ -551,11 +551,11 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, co
                            rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
-                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t, int big)
+                            SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
     if (big)
-        hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so, seg_pos,
-                           seg_cnt, sk, sc);
+        hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, dim3(nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
+                           seg_pos, seg_cnt, sk, sc, rem_bits, (uint32_t)(big - 1));
     else
         hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
 }
@@ -886,12 +886,11 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && keybits >= (uint32_t)kSegBits + 8 + 2)
         for (int r = std::max(0, c->big_rounds_min); r <= c->big_rounds_max; ++r)
             if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
-    // two-word keys: the 4096-slot table, one workgroup per segment only
-    if (!kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && (m_est >> kSegBits) <= (uint64_t)kSegBigLimit2 * 3 / 4)
-    {
-        segbits = kSegBits;
-        big_table = 1;
-    }
+    // two-word keys: the 4096-slot table, up to two workgroups per segment (a pass over 16-byte
+    // keys costs more than one over 8-byte keys)
+    if (!kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits)
+        for (int r = std::max(0, c->big_rounds_min); r <= std::min(1, c->big_rounds_max); ++r)
+            if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit2 * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
     if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;

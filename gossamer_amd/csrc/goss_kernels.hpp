@@ -2249,8 +2249,11 @@ template <int NT, int SLOTS>
 __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                       const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                       uint64_t* __restrict__ seg_cnt,
-                                                      Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+                                                      Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                      uint32_t rem_bits_all = 0, uint32_t round_bits = 0)
 {
+    // round_bits > 0: unit (segment, r) as in seg_hash_reduce_body -- 2^round_bits workgroups stream
+    // the segment, each counting the keys whose next round_bits bits equal r
     constexpr int kLimit = SLOTS / 4 * 3;
     constexpr int kSlotBits = SLOTS == 2048 ? 11 : SLOTS == 4096 ? 12 : -1;
     static_assert(kSlotBits > 0 && SLOTS % NT == 0, "table size");
@@ -2261,7 +2264,9 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const uint64_t b = seg_off[s], e = seg_end[s];
+    const uint32_t sseg = s >> round_bits, rnd = s & ((1u << round_bits) - 1u);
+    const uint32_t rsh = rem_bits_all - round_bits;            // position of the round bits in the key
+    const uint64_t b = seg_off[sseg], e = seg_end[sseg];
     if (b == e)
     {
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
@@ -2301,7 +2306,11 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
         uint32_t slots[kU];
         uint32_t pend = 0;
 #pragma unroll
-        for (int u = 0; u < kU; ++u) kv[u] = nxt[u];
+        for (int u = 0; u < kU; ++u)
+        {
+            kv[u] = nxt[u];
+            if (round_bits && ((uint32_t)key_shr64(kv[u], rsh) & ((1u << round_bits) - 1u)) != rnd) kv[u].hi = ~0ULL;   // another workgroup's key
+        }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
         {
@@ -2469,9 +2478,10 @@ constexpr int kSegBigLimit2 = kSegBigSlots2 / 4 * 3;
 __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce2_big_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                               uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
-                                                                              Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+                                                                              Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                              uint32_t rem_bits, uint32_t round_bits)
 {
-    seg_hash_reduce2_body<kSegBigThreads, kSegBigSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+    seg_hash_reduce2_body<kSegBigThreads, kSegBigSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, round_bits);
 }
 
 // --------------------------------------------------------------------------------------

@@ -269,13 +269,14 @@ def test_big_counting_table_two_level_form():
 def test_big_counting_table_two_word_keys():
     """k = 45, 1.1e8 distinct two-word k-mers in one chunk: more than 65 536 segments of the
     2048-slot table take with margin (1152 each), fewer than seg_hash_reduce2_big_kernel's 4096
-    slots do -- the two-level form with the big table against the three-digit form."""
+    slots do -- the two-level form with the big table (also with two workgroups sharing every
+    segment) against the three-digit form."""
     import torch
     from gossamer_amd import dist as gd
     n, L, G = 4_600_000, 150, 110_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
-    for env in ({}, {"GOSS_GPU_NO_BIG_TABLE": "1"}):
+    for env in ({}, {"GOSS_GPU_NO_BIG_TABLE": "1"}, {"GOSS_GPU_BIG_ROUNDS_MIN": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -293,14 +294,16 @@ def test_big_counting_table_two_word_keys():
         c = ctx.finish()
         assert c.key_words == 2
         assert ctx.stat("fused_chunks") == 1 and ctx.stat("segment_retries") == 0
-        assert ctx.stat("big_table_chunks") == (0 if env else 1)
-        assert ctx.stat("fused_msd_chunks") == (0 if env else 1)
+        plain = "GOSS_GPU_NO_BIG_TABLE" in env
+        assert ctx.stat("big_table_chunks") == (0 if plain else 1)
+        assert ctx.stat("fused_msd_chunks") == (0 if plain else 1)
         kp, cp, m = ctx.result_ptrs()
         assert 100_000_000 < m < 110_000_000
         res.append((gd.key_view(kp, m, 2, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
         ctx.close()
-    assert res[0][2] == res[1][2]
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert res[0][2] == other[2]
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
