@@ -2288,7 +2288,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     lds_vu64 vlo = (lds_vu64)tlo;
     lds_vu64 vhi = (lds_vu64)thi;
 #ifndef GOSS_SEG_UNROLL2
-#define GOSS_SEG_UNROLL2 4
+#define GOSS_SEG_UNROLL2 8
 #endif
     constexpr int kU = GOSS_SEG_UNROLL2;
     // software pipeline: the next batch's loads are in flight while this one is inserted
