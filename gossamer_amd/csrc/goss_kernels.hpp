@@ -2323,8 +2323,12 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
             slots[u] = 0;
             if (kv[u].hi != ~0ULL)
             {
-                uint64_t h = (kv[u].lo ^ (kv[u].hi * 0xD6E8FEB86659FD93ULL)) * 0x9E3779B97F4A7C15ULL;
-                slots[u] = (uint32_t)(h >> (64 - kSlotBits));
+                // one 32-bit multiply: the four words rotated against each other and folded (two
+                // 64-bit multiplies are seven quarter-rate instructions)
+                const uint32_t w0 = (uint32_t)kv[u].lo, w1 = (uint32_t)(kv[u].lo >> 32);
+                const uint32_t w2 = (uint32_t)kv[u].hi, w3 = (uint32_t)(kv[u].hi >> 32);
+                const uint32_t f = w0 ^ __builtin_rotateleft32(w1, 15) ^ __builtin_rotateleft32(w2, 7) ^ __builtin_rotateleft32(w3, 23);
+                slots[u] = (f * 0x9E3779B1u) >> (32 - kSlotBits);
             }
         }
         // fast path: the home slots of the whole batch are read together (plain LDS loads, the
