@@ -536,28 +536,44 @@ template <class K> struct SegCfg;
 template <> struct SegCfg<Key1> { static constexpr uint64_t kLimit = kSegLimit; };
 template <> struct SegCfg<Key2> { static constexpr uint64_t kLimit = kSegLimit2; };
 
+// Grid of `units` workgroups for the kernels that number their workgroup with unit_block(): x up
+// to 2^20, the rest in y (units is a power of two above that).  HIP refuses gridDim.x * blockDim.x
+// >= 2^32 -- and a refused launch leaves the output counters at zero, which reads as "no keys".
+inline dim3 unit_grid(uint64_t units)
+{
+    const uint64_t kx = 1u << 20;
+    if (units <= kx) return dim3((uint32_t)std::max<uint64_t>(units, 1));
+    return dim3((uint32_t)kx, (uint32_t)((units + kx - 1) / kx));
+}
+inline void check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)};
+}
+
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
                             SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key1* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
     // big: 0 = the 4096-slot table; 1 + r = the 8192-slot table, every segment shared by 2^r workgroups
     if (big > 1)
-        hipLaunchKernelGGL(seg_hash_reduce_shared_kernel, dim3(nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
+        hipLaunchKernelGGL(seg_hash_reduce_shared_kernel, unit_grid((uint64_t)nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
                            so, seg_pos, seg_cnt, sk, sc, rem_bits, (uint32_t)(big - 1));
     else if (big)
-        hipLaunchKernelGGL(seg_hash_reduce_big_kernel, dim3(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
+        hipLaunchKernelGGL(seg_hash_reduce_big_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end,
                            so, seg_pos, seg_cnt, sk, sc, rem_bits, 0u);
     else
-        hipLaunchKernelGGL(seg_hash_reduce_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
+        hipLaunchKernelGGL(seg_hash_reduce_kernel, unit_grid(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
                            rem_bits);
 }
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
                             SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
     if (big)
-        hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, dim3(nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
+        hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, unit_grid((uint64_t)nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
                            seg_pos, seg_cnt, sk, sc, rem_bits, (uint32_t)(big - 1));
     else
-        hipLaunchKernelGGL(seg_hash_reduce2_kernel, dim3(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc);
+        hipLaunchKernelGGL(seg_hash_reduce2_kernel, unit_grid(nseg), dim3(kTB), 0, c->stream, keys, seg_off, seg_end, so, seg_pos, seg_cnt, sk, sc,
+                           rem_bits);
 }
 
 // Number of distinct keys in the chunk, estimated from its first keys (reads arrive in no
@@ -679,6 +695,7 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
         seg_beg = seg_off; seg_end = seg_off + 1;
     }
     launch_seg_hash(c, nseg, (const K*)part, seg_beg, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, shift, big);
+    check_launch("segment counting kernel");
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -695,7 +712,7 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     out->m = m;
     out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
     out->counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nunit), dim3(kTB), 0, c->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), unit_grid(nunit), dim3(kTB), 0, c->stream,
                        (const K*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
                        (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)out->keys, out->counts);
     t.stop();
@@ -726,6 +743,8 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
             {
                 if ((m_est >> segbits) > limit) continue;
                 int rc = segment_count<K>(c, ka, kb, n, segbits, &in_b, &r);
+                if (c->debug) std::fprintf(stderr, "libgossgpu: count_keys: %llu keys, %u segment bits -> %d (%llu distinct)\n",
+                                           (unsigned long long)n, segbits, rc, (unsigned long long)(rc == 0 ? r.m : 0));
                 if (rc == 0) return r;
                 if (rc == 2) break;
                 c->segment_retries++;
@@ -738,6 +757,7 @@ Run count_keys(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n)
     PhaseTimer t(c, GOSS_T_REDUCE, n);
     r = reduce_runs<K>(c, moved ? dst : src, nullptr, n, moved ? src : dst);
     t.stop();
+    if (c->debug) std::fprintf(stderr, "libgossgpu: count_keys: full sort of %llu keys -> %llu distinct\n", (unsigned long long)n, (unsigned long long)r.m);
     return r;
 }
 
@@ -1321,7 +1341,7 @@ void merge_runs(goss_gpu_ctx* c)
             SegOut hso{};
             hso.stage_cap = total;
             HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_merge_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream, (const K*)ka, (const uint32_t*)va,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_merge_kernel<K>), unit_grid(nseg), dim3(kTB), 0, c->stream, (const K*)ka, (const uint32_t*)va,
                                (const uint64_t*)d_off, (const uint64_t*)bounds, nruns, nseg, so, seg_pos, seg_cnt, kb, vb, c->d_flags);
             SegOut* h = (SegOut*)c->h_pinned;
             HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
@@ -1333,7 +1353,7 @@ void merge_runs(goss_gpu_ctx* c)
             Run r{nullptr, nullptr, m};
             r.keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
             r.counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), dim3(nseg), dim3(kTB), 0, c->stream,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), unit_grid(nseg), dim3(kTB), 0, c->stream,
                                (const K*)kb, (const uint32_t*)vb, (const uint64_t*)seg_pos,
                                (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)r.keys, r.counts);
             t.stop();
@@ -1797,6 +1817,9 @@ int guarded(goss_gpu_ctx* c, F&& f)
     {
         if (c) HIP_TRY(hipSetDevice(c->device));
         f();
+        // a refused kernel launch raises no exception by itself and leaves its outputs untouched:
+        // no entry point returns success over one
+        check_launch("a kernel launch was refused");
         return GOSS_OK;
     }
     catch (const HipError& e)

@@ -26,6 +26,10 @@ typedef volatile __attribute__((address_space(3))) unsigned long long* lds_vu64;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+// Kernels with one workgroup per segment are launched on a (x, y) grid (unit_grid in goss_gpu.hip):
+// HIP refuses a launch whose gridDim.x * blockDim.x reaches 2^32, which 2^24 segments of 256
+// threads do.  The workgroup's unit number:
+__device__ __forceinline__ uint32_t unit_block() { return blockIdx.y * gridDim.x + blockIdx.x; }
 
 template <class T>
 __device__ __forceinline__ T wave_incl_scan(T v)
@@ -1929,7 +1933,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;          // unit (segment, round)
+    const uint32_t s = unit_block(), tid = threadIdx.x;        // unit (segment, round)
     const uint32_t sseg = s >> round_bits, rnd = s & ((1u << round_bits) - 1u);
     const uint32_t rem_bits = rem_bits_all - round_bits;       // key bits below the unit's prefix
     const uint64_t b = seg_off[sseg], e = seg_end[sseg];
@@ -2250,7 +2254,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
                                                       const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                       uint64_t* __restrict__ seg_cnt,
                                                       Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                      uint32_t rem_bits_all = 0, uint32_t round_bits = 0)
+                                                      uint32_t rem_bits_all, uint32_t round_bits)
 {
     // round_bits > 0: unit (segment, r) as in seg_hash_reduce_body -- 2^round_bits workgroups stream
     // the segment, each counting the keys whose next round_bits bits equal r
@@ -2263,7 +2267,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     __shared__ uint32_t ndist;
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t s = unit_block(), tid = threadIdx.x;
     const uint32_t sseg = s >> round_bits, rnd = s & ((1u << round_bits) - 1u);
     const uint32_t rsh = rem_bits_all - round_bits;            // position of the round bits in the key
     const uint64_t b = seg_off[sseg], e = seg_end[sseg];
@@ -2404,49 +2408,103 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
         if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    // Compact the occupied slots to the front (every thread takes its 8 slots into registers, then
-    // all write) and sort only the next power of two above the number of distinct keys: a segment
-    // of a high-coverage input holds far fewer keys than the table has slots.  Empty slots sort
-    // last: hi = all ones is never a key (2*len <= 126 bits).
+    // Order the occupied slots as the one-word kernel does: every thread takes its slots into
+    // registers (all reads before any write), the entries are bucket-sorted in place on the key bits
+    // just below the unit's prefix -- rank inside the bucket by an LDS atomic, exclusive scan of the
+    // bucket sizes, scatter, insertion sort of every bucket -- and only a bucket above 24 keys (skewed
+    // bits) sends the compacted entries through the bitonic network (66 barriers for 2048 of them).
     constexpr int kPer2 = SLOTS / NT;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kSlotBits - 2;
+    static_assert(kBins % NT == 0, "bins per thread");
+    __shared__ uint32_t bins[kBins];
     __shared__ uint32_t sh_scan2[NT / 64 + 1];
+    __shared__ uint32_t big;
     unsigned long long cl[kPer2], ch[kPer2];
     uint32_t cs[kPer2];
-    uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < kPer2; ++j)
     {
         cl[j] = tlo[tid * kPer2 + j]; ch[j] = thi[tid * kPer2 + j]; cs[j] = st[tid * kPer2 + j];
-        mine += cs[j] != 0 ? 1u : 0u;
     }
-    uint32_t tot_occ;
-    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);      // syncs: every slot has been read
-    uint32_t nsort = 64;
-    while (nsort < tot_occ) nsort <<= 1;
+    for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
+    if (tid == 0) big = 0;
+    __syncthreads();
+    const uint32_t rem_unit = rem_bits_all - round_bits;
+    const uint32_t bsh = rem_unit > (uint32_t)kBinBits ? rem_unit - kBinBits : 0;
+    uint32_t rnk[kPer2], bin[kPer2];
 #pragma unroll
     for (int j = 0; j < kPer2; ++j)
-        if (cs[j] != 0) { tlo[at] = cl[j]; thi[at] = ch[j]; st[at] = cs[j]; ++at; }
-    __syncthreads();
-    for (uint32_t i = tot_occ + tid; i < nsort; i += NT) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
-    __syncthreads();
-    for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
-    {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+        if (cs[j] != 0)
         {
-            for (uint32_t t = tid; t < nsort / 2; t += NT)
+            bin[j] = (uint32_t)key_shr64(Key2{cl[j], ch[j]}, bsh) & (kBins - 1);
+            rnk[j] = atomicAdd(&bins[bin[j]], 1u);
+        }
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
+    lds_vu32 vbig = (lds_vu32)&big;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        if (bn[q] > 24) *vbig = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer2; ++j)
+        if (cs[j] != 0)
+        {
+            const uint32_t pos = bins[bin[j]] + rnk[j];
+            tlo[pos] = cl[j]; thi[pos] = ch[j]; st[pos] = cs[j];
+        }
+    __syncthreads();
+    if (!big)
+    {
+#pragma unroll
+        for (int q = 0; q < kBinsPer; ++q)
+            for (uint32_t i = 1; i < bn[q]; ++i)
             {
-                uint32_t i = 2 * t - (t & (j - 1));
-                uint32_t p = i + j;
-                bool up = (i & k2) == 0;
-                unsigned long long ah = thi[i], al = tlo[i], bh = thi[p], bl = tlo[p];
-                bool gt = ah > bh || (ah == bh && al > bl);
-                if (gt == up)
+                const unsigned long long kl = tlo[bs[q] + i], kh = thi[bs[q] + i];
+                const uint32_t vv = st[bs[q] + i];
+                uint32_t j = i;
+                while (j > 0 && (thi[bs[q] + j - 1] > kh || (thi[bs[q] + j - 1] == kh && tlo[bs[q] + j - 1] > kl)))
                 {
-                    thi[i] = bh; tlo[i] = bl; thi[p] = ah; tlo[p] = al;
-                    uint32_t ca = st[i]; st[i] = st[p]; st[p] = ca;
+                    tlo[bs[q] + j] = tlo[bs[q] + j - 1]; thi[bs[q] + j] = thi[bs[q] + j - 1]; st[bs[q] + j] = st[bs[q] + j - 1];
+                    --j;
                 }
+                tlo[bs[q] + j] = kl; thi[bs[q] + j] = kh; st[bs[q] + j] = vv;
             }
-            __syncthreads();
+        __syncthreads();
+    }
+    else
+    {
+        uint32_t nsort = 64;
+        while (nsort < tot_occ) nsort <<= 1;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += NT) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
+        __syncthreads();
+        // empty slots sort last: hi = all ones is never a key (2*len <= 126 bits)
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+        {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += NT)
+                {
+                    uint32_t i = 2 * t - (t & (j - 1));
+                    uint32_t p = i + j;
+                    bool up = (i & k2) == 0;
+                    unsigned long long ah = thi[i], al = tlo[i], bh = thi[p], bl = tlo[p];
+                    bool gt = ah > bh || (ah == bh && al > bl);
+                    if (gt == up)
+                    {
+                        thi[i] = bh; tlo[i] = bl; thi[p] = ah; tlo[p] = al;
+                        uint32_t ca = st[i]; st[i] = st[p]; st[p] = ca;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     uint32_t d = ndist;
@@ -2470,9 +2528,10 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
 __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                                const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                                uint64_t* __restrict__ seg_cnt,
-                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts)
+                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                               uint32_t rem_bits)
 {
-    seg_hash_reduce2_body<kTB, kSegSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts);
+    seg_hash_reduce2_body<kTB, kSegSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, 0u);
 }
 
 // One 1024-thread workgroup per CU and 4096 slots (80 KB of LDS): 16-bit segments of up to 2 300
@@ -2535,7 +2594,7 @@ __global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ ke
     __shared__ uint32_t rpre[kMergeRuns + 1];    // entries of runs < r
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ unsigned long long sh_base;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t s = unit_block(), tid = threadIdx.x;
     if (tid == 0)
     {
         uint32_t n0 = 0;
@@ -2639,7 +2698,7 @@ __global__ __launch_bounds__(kTB) void seg_gather_kernel(const K* __restrict__ s
                                                          const uint64_t* __restrict__ seg_cnt_unscanned,
                                                          K* __restrict__ out_keys, uint32_t* __restrict__ out_counts)
 {
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = unit_block();
     const uint64_t d = seg_cnt_unscanned[s];
     const uint64_t src = seg_pos[s], dst = seg_dst[s];
     for (uint64_t i = threadIdx.x; i < d; i += kTB)

@@ -330,6 +330,24 @@ def test_segment_sort_skewed_low_bits(oracle):
         got = ctx.emit()
     assert c.windows == nwin
     _same(got, _suffix_map(exp, "gr"))
+    # two-word keys: one fixed 38-base prefix + 7 random bases, k = 45 (the canonical forms of
+    # 3000 windows agree on far more than the bits the bucket sort of seg_hash_reduce2_kernel bins
+    # on: its bitonic fallback), k-mer set and graph
+    prefix2 = "ACGTTGCAAGCTTAGGCATTGACCGTAAGCTTGACAGT"
+    reads = [prefix2 + "".join(rng.choice("ACGT") for _ in range(7)) for _ in range(3000)]
+    reads += [rng.choice(reads) for _ in range(3000)]
+    txt = "\n".join(reads) + "\n"
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", txt)], 45, out="ks")
+    c, got, st = _build(txt.encode(), 45)
+    assert c.windows == nwin == 6000 and c.key_words == 2
+    _same(got, _suffix_map(exp, "ks"))
+    exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], 44, out="gr")
+    with g.Context(44, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
+        ctx.push_host(txt.encode())
+        c = ctx.finish()
+        got = ctx.emit()
+    assert c.windows == nwin and c.key_words == 2
+    _same(got, _suffix_map(exp, "gr"))
 
 
 def test_fused_path_declines_unique_input(oracle):
