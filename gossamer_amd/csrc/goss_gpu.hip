@@ -2296,16 +2296,16 @@ int goss_gpu_select_normal(goss_gpu_ctx* c)
         PhaseTimer t(c, GOSS_T_REDUCE, c->M);
         if (c->M)
         {
-            const uint32_t grid = (uint32_t)((c->M + kTB - 1) / kTB);
+            const dim3 grid = unit_grid((c->M + kTB - 1) / kTB);
             if (c->words == 1)
             {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key1>), dim3(grid), dim3(kTB), 0, c->stream,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key1>), grid, dim3(kTB), 0, c->stream,
                                    (const Key1*)c->res_keys, c->M, c->len, c->res_counts);
                 select_counts<Key1>(c, 1, 1);
             }
             else
             {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key2>), dim3(grid), dim3(kTB), 0, c->stream,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(mark_normal_kernel<Key2>), grid, dim3(kTB), 0, c->stream,
                                    (const Key2*)c->res_keys, c->M, c->len, c->res_counts);
                 select_counts<Key2>(c, 1, 1);
             }

@@ -1667,7 +1667,7 @@ template <class K>
 __global__ __launch_bounds__(kTB) void mark_normal_kernel(const K* __restrict__ keys, uint64_t n, uint32_t len,
                                                           uint32_t* __restrict__ counts)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    const uint64_t i = (uint64_t)unit_block() * kTB + threadIdx.x;
     if (i >= n) return;
     const K x = keys[i];
     const K rc = revcomp(x, len);
