@@ -350,6 +350,32 @@ def test_segment_sort_skewed_low_bits(oracle):
     _same(got, _suffix_map(exp, "gr"))
 
 
+def test_one_segment_with_more_keys_than_any_table(oracle):
+    """One fixed prefix, 9 random bases behind it: ~2x 20 000 distinct keys of which half share
+    their top 32 bits -- the 4096-slot table overflows with 16, 20 and 24 segment bits (2^24
+    workgroups: the launch HIP used to refuse), and the full radix sort must take over.  One- and
+    two-word keys, k-mer set and graph."""
+    import random
+    rng = random.Random(12)
+    for k, prefix in ((25, "ACGTTGCAAGCTTAGG"), (45, "ACGTTGCAAGCTTAGGCATTGACCGTAAGCTTGACA")):
+        reads = [prefix + "".join(rng.choice("ACGT") for _ in range(9)) for _ in range(20000)]
+        reads += [rng.choice(reads) for _ in range(10000)]
+        txt = "\n".join(reads) + "\n"
+        exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", txt)], k, out="ks")
+        c, got, st = _build(txt.encode(), k)
+        assert c.windows == nwin == 30000
+        assert st["segment_retries"] >= 3
+        _same(got, _suffix_map(exp, "ks"))
+        exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], k - 1, out="gr")
+        with g.Context(k - 1, g.MODE_GRAPH, hbm_budget=2 << 30) as ctx:
+            ctx.push_host(txt.encode())
+            c = ctx.finish()
+            assert ctx.stat("segment_retries") >= 3
+            got = ctx.emit()
+        assert c.windows == nwin
+        _same(got, _suffix_map(exp, "gr"))
+
+
 def test_fused_path_declines_unique_input(oracle):
     """No duplication (every k-mer once): the sample says so and the plain sequence runs."""
     import numpy as np
