@@ -548,7 +548,9 @@ inline dim3 unit_grid(uint64_t units)
 inline void check_launch(const char* what)
 {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)};
+    // (hipErrorNotReady is what a poll of an unfinished event or stream leaves behind -- the host
+    // process may poll its own, e.g. torch's allocator)
+    if (e != hipSuccess && e != hipErrorNotReady) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)};
 }
 
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
