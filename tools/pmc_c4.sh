@@ -1,3 +1,6 @@
+#!/bin/bash
+# PMC passes for C4 (build-graph k=55, 200 M reads): the two-word counting kernel.
+# usage (through gpurun): bash tools/pmc_c4.sh
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_c4
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
