@@ -59,9 +59,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 100 M on one GPU = BASELINE config C2; "
+                    "125 M with several GPUs = C3's 10^9 reads on 8 GPUs)")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--genome", type=int, default=100_000_000, help="genome length per GPU's worth of reads")
+    ap.add_argument("--genome", type=int, default=0, help="genome length per GPU's worth of reads (default: 100 Mbp on one GPU; "
+                    "125 Mbp per GPU with several = C3's 1 Gbp genome on 8 GPUs)")
     ap.add_argument("-k", type=int, default=25)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
@@ -92,8 +94,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     k, L = args.k, args.read_len
-    nreads = args.reads
-    genome_len = args.genome * world
+    # BASELINE.json configs: C2 on one GPU; with N GPUs the per-GPU share of C3 (10^9 reads of a
+    # 1 Gbp genome on 8 GPUs), so that --gpus 8 IS C3 and per-GPU work is fixed as N grows
+    nreads = args.reads or (100_000_000 if world == 1 else 125_000_000)
+    genome_len = (args.genome or (100_000_000 if world == 1 else 125_000_000)) * world
+    if args.graph:
+        config_name = "build-graph"
+    elif args.reads or args.genome:
+        config_name = "custom"
+    else:
+        config_name = "C2" if world == 1 else ("C3" if world == 8 else "C3 share per GPU")
     nbytes = nreads * (L + 1)
 
     # ---- synthetic input, generated on the device (untimed) ------------------------------
@@ -168,7 +178,7 @@ def main():
             per_unit = L / (L - klen + 1) * 3.0 / 8.0 + kbytes * keys_per_window
             per_launch_units = w_local / args.steps / max(1, d["launches"] / args.steps)
         else:
-            per_unit = 16.0
+            per_unit = 2.0 * kbytes
         achieved = per_unit * per_launch_units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         dev_ms = sum(v["ms"] for n, v in tim.items())
         tr = measured_traffic(dom)
@@ -187,8 +197,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "k=%d, %d x %d bp synthetic reads per GPU (genome %d bp, seed %d), in-HBM "
-                                   "sort-count, KmerSet SparseArray emitted" % (k, nreads, L, genome_len, args.seed),
+            "config": {"workload": "%s: k=%d, %d x %d bp synthetic reads per GPU (genome %d bp, seed %d), in-HBM "
+                                   "sort-count, %s emitted" % (config_name, k, nreads, L, genome_len, args.seed,
+                                                               "Graph (edge SparseArray + counts)" if args.graph else "KmerSet SparseArray"),
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
                        "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
             "roofline": {"bound": "hbm", "kernel": {"extract": "extract1_part_kernel" if fused else "extract1_kernel",

@@ -163,6 +163,11 @@ class Context:
         _torch_ready()
         self._check(self._L.goss_gpu_push_run_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
 
+    def push_run_host(self, keys_ptr, counts_ptr, m):
+        """A counted run in host memory (goss_gpu_push_run_host): m keys of key_words u64, m u32 counts."""
+        self._L.goss_gpu_push_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_push_run_host(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
+
     def set_path(self, path):
         """0: segment hash path with LSD fallback (default); 1: LSD radix sort only."""
         self._check(self._L.goss_gpu_set_path(self._h, path))

@@ -242,6 +242,7 @@ bool grow_arena(goss_gpu_ctx* c, uint64_t want_avail)
     };
     for (auto& r : c->runs) { rebase(r.keys); rebase(r.counts); }
     rebase(c->res_keys); rebase(c->res_counts);
+    for (auto& f : c->files) rebase(f.dev);          // file images already emitted (stand-alone SparseArray builds)
     if (c->stage) c->stage = nb + target - top + (c->stage - (a.base + a.hi));
     (void)hipFree(a.base);
     a.base = nb; a.hi = target - top; a.size = target;
@@ -547,10 +548,11 @@ inline dim3 unit_grid(uint64_t units)
 }
 inline void check_launch(const char* what)
 {
+    // the thread's error state was cleared when the entry point was entered (guarded): whatever
+    // is there now was raised by this library's own calls -- it never polls, so not even
+    // hipErrorNotReady is expected
     hipError_t e = hipGetLastError();
-    // (hipErrorNotReady is what a poll of an unfinished event or stream leaves behind -- the host
-    // process may poll its own, e.g. torch's allocator)
-    if (e != hipSuccess && e != hipErrorNotReady) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)};
+    if (e != hipSuccess) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)};
 }
 
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, const uint64_t* seg_off, const uint64_t* seg_end,
@@ -1818,6 +1820,9 @@ int guarded(goss_gpu_ctx* c, F&& f)
     try
     {
         if (c) HIP_TRY(hipSetDevice(c->device));
+        // forget what the calling thread left behind (e.g. hipErrorNotReady from an event or stream
+        // poll of the host process): from here on an error is ours
+        (void)hipGetLastError();
         f();
         // a refused kernel launch raises no exception by itself and leaves its outputs untouched:
         // no entry point returns success over one
@@ -2067,6 +2072,13 @@ int goss_gpu_emit_sparse_array(goss_gpu_ctx* c, const void* d_positions, uint32_
                                uint64_t N_lo, uint64_t N_hi, uint64_t M, uint64_t Nend_lo, uint64_t Nend_hi)
 {
     if (!c || (key_words != 1 && key_words != 2) || (!d_positions && n)) return GOSS_ERR_INVALID_ARG;
+    // its key copy and file images are permanent allocations: between pushes a later merge or an
+    // out-of-memory rollback would rewind the permanent end underneath them
+    if (!c->finished && (!c->runs.empty() || c->stage_fill))
+    {
+        c->last_error = "emit_sparse_array while a count is in progress (reset or finish first)";
+        return GOSS_ERR_STATE;
+    }
     return guarded(c, [&]() {
         ensure_arena(c);
         c->files.clear();
@@ -2170,6 +2182,7 @@ int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t
     if (m == 0) return GOSS_OK;
     return guarded(c, [&]() {
         ensure_arena(c);
+        flush_staging(c);
         const uint64_t ksz = c->words * 8;
         if (c->arena.avail() < m * (ksz + 4) + (64u << 20)) grow_arena(c, m * (ksz + 4) + (64u << 20));
         Run r{nullptr, nullptr, m};
@@ -2179,10 +2192,8 @@ int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t
         HIP_TRY(hipMemcpyAsync(r.counts, d_counts, m * 4, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->runs.push_back(r);
-        uint64_t sum = 0;
         // keys_total keeps meaning "keys inserted": a run stands for the sum of its counts,
         // which the caller accounts for; windows are not known here.
-        (void)sum;
     });
 }
 

@@ -9,37 +9,94 @@ fixes the Elias-Fano split D) and each range's rank offset.  There is no ring al
 bulk data anywhere.  The reference has no distributed path; this module
 is new design, constrained only by having to produce the reference's single-pass result.
 
+Per exchange there are two collectives and one host synchronisation: an all-gather of the
+P x P matrix of run lengths (every rank then knows what it receives), and one all-to-all(v) of
+bytes in which the segment for destination p holds that range's keys followed by its counts.
+Splitters are quantiles of a sample of every rank's distinct keys (all-gathered, a few KB), so
+skewed key distributions still give ranges of equal size; uniform splitters remain available.
+
 The functions below work on torch tensors and a process group only, so the same code runs
-under gloo on CPU (tests, world_size 2) and under RCCL on GPUs (bench.py).  One-word keys
-(2*len <= 62 bits) are int64 tensors of shape [m]: their sign bit is never set, so signed
-comparisons order them correctly.  Two-word keys (2*len <= 128) are int64 tensors of shape
-[m, 2] with columns (lo, hi) -- the library's Key2 layout; both words are unsigned, so they are
-compared after flipping the sign bit.
+under gloo (tests: CPU tensors, also with libgossgpu.so doing the counting of several ranks on
+one GPU -- keys are then staged through host memory for the exchange) and under RCCL on GPUs
+(bench.py).  One-word keys (2*len <= 62 bits) are int64 tensors of shape [m]: their sign bit is
+never set, so signed comparisons order them correctly.  Two-word keys (2*len <= 128) are int64
+tensors of shape [m, 2] with columns (lo, hi) -- the library's Key2 layout; both words are
+unsigned, so they are compared after flipping the sign bit.
+
+Stream order: the library works on its own HIP stream and waits for no other.  Every tensor
+handed to it here is either complete because a collective on it has been waited for
+(`_sync`), or was produced by torch kernels that the binding's per-push
+`torch.cuda.synchronize()` covers (gossamer_amd.binding._torch_ready); a C caller of the ABI
+orders its streams itself (include/goss_gpu.h, goss_gpu_push_run_device).
 """
 import torch
 import torch.distributed as dist
 
 
 _SIGN = -(1 << 63)
+_MASK = (1 << 64) - 1
 
 
 def _as_i64(v):
     """unsigned 64-bit value -> the int64 with the same bits"""
-    v &= (1 << 64) - 1
+    v &= _MASK
     return v - (1 << 64) if v >> 63 else v
+
+
+def _key_ints(t):
+    """python ints of a key tensor ([m] or [m, 2] = (lo, hi))"""
+    if t.dim() == 1:
+        return [int(x) for x in t.tolist()]
+    return [((h & _MASK) << 64) | (l & _MASK) for l, h in t.tolist()]
+
+
+def _key_tensor(vals, two, device="cpu"):
+    if not two:
+        return torch.tensor(vals, dtype=torch.int64, device=device).reshape(len(vals))
+    rows = [[_as_i64(v), _as_i64(v >> 64)] for v in vals]
+    return torch.tensor(rows, dtype=torch.int64, device=device).reshape(len(rows), 2)
 
 
 def uniform_splitters(key_bits, parts, dtype=torch.int64, device="cpu"):
     """parts-1 interior splitters cutting [0, 2^key_bits) into equal ranges: shape [parts-1] for
     one-word keys (key_bits <= 62), [parts-1, 2] = (lo, hi) for two-word keys.  Hash-chosen
-    canonical k-mers of an i.i.d. genome are uniform on the top bits (SURVEY.md section 8(e));
-    sampled splitters can replace this for skewed data without changing anything else."""
+    canonical k-mers of an i.i.d. genome are uniform on the top bits."""
     total = 1 << key_bits
     cuts = [(total * p) // parts for p in range(1, parts)]
-    if key_bits <= 62:
-        return torch.tensor(cuts, dtype=dtype, device=device)
-    rows = [[_as_i64(c), _as_i64(c >> 64)] for c in cuts]
-    return torch.tensor(rows, dtype=dtype, device=device).reshape(len(rows), 2)
+    return _key_tensor(cuts, key_bits > 62, device).to(dtype)
+
+
+def sampled_splitters(sorted_keys, parts, group=None, per_rank=1024):
+    """Splitters for skewed data: every rank contributes `per_rank` evenly spaced keys of its
+    sorted distinct set, the samples are all-gathered (a few KB) and the p/parts quantiles of
+    their union cut the key space.  Every rank computes the same splitters.  A rank with no
+    keys contributes nothing; with no keys anywhere the result is all zeros (every key would go
+    to the last range -- there are none)."""
+    world = dist.get_world_size(group)
+    two = sorted_keys.dim() == 2
+    m = int(sorted_keys.shape[0])
+    width = 2 if two else 1
+    sample = torch.zeros((per_rank, width), dtype=torch.int64)
+    n = min(m, per_rank)
+    if n:
+        idx = torch.div(torch.arange(n, dtype=torch.int64) * m, n, rounding_mode="floor").to(sorted_keys.device)
+        sample[:n] = sorted_keys.index_select(0, idx).reshape(n, width).cpu()
+    xdev = _exchange_device(sorted_keys.device, group)
+    mine = torch.cat([torch.tensor([n], dtype=torch.int64), sample.reshape(-1)]).to(xdev)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    vals = []
+    for v in allv:
+        v = v.cpu()
+        c = int(v[0].item())
+        rows = v[1:].reshape(per_rank, width)[:c]
+        vals += _key_ints(rows if two else rows.reshape(-1))
+    vals.sort()
+    if not vals:
+        cuts = [0] * (parts - 1)
+    else:
+        cuts = [vals[min(len(vals) - 1, (len(vals) * p) // parts)] for p in range(1, parts)]
+    return _key_tensor(cuts, two, sorted_keys.device)
 
 
 def _lower_bound2(keys, lo, hi):
@@ -61,28 +118,76 @@ def split_sizes(sorted_keys, splitters):
     if splitters.shape[0] == 0:
         return [n]
     if sorted_keys.dim() == 1:
-        cuts = torch.searchsorted(sorted_keys, splitters, right=False).tolist()
+        cuts = torch.searchsorted(sorted_keys, splitters.to(sorted_keys.device), right=False).tolist()
     else:
         cuts = [_lower_bound2(sorted_keys, int(lo), int(hi)) for lo, hi in splitters.tolist()]
     edges = [0] + cuts + [n]
     return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
 
 
-def exchange_runs(keys, counts, splitters, group=None):
-    """all-to-all(v): send range p of (keys, counts) to rank p.
-    Returns (recv_keys, recv_counts, recv_sizes): the concatenation of one sorted run per
-    source rank, and the run lengths."""
+def _exchange_device(device, group=None):
+    """Where the collectives' buffers live: the GPU under RCCL, host memory under gloo."""
+    return torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def _segment_bytes(n, words):
+    """bytes of one all-to-all segment: n keys (8*words each), then n u32 counts padded to 8"""
+    return n * 8 * words + 8 * ((n + 1) // 2)
+
+
+def exchange_packed(keys, counts, splitters, group=None):
+    """all-to-all(v): send range p of (keys, counts) to rank p.  Returns (rbuf, recv, segs): a byte
+    buffer on the exchange device (the keys' device under RCCL, host memory under gloo) holding one
+    segment per source rank -- that rank's keys of this range, then their u32 counts -- the run
+    lengths, and the byte offset of every segment."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    words = 1 if keys.dim() == 1 else 2
+    xdev = _exchange_device(keys.device, group)
     send = split_sizes(keys, splitters)
     assert len(send) == world
-    send_t = torch.tensor(send, dtype=torch.int64, device=keys.device)
-    recv_t = torch.empty(world, dtype=torch.int64, device=keys.device)
-    dist.all_to_all_single(recv_t, send_t, group=group)
-    recv = [int(x) for x in recv_t.tolist()]
-    rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
-    rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
-    dist.all_to_all_single(rk, keys, recv, send, group=group)        # splits along dim 0: whole keys
-    dist.all_to_all_single(rc, counts, recv, send, group=group)
+    # every rank learns the whole matrix of run lengths: one collective, one host synchronisation
+    mine = torch.tensor(send, dtype=torch.int64, device=xdev)
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine, group=group)
+    matrix = torch.stack(rows).cpu().tolist()
+    recv = [int(matrix[q][rank]) for q in range(world)]
+    # one buffer of bytes: for destination p the keys of range p, then their counts
+    sbytes = [_segment_bytes(n, words) for n in send]
+    rbytes = [_segment_bytes(n, words) for n in recv]
+    sbuf = torch.zeros(max(1, sum(sbytes)), dtype=torch.uint8, device=xdev)
+    kflat = keys.reshape(-1)
+    off = at = 0
+    for n, nb in zip(send, sbytes):
+        if n:
+            sbuf[at:at + 8 * words * n].view(torch.int64).copy_(kflat[off * words:(off + n) * words])
+            sbuf[at + 8 * words * n:at + 8 * words * n + 4 * n].view(torch.int32).copy_(counts[off:off + n])
+        off += n
+        at += nb
+    rbuf = torch.empty(max(1, sum(rbytes)), dtype=torch.uint8, device=xdev)
+    dist.all_to_all_single(rbuf[:sum(rbytes)], sbuf[:sum(sbytes)], rbytes, sbytes, group=group)
+    segs, at = [], 0
+    for nb in rbytes:
+        segs.append(at)
+        at += nb
+    return rbuf, recv, segs
+
+
+def exchange_runs(keys, counts, splitters, group=None):
+    """exchange_packed, unpacked: (recv_keys, recv_counts, recv_sizes) -- the concatenation of one
+    sorted run per source rank, and the run lengths."""
+    words = 1 if keys.dim() == 1 else 2
+    rbuf, recv, segs = exchange_packed(keys, counts, splitters, group)
+    total = sum(recv)
+    rk = torch.empty((total,) + tuple(keys.shape[1:]), dtype=torch.int64, device=rbuf.device)
+    rc = torch.empty(total, dtype=torch.int32, device=rbuf.device)
+    rkf = rk.reshape(-1)
+    off = 0
+    for n, at in zip(recv, segs):
+        if n:
+            rkf[off * words:(off + n) * words].copy_(rbuf[at:at + 8 * words * n].view(torch.int64))
+            rc[off:off + n].copy_(rbuf[at + 8 * words * n:at + 8 * words * n + 4 * n].view(torch.int32))
+        off += n
     return rk, rc, recv
 
 
@@ -90,10 +195,11 @@ def gather_counts(m_local, device, group=None):
     """all-gather of the per-range distinct counts -> (list M_p, global M, this rank's offset)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    mine = torch.tensor([m_local], dtype=torch.int64, device=device)
-    allm = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
+    xdev = _exchange_device(device, group)
+    mine = torch.tensor([m_local], dtype=torch.int64, device=xdev)
+    allm = [torch.empty(1, dtype=torch.int64, device=xdev) for _ in range(world)]
     dist.all_gather(allm, mine, group=group)
-    ms = [int(x.item()) for x in allm]
+    ms = [int(x) for x in torch.cat(allm).cpu().tolist()]
     return ms, sum(ms), sum(ms[:rank])
 
 
@@ -102,11 +208,13 @@ def gather_ranges_to_root(keys, counts, ms, group=None):
     the concatenation is the globally sorted distinct key set)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    xdev = _exchange_device(keys.device, group)
+    keys, counts = keys.to(xdev), counts.to(xdev)
     send = [int(keys.shape[0])] + [0] * (world - 1)
     recv = ms if rank == 0 else [0] * world
-    rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
-    rc = torch.empty(sum(recv), dtype=counts.dtype, device=counts.device)
-    dist.all_to_all_single(rk, keys, recv, send, group=group)
+    rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=xdev)
+    rc = torch.empty(sum(recv), dtype=counts.dtype, device=xdev)
+    dist.all_to_all_single(rk, keys, recv, send, group=group)        # splits along dim 0: whole keys
     dist.all_to_all_single(rc, counts, recv, send, group=group)
     return rk, rc
 
@@ -136,62 +244,79 @@ def _sync(device):
         torch.cuda.synchronize(device)
 
 
-def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None):
+def _push_run(ctx, on_gpu, keys_ptr, counts_ptr, n):
+    if on_gpu:
+        ctx.push_run(keys_ptr, counts_ptr, n)
+    else:
+        ctx.push_run_host(keys_ptr, counts_ptr, n)
+
+
+def _push_packed(ctx, rbuf, recv, segs, words):
+    """the segments of an exchange buffer (on the GPU or in host memory) -> runs of the context"""
+    for n, at in zip(recv, segs):
+        if n:
+            _push_run(ctx, rbuf.device.type == "cuda", rbuf.data_ptr() + at, rbuf.data_ptr() + at + 8 * words * n, n)
+
+
+def result_views(ctx, words, device):
+    """zero-copy views of the context's result: valid until its next emit, reset, push or close"""
+    kp, cp, m = ctx.result_ptrs()
+    return key_view(kp, m, words, device), device_view(cp, m, torch.int32, device)
+
+
+def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled"):
     """local count -> exchange -> merge of the received runs: this rank's range of the global
-    result stays in the Context.  Returns (this rank's windows, key words)."""
+    result stays in the Context.  Returns (this rank's windows, key words, the splitters used).
+    `splitters`: "sampled", "uniform", or a tensor from an earlier call (set algebra: every set
+    must be cut at the same places)."""
     world = dist.get_world_size(group)
     ctx.reset()
     ctx.push_device(bases_ptr, nbytes)
     c = ctx.finish()
     words = c.key_words
     windows = c.windows
-    kp, cp, m = ctx.result_ptrs()
-    keys = key_view(kp, m, words, device)
-    counts = device_view(cp, m, torch.int32, device)
-    splitters = uniform_splitters(key_bits, world, device=device)
-    if (splitters.dim() == 2) != (words == 2):
+    if (key_bits > 62) != (words == 2):
         raise ValueError("key_bits = %d does not match the context's %d-word keys (2*len: len = k, or k+1 for graphs)" % (key_bits, words))
-    rk, rc, recv = exchange_runs(keys, counts, splitters, group)
+    keys, counts = result_views(ctx, words, device)
+    xdev = _exchange_device(device, group)
+    if xdev.type == "cpu":
+        keys, counts = keys.cpu(), counts.cpu()
+    if isinstance(splitters, str):
+        splitters = sampled_splitters(keys, world, group) if splitters == "sampled" else uniform_splitters(key_bits, world, device=keys.device)
+    rbuf, recv, segs = exchange_packed(keys, counts, splitters, group)
     _sync(device)          # the library runs on its own stream: finish the collectives first
+    del keys, counts
     # merge the received runs: they replace the local result
     ctx.reset()
-    off = 0
-    for n in recv:
-        if n:
-            ctx.push_run(rk.data_ptr() + off * 8 * words, rc.data_ptr() + off * 4, n)
-        off += n
+    _push_packed(ctx, rbuf, recv, segs, words)
     ctx.finish()
-    del rk, rc             # the runs were copied into the library's arena
-    return windows, words
-
-
-def _range_tensors(ctx, words, device):
-    kp, cp, m = ctx.result_ptrs()
-    return key_view(kp, m, words, device).clone(), device_view(cp, m, torch.int32, device).clone()
+    del rbuf               # the runs were copied into the library's arena
+    return windows, words, splitters
 
 
 def _assemble_on_root(ctx, keys, counts, ms, M, device, group):
     """ranges -> rank 0 -> one run -> on-disk arrays (in HBM) on rank 0"""
     ak, ac = gather_ranges_to_root(keys, counts, ms, group)
     _sync(device)
+    del keys, counts        # views of the result: gone with the reset below
     if dist.get_rank(group) == 0:
         ctx.reset()
         if M:
-            ctx.push_run(ak.data_ptr(), ac.data_ptr(), M)
+            _push_run(ctx, ak.device.type == "cuda", ak.data_ptr(), ac.data_ptr(), M)
         ctx.finish()
         ctx.emit_device()
 
 
-def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True):
+def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True, splitters="sampled"):
     """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
     local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
     Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
-    windows, words = count_range(ctx, bases_ptr, nbytes, key_bits, device, group)
+    windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters)
     m_range = ctx.counts.distinct
     ms, M, _ = gather_counts(m_range, device, group)
-    out = {"windows": windows, "M": M, "m_range": m_range}
+    out = {"windows": windows, "M": M, "m_range": m_range, "ranges": ms}
     if emit_on_root:
-        keys, counts = _range_tensors(ctx, words, device)
+        keys, counts = result_views(ctx, words, device)
         _assemble_on_root(ctx, keys, counts, ms, M, device, group)
     return out
 
@@ -199,18 +324,21 @@ def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit
 def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_on_root=True):
     """BASELINE config C5 across ranks: every input (bases_ptr, nbytes) is this rank's share of the
     reads of one k-mer set.  The sets are counted and range-partitioned one after the other with
-    the same splitters, so the set operation needs no further exchange: each rank combines its
-    ranges (goss_gpu_select_counts on weighted runs, as the single-GPU commands do), rank 0
-    assembles the result.  op = "intersect" (all sets; globally empty ones are skipped, as
-    GossCmdIntersectKmerSets.cc:29-79 does) or "subtract" (first minus second,
-    GossCmdSubtractKmerSet.cc:47-66).  Returns dict(sizes=<global size of every input>, M=<result>)."""
+    the same splitters (those sampled from the first set), so the set operation needs no further
+    exchange: each rank combines its ranges (goss_gpu_select_counts on weighted runs, as the
+    single-GPU commands do), rank 0 assembles the result.  op = "intersect" (all sets; globally
+    empty ones are skipped, as GossCmdIntersectKmerSets.cc:29-79 does) or "subtract" (first minus
+    second, GossCmdSubtractKmerSet.cc:47-66).  Returns dict(sizes=<global size of every input>,
+    M=<result>)."""
     if op not in ("intersect", "subtract") or (op == "subtract" and len(inputs) != 2):
         raise ValueError("op must be 'intersect' or 'subtract' (exactly two sets)")
     ranges, sizes, words = [], [], 1
+    splitters = "sampled"
     for ptr, nbytes in inputs:
-        _, words = count_range(ctx, ptr, nbytes, key_bits, device, group)
-        ranges.append(_range_tensors(ctx, words, device))
-        sizes.append(gather_counts(ranges[-1][0].shape[0], device, group)[1])
+        _, words, splitters = count_range(ctx, ptr, nbytes, key_bits, device, group, splitters)
+        keys, _ = result_views(ctx, words, device)
+        ranges.append(keys.clone())          # the context is reused for the next set
+        sizes.append(gather_counts(ranges[-1].shape[0], device, group)[1])
     ctx.reset()
     if op == "intersect":
         use = [i for i, n in enumerate(sizes) if n]
@@ -222,18 +350,18 @@ def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_
         keep = 1
     held = []
     for i in use:
-        keys, _ = ranges[i]
+        keys = ranges[i]
         if keys.shape[0]:
-            w = torch.full((keys.shape[0],), weights[i], dtype=torch.int32, device=device)
-            held.append(w)
-            ctx.push_run(keys.data_ptr(), w.data_ptr(), keys.shape[0])
-    _sync(device)
+            held.append(torch.full((keys.shape[0],), weights[i], dtype=torch.int32, device=device))
+    _sync(device)          # the weights are written on torch's stream, the library copies on its own
+    for keys, w in zip([ranges[i] for i in use if ranges[i].shape[0]], held):
+        ctx.push_run(keys.data_ptr(), w.data_ptr(), keys.shape[0])
     ctx.finish()
     ctx.select_counts(keep, keep)
-    kp, cp, m = ctx.result_ptrs()
+    keys, _ = result_views(ctx, words, device)
+    m = int(keys.shape[0])
     ms, M, _ = gather_counts(m, device, group)
     if emit_on_root:
-        keys = key_view(kp, m, words, device).clone()
         counts = torch.ones(m, dtype=torch.int32, device=device)
         _assemble_on_root(ctx, keys, counts, ms, M, device, group)
     return {"sizes": sizes, "M": M}

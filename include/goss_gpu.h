@@ -98,7 +98,9 @@ typedef struct {
 int goss_gpu_finish(goss_gpu_ctx* ctx, goss_gpu_counts* out);
 
 /* Device-resident result: sorted distinct keys (key_words u64 per key) and u32 counts.
- * Valid until destroy.  Either pointer may be NULL. */
+ * The pointers are valid until the next emit, select, reset, push or destroy on this context
+ * (an emit may move the arena when goss_gpu_set_budget_limit allows it to grow; a reset
+ * recycles the memory).  Either pointer may be NULL. */
 int goss_gpu_result(goss_gpu_ctx* ctx, const void** d_keys, const uint32_t** d_counts,
                     uint64_t* distinct);
 
@@ -131,6 +133,7 @@ int goss_gpu_file_read(goss_gpu_ctx* ctx, uint32_t i, uint64_t offset, void* dst
  * (SparseArray::Builder(base, fac, N, M) + push_back* + end(N_end)).  Positions are
  * key_words u64 each, strictly increasing.  N is given as {lo,hi}.  Produces the files
  * ".header", ".high-bits", "-d0", "-d1", ".low-bits*" retrievable through goss_gpu_file_*.
+ * Not while a count is in progress (bases or runs pushed and not finished): GOSS_ERR_STATE.
  */
 int goss_gpu_emit_sparse_array(goss_gpu_ctx* ctx, const void* d_positions, uint32_t key_words,
                                uint64_t n, uint64_t N_lo, uint64_t N_hi, uint64_t M,
@@ -141,11 +144,15 @@ int goss_gpu_emit_sparse_array(goss_gpu_ctx* ctx, const void* d_positions, uint3
  * units[] = items processed by the launches of that class (keys for the sort kernels,
  * window starts for extraction, distinct keys for emit). */
 enum {
-    GOSS_T_EXTRACT = 0,   /* extract_kernel */
-    GOSS_T_HIST    = 1,   /* radix_hist_kernel */
-    GOSS_T_SCAN    = 2,   /* scan_reduce/scan_apply over the digit tables */
-    GOSS_T_SCATTER = 3,   /* radix_scatter_kernel */
-    GOSS_T_REDUCE  = 4,   /* heads_count/heads_write/run_lengths */
+    GOSS_T_EXTRACT = 0,   /* extraction: extract1/2_kernel, and extract1/2_part_kernel (extraction fused
+                             with the first partition level) */
+    GOSS_T_HIST    = 1,   /* digit histograms: global_hist_kernel, radix_hist_kernel */
+    GOSS_T_SCAN    = 2,   /* scans over digit tables */
+    GOSS_T_SCATTER = 3,   /* partition passes: radix_onesweep_kernel (look-back, cursor and sub-region
+                             forms), radix_scatter_kernel */
+    GOSS_T_REDUCE  = 4,   /* counting: seg_hash_reduce*_kernel + seg_gather_kernel, seg_merge_kernel,
+                             heads_* / run_* compaction after a full sort, the re-ordering of
+                             strand representatives into canonical order */
     GOSS_T_EMIT    = 5,   /* Elias-Fano / DenseSelect / VariableByteArray image build */
     GOSS_T_CLASSES = 8
 };

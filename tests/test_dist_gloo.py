@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q):
+def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q, mode="uniform"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
@@ -44,7 +44,7 @@ def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q):
 
         kt = to_tensor(ks)
         ct = torch.tensor([d[x] for x in ks], dtype=torch.int32)
-        splitters = gd.uniform_splitters(2 * k, world)
+        splitters = gd.uniform_splitters(2 * k, world) if mode == "uniform" else gd.sampled_splitters(kt, world)
         rk, rc, recv = gd.exchange_runs(kt, ct, splitters)
         assert len(recv) == world and sum(recv) == rk.shape[0]
         # every received key belongs to this rank's range, and each run is sorted
@@ -81,8 +81,8 @@ def _worker(rank, world, port, k, shards, expect_keys, expect_counts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [13, 40])
-def test_range_partition_exchange_world2(k):
+@pytest.mark.parametrize("k,mode", [(13, "uniform"), (40, "uniform"), (13, "sampled"), (40, "sampled")])
+def test_range_partition_exchange_world2(k, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
     rng = random.Random(31)
@@ -98,7 +98,7 @@ def test_range_partition_exchange_world2(k):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + random.randrange(2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, shards, ek, ec, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, shards, ek, ec, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
