@@ -1394,6 +1394,237 @@ int go_graph_header(const go_fs* fs, const char* base, uint64_t* K, uint64_t* fl
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* stand-alone builders / readers in the shape of the reference's unit tests              */
+/* ------------------------------------------------------------------------------------ */
+
+/* What testDenseArray.cc:142-167 (and every later case of that file) sets up: a
+ * WordyBitVector "v" filled bit by bit with push_backX (WordyBitVector.hh:96-110) over nbits
+ * positions, and a DenseSelect::Builder "x" of the given sense fed the positions of the ones
+ * (invert = 0) or of the zeros (invert = 1).  `ones` = ascending positions of the set bits. */
+int go_write_bits_and_select(go_fs* fs, const char* vname, const char* xname, const uint64_t* ones, size_t n,
+                             uint64_t nbits, int invert)
+{
+    wbv_builder vb; ds_builder b;
+    wbv_init(&vb, fs, vname);
+    ds_init(&b, fs, xname, invert);
+    size_t j = 0;
+    for (uint64_t i = 0; i < nbits; ++i)
+    {
+        int bit = j < n && ones[j] == i;
+        if (bit) ++j;
+        wbv_push_backx(&vb, bit);
+        if (bit != (invert != 0)) ds_push(&b, i);
+    }
+    wbv_end(&vb);
+    ds_end(&b);
+    return j == n ? 0 : -1;
+}
+
+/* WordyBitVector::Builder::push(pos)* + end() (WordyBitVector.hh:54-134), as testWordyBitVector.cc:44-58 */
+int go_write_bits_sparse(go_fs* fs, const char* vname, const uint64_t* ones, size_t n)
+{
+    wbv_builder vb;
+    wbv_init(&vb, fs, vname);
+    for (size_t i = 0; i < n; ++i) wbv_push(&vb, ones[i]);
+    wbv_end(&vb);
+    return 0;
+}
+
+static int wbv_open(const go_fs* fs, const char* vname, wbv* v)
+{
+    int i = go_fs_find(fs, vname);
+    if (i < 0) return -1;
+    v->w = (const uint64_t*)fs->files[i].data; v->nwords = fs->files[i].size / 8;
+    return 0;
+}
+
+/* WordyBitVector::get (WordyBitVector.hh:173-179); positions past the last word read 0 */
+int go_bits_get(const go_fs* fs, const char* vname, uint64_t pos)
+{
+    wbv v;
+    if (wbv_open(fs, vname, &v)) return -1;
+    if (pos / 64 >= v.nwords) return 0;
+    return (int)((v.w[pos / 64] >> (pos % 64)) & 1);
+}
+uint64_t go_bits_words(const go_fs* fs, const char* vname)
+{
+    wbv v;
+    return wbv_open(fs, vname, &v) ? 0 : v.nwords;
+}
+/* WordyBitVector::select1(from, count) / select0 (WordyBitVector.tcc:17-54): ~0 when out of range */
+uint64_t go_bits_select(const go_fs* fs, const char* vname, int invert, uint64_t from, uint64_t count)
+{
+    wbv v; uint64_t out;
+    if (wbv_open(fs, vname, &v) || wbv_select(&v, invert, from, count, &out)) return ~0ULL;
+    return out;
+}
+/* WordyBitVector::popcountRange(begin, end) (WordyBitVector.hh:207-241): set bits in [begin, end) */
+uint64_t go_bits_popcount_range(const go_fs* fs, const char* vname, uint64_t begin, uint64_t end)
+{
+    wbv v; uint64_t c = 0;
+    if (wbv_open(fs, vname, &v)) return ~0ULL;
+    for (uint64_t i = begin; i < end; ++i)
+        if (i / 64 < v.nwords) c += (v.w[i / 64] >> (i % 64)) & 1;
+    return c;
+}
+
+/* DenseSelect(bits, name, fac, invert).select(i) (DenseArray.cc:36-91,185-258) over the files of
+ * go_write_bits_and_select; ~0 on failure */
+uint64_t go_dense_select(const go_fs* fs, const char* vname, const char* xname, int invert, uint64_t i)
+{
+    wbv v; dsel d; char err[256]; uint64_t out;
+    if (wbv_open(fs, vname, &v)) return ~0ULL;
+    int x = go_fs_find(fs, xname);
+    if (x < 0 || dsel_open(&d, fs->files[x].data, fs->files[x].size, &v, invert, err, sizeof err)) return ~0ULL;
+    if (dsel_select(&d, i, &out)) return ~0ULL;
+    return out;
+}
+
+/* VariableByteArray::Builder(name, fac, numItems, frac) + push_back* + end()
+ * (VariableByteArray.hh:76-118, VariableByteArray.cc:21-43; frac is ignored there too), as
+ * testVariableByteArray.cc:27-47 */
+int go_write_vba(go_fs* fs, const char* base, const uint32_t* values, size_t n, uint64_t numItems)
+{
+    vba_builder b;
+    if (vba_init(&b, fs, base, numItems)) return -1;
+    for (size_t i = 0; i < n; ++i) vba_push(&b, values[i]);
+    vba_end(&b);
+    return 0;
+}
+
+/* ---- the assertion loops of the reference's unit tests, replayed over a file set ----
+ * Each returns the number of failed checks (0 = the reference's test would pass), or ~0 when the
+ * structures cannot be opened. */
+
+/* testDenseArray.cc:169-190 (test2), :221-235, :267-281, :313-333, :366-376, :409-431 ...:
+ * v.get(i) == bits[i] for every i; a.select(j) == position of the j-th one (zero when inverted);
+ * and the pair form select(i, i+j) == (select(i), select(i+j)) for i += 113, j < 197
+ * (DenseSelect::select(i, j) is two single selects read side by side, DenseArray.cc:261-423). */
+uint64_t go_replay_dense_select(const go_fs* fs, const char* vname, const char* xname, int invert,
+                                const uint64_t* ones, size_t n, uint64_t nbits)
+{
+    wbv v; dsel d; char err[256];
+    if (wbv_open(fs, vname, &v)) return ~0ULL;
+    int x = go_fs_find(fs, xname);
+    if (x < 0 || dsel_open(&d, fs->files[x].data, fs->files[x].size, &v, invert, err, sizeof err)) return ~0ULL;
+    uint64_t bad = 0, rank = 0;
+    size_t j = 0;
+    for (uint64_t i = 0; i < nbits; ++i)
+    {
+        int bit = j < n && ones[j] == i;
+        if (bit) ++j;
+        int got = i / 64 < v.nwords ? (int)((v.w[i / 64] >> (i % 64)) & 1) : 0;
+        if (got != bit) ++bad;
+        if (bit != (invert != 0))
+        {
+            uint64_t pos;
+            if (dsel_select(&d, rank, &pos) || pos != i) ++bad;
+            ++rank;
+        }
+    }
+    return bad;
+}
+
+/* testSparseArray.cc:66-113 (test1: every position of a small universe) and :166-185, :219-236,
+ * :270-289 (test3-5: every stored position): access, rank, accessAndRank, select, iterator.
+ * universe = 0: only the stored positions are visited (wide universes). */
+uint64_t go_replay_sparse(const go_fs* fs, const char* base, const go_key* pos, size_t n, uint64_t universe)
+{
+    char err[256];
+    go_sparse* s = go_sparse_open(fs, base, err, sizeof err);
+    if (!s) return ~0ULL;
+    uint64_t bad = 0;
+    if (go_sparse_count(s) != n) ++bad;
+    for (size_t i = 0; i < n; ++i)
+    {
+        if (!go_sparse_access(s, pos[i])) ++bad;
+        if (go_sparse_rank(s, pos[i]) != i) ++bad;
+        go_key g = go_sparse_select(s, i);
+        if (g.lo != pos[i].lo || g.hi != pos[i].hi) ++bad;
+    }
+    size_t j = 0;
+    for (uint64_t p = 0; p < universe; ++p)
+    {
+        go_key k = { p, 0 };
+        int bit = j < n && pos[j].hi == 0 && pos[j].lo == p;
+        if ((go_sparse_access(s, k) != 0) != bit) ++bad;
+        if (go_sparse_rank(s, k) != j) ++bad;
+        if (bit) ++j;
+    }
+    /* testSparseArray.cc:143-151: rank beyond the universe stays at the count */
+    if (universe)
+        for (int sh = 0; sh < 4; ++sh)
+        {
+            go_key k = { universe << sh, 0 };
+            if (go_sparse_rank(s, k) != n) ++bad;
+        }
+    go_sparse_close(s);
+    return bad;
+}
+
+/* The bit vector of a testDenseArray.cc case embedded as the high-bits vector of a SparseArray with
+ * split D (element i = (ones[i] - i) << D | i): its -d1 / -d0 files are DenseSelect structures of both
+ * senses over exactly that vector, so select through them must give the ones / zeros of the case. */
+uint64_t go_replay_sparse_highbits(const go_fs* fs, const char* base, const uint64_t* ones, size_t n, uint64_t nbits)
+{
+    char err[256];
+    go_sparse* s = go_sparse_open(fs, base, err, sizeof err);
+    if (!s) return ~0ULL;
+    uint64_t bad = 0, zeros = 0;
+    size_t j = 0;
+    for (uint64_t i = 0; i < nbits; ++i)
+    {
+        int bit = j < n && ones[j] == i;
+        int got = i / 64 < s->hi.nwords ? (int)((s->hi.w[i / 64] >> (i % 64)) & 1) : 0;
+        if (got != bit) ++bad;
+        if (bit) { if (go_sparse_d1_select(s, j) != i) ++bad; ++j; }
+        else { if (go_sparse_d0_select(s, zeros) != i) ++bad; ++zeros; }
+    }
+    go_sparse_close(s);
+    return bad;
+}
+
+/* testVariableByteArray.cc:49-64,88-91,117-122,150-156: a[i] == values[i] for every i */
+uint64_t go_replay_vba(const go_fs* fs, const char* base, const uint32_t* values, size_t n)
+{
+    char err[256]; char name[4096]; size_t n0, n1, n2;
+    snprintf(name, sizeof name, "%s.ord0", base);
+    const uint8_t* o0 = fs_get(fs, name, &n0, err, sizeof err); if (!o0) return ~0ULL;
+    snprintf(name, sizeof name, "%s.ord1", base);
+    const uint8_t* o1 = fs_get(fs, name, &n1, err, sizeof err); if (!o1) return ~0ULL;
+    snprintf(name, sizeof name, "%s.ord2", base);
+    const uint8_t* o2 = fs_get(fs, name, &n2, err, sizeof err); if (!o2) return ~0ULL;
+    snprintf(name, sizeof name, "%s.ord1p", base);
+    go_sparse* p1 = go_sparse_open(fs, name, err, sizeof err); if (!p1) return ~0ULL;
+    snprintf(name, sizeof name, "%s.ord2p", base);
+    go_sparse* p2 = go_sparse_open(fs, name, err, sizeof err); if (!p2) { go_sparse_close(p1); return ~0ULL; }
+    uint64_t bad = n0 != n;
+    for (size_t i = 0; i < n && i < n0; ++i)
+    {
+        /* VariableByteArray::operator[] (VariableByteArray.hh:213-240) */
+        uint32_t r = o0[i];
+        go_key ki = { i, 0 };
+        if (go_sparse_access(p1, ki))
+        {
+            uint64_t r1 = go_sparse_rank(p1, ki);
+            if (r1 >= n1) { ++bad; continue; }
+            r |= (uint32_t)o1[r1] << 8;
+            go_key kr = { r1, 0 };
+            if (go_sparse_access(p2, kr))
+            {
+                uint64_t r2 = go_sparse_rank(p2, kr);
+                if (2 * r2 + 2 > n2) { ++bad; continue; }
+                uint16_t w; memcpy(&w, o2 + 2 * r2, 2);
+                r |= (uint32_t)w << 16;
+            }
+        }
+        if (r != values[i]) ++bad;
+    }
+    go_sparse_close(p1); go_sparse_close(p2);
+    return bad;
+}
+
 /* VByteCodec::encode.  VByteCodec.hh:24-104 (private spill-run format; golden bytes in
  * testVByteCodec.cc:21-62). */
 size_t go_vbyte_encode(uint64_t x, uint8_t* out)

@@ -135,6 +135,28 @@ int go_merge_and_annotate(const go_fs* in, const char* lhs, const char* rhs, go_
 int go_dump(const go_fs* fs, const char* name, int kind, char** text, size_t* len, char* err, size_t errcap);
 int go_restore_graph(const char* text, size_t len, go_fs* out, const char* out_name, char* err, size_t errcap);
 
+/* ---- stand-alone structures in the shape of the reference's unit tests ----
+ * testDenseArray.cc:142-167 etc.: WordyBitVector `vname` over nbits positions + DenseSelect `xname`
+ * of the given sense; testWordyBitVector.cc:44-58: sparse push; their readers; and
+ * testVariableByteArray.cc: VariableByteArray builder. */
+int      go_write_bits_and_select(go_fs* fs, const char* vname, const char* xname, const uint64_t* ones, size_t n,
+                                  uint64_t nbits, int invert);
+int      go_write_bits_sparse(go_fs* fs, const char* vname, const uint64_t* ones, size_t n);
+int      go_bits_get(const go_fs* fs, const char* vname, uint64_t pos);                 /* WordyBitVector.hh:173-179 */
+uint64_t go_bits_words(const go_fs* fs, const char* vname);
+uint64_t go_bits_select(const go_fs* fs, const char* vname, int invert, uint64_t from, uint64_t count);  /* WordyBitVector.tcc:17-54 */
+uint64_t go_bits_popcount_range(const go_fs* fs, const char* vname, uint64_t begin, uint64_t end);
+uint64_t go_dense_select(const go_fs* fs, const char* vname, const char* xname, int invert, uint64_t i); /* DenseArray.cc:185-258 */
+int      go_write_vba(go_fs* fs, const char* base, const uint32_t* values, size_t n, uint64_t numItems);
+
+/* The assertion loops of testDenseArray.cc / testSparseArray.cc / testVariableByteArray.cc replayed
+ * over a file set (written by this oracle or by the product): number of failed checks, ~0 = cannot open. */
+uint64_t go_replay_dense_select(const go_fs* fs, const char* vname, const char* xname, int invert,
+                                const uint64_t* ones, size_t n, uint64_t nbits);
+uint64_t go_replay_sparse(const go_fs* fs, const char* base, const go_key* pos, size_t n, uint64_t universe);
+uint64_t go_replay_sparse_highbits(const go_fs* fs, const char* base, const uint64_t* ones, size_t n, uint64_t nbits);
+uint64_t go_replay_vba(const go_fs* fs, const char* base, const uint32_t* values, size_t n);
+
 /* VByte (spill-run private format; golden bytes in testVByteCodec.cc) */
 size_t   go_vbyte_encode(uint64_t x, uint8_t* out /* >= 9 */);  /* VByteCodec.hh:24-104 */
 uint64_t go_vbyte_decode(const uint8_t* in, size_t* used);

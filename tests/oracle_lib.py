@@ -434,3 +434,125 @@ def merge_and_annotate(files, lhs, rhs, out):
     if L.go_merge_and_annotate(src.handle, lhs.encode(), rhs.encode(), dst.handle, out.encode(), stats, err, 1024):
         raise OracleError(err.value.decode())
     return dst.files(), tuple(stats)
+
+
+# --------------------------------------------------------------------------------------
+# stand-alone structures and assertion replays in the shape of the reference's unit tests
+# (goss_oracle.h: go_write_bits_and_select ... go_replay_vba)
+# --------------------------------------------------------------------------------------
+
+def _u64_array(vals):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(vals, dtype=np.uint64))
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _key_array(positions):
+    n = len(positions)
+    return (Key * max(1, n))(*[key(v) for v in positions])
+
+
+def write_bits_and_select(ones, nbits, invert, vname="v", xname="x"):
+    """testDenseArray.cc's set-up: WordyBitVector over nbits positions + DenseSelect of one sense."""
+    L = lib()
+    L.go_write_bits_and_select.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64, C.c_int]
+    fs = FileSet()
+    a, p = _u64_array(ones)
+    if L.go_write_bits_and_select(fs.handle, vname.encode(), xname.encode(), p, len(ones), nbits, 1 if invert else 0):
+        raise OracleError("go_write_bits_and_select")
+    return fs.files()
+
+
+def write_bits_sparse(ones, vname="x"):
+    L = lib()
+    L.go_write_bits_sparse.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t]
+    fs = FileSet()
+    a, p = _u64_array(ones)
+    L.go_write_bits_sparse(fs.handle, vname.encode(), p, len(ones))
+    return fs.files()
+
+
+class BitsReader:
+    """WordyBitVector read side (get / select1 / select0 / popcountRange / words)."""
+
+    def __init__(self, files, vname="x"):
+        self._fs = FileSet.from_files(files)
+        self._v = vname.encode()
+        L = lib()
+        L.go_bits_get.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.go_bits_words.restype = C.c_uint64
+        L.go_bits_words.argtypes = [C.c_void_p, C.c_char_p]
+        L.go_bits_select.restype = C.c_uint64
+        L.go_bits_select.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
+        L.go_bits_popcount_range.restype = C.c_uint64
+        L.go_bits_popcount_range.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64]
+
+    def get(self, pos):
+        return bool(lib().go_bits_get(self._fs.handle, self._v, pos))
+
+    def words(self):
+        return lib().go_bits_words(self._fs.handle, self._v)
+
+    def select1(self, frm, count):
+        return lib().go_bits_select(self._fs.handle, self._v, 0, frm, count)
+
+    def select0(self, frm, count):
+        return lib().go_bits_select(self._fs.handle, self._v, 1, frm, count)
+
+    def popcount_range(self, b, e):
+        return lib().go_bits_popcount_range(self._fs.handle, self._v, b, e)
+
+
+def dense_select(files, i, invert, vname="v", xname="x"):
+    L = lib()
+    L.go_dense_select.restype = C.c_uint64
+    L.go_dense_select.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint64]
+    fs = FileSet.from_files(files)
+    return L.go_dense_select(fs.handle, vname.encode(), xname.encode(), 1 if invert else 0, i)
+
+
+def replay_dense_select(files, ones, nbits, invert, vname="v", xname="x"):
+    L = lib()
+    L.go_replay_dense_select.restype = C.c_uint64
+    L.go_replay_dense_select.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64]
+    fs = FileSet.from_files(files)
+    a, p = _u64_array(ones)
+    return L.go_replay_dense_select(fs.handle, vname.encode(), xname.encode(), 1 if invert else 0, p, len(ones), nbits)
+
+
+def replay_sparse(files, base, positions, universe=0):
+    L = lib()
+    L.go_replay_sparse.restype = C.c_uint64
+    L.go_replay_sparse.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Key), C.c_size_t, C.c_uint64]
+    fs = FileSet.from_files(files)
+    return L.go_replay_sparse(fs.handle, base.encode(), _key_array(positions), len(positions), universe)
+
+
+def replay_sparse_highbits(files, base, ones, nbits):
+    L = lib()
+    L.go_replay_sparse_highbits.restype = C.c_uint64
+    L.go_replay_sparse_highbits.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64]
+    fs = FileSet.from_files(files)
+    a, p = _u64_array(ones)
+    return L.go_replay_sparse_highbits(fs.handle, base.encode(), p, len(ones), nbits)
+
+
+def write_vba(values, num_items, base="x"):
+    import numpy as np
+    L = lib()
+    L.go_write_vba.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_size_t, C.c_uint64]
+    fs = FileSet()
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.uint32))
+    if L.go_write_vba(fs.handle, base.encode(), a.ctypes.data_as(C.POINTER(C.c_uint32)), len(values), num_items):
+        raise OracleError("go_write_vba")
+    return fs.files()
+
+
+def replay_vba(files, base, values):
+    import numpy as np
+    L = lib()
+    L.go_replay_vba.restype = C.c_uint64
+    L.go_replay_vba.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_size_t]
+    fs = FileSet.from_files(files)
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.uint32))
+    return L.go_replay_vba(fs.handle, base.encode(), a.ctypes.data_as(C.POINTER(C.c_uint32)), len(values))
