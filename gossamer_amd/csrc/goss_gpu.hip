@@ -92,6 +92,8 @@ struct goss_gpu_ctx {
     bool mute_timing = false;           // set around auxiliary launches (the distinct-count estimate)
     uint32_t segment_retries = 0;       // segment path attempts that overflowed an LDS table
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
+    bool extract_rep = false;           // the next one-word k-mer extraction stores strand representatives (fused path's sample)
+    uint32_t rep_chunks = 0;            // chunks counted in strand-representative space and mapped to canonical order afterwards
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
@@ -460,6 +462,12 @@ void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G, NB>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, \
                        nstarts, navail, c->len, out, c->d_ctr, c->extract_hist_shift, nsuper)
     if (MODE == 1) { GOSS_LAUNCH_E1(8); return; }          // graph mode does not hash
+    if (MODE == 0 && c->extract_rep)
+    {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, G, 8, true>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis,
+                           nstarts, navail, c->len, out, c->d_ctr, c->extract_hist_shift, nsuper);
+        return;
+    }
     switch ((2 * c->len + 7) / 8)
     {
         case 1: GOSS_LAUNCH_E1(1); break;
@@ -781,10 +789,44 @@ template <class K>
 int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segbits, Run* out, const uint64_t* seg_beg,
                    const uint64_t* seg_end, int big);
 
+// A run counted in strand-representative space (extract1_part_kernel, MODE 0) -> the run the rest of
+// the library expects: every key replaced by gossamer's canonical form (the strand with the smaller
+// FNV-1a hash), then (key,count) pairs put back in key order.  The map is a bijection between the
+// two choices of representative, so counts carry over and no two entries collide.  `scratch` (the
+// chunk's first key buffer, dead by now) holds the sort's ping-pong.
+template <class K>
+void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slots)
+{
+    const uint64_t m = r.m;
+    if (m == 0) return;
+    PhaseTimer t(c, GOSS_T_REDUCE, m);
+    const uint64_t need = 2 * m * sizeof(K) + 2 * m * 4 + 64;
+    uint64_t mark = c->arena.mark();
+    uint8_t* p = (uint8_t*)scratch;
+    if (scratch_slots * sizeof(K) < need) p = (uint8_t*)c->arena.temp(need);
+    K* ka = (K*)p;
+    K* kb = ka + m;
+    uint32_t* va = (uint32_t*)(kb + m);
+    uint32_t* vb = va + m;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(canonical_map_kernel<K>), dim3(grid_for(m, kTB)), dim3(kTB), 0, c->stream,
+                       (const K*)r.keys, ka, m, c->len);
+    HIP_TRY(hipMemcpyAsync(va, r.counts, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    const bool mute = c->mute_timing;
+    c->mute_timing = true;                  // the sort's passes belong to this phase, not to the partition classes
+    const bool in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, key_digits(c));
+    c->mute_timing = mute;
+    HIP_TRY(hipMemcpyAsync(r.keys, in_b ? kb : ka, m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(r.counts, in_b ? vb : va, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    t.stop();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+}
+
 // Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
 // buffers of one key per window start).
 enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2 };
+constexpr uint32_t kFusedGrid = 768;                         // workgroups of extract1_part_kernel: 3 per CU (52 KB of LDS each)
 constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
 constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
 
@@ -841,7 +883,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     {
         const uintptr_t addr0 = (uintptr_t)d_bases;
         const uint32_t mis0 = (uint32_t)(addr0 & 15u);
-        if (nslices == 1) extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
+        if (nslices == 1)
+        {
+            c->extract_rep = kOne && !graph_mode;
+            extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
+            c->extract_rep = false;
+        }
         else if constexpr (!kOne)
         {
             const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
@@ -854,25 +901,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
-#define GOSS_LAUNCH_ES(NB)                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, NB>), dim3(grid), dim3(kTB), 0, c->stream,              \
-                       (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper, \
-                       slice_tiles, slice_stride)
             if (graph_mode)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<1, 8, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
                                    (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
                                    slice_tiles, slice_stride);
-            else
-            switch ((2 * c->len + 7) / 8)
-            {
-                case 3: GOSS_LAUNCH_ES(3); break;
-                case 4: GOSS_LAUNCH_ES(4); break;
-                case 5: GOSS_LAUNCH_ES(5); break;
-                case 6: GOSS_LAUNCH_ES(6); break;
-                case 7: GOSS_LAUNCH_ES(7); break;
-                default: GOSS_LAUNCH_ES(8); break;
-            }
-#undef GOSS_LAUNCH_ES
+            else      // strand representatives: the key space the fused kernel counts in
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, 8, true>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
+                                   slice_tiles, slice_stride);
         }
     }
     c->extract_hist_shift = 0xFFFFFFFFu;
@@ -991,6 +1027,20 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // bucket regions of the first buffer: expected size of every bucket plus five standard
     // deviations of the sample count; whatever room the key buffer has beyond that (up to 25 %)
     // is handed out proportionally, so that a mildly non-stationary input still fits
+    // One-word keys: every workgroup of the fused kernel appends to a private block of B slots per
+    // bucket and pads the unused tail of its last blocks, so a region also needs one block per
+    // workgroup; B is the largest power of two (8 .. 256) that keeps that padding near 1 % of the keys.
+    // (up to 3 % of the keys in all: a small chunk gets fewer workgroups, then smaller blocks)
+    const uint64_t kSuperOne = (uint64_t)kTB * (graph_mode ? 8 : 16);
+    const double pad_budget = 0.03 * (double)n_exp;
+    uint32_t fgrid = (uint32_t)std::min<uint64_t>((nstarts + kSuperOne - 1) / kSuperOne, (uint64_t)kFusedGrid);
+    if (c->fused_grid) fgrid = std::min(fgrid, c->fused_grid);
+    if (kOne) fgrid = (uint32_t)std::max(16.0, std::min((double)fgrid, pad_budget / (256.0 * 8.0)));
+    uint32_t blk_log2 = 3;
+    if (kOne)
+        while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
+    const uint64_t B = kOne ? (1ULL << blk_log2) : 16;
+    const double blk_extra = kOne ? (double)fgrid * (double)B : 0.0;
     GapTable gt{};
     double base[256], base_sum = 0;
     for (int d = 0; d < 256; ++d)
@@ -999,13 +1049,18 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         base[d] = exact ? h + 64.0 : (h + 5.0 * std::sqrt(h + 1.0) + 16.0) * scale + 1024.0;    // exact counts need no slack
         base_sum += base[d];
     }
-    double slack = std::min(1.25, ((double)ka_slots - 256.0 * 16.0) / base_sum);
-    if (slack < (exact ? 1.0 : 1.02)) return decline("bucket regions do not fit the key buffer");
+    double slack = std::min(1.25, ((double)ka_slots - 256.0 * ((double)B + blk_extra)) / base_sum);
+    if (slack < (exact ? 1.0 : 1.02))
+    {
+        // buffers sized from the share of valid windows: the caller retries with one slot per window start
+        if (reduced) return (int)kFusedNeedFull;
+        return decline("bucket regions do not fit the key buffer");
+    }
     slack *= c->fused_capscale;
     uint64_t at = 0;
     for (int d = 0; d < 256; ++d)
     {
-        uint64_t cap = ((uint64_t)(base[d] * slack) + 15) & ~15ULL;
+        uint64_t cap = ((uint64_t)(base[d] * slack + blk_extra * c->fused_capscale) + B - 1) & ~(B - 1);
         gt.reg_start[d] = at; gt.reg_cap[d] = cap;
         at += cap;
     }
@@ -1026,44 +1081,33 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 #ifndef GOSS_FUSED_NKEYS2
 #define GOSS_FUSED_NKEYS2 16
 #endif
-        const uint64_t kSuper = kOne ? (uint64_t)GOSS_FUSED_G * kTB * (graph ? 8 : 16)
+        const uint64_t kSuper = kOne ? (uint64_t)kTB * (graph ? 8 : 16)
                                      : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
         uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);
         if (c->fused_grid) grid = std::min(grid, c->fused_grid);      // experiments: leave room for a second context's kernels
+        if (kOne) grid = fgrid;                                        // the regions were sized for this many workgroups
         const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         if constexpr (kOne)
         {
-#define GOSS_LAUNCH_EP3(MODE, NB, NH)                                                                                 \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NB, GOSS_FUSED_G, NH>), dim3(grid), dim3(kTB), 0, c->stream,     \
-                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
-#define GOSS_LAUNCH_EP2(NB, NH) GOSS_LAUNCH_EP3(0, NB, NH)
-#define GOSS_LAUNCH_EP(NB)                                                                                            \
-    do {                                                                                                              \
-        if (nh == 0) GOSS_LAUNCH_EP2(NB, 0);                                                                          \
-        else if (nh == 1) GOSS_LAUNCH_EP2(NB, 1);                                                                     \
-        else GOSS_LAUNCH_EP2(NB, 2);                                                                                  \
-    } while (0)
+#define GOSS_LAUNCH_EP3(MODE, NH)                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH>), dim3(grid), dim3(kTB), 0, c->stream,              \
+                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2)
             if (graph)
             {
-                // graph mode does not hash: one instantiation serves every key width
-                if (nh == 0) GOSS_LAUNCH_EP3(1, 8, 0);
-                else if (nh == 1) GOSS_LAUNCH_EP3(1, 8, 1);
-                else GOSS_LAUNCH_EP3(1, 8, 2);
+                if (nh == 0) GOSS_LAUNCH_EP3(1, 0);
+                else if (nh == 1) GOSS_LAUNCH_EP3(1, 1);
+                else GOSS_LAUNCH_EP3(1, 2);
             }
             else
-                switch ((2 * c->len + 7) / 8)
-                {
-                    case 3: GOSS_LAUNCH_EP(3); break;
-                    case 4: GOSS_LAUNCH_EP(4); break;
-                    case 5: GOSS_LAUNCH_EP(5); break;
-                    case 6: GOSS_LAUNCH_EP(6); break;
-                    case 7: GOSS_LAUNCH_EP(7); break;
-                    default: GOSS_LAUNCH_EP(8); break;
-                }
-#undef GOSS_LAUNCH_EP
-#undef GOSS_LAUNCH_EP2
+            {
+                // k-mer sets are counted as strand representatives and mapped to the canonical form
+                // afterwards (canonicalize_run)
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1);
+                else GOSS_LAUNCH_EP3(0, 2);
+            }
 #undef GOSS_LAUNCH_EP3
         }
         else
@@ -1099,13 +1143,15 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     uint64_t tiles = 0, sum = 0;
     for (int d = 0; d < 256; ++d)
     {
+        // one-word keys: slots handed out in whole blocks, padding included (the next pass skips it)
         gt.cnt[d] = hp->cursors[d * kCursorStride];
         gt.tile_first[d] = tiles;
         tiles += (gt.cnt[d] + kTile - 1) / kTile;
         sum += gt.cnt[d];
     }
     gt.tile_first[256] = tiles;
-    if (sum != n) throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
+    if (kOne ? (sum < n || sum > n + (uint64_t)fgrid * 256 * (B + 8)) : sum != n)
+        throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
     HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
 
     LookbackCtl* ctl = (LookbackCtl*)c->arena.temp(sizeof(LookbackCtl));
@@ -1193,6 +1239,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
     }
     lap("segments counted");
+    if (kOne && !graph_mode)
+    {
+        canonicalize_run<K>(c, r, ka, ka_slots);
+        c->rep_chunks++;
+        lap("canonical order");
+    }
     c->runs.push_back(r);
     c->windows += hp->windows;
     c->keys_total += n;
@@ -2400,6 +2452,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (!c || !name || !value) return GOSS_ERR_INVALID_ARG;
     const std::string n = name;
     if (n == "fused_chunks") *value = c->fused_chunks;
+    else if (n == "rep_chunks") *value = c->rep_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;

@@ -184,6 +184,26 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
     if ((threadIdx.x & 63u) == 0 && seen) { atomicAdd(&out[0], bad); atomicAdd(&out[1], seen); }
 }
 
+// Strand representative of a k-mer for COUNTING: of {x, rc(x)} the one whose bits, rotated left
+// by len (the central bases first), are smaller.  It is a function of the unordered pair, so both
+// strands of a k-mer count as one key; the rotation makes the choice depend on the central bases,
+// which leaves the leading bases -- the partition digits -- uniform; and it costs a handful of
+// integer operations where gossamer's canonical form (the smaller FNV-1a hash, RankSelect.hh:126-140)
+// costs two chains of 64-bit multiplies per window.  The distinct representatives are mapped to
+// that canonical form once, after counting (canonical_map_kernel): 126 x fewer hashes on 150 x
+// coverage.  x == rc(x) is the only tie.
+__device__ __forceinline__ uint64_t rot_half(uint64_t v, uint32_t len, uint64_t lmask)
+{
+    return ((v & lmask) << len) | (v >> len);
+}
+__device__ __forceinline__ Key1 strand_rep(const Key1& f, const Key1& rc, uint32_t len, uint64_t lmask)
+{
+    return rot_half(rc.lo, len, lmask) < rot_half(f.lo, len, lmask) ? rc : f;
+}
+
+__device__ __forceinline__ bool is_pad_key(const Key1& k) { return k.lo == ~0ULL; }
+__device__ __forceinline__ bool is_pad_key(const Key2& k) { return (k.lo & k.hi) == ~0ULL; }
+
 template <class K> struct KeyOps;
 template <> struct KeyOps<Key1> {
     static __device__ __forceinline__ Key1 zero() { return Key1{0}; }
@@ -343,7 +363,9 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 
 // NB = number of significant key bytes, ceil(2*len / 8): the FNV rounds of the zero bytes above
 // them fold into one multiplication (goss_key.hpp, key_hash_short).
-template <int MODE, int P, int G, int NB>
+// REP: MODE 0 stores the strand representative (strand_rep) instead of the canonical form -- the
+// key space extract1_part_kernel counts in; its sample must be drawn from the same space.
+template <int MODE, int P, int G, int NB, bool REP = false>
 __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
@@ -487,7 +509,7 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
                 if ((vm >> i) & 1u)
                 {
                     Key1 fk{f}, rk{(~e) & kmask};
-                    if (MODE == 0) stage[s++] = canonical_short<NB>(fk, rk);
+                    if (MODE == 0) stage[s++] = REP ? strand_rep(fk, rk, len, lmask) : canonical_short<NB>(fk, rk);
                     else { stage[s++] = fk; stage[s++] = rk; }
                 }
             }
@@ -715,27 +737,51 @@ struct SubTable {
     unsigned long long cap[65536];
 };
 
-template <int MODE, int NB, int G, int NH>
+constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at most 62 bits
+
+// Extraction fused with the first partition level, third form.  What bounded the second form
+// (one returning atomic per tile and bucket on 256 cursor words, bucket runs of ~128 bytes landing
+// on partial 64-byte granules of HBM, two FNV chains per window) is designed out:
+//   * a workgroup owns a private BLOCK of B key slots in every bucket region and appends to it;
+//     a bucket cursor is touched only when a block is used up (B = 256: 16 x fewer atomics);
+//   * stores reach HBM as they are issued (nothing merges two partial writes of a 64-byte granule
+//     on the way: 1.4-1.5 x the bytes when runs start anywhere), so a tile stores only whole
+//     granules: per bucket the keys beyond a multiple of 8 wait in the registers of the thread that
+//     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket; in LDS the
+//     stored parts of all buckets lie back to back, each a multiple of 8 keys, so that 8 aligned
+//     lanes of ONE store instruction cover one aligned granule;
+//   * MODE 0 stores the strand representative (strand_rep) instead of the canonical form.
+// The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
+// skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
+// The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
+template <int MODE, int NH>
 __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
-                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper)
+                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
+                                                            uint32_t blk_log2)
 {
-    // MODE 0: canonical key per window, 16 windows per thread.  MODE 1 (graph): forward key and
+    // MODE 0: one key per window, 16 windows per thread.  MODE 1 (graph): forward key and
     // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
     constexpr int S = MODE == 1 ? 2 : 1;
     constexpr int P = 16 / S;
-    constexpr int T = kTB * P;
-    constexpr int NVEC = G * T / 16 + 4;
-    constexpr int NK = G * P * S;                // keys per thread
-    __shared__ uint32_t pk[NVEC];
-    __shared__ uint32_t iv[NVEC];
-    __shared__ Key1 sorted[G * T * S];
-    __shared__ uint32_t dh[256];                 // keys of this super-tile per digit (and rank counter)
-    __shared__ uint64_t gbase[256];              // global slot of sorted[i] with digit d = gbase[d] + i
+    constexpr int T = kTB * P;                   // window starts per tile
+    constexpr int NVEC = T / 16 + 4;
+    constexpr int NK = P * S;                    // keys per thread
+    constexpr int kCarry = 7;
+    // the tile's keys and the keys carried in: first the parts stored now, bucket after bucket
+    // (each a multiple of 8), then the parts carried out
+    __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry];
+    __shared__ uint32_t dh[256];                 // new keys of this tile per digit (rank counter)
+    __shared__ uint32_t t_store[256];            // first slot in `sorted` of the stored part | its length << 16
+    __shared__ uint32_t t_left[256];             // first slot in `sorted` of the part carried out | keys carried in << 16
+    __shared__ uint32_t t_thr[256];              // how many stored keys fit the current block
+    __shared__ uint32_t base0[256], base1[256];  // slot / 8 of the current block's write position and of the new block(s)
     __shared__ uint32_t sh_ovf;
     __shared__ uint32_t lh[NH ? 256 * NH : 1];   // histograms of the next NH digits
     __shared__ uint32_t sh_scan[kWaves + 1];
+    uint32_t* pk = reinterpret_cast<uint32_t*>(sorted);
+    uint32_t* iv = pk + NVEC;
 
     const uint32_t tid = threadIdx.x;
     if (NH > 0) lh[tid] = 0;
@@ -743,14 +789,20 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     dh[tid] = 0;
     if (tid == 0) sh_ovf = 0;
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t B = 1u << blk_log2;
     const uint32_t bits = 2 * len;
     const uint64_t kmask = (1ULL << bits) - 1;               // len <= 31
     const uint64_t lmask = (1ULL << len) - 1;
     unsigned long long nvalid = 0;
+    uint64_t wpos = 0;                           // next slot of bucket tid's open block (a block boundary = none open)
+    uint32_t ccnt = 0;                           // keys of bucket tid carried over from the previous tile
+    Key1 kc[kCarry];                             // ... and the keys themselves
+#pragma unroll
+    for (int j = 0; j < kCarry; ++j) kc[j].lo = 0;
 
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
     {
-        const uint64_t tile_base = st * (uint64_t)(G * T);
+        const uint64_t tile_base = st * (uint64_t)T;
 
         // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
         for (uint32_t v = tid; v < NVEC; v += kTB)
@@ -791,16 +843,14 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         }
         __syncthreads();
 
-        // ---- phase B: windows out of registers, canonical keys, rank inside their digit ---------
+        // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
         Key1 kreg[NK];
         uint16_t rk[NK];
-        uint32_t vm[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
+        uint32_t vm;
         {
-            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t q0 = tid * P + mis;
             const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
-            const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+            const uint64_t p0 = tile_base + (uint64_t)tid * P;
             uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
             const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
             uint32_t m = 0;
@@ -810,7 +860,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 bool ok = ((inv >> i) & lmask) == 0 && (p0 + i < nstarts);
                 m |= ok ? (1u << i) : 0u;
             }
-            vm[g] = m;
+            vm = m;
             nvalid += __popc(m);
             if (m)
             {
@@ -836,16 +886,16 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                         Key1 fk{f}, rck{(~e) & kmask};
                         if (MODE == 0)
                         {
-                            const Key1 k = canonical_short<NB>(fk, rck);
-                            kreg[g * P + i] = k;
-                            rk[g * P + i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
+                            const Key1 k = strand_rep(fk, rck, len, lmask);
+                            kreg[i] = k;
+                            rk[i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
                         }
                         else
                         {
-                            kreg[(g * P + i) * 2] = fk;
-                            rk[(g * P + i) * 2] = (uint16_t)atomicAdd(&dh[(uint32_t)(fk.lo >> shift) & 0xFFu], 1u);
-                            kreg[(g * P + i) * 2 + 1] = rck;
-                            rk[(g * P + i) * 2 + 1] = (uint16_t)atomicAdd(&dh[(uint32_t)(rck.lo >> shift) & 0xFFu], 1u);
+                            kreg[i * 2] = fk;
+                            rk[i * 2] = (uint16_t)atomicAdd(&dh[(uint32_t)(fk.lo >> shift) & 0xFFu], 1u);
+                            kreg[i * 2 + 1] = rck;
+                            rk[i * 2 + 1] = (uint16_t)atomicAdd(&dh[(uint32_t)(rck.lo >> shift) & 0xFFu], 1u);
                         }
                     }
                 }
@@ -853,68 +903,130 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         }
         __syncthreads();
 
-        // ---- phase C: reserve the tile's share of every bucket (thread tid owns digit tid) -------
-        uint32_t total;
+        // ---- phase C: bookkeeping of bucket tid: what is stored now, where, what is carried out ----
+        uint32_t total_store;
         {
             const uint32_t cnt = dh[tid];
-            const uint32_t start = block_excl_scan<uint32_t>(cnt, sh_scan, &total);
-            dh[tid] = start;                           // the counter becomes the digit's first slot in `sorted`
-            unsigned long long at = cnt ? atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)cnt) : 0ULL;
-            gbase[tid] = my_start + at - start;
-            // a region that is too small: nothing of this super-tile is stored, the host redoes the chunk
-            if (cnt && at + cnt > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+            const uint32_t tot = ccnt + cnt;           // the bucket's stream: carried keys, then the new ones by rank
+            const uint32_t fl = tot & ~7u, rem = tot & 7u;
+            uint32_t sums;
+            const uint32_t pre = block_excl_scan<uint32_t>(fl | (rem << 16), sh_scan, &sums);
+            total_store = sums & 0xFFFFu;
+            const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
+            t_store[tid] = f_at | (fl << 16);
+            t_left[tid] = l_at | (ccnt << 16);
+            dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            uint32_t thr = fl;
+            base0[tid] = (uint32_t)(wpos >> 3);
+            if (fl > room)
+            {
+                thr = room;
+                const uint32_t need = fl - room;
+                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                // a region that is too small: nothing of this tile is stored, the host redoes the chunk
+                if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+                base1[tid] = (uint32_t)((my_start + at) >> 3);
+                wpos = my_start + at + need;
+            }
+            else wpos += fl;
+            t_thr[tid] = thr;
+            // the keys carried in go first (phase A's arrays in `sorted` are dead: every thread is past phase B)
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) sorted[(uint32_t)j < fl ? f_at + j : l_at + j] = kc[j];
+            ccnt = rem;
         }
         __syncthreads();
+        // new keys to their place: position ccnt_in + rank of the bucket's stream
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-        {
+        for (int i = 0; i < P; ++i)
+            if ((vm >> i) & 1u)
+            {
 #pragma unroll
-            for (int i = 0; i < P; ++i)
-                if ((vm[g] >> i) & 1u)
+                for (int q = 0; q < S; ++q)
                 {
-#pragma unroll
-                    for (int q = 0; q < S; ++q)
-                    {
-                        const Key1 k = kreg[(g * P + i) * S + q];
-                        sorted[dh[(uint32_t)(k.lo >> shift) & 0xFFu] + rk[(g * P + i) * S + q]] = k;
-                    }
+                    const Key1 k = kreg[i * S + q];
+                    const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
+                    const uint32_t ts = t_store[d], tl = t_left[d];
+                    const uint32_t p = (tl >> 16) + rk[i * S + q];
+                    const uint32_t fl = ts >> 16;
+                    sorted[p < fl ? (ts & 0xFFFFu) + p : (tl & 0xFFFFu) + (p - fl)] = k;
+                    if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
+                    if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
                 }
-        }
+            }
         __syncthreads();
 
-        // ---- phase D: coalesced bucket runs + histograms of the next two digits -----------------
-        dh[tid] = 0;                                   // ready for the next super-tile
-        if (!sh_ovf)
+        // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------
+        if (sh_ovf == 0)
+            for (uint32_t i = tid; i < total_store; i += kTB)
+            {
+                const Key1 k = sorted[i];
+                const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
+                const uint32_t p = i - (t_store[d] & 0xFFFFu);
+                const uint32_t thr = t_thr[d];
+                const uint64_t o = p < thr ? ((uint64_t)base0[d] << 3) + p : ((uint64_t)base1[d] << 3) + (p - thr);
+                out[o] = k;
+            }
+        // what bucket tid carries out, back into registers
         {
-            if (NH > 1)
-                for (uint32_t i = tid; i < total; i += kTB)
-                {
-                    const Key1 k = sorted[i];
-                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
-                    atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
-                    atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
-                }
-            else if (NH == 1)
-                for (uint32_t i = tid; i < total; i += kTB)
-                {
-                    const Key1 k = sorted[i];
-                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
-                    atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
-                }
-            else
-                for (uint32_t i = tid; i < total; i += kTB)
-                {
-                    const Key1 k = sorted[i];
-                    out[gbase[(uint32_t)(k.lo >> shift) & 0xFFu] + i] = k;
-                }
+            const uint32_t l_at = t_left[tid] & 0xFFFFu;
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) kc[j] = sorted[l_at + j];
         }
         __syncthreads();
+    }
+
+    // ---- the end: carried keys and the unused tail of every open block ---------------------------
+    if (sh_ovf == 0)
+    {
+        if (ccnt)
+        {
+            // one more granule: the carried keys, padding behind them
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            if (room == 0)
+            {
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
+                else wpos = my_start + at;
+            }
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) out[wpos + j] = kc[j];
+            wpos += ccnt;
+        }
+        const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+        // pad [wpos, end of block) of every bucket: all threads share the work through LDS
+        __syncthreads();
+        base0[tid] = tail;
+        reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        __syncthreads();
+        for (uint32_t d = 0; d < 256; ++d)
+        {
+            const uint32_t n = base0[d];
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{kPadKey};
+        }
     }
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
     if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
     // valid windows of this workgroup
     for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
     if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
+}
+
+// Strand representatives -> gossamer's canonical form (position_type::normalize, RankSelect.hh:126-140),
+// for the distinct keys only; the result is no longer sorted.
+template <class K>
+__global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* __restrict__ in, K* __restrict__ outk, uint64_t m, uint32_t len)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= m) return;
+    const K x = in[i];
+    outk[i] = canonical(x, revcomp(x, len));
 }
 
 // The same fusion for two-word keys (32 <= len <= 63): windows out of a 192-bit register buffer
@@ -1329,6 +1441,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     __shared__ uint32_t sh_tile;
     __shared__ uint32_t sh_bucket;
     __shared__ uint32_t sh_skip;
+    __shared__ uint32_t sh_total;
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
     // Tile number.  ORDERED: a ticket (one returning atomic per tile: every lower-numbered tile
@@ -1364,6 +1477,10 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     uint16_t rank[kSortItems];
     const uint32_t wbase = w * 64 * kSortItems;
     const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+    // GAPPED: slots of a bucket region that hold no key (the padding of extract1_part_kernel's
+    // last blocks) are skipped: bit r of `have` = item r of this thread is a key
+    uint32_t have = 0;
+    static_assert(kSortItems <= 32, "one validity bit per item");
 
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r)
@@ -1373,7 +1490,15 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         {
             key[r] = keys_in[tile_base + li];
             if (HAS_VAL) val[r] = vals_in[tile_base + li];
+            have |= 1u << r;
         }
+    }
+    // (a second loop: looking at a key inside the load loop would wait for every load in turn)
+    if (GAPPED)
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+            if (((have >> r) & 1u) && is_pad_key(key[r])) have &= ~(1u << r);
     }
     // Does this tile need a STABLE rank?  Stability only matters when the tile holds keys
     // that differ in the bits the previous passes sorted (bits [sorted_lo, digit)): a tile whose
@@ -1403,8 +1528,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r)
         {
-            uint32_t li = wbase + r * 64 + lane;
-            bool valid = li < tile_n;
+            bool valid = (have >> r) & 1u;
             uint32_t d = valid ? key_digit(key[r], digit) : 0u;
             uint64_t peers = match_digit(d, valid);
             uint32_t before = __popcll(peers & lt_mask);
@@ -1421,10 +1545,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     {
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r)
-        {
-            uint32_t li = wbase + r * 64 + lane;
-            if (li < tile_n) rank[r] = (uint16_t)atomicAdd(&wave_hist[0][key_digit(key[r], digit)], 1u);
-        }
+            if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&wave_hist[0][key_digit(key[r], digit)], 1u);
     }
     __syncthreads();
 
@@ -1465,6 +1586,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         uint32_t tile_total;
         const uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
         digit_start[tid] = start;
+        if (tid == 0) sh_total = tile_total;
         __syncthreads();
 
         // the keys go to their sorted place in LDS before the look-back: that work needs only the
@@ -1472,8 +1594,7 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r)
         {
-            uint32_t li = wbase + r * 64 + lane;
-            if (li < tile_n)
+            if ((have >> r) & 1u)
             {
                 uint32_t d = key_digit(key[r], digit);
                 // unstable ranks are tile-wide already: no per-wave offset to read
@@ -1538,7 +1659,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     __syncthreads();
 
     if (GAPPED && sh_skip) return;
-    for (uint32_t i = tid; i < tile_n; i += kTB)
+    const uint32_t tile_keys = GAPPED ? sh_total : tile_n;      // padding slots hold no key
+    for (uint32_t i = tid; i < tile_keys; i += kTB)
     {
         K k = stage[i];
         uint64_t o = global_base[key_digit(k, digit)] + i;
