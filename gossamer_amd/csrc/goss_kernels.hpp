@@ -800,48 +800,73 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
 #pragma unroll
     for (int j = 0; j < kCarry; ++j) kc[j].lo = 0;
 
+    // 16 bytes of the input at `byte0` -> 32 bits of 2-bit codes + 16 non-base flags
+    auto fetch = [&](uint64_t byte0, uint4& q) -> bool {
+        if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return true; }
+        q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        if (byte0 < navail + mis)
+        {
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return true;
+    };
+    auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        codes = 0; bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+    };
+    // The bytes of a tile are fetched one tile ahead and wait, encoded, in registers: the load's
+    // latency passes behind the previous tile's ranking and sorting, and the stores of a tile have
+    // half a tile's time to drain before anything waits on this wave's memory counter again.
+    constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..3 also vector NV0 + tid
+    static_assert(NVEC == NV0 + 4 && NV0 <= kTB, "one vector per thread and four more");
+    uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
+    if (blockIdx.x < nsuper)
+    {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const uint64_t tb = (uint64_t)blockIdx.x * T;
+        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+        if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        encode(q0, c0, b0);
+        if (tid < 4) encode(q1, c1, b1);
+    }
+
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
     {
         const uint64_t tile_base = st * (uint64_t)T;
 
-        // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
-        for (uint32_t v = tid; v < NVEC; v += kTB)
-        {
-            uint64_t byte0 = tile_base + (uint64_t)v * 16;
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-            if (byte0 + 16 <= navail + mis)
-            {
-                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            }
-            else if (byte0 < navail + mis)
-            {
-                for (int j = 0; j < 16; ++j)
-                {
-                    uint64_t b = byte0 + j;
-                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
-                }
-            }
-            uint32_t codes = 0, bads = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                uint32_t l = w[i] | 0x20202020u;
-                uint32_t x = (l >> 1) & 0x03030303u;
-                x ^= (x >> 1) & 0x01010101u;
-                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-                uint32_t b1 = bad >> 7;
-                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-                codes |= c8 << (8 * i);
-                bads |= b4 << (4 * i);
-            }
-            pk[v] = codes;
-            iv[v] = bads;
-        }
+        // ---- phase A: this tile's codes from registers to LDS, the next tile's bytes on their way ----
+        if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
+        if (tid < 4) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
         __syncthreads();
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const bool more = st + gridDim.x < nsuper;
+        if (more)
+        {
+            const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
+            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+            if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        }
 
         // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
         Key1 kreg[NK];
@@ -957,6 +982,11 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                     if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
                 }
             }
+        if (more)
+        {
+            encode(q0, c0, b0);
+            if (tid < 4) encode(q1, c1, b1);
+        }
         __syncthreads();
 
         // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------
