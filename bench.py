@@ -38,20 +38,168 @@ def measured_traffic(kernel_class):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(k, read_len, genome_len, seed, sample_reads):
-    """The CPU oracle (oracle/, a restatement of the reference algorithm: kind "port") timed
-    on a bounded sample of the same synthetic workload, one thread."""
+    """The CPU oracle (oracle/, a restatement of the reference algorithm: kind "port") timed on
+    bounded samples of the same synthetic workload: on one core, and with T = min(cores, 64) worker
+    threads in the thread structure of the reference (GossCmdBuildKmerSet.tcc:226-256: T consumers,
+    T sort workers, serial flush).  The reported value is the T-thread figure."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gossamer_amd as g
     import oracle_lib as o
-    reads = g.synth_reads_host(sample_reads, read_len, genome_len, seed=seed)
     o.lib()
+    cores = os.cpu_count() or 1
+    T = max(1, min(cores, 64))
+    reads1 = g.synth_reads_host(sample_reads, read_len, genome_len, seed=seed)
     t0 = time.perf_counter()
-    files, nwin = o.build_kmer_set([(o.LINE, "reads", reads)], k)
-    dt = time.perf_counter() - t0
-    return {"value": nwin / dt / 1e6, "unit": "M k-mers/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the same synthetic set (%d k-mers) through oracle go_build_kmer_set "
-                      "(parse + canonicalise + sort + KmerSet emit, in memory), %.1f s" % (sample_reads, nwin, dt)}
+    files, nwin1 = o.build_kmer_set([(o.LINE, "reads", reads1)], k)
+    dt1 = time.perf_counter() - t0
+    one = {"value": nwin1 / dt1 / 1e6, "unit": "M k-mers/s", "cores": 1,
+           "sample": "first %d reads (%d k-mers) through oracle go_build_kmer_set, %.1f s" % (sample_reads, nwin1, dt1)}
+    del files
+    # the threaded run gets a sample that grows with the cores, bounded by a quarter of the host's
+    # memory (40 bytes per k-mer while sorting) and by 6 M reads
+    try:
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError):
+        ram = 64 << 30
+    kmers_per_read = read_len - k + 1
+    nT = int(min(6_000_000, sample_reads // 4 * T, ram / 4 / 40 / kmers_per_read))
+    nT = max(nT, sample_reads // 4)
+    readsT = reads1 if nT == sample_reads else g.synth_reads_host(nT, read_len, genome_len, seed=seed)
+    t0 = time.perf_counter()
+    files, nwinT = o.build_kmer_set_mt(readsT, k, T)
+    dtT = time.perf_counter() - t0
+    return {"value": nwinT / dtT / 1e6, "unit": "M k-mers/s", "cores": T, "kind": "port", "cpu_model": cpu_model(),
+            "host_cores": cores,
+            "sample": "first %d reads of the same synthetic set (%d k-mers) through oracle go_build_kmer_set_mt with %d "
+                      "threads (per shard: parse + canonicalise + sort-count; parallel merge by key range; serial "
+                      "KmerSet emit, in memory), %.1f s" % (nT, nwinT, T, dtT),
+            "one_core": one}
+
+
+def fastq_from_reads(reads_u8, nreads, read_len, path):
+    """The device-generated read text (read_len bases + newline per read) as 4-line FASTQ with
+    fixed-width titles, written in pieces: @r%09d / bases / + / I * read_len."""
+    import numpy as np
+    rec = 2 + 9 + 1 + (read_len + 1) + 2 + (read_len + 1)
+    step = 2_000_000
+    with open(path, "wb") as f:
+        for first in range(0, nreads, step):
+            m = min(step, nreads - first)
+            a = np.empty((m, rec), dtype=np.uint8)
+            a[:, 0] = ord("@"); a[:, 1] = ord("r")
+            idx = np.arange(first, first + m, dtype=np.int64)
+            for d in range(9):
+                a[:, 2 + 8 - d] = (idx // (10 ** d)) % 10 + ord("0")
+            a[:, 11] = ord("\n")
+            a[:, 12:12 + read_len + 1] = reads_u8[first:first + m]
+            a[:, 12 + read_len + 1] = ord("+"); a[:, 12 + read_len + 2] = ord("\n")
+            a[:, 12 + read_len + 3:rec - 1] = ord("I"); a[:, rec - 1] = ord("\n")
+            f.write(a.tobytes())
+    return nreads * rec
+
+
+def e2e_record(bases_dev, nreads, read_len, k, threads):
+    """SURVEY.md section 8(d)'s metric on a bounded sample: FASTQ file -> `goss build-kmer-set -T n` ->
+    KmerSet files closed, wall clock of the command (process start-up, parsing, PCIe, HBM mapping,
+    counting, emit, file writes included), in a fresh process."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    goss = os.path.join(ROOT, "gossamer_amd", "goss")
+    need = nreads * (2 * read_len + 16) + (4 << 30)
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir(), ROOT):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > need and os.access(cand, os.W_OK):
+                base = cand
+                break
+        except OSError:
+            continue
+    if base is None or not os.path.exists(goss):
+        return {"skipped": "no room for the FASTQ sample or no goss executable"}
+    d = tempfile.mkdtemp(prefix="goss_e2e_", dir=base)
+    try:
+        host = bases_dev[: nreads * (read_len + 1)].cpu().numpy().reshape(nreads, read_len + 1)
+        fq = os.path.join(d, "reads.fq")
+        nbytes = fastq_from_reads(host, nreads, read_len, fq)
+        del host
+        t0 = time.perf_counter()
+        p = subprocess.run([goss, "dump-bases", "-i", fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        parse_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        p = subprocess.run([goss, "build-kmer-set", "-k", str(k), "-T", str(threads), "-i", fq, "-O", os.path.join(d, "ks"), "-v"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        secs = time.perf_counter() - t0
+        log = p.stderr.decode(errors="replace")
+        if p.returncode != 0:
+            return {"failed": log[-400:]}
+        m = re.search(r"HBM arena: (\d+) GB mapped in ([0-9.]+)s", log)
+        w = re.search(r"k-mer windows: (\d+)", log)
+        out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("ks"))
+        windows = nreads * (read_len - k + 1)
+        rec = {"what": "goss build-kmer-set -k %d -T %d on a %d-read 4-line FASTQ file in %s (first reads of the bench set): "
+                       "process start -> KmerSet files closed" % (k, threads, nreads, base),
+               "reads": nreads, "fastq_bytes": nbytes, "seconds": secs, "value": windows / secs / 1e6, "unit": "M k-mers/s",
+               "parse_only_seconds": parse_s, "parser_GB_per_s": nbytes / parse_s / 1e9,
+               "arena_GB": int(m.group(1)) if m else None, "arena_map_ms": float(m.group(2)) * 1e3 if m else None,
+               "output_bytes": out_bytes}
+        if w:
+            rec["value"] = int(w.group(1)) / secs / 1e6
+        return rec
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def c4_record(g, torch, device, local_rank):
+    """BASELINE config C4: build-graph k = 55 (112-bit edge keys, both strands), 200 M x 150 bp reads of a
+    100 Mbp genome, one GPU, Graph emitted; one warm-up and one timed build, inputs resident in HBM."""
+    k, L, n, G = 55, 150, 200_000_000, 100_000_000
+    try:
+        bases = torch.empty(n * (L + 1), dtype=torch.uint8, device=device)
+        free_b, _ = torch.cuda.mem_get_info(device)
+        ctx = g.Context(k, g.MODE_GRAPH, device=local_rank, hbm_budget=int(free_b * 0.94))
+        ctx.synth_reads(bases.data_ptr(), n, L, G, seed=1)
+        torch.cuda.synchronize(device)
+        ms, c = [], None
+        for it in range(2):
+            ctx.reset()
+            ctx.timing(reset=True)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            ctx.push_device(bases.data_ptr(), bases.numel())
+            c = ctx.finish()
+            ctx.emit_device()
+            torch.cuda.synchronize(device)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        tim = ctx.timing().as_dict()
+        b = algorithmic_bytes_per_window(k + 1, L, 16, 2)
+        rec = {"workload": "C4: build-graph k=55, %d x %d bp synthetic reads (genome %d bp, seed 1), Graph emitted" % (n, L, G),
+               "ms": ms[-1], "warmup_ms": ms[0], "windows": c.windows, "keys": c.keys, "distinct_edges": c.distinct,
+               "windows_per_s": c.windows / (ms[-1] * 1e-3), "value": c.windows / (ms[-1] * 1e-3) / 1e6,
+               "unit": "M rho-mer windows/s", "dtype": "u128",
+               "roofline": {"bound": "hbm", "algorithmic_bytes_per_window": b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "achieved": b * c.windows / (ms[-1] * 1e-3) / 1e9,
+                            "frac": b * c.windows / (ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "device_ms": {nm: v["ms"] for nm, v in tim.items()}},
+               "chunks": ctx.stat("fused_chunks")}
+        ctx.close()
+        return rec
+    except Exception as e:          # the headline line must not be lost to the side record
+        return {"failed": repr(e)[:300]}
 
 
 def main():
@@ -68,6 +216,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end CLI sample (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed-by-the-headline C4 record (build-graph k=55, 200 M reads)")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     ap.add_argument("--graph", action="store_true", help="build-graph instead of build-kmer-set (windows are (k+1)-mers, "
@@ -203,6 +353,7 @@ def main():
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
                        "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
             "roofline": {"bound": "hbm", "kernel": {"extract": "extract1_part_kernel" if fused else "extract1_kernel",
+                                                    "order": "canonical_map_kernel + radix passes over (key,count) pairs",
                                                     "hist": "radix_hist_kernel",
                                                     "scan": "scan_*_kernel", "scatter": "radix_onesweep_kernel",
                                                     "reduce": "seg_hash_reduce_kernel"}.get(dom, dom),
@@ -230,12 +381,23 @@ def main():
         out["roofline"]["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
+        # beside the headline, never part of `value`: the end-to-end CLI on a bounded FASTQ sample, and
+        # BASELINE config C4 (build-graph k = 55, 200 M x 150 bp reads) through the same library
+        if world == 1 and not use_dist and not args.graph:
+            ctx.close()
+            if args.e2e_reads > 0:
+                n_e2e = min(args.e2e_reads, nreads)
+                out["e2e"] = e2e_record(bases, n_e2e, L, k, max(1, min(os.cpu_count() or 1, 64)))
+            if not args.no_extra and not (args.reads or args.genome):
+                del bases
+                torch.cuda.empty_cache()
+                out["extra"] = c4_record(g, torch, device, local_rank)
         # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    ctx.close()          # (idempotent)
     if use_dist:
         dist.destroy_process_group()
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
-    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range",
+    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare",
 ]
 
 
@@ -37,8 +37,8 @@ class Counts(C.Structure):
                 ("key_words", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-T_EXTRACT, T_HIST, T_SCAN, T_SCATTER, T_REDUCE, T_EMIT, T_CLASSES = 0, 1, 2, 3, 4, 5, 8
-T_NAMES = ["extract", "hist", "scan", "scatter", "reduce", "emit"]
+T_EXTRACT, T_HIST, T_SCAN, T_SCATTER, T_REDUCE, T_EMIT, T_ORDER, T_CLASSES = 0, 1, 2, 3, 4, 5, 6, 8
+T_NAMES = ["extract", "hist", "scan", "scatter", "reduce", "emit", "order"]
 
 
 class Timing(C.Structure):
@@ -167,6 +167,11 @@ class Context:
         """A counted run in host memory (goss_gpu_push_run_host): m keys of key_words u64, m u32 counts."""
         self._L.goss_gpu_push_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         self._check(self._L.goss_gpu_push_run_host(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
+
+    def prepare(self):
+        """Start mapping the HBM arena in the background (goss_gpu_prepare)."""
+        self._L.goss_gpu_prepare.argtypes = [C.c_void_p]
+        self._check(self._L.goss_gpu_prepare(self._h))
 
     def set_path(self, path):
         """0: segment hash path with LSD fallback (default); 1: LSD radix sort only."""

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "goss_kernels.hpp"
@@ -105,6 +106,9 @@ struct goss_gpu_ctx {
     uint64_t budget_limit = 0;          // the arena may grow up to this many bytes (goss_gpu_set_budget_limit; 0 = fixed)
     uint32_t arena_grows = 0;
     uint64_t arena_ms = 0;              // time hipMalloc took to map the arena
+    std::thread arena_thread;           // goss_gpu_prepare: the arena is being mapped in the background
+    int arena_status = GOSS_OK;         // ... and how that went
+    std::string arena_error;
     uint32_t fused_grid = 0;            // GOSS_GPU_FUSED_GRID: workgroups of the fused extraction kernel (0 = 1024)
     bool seg_merge = true;              // GOSS_GPU_NO_SEG_MERGE=1: merge runs by sorting their concatenation
     uint32_t seg_merges = 0;            // merges done by segments
@@ -192,9 +196,8 @@ inline uint32_t grid_for(uint64_t n, uint32_t per_block)
     return (uint32_t)g;
 }
 
-void ensure_arena(goss_gpu_ctx* c)
+void map_arena(goss_gpu_ctx* c)
 {
-    if (c->arena.base) return;
     uint64_t budget = c->budget;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -210,6 +213,17 @@ void ensure_arena(goss_gpu_ctx* c)
     c->arena.lo = 0;
     c->arena.hi = budget;
     c->budget = budget;
+}
+
+void ensure_arena(goss_gpu_ctx* c)
+{
+    if (c->arena_thread.joinable())
+    {
+        c->arena_thread.join();
+        if (c->arena_status != GOSS_OK) throw StatusError{c->arena_status, c->arena_error};
+    }
+    if (c->arena.base) return;
+    map_arena(c);
 }
 
 // Grow the arena so that at least `want_avail` bytes are free (or double it when want_avail is 0),
@@ -799,7 +813,7 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
 {
     const uint64_t m = r.m;
     if (m == 0) return;
-    PhaseTimer t(c, GOSS_T_REDUCE, m);
+    PhaseTimer t(c, GOSS_T_ORDER, m);
     const uint64_t need = 2 * m * sizeof(K) + 2 * m * 4 + 64;
     uint64_t mark = c->arena.mark();
     uint8_t* p = (uint8_t*)scratch;
@@ -1091,22 +1105,28 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         if constexpr (kOne)
         {
-#define GOSS_LAUNCH_EP3(MODE, NH)                                                                                     \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH>), dim3(grid), dim3(kTB), 0, c->stream,              \
+#define GOSS_LAUNCH_EP3(MODE, NH, ODD)                                                                                \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD>), dim3(grid), dim3(kTB), 0, c->stream,         \
                        aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2)
             if (graph)
             {
-                if (nh == 0) GOSS_LAUNCH_EP3(1, 0);
-                else if (nh == 1) GOSS_LAUNCH_EP3(1, 1);
-                else GOSS_LAUNCH_EP3(1, 2);
+                if (nh == 0) GOSS_LAUNCH_EP3(1, 0, false);
+                else if (nh == 1) GOSS_LAUNCH_EP3(1, 1, false);
+                else GOSS_LAUNCH_EP3(1, 2, false);
+            }
+            else if (c->len & 1u)
+            {
+                // k-mer sets are counted as strand representatives and mapped to the canonical form
+                // afterwards (canonicalize_run); odd k: the central base picks the strand
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, true);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, true);
+                else GOSS_LAUNCH_EP3(0, 2, true);
             }
             else
             {
-                // k-mer sets are counted as strand representatives and mapped to the canonical form
-                // afterwards (canonicalize_run)
-                if (nh == 0) GOSS_LAUNCH_EP3(0, 0);
-                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1);
-                else GOSS_LAUNCH_EP3(0, 2);
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, false);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, false);
+                else GOSS_LAUNCH_EP3(0, 2, false);
             }
 #undef GOSS_LAUNCH_EP3
         }
@@ -1974,9 +1994,27 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     return GOSS_OK;
 }
 
+int goss_gpu_prepare(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (c->arena.base || c->arena_thread.joinable()) return GOSS_OK;
+    c->arena_status = GOSS_OK;
+    c->arena_thread = std::thread([c]() {
+        try
+        {
+            HIP_TRY(hipSetDevice(c->device));
+            map_arena(c);
+        }
+        catch (const HipError& e) { c->arena_status = GOSS_ERR_HIP; c->arena_error = std::string(e.what) + ": " + hipGetErrorString(e.e); }
+        catch (const StatusError& e) { c->arena_status = e.status; c->arena_error = e.msg; }
+    });
+    return GOSS_OK;
+}
+
 void goss_gpu_destroy(goss_gpu_ctx* c)
 {
     if (!c) return;
+    if (c->arena_thread.joinable()) c->arena_thread.join();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& pe : c->events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
@@ -2214,6 +2252,7 @@ int goss_gpu_reset(goss_gpu_ctx* c)
 {
     if (!c) return GOSS_ERR_INVALID_ARG;
     return guarded(c, [&]() {
+        if (c->arena_thread.joinable()) ensure_arena(c);      // a background mapping (goss_gpu_prepare) ends first
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->runs.clear();
         c->files.clear();

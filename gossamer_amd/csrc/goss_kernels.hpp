@@ -754,7 +754,7 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
 // skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
 // The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
-template <int MODE, int NH>
+template <int MODE, int NH, bool ODD>
 __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
@@ -773,10 +773,11 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     // (each a multiple of 8), then the parts carried out
     __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry];
     __shared__ uint32_t dh[256];                 // new keys of this tile per digit (rank counter)
-    __shared__ uint32_t t_store[256];            // first slot in `sorted` of the stored part | its length << 16
-    __shared__ uint32_t t_left[256];             // first slot in `sorted` of the part carried out | keys carried in << 16
-    __shared__ uint32_t t_thr[256];              // how many stored keys fit the current block
-    __shared__ uint32_t base0[256], base1[256];  // slot / 8 of the current block's write position and of the new block(s)
+    // per bucket: x = first slot in `sorted` of the stored part | its length << 16,
+    //             y = first slot of the part carried out | keys carried in << 13 | stored keys that fit the current block << 16
+    __shared__ uint2 t_lay[256];
+    // per bucket: slot / 8 of the current block's write position (x) and of the new block(s) (y)
+    __shared__ uint2 t_base[256];
     __shared__ uint32_t sh_ovf;
     __shared__ uint32_t lh[NH ? 256 * NH : 1];   // histograms of the next NH digits
     __shared__ uint32_t sh_scan[kWaves + 1];
@@ -894,24 +895,27 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 const uint32_t s2 = 2 * sh;
                 const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
                 const uint64_t bhi = hi >> s2;
+                // forward key f and reverse complement r of window 0, then one base rolled in per window
                 uint64_t f = rev64(blo & kmask) >> (64 - bits);
+                uint64_t r = (~blo) & kmask;
+                const uint32_t top = bits - 2;
 #pragma unroll
                 for (int i = 0; i < P; ++i)
                 {
-                    uint64_t e = i ? ((blo >> (2 * i)) | (bhi << (64 - 2 * i))) : blo;
-                    e &= kmask;
                     if (i)
                     {
-                        uint32_t pos = 2 * (i + len - 1);
-                        uint64_t nb = (pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                        const uint32_t pos = 2 * (i + len - 1);
+                        const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
                         f = ((f << 2) | nb) & kmask;
+                        r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
                     }
                     if ((m >> i) & 1u)
                     {
-                        Key1 fk{f}, rck{(~e) & kmask};
+                        const Key1 fk{f}, rck{r};
                         if (MODE == 0)
                         {
-                            const Key1 k = strand_rep(fk, rck, len, lmask);
+                            // odd length: the central base decides (its low bit differs between the strands)
+                            const Key1 k = ODD ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
                             kreg[i] = k;
                             rk[i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
                         }
@@ -938,12 +942,10 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             const uint32_t pre = block_excl_scan<uint32_t>(fl | (rem << 16), sh_scan, &sums);
             total_store = sums & 0xFFFFu;
             const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
-            t_store[tid] = f_at | (fl << 16);
-            t_left[tid] = l_at | (ccnt << 16);
             dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
             const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
             uint32_t thr = fl;
-            base0[tid] = (uint32_t)(wpos >> 3);
+            uint2 tb = make_uint2((uint32_t)(wpos >> 3), 0u);
             if (fl > room)
             {
                 thr = room;
@@ -952,11 +954,12 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
                 // a region that is too small: nothing of this tile is stored, the host redoes the chunk
                 if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
-                base1[tid] = (uint32_t)((my_start + at) >> 3);
+                tb.y = (uint32_t)((my_start + at) >> 3);
                 wpos = my_start + at + need;
             }
             else wpos += fl;
-            t_thr[tid] = thr;
+            t_base[tid] = tb;
+            t_lay[tid] = make_uint2(f_at | (fl << 16), l_at | (ccnt << 13) | (thr << 16));
             // the keys carried in go first (phase A's arrays in `sorted` are dead: every thread is past phase B)
 #pragma unroll
             for (int j = 0; j < kCarry; ++j)
@@ -974,10 +977,10 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 {
                     const Key1 k = kreg[i * S + q];
                     const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
-                    const uint32_t ts = t_store[d], tl = t_left[d];
-                    const uint32_t p = (tl >> 16) + rk[i * S + q];
-                    const uint32_t fl = ts >> 16;
-                    sorted[p < fl ? (ts & 0xFFFFu) + p : (tl & 0xFFFFu) + (p - fl)] = k;
+                    const uint2 tl = t_lay[d];
+                    const uint32_t p = ((tl.y >> 13) & 7u) + rk[i * S + q];
+                    const uint32_t fl = tl.x >> 16;
+                    sorted[p < fl ? (tl.x & 0xFFFFu) + p : (tl.y & 0x1FFFu) + (p - fl)] = k;
                     if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
                     if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
                 }
@@ -995,14 +998,15 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             {
                 const Key1 k = sorted[i];
                 const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
-                const uint32_t p = i - (t_store[d] & 0xFFFFu);
-                const uint32_t thr = t_thr[d];
-                const uint64_t o = p < thr ? ((uint64_t)base0[d] << 3) + p : ((uint64_t)base1[d] << 3) + (p - thr);
+                const uint2 tl = t_lay[d], tb = t_base[d];
+                const uint32_t p = i - (tl.x & 0xFFFFu);
+                const uint32_t thr = tl.y >> 16;
+                const uint64_t o = p < thr ? ((uint64_t)tb.x << 3) + p : ((uint64_t)tb.y << 3) + (p - thr);
                 out[o] = k;
             }
         // what bucket tid carries out, back into registers
         {
-            const uint32_t l_at = t_left[tid] & 0xFFFFu;
+            const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
 #pragma unroll
             for (int j = 0; j < kCarry; ++j)
                 if ((uint32_t)j < ccnt) kc[j] = sorted[l_at + j];
@@ -1031,12 +1035,12 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
         // pad [wpos, end of block) of every bucket: all threads share the work through LDS
         __syncthreads();
-        base0[tid] = tail;
+        t_base[tid].x = tail;
         reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
         __syncthreads();
         for (uint32_t d = 0; d < 256; ++d)
         {
-            const uint32_t n = base0[d];
+            const uint32_t n = t_base[d].x;
             const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
             for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{kPadKey};
         }

@@ -649,6 +649,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     // a budget the user did not ask for is a starting size: inputs with little duplication (a
     // genome in FASTA: every k-mer once) need room for runs that do not shrink
     if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
+    // the arena is mapped while the first buffers are read and parsed
+    g.check(goss_gpu_prepare(g.h), "mapping HBM");
 
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));

@@ -67,6 +67,16 @@ int goss_gpu_create(goss_gpu_ctx** ctx, int device, uint32_t k, int mode,
 void goss_gpu_destroy(goss_gpu_ctx* ctx);
 
 /*
+ * Start mapping the context's HBM arena in the background and return at once; the first call that
+ * needs the arena waits for it (and reports its failure).  Mapping HBM costs up to 30 ms/GB when the
+ * driver has to clear pages a previous process left behind: a caller that still has input to read
+ * and parse -- the goss commands -- hides that time behind its own start-up.  Without this call the
+ * arena is mapped by the first push.  No reference counterpart (BackyardHash allocates its table in
+ * its constructor, BackyardHash.cc:273-285).
+ */
+int goss_gpu_prepare(goss_gpu_ctx* ctx);
+
+/*
  * Feed read bases.  `bases` is a byte string in which A/C/G/T (either case) are bases and
  * ANY other byte ends the current run of k-windows -- the caller separates reads with one
  * such byte (the host parsers emit '\n').  Windows never span two push calls.
@@ -151,9 +161,10 @@ enum {
     GOSS_T_SCATTER = 3,   /* partition passes: radix_onesweep_kernel (look-back, cursor and sub-region
                              forms), radix_scatter_kernel */
     GOSS_T_REDUCE  = 4,   /* counting: seg_hash_reduce*_kernel + seg_gather_kernel, seg_merge_kernel,
-                             heads_* / run_* compaction after a full sort, the re-ordering of
-                             strand representatives into canonical order */
+                             heads_* / run_* compaction after a full sort */
     GOSS_T_EMIT    = 5,   /* Elias-Fano / DenseSelect / VariableByteArray image build */
+    GOSS_T_ORDER   = 6,   /* strand representatives -> canonical forms + re-ordering of the distinct keys
+                             (canonical_map_kernel and the radix passes over the (key,count) pairs) */
     GOSS_T_CLASSES = 8
 };
 typedef struct {

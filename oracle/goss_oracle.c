@@ -1102,6 +1102,114 @@ int go_build_kmer_set(go_fs* fs, const char* out, unsigned K, const go_input* in
     return rc ? -1 : 0;
 }
 
+/* The same command with T worker threads, for the CPU side-by-side figure of bench.py on a
+ * many-core host.  The reference feeds one hash table from T consumer threads
+ * (GossCmdBuildKmerSet.tcc:226-256: one producer of k-mers, T BackgroundMultiConsumers inserting
+ * into the shared BackyardHash) and then sorts it with T threads (BackyardHash::sort,
+ * BackyardHash.cc:244-271); its flush into the Builder is serial (:167-210).  This restatement
+ * keeps that shape with the sort-based counting of go_build_kmer_set: the reads (one line-kind
+ * input) are cut into T shards at line ends, every thread parses, canonicalises, sorts and counts
+ * its shard, the T sorted runs are merged range by range in parallel (equal keys summed), and the
+ * KmerSet is written by one thread.  The files are those of go_build_kmer_set. */
+#include <pthread.h>
+
+typedef struct {
+    const char* data; size_t size; unsigned K;
+    go_keys ks; uint64_t* counts; size_t m; int rc;
+} mt_shard;
+static void* mt_count_shard(void* v)
+{
+    mt_shard* s = (mt_shard*)v;
+    char err[256];
+    go_input in = { GO_IN_LINE, "shard", s->data, s->size };
+    memset(&s->ks, 0, sizeof s->ks);
+    s->rc = go_collect(&in, 1, s->K, 0, &s->ks, err, sizeof err);
+    if (s->rc) return NULL;
+    s->counts = (uint64_t*)malloc((s->ks.n ? s->ks.n : 1) * 8);
+    s->m = go_sort_count(s->ks.keys, s->ks.n, s->counts);
+    return NULL;
+}
+static size_t key_lower_bound(const go_key* a, size_t n, u128 v)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (k2u(a[mid]) < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+typedef struct { mt_shard* sh; unsigned T; u128 lo, hi; go_key* out; size_t m; } mt_range;
+static void* mt_merge_range(void* v)
+{
+    mt_range* r = (mt_range*)v;
+    size_t at[64], end[64], total = 0;
+    for (unsigned t = 0; t < r->T; ++t)
+    {
+        at[t] = key_lower_bound(r->sh[t].ks.keys, r->sh[t].m, r->lo);
+        end[t] = key_lower_bound(r->sh[t].ks.keys, r->sh[t].m, r->hi);
+        total += end[t] - at[t];
+    }
+    r->out = (go_key*)malloc((total ? total : 1) * sizeof(go_key));
+    size_t m = 0;
+    for (;;)
+    {
+        int best = -1; u128 bv = 0;
+        for (unsigned t = 0; t < r->T; ++t)
+            if (at[t] < end[t]) { u128 x = k2u(r->sh[t].ks.keys[at[t]]); if (best < 0 || x < bv) { best = (int)t; bv = x; } }
+        if (best < 0) break;
+        for (unsigned t = 0; t < r->T; ++t)          /* equal keys of every run are one entry (a k-mer set keeps no counts) */
+            if (at[t] < end[t] && k2u(r->sh[t].ks.keys[at[t]]) == bv) ++at[t];
+        r->out[m++] = u2k(bv);
+    }
+    r->m = m;
+    return NULL;
+}
+int go_build_kmer_set_mt(go_fs* fs, const char* out, unsigned K, const char* reads, size_t size, unsigned T,
+                         uint64_t* nwindows, char* err, size_t errcap)
+{
+    if (T < 1) T = 1;
+    if (T > 64) T = 64;
+    mt_shard sh[64]; pthread_t th[64];
+    size_t begin = 0;
+    for (unsigned t = 0; t < T; ++t)
+    {
+        size_t end = t + 1 == T ? size : size / T * (t + 1);
+        if (end < begin) end = begin;
+        while (end < size && end > begin && reads[end - 1] != '\n') ++end;
+        sh[t].data = reads + begin; sh[t].size = end - begin; sh[t].K = K; sh[t].counts = NULL; sh[t].m = 0; sh[t].rc = 0;
+        begin = end;
+    }
+    for (unsigned t = 0; t < T; ++t) pthread_create(&th[t], NULL, mt_count_shard, &sh[t]);
+    for (unsigned t = 0; t < T; ++t) pthread_join(th[t], NULL);
+    int rc = 0; uint64_t nw = 0, nreads = 0;
+    for (unsigned t = 0; t < T; ++t) { if (sh[t].rc) rc = -1; nw += sh[t].ks.nwindows; nreads += sh[t].ks.nreads; }
+    mt_range rg[64];
+    size_t M = 0;
+    if (!rc)
+    {
+        /* canonical k-mers are uniform on their leading bits: equal slices of the key space */
+        const u128 space = 2 * K >= 128 ? ~(u128)0 : ((u128)1 << (2 * K));
+        for (unsigned t = 0; t < T; ++t)
+        {
+            rg[t].sh = sh; rg[t].T = T; rg[t].out = NULL; rg[t].m = 0;
+            rg[t].lo = space / T * t;
+            rg[t].hi = t + 1 == T ? ~(u128)0 : space / T * (t + 1);
+        }
+        /* (the last range is closed above by the largest value: no key equals ~0) */
+        for (unsigned t = 0; t < T; ++t) pthread_create(&th[t], NULL, mt_merge_range, &rg[t]);
+        for (unsigned t = 0; t < T; ++t) { pthread_join(th[t], NULL); M += rg[t].m; }
+    }
+    for (unsigned t = 0; t < T; ++t) { free(sh[t].counts); go_keys_free(&sh[t].ks); }
+    if (rc) { snprintf(err, errcap, "parse error in a shard"); return -1; }
+    if (nreads == 0) { for (unsigned t = 0; t < T; ++t) free(rg[t].out); snprintf(err, errcap, "No valid reads."); return -1; }
+    go_key* all = (go_key*)malloc((M ? M : 1) * sizeof(go_key));
+    size_t off = 0;
+    for (unsigned t = 0; t < T; ++t) { memcpy(all + off, rg[t].out, rg[t].m * sizeof(go_key)); off += rg[t].m; free(rg[t].out); }
+    if (nwindows) *nwindows = nw;
+    rc = go_write_kmer_set(fs, out, K, all, M, M);
+    free(all);
+    if (rc == -2) snprintf(err, errcap, "unable to build a graph with k=%u", K);
+    else if (rc) snprintf(err, errcap, "write error");
+    return rc ? -1 : 0;
+}
+
 /* GossCmdBuildGraph::operator().  GossCmdBuildGraph.cc:270-426 (rho = K+1, both strands),
  * flush :222-266. */
 int go_build_graph(go_fs* fs, const char* out, unsigned K, const go_input* in, size_t nin, uint64_t* nwindows, char* err, size_t errcap)

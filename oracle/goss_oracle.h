@@ -94,6 +94,11 @@ int go_write_sparse_array(go_fs* fs, const char* base, go_key N_ctor, uint64_t M
  * branch), GossCmdBuildGraph.cc:270-426 */
 int go_build_kmer_set(go_fs* fs, const char* out, unsigned K, const go_input* in, size_t nin, uint64_t* nwindows, char* err, size_t errcap);
 int go_build_graph(go_fs* fs, const char* out, unsigned K, const go_input* in, size_t nin, uint64_t* nwindows, char* err, size_t errcap);
+/* go_build_kmer_set over one line-kind input with T worker threads (parse / canonicalise / sort-count per
+ * shard, parallel merge by key ranges, serial write -- the thread structure of GossCmdBuildKmerSet.tcc:226-256
+ * and BackyardHash.cc:244-271); same files. */
+int go_build_kmer_set_mt(go_fs* fs, const char* out, unsigned K, const char* reads, size_t size, unsigned T,
+                         uint64_t* nwindows, char* err, size_t errcap);
 
 /* ---- readers (restated from the reference's read side; used to round-trip files) ---- */
 typedef struct go_sparse go_sparse;

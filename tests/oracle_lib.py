@@ -556,3 +556,18 @@ def replay_vba(files, base, values):
     fs = FileSet.from_files(files)
     a = np.ascontiguousarray(np.asarray(values, dtype=np.uint32))
     return L.go_replay_vba(fs.handle, base.encode(), a.ctypes.data_as(C.POINTER(C.c_uint32)), len(values))
+
+
+def build_kmer_set_mt(reads, K, threads, out="ks"):
+    """go_build_kmer_set_mt: the line-kind read text counted with `threads` worker threads."""
+    L = lib()
+    L.go_build_kmer_set_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_char_p, C.c_size_t, C.c_uint,
+                                       C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    fs = FileSet()
+    err = C.create_string_buffer(512)
+    nwin = C.c_uint64(0)
+    if isinstance(reads, str):
+        reads = reads.encode()
+    if L.go_build_kmer_set_mt(fs.handle, out.encode(), K, reads, len(reads), threads, C.byref(nwin), err, 512):
+        raise OracleError(err.value.decode())
+    return fs.files(), nwin.value

@@ -392,3 +392,16 @@ def test_set_algebra_commands(oracle):
             assert ((words[i // 64] >> (i % 64)) & 1) == (x in members)
     with pytest.raises(oracle.OracleError, match="nonsense"):
         oracle.merge_and_annotate(files, "s0", "empty", "u")
+
+
+def test_threaded_build_gives_the_same_files(oracle):
+    """go_build_kmer_set_mt (bench.py's CPU baseline at T threads) is the single-thread restatement
+    with the counting sharded: identical files for any number of threads"""
+    import gossamer_amd as g
+    reads = g.synth_reads_host(3000, 150, 40000, seed=5)
+    want, nwin = oracle.build_kmer_set([(oracle.LINE, "r", reads)], 25)
+    for T in (1, 2, 3, 8):
+        got, n = oracle.build_kmer_set_mt(reads, 25, T)
+        assert n == nwin and got == want, T
+    with pytest.raises(oracle.OracleError):
+        oracle.build_kmer_set_mt(b"NNNN\n", 25, 4)
