@@ -1693,68 +1693,79 @@ void emit_dense_select(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, i
 struct SaHeader { uint64_t version, D, quantizedD, mask_lo, mask_hi, size_lo, size_hi, count; };
 static_assert(sizeof(SaHeader) == 64, "SparseArray header is 64 bytes");
 
+// nd = Nend >> D, which must fit 64 bits (SparseArray.cc:79-86)
+uint64_t sparse_nd(uint32_t D, uint64_t Nend_lo, uint64_t Nend_hi)
+{
+    if (D >= 128) return 0;
+    if (D >= 64) return Nend_hi >> (D - 64);
+    if (D > 0 && (Nend_hi >> D) != 0) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
+    if (D == 0 && Nend_hi) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
+    return D == 0 ? Nend_lo : ((Nend_lo >> D) | (Nend_hi << (64 - D)));
+}
+
+// SparseArray::Header (SparseArray.hh:60-72) as the ".header" file
+void emit_sparse_header(goss_gpu_ctx* c, uint32_t D, uint64_t Nend_lo, uint64_t Nend_hi, uint64_t count, const std::string& base)
+{
+    SaHeader h{};
+    h.version = 2012030501ULL; h.D = D; h.quantizedD = 8 * ((D + 7) / 8);
+    if (D >= 128) { h.mask_lo = ~0ULL; h.mask_hi = ~0ULL; }
+    else if (D >= 64) { h.mask_lo = ~0ULL; h.mask_hi = D == 64 ? 0 : ((1ULL << (D - 64)) - 1); }
+    else { h.mask_lo = (1ULL << D) - 1; h.mask_hi = 0; }
+    h.size_lo = Nend_lo; h.size_hi = Nend_hi; h.count = count;
+    OutFile f; f.suffix = base + ".header"; f.size = sizeof h;
+    f.host.assign((uint8_t*)&h, (uint8_t*)&h + sizeof h);
+    c->files.push_back(std::move(f));
+}
+
+// The index part of a SparseArray: high-bits bitmap, -d0 (zeros), -d1 (ones), from keys whose high part
+// is key >> D -- or from the high parts themselves with D = 0 (distributed emission).
+template <class K>
+void emit_sparse_index(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, uint64_t nd, const std::string& base)
+{
+    const uint64_t nwords = (nd + m + 3) / 64 + 1;
+    uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
+                       keys, m, D, nwords, words);
+    OutFile f; f.suffix = base + ".high-bits"; f.size = nwords * 8; f.dev = (const uint8_t*)words;
+    c->files.push_back(std::move(f));
+    emit_dense_select<K>(c, keys, m, D, 1, nd + 2, base + "-d0");
+    emit_dense_select<K>(c, keys, m, D, 0, m, base + "-d1");
+}
+
+// The low-bits column files of m keys (IntegerArray / StackedArray columns of quantizedD bits)
+template <class K>
+void emit_sparse_low_bits(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, const std::string& base)
+{
+    const uint32_t qD = 8 * ((D + 7) / 8);
+    std::vector<IaCol> cols;
+    if (!ia_layout(qD, "", 0, cols)) throw StatusError{GOSS_ERR_INVALID_ARG, "IntegerArray::builder: unsupported integer width"};
+    EfColumns ec{};
+    ec.n = (uint32_t)cols.size();
+    for (size_t i = 0; i < cols.size(); ++i)
+    {
+        uint8_t* dst = (uint8_t*)c->arena.perm(std::max<uint64_t>(m * cols[i].bytes, 8));
+        ec.c[i] = EfColumn{dst, cols[i].bytes, cols[i].shift};
+        OutFile f; f.suffix = base + ".low-bits" + cols[i].suffix; f.size = m * cols[i].bytes; f.dev = dst;
+        c->files.push_back(std::move(f));
+    }
+    if (m)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_low_bits_kernel<K>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
+                           keys, m, D, ec);
+}
+
 // SparseArray at suffix `base` (SparseArray::Builder ctor + push_back* + end).
 template <class K>
 void emit_sparse_array(goss_gpu_ctx* c, const K* keys, uint64_t m, uint64_t N_lo, uint64_t N_hi, uint64_t Mest,
                        uint64_t Nend_lo, uint64_t Nend_hi, const std::string& base)
 {
     const uint32_t D = (uint32_t)sparse_d(N_lo, N_hi, Mest);
-    const uint32_t qD = 8 * ((D + 7) / 8);
-    // nd = Nend >> D must fit 64 bits (SparseArray.cc:79-86)
-    uint64_t nd;
-    if (D >= 128) nd = 0;
-    else if (D >= 64) nd = Nend_hi >> (D - 64);
-    else
-    {
-        if (D > 0 && (Nend_hi >> D) != 0) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
-        nd = D == 0 ? Nend_lo : ((Nend_lo >> D) | (Nend_hi << (64 - D)));
-        if (D == 0 && Nend_hi) throw StatusError{GOSS_ERR_TOO_LARGE, "Internal error in SparseArray; nd does not fit 64 bits"};
-    }
+    const uint64_t nd = sparse_nd(D, Nend_lo, Nend_hi);
     // every key's high part must fit too (SparseArray.hh:91-95)
     HIP_TRY(hipMemsetAsync(c->d_flags + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_check_kernel<K>), dim3(1), dim3(64), 0, c->stream, keys, m, D, c->d_flags + 1);
-
-    // header
-    SaHeader h{};
-    h.version = 2012030501ULL; h.D = D; h.quantizedD = qD;
-    if (D >= 128) { h.mask_lo = ~0ULL; h.mask_hi = ~0ULL; }
-    else if (D >= 64) { h.mask_lo = ~0ULL; h.mask_hi = D == 64 ? 0 : ((1ULL << (D - 64)) - 1); }
-    else { h.mask_lo = (1ULL << D) - 1; h.mask_hi = 0; }
-    h.size_lo = Nend_lo; h.size_hi = Nend_hi; h.count = m;
-    {
-        OutFile f; f.suffix = base + ".header"; f.size = sizeof h;
-        f.host.assign((uint8_t*)&h, (uint8_t*)&h + sizeof h);
-        c->files.push_back(std::move(f));
-    }
-    // high bits
-    {
-        const uint64_t nwords = (nd + m + 3) / 64 + 1;
-        uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
-                           keys, m, D, nwords, words);
-        OutFile f; f.suffix = base + ".high-bits"; f.size = nwords * 8; f.dev = (const uint8_t*)words;
-        c->files.push_back(std::move(f));
-    }
-    // d0 (zeros, inverted sense) and d1 (ones)
-    emit_dense_select<K>(c, keys, m, D, 1, nd + 2, base + "-d0");
-    emit_dense_select<K>(c, keys, m, D, 0, m, base + "-d1");
-    // low bits columns
-    {
-        std::vector<IaCol> cols;
-        if (!ia_layout(qD, "", 0, cols)) throw StatusError{GOSS_ERR_INVALID_ARG, "IntegerArray::builder: unsupported integer width"};
-        EfColumns ec{};
-        ec.n = (uint32_t)cols.size();
-        for (size_t i = 0; i < cols.size(); ++i)
-        {
-            uint8_t* dst = (uint8_t*)c->arena.perm(std::max<uint64_t>(m * cols[i].bytes, 8));
-            ec.c[i] = EfColumn{dst, cols[i].bytes, cols[i].shift};
-            OutFile f; f.suffix = base + ".low-bits" + cols[i].suffix; f.size = m * cols[i].bytes; f.dev = dst;
-            c->files.push_back(std::move(f));
-        }
-        if (m)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_low_bits_kernel<K>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
-                               keys, m, D, ec);
-    }
+    emit_sparse_header(c, D, Nend_lo, Nend_hi, m, base);
+    emit_sparse_index<K>(c, keys, m, D, nd, base);
+    emit_sparse_low_bits<K>(c, keys, m, D, base);
     uint32_t* hf = (uint32_t*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(hf, c->d_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

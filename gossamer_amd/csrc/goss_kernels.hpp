@@ -3143,6 +3143,25 @@ __global__ void vba_ord2_kernel(const uint32_t* __restrict__ hi16, uint64_t n1, 
     }
 }
 
+// Distributed emission: the high part key >> D of every key of a range, as u32 or u64.
+template <class K, class T>
+__global__ void ef_high_part_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, T* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = (T)(D >= 128 ? 0 : key_shr64(keys[i], D));
+}
+
+// ... and the entries with count > 255 as (global index, count) pairs, after a scan of vba_ord0_kernel's flags
+struct BigCount { unsigned long long index; uint32_t count, pad; };
+__global__ void vba_big_kernel(const uint32_t* __restrict__ counts, uint64_t m, const uint64_t* __restrict__ slot,
+                               uint64_t first_index, BigCount* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t c = counts[i];
+    if (c >> 8) out[slot[i]] = BigCount{first_index + i, c, 0u};
+}
+
 __global__ void widen_counts_kernel(const uint32_t* __restrict__ counts, uint64_t m, Key1* __restrict__ out)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

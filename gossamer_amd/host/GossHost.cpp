@@ -460,7 +460,7 @@ size_t parseChunkBytes()
 {
     const char* e = std::getenv("GOSS_PARSE_CHUNK");
     if (e && *e) { long v = atol(e); if (v >= 256) return (size_t)v; }
-    return 32u << 20;
+    return 8u << 20;      // small enough that page-locking the buffer pool (threads + 4 buffers of half this size) takes ~0.1 s
 }
 
 // Parse a plain FASTQ file with `threads` workers (see "parallel FASTQ parsing" above).  Batches of
@@ -495,17 +495,26 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     std::condition_variable cv;
     // a bounded pool of reusable output buffers (a chunk of file yields at most as many bases):
     // bounds the memory in flight and keeps the pages warm / pinned for the copy to the device
-    const size_t bufCap = chunkBytes + (1u << 16);
-    const size_t nbuf = 2 * (size_t)threads + 2;
+    // (the bases are at most half of a FASTQ chunk's bytes: as many quality values as bases, plus
+    // titles and separators).  Page-locking memory costs ~0.3 s/GB, so the pool is filled by a thread
+    // of its own, one buffer after the other, while the workers already parse: a short file never
+    // pays for buffers it does not use and a long one does not wait for them up front.
+    const size_t bufCap = chunkBytes / 2 + (1u << 16);
+    const size_t nbuf = std::min<size_t>((size_t)threads + 4, nchunks + 1);
     std::vector<char*> freeBufs;
     std::vector<void*> allBufs;
+    std::atomic<bool> allocFailed{false};
     struct FreeAll { std::vector<void*>& v; const HostAlloc& h; ~FreeAll() { for (void* b : v) h.release(b); } } freeAll{allBufs, ha};
-    for (size_t i = 0; i < nbuf; ++i)
-    {
-        void* b = ha.alloc(bufCap);
-        if (!b) throw Error::General("cannot allocate parser buffers\n");
-        allBufs.push_back(b); freeBufs.push_back((char*)b);
-    }
+    std::thread allocator([&]() {
+        for (size_t i = 0; i < nbuf && !abortAll.load() && nextChunk.load() < nchunks; ++i)
+        {
+            void* b = ha.alloc(bufCap);
+            if (!b) { allocFailed.store(true); abortAll.store(true); cv.notify_all(); return; }
+            { std::lock_guard<std::mutex> lk(m); allBufs.push_back(b); freeBufs.push_back((char*)b); }
+            cv.notify_all();
+        }
+    });
+    struct JoinAlloc { std::thread& t; ~JoinAlloc() { if (t.joinable()) t.join(); } } joinAlloc{allocator};
 
     auto worker = [&]() {
         for (;;)
@@ -583,6 +592,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         baseLine += r.lines;
         expected = r.end;
     }
+    if (allocFailed.load()) throw Error::General("cannot allocate parser buffers\n");
     if (serialRest || expected < size)
     {
         // a boundary guess did not line up (wrapped records, '@' starting quality lines, ...):
