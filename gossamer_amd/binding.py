@@ -22,7 +22,8 @@ SYMBOLS = [
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
-    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare",
+    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
+    "goss_gpu_file_device",
 ]
 
 
@@ -237,6 +238,44 @@ class Context:
     def emit(self):
         self.emit_device()
         return self.files()
+
+    def emit_part(self, first_index, total, estimate=0):
+        """Distributed emission, this range's part (goss_gpu_emit_part)."""
+        self._L.goss_gpu_emit_part.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        self._check(self._L.goss_gpu_emit_part(self._h, first_index, total, estimate))
+
+    def emit_assemble(self, high_ptr, high_bytes, total, estimate=0, big=b"", hist=b""):
+        """Distributed emission, the files that need all ranges (goss_gpu_emit_assemble): high_ptr =
+        device address of the concatenated high parts, big / hist = the concatenated records (bytes)."""
+        self._L.goss_gpu_emit_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64,
+                                                   C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        _torch_ready()
+        self._check(self._L.goss_gpu_emit_assemble(self._h, C.c_void_p(high_ptr), high_bytes, total, estimate,
+                                                   big, len(big) // 16, hist, len(hist) // 16))
+
+    def file_list(self):
+        """[(suffix, size, device address or None)] of the emitted files"""
+        self._L.goss_gpu_file_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        n = C.c_uint32()
+        self._check(self._L.goss_gpu_file_count(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.create_string_buffer(256)
+            size = C.c_uint64()
+            self._check(self._L.goss_gpu_file_info(self._h, i, name, 256, C.byref(size)))
+            p = C.c_void_p()
+            self._check(self._L.goss_gpu_file_device(self._h, i, C.byref(p)))
+            out.append((name.value.decode(), size.value, p.value))
+        return out
+
+    def read_file(self, suffix):
+        """bytes of one emitted file"""
+        for i, (name, size, _) in enumerate(self.file_list()):
+            if name == suffix:
+                buf = C.create_string_buffer(max(1, size))
+                self._check(self._L.goss_gpu_file_read(self._h, i, 0, buf, size))
+                return buf.raw[:size]
+        raise KeyError(suffix)
 
     def emit_sparse_array(self, dev_ptr, key_words, n, N, M, N_end=None):
         if N_end is None:

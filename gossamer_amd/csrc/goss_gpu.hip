@@ -1897,6 +1897,174 @@ void emit_object(goss_gpu_ctx* c)
     t.stop();
 }
 
+// N = 4^len of the object's SparseArray (KmerSet.hh:84, Graph.cc:120-124) and its file name base
+void object_universe(const goss_gpu_ctx* c, uint64_t* nlo, uint64_t* nhi, std::string* base)
+{
+    const uint32_t bits = c->mode == GOSS_MODE_KMER_SET ? 2 * c->k : 2 * c->k + 2;
+    *nlo = bits < 64 ? (1ULL << bits) : 0;
+    *nhi = bits >= 64 ? (1ULL << (bits - 64)) : 0;
+    *base = c->mode == GOSS_MODE_KMER_SET ? ".kmers" : "-edges";
+}
+
+// Distributed emission, the part a range's owner builds from its own keys (goss_gpu_emit_part).
+template <class K>
+void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
+{
+    const K* keys = (const K*)c->res_keys;
+    const uint64_t m = c->M;
+    PhaseTimer t(c, GOSS_T_EMIT, m);
+    uint64_t nlo, nhi; std::string base;
+    object_universe(c, &nlo, &nhi, &base);
+    const uint32_t D = (uint32_t)sparse_d(nlo, nhi, estimate);
+    const uint64_t nd = sparse_nd(D, nlo, nhi);
+    HIP_TRY(hipMemsetAsync(c->d_flags + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_check_kernel<K>), dim3(1), dim3(64), 0, c->stream, keys, m, D, c->d_flags + 1);
+    emit_sparse_low_bits<K>(c, keys, m, D, base);
+    // high parts for the assembling rank: u32 when every one of them fits (nd = N >> D bounds them)
+    const bool narrow = nd < (1ULL << 32);
+    {
+        const uint64_t bytes = m * (narrow ? 4 : 8);
+        uint8_t* hv = (uint8_t*)c->arena.perm(std::max<uint64_t>(bytes, 8));
+        if (m)
+        {
+            if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_part_kernel<K, uint32_t>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream, keys, m, D, (uint32_t*)hv);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_part_kernel<K, uint64_t>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream, keys, m, D, (uint64_t*)hv);
+        }
+        OutFile f; f.suffix = narrow ? ".part.high32" : ".part.high64"; f.size = bytes; f.dev = hv;
+        c->files.push_back(std::move(f));
+    }
+    if (c->mode == GOSS_MODE_GRAPH)
+    {
+        const uint32_t* counts = c->res_counts;
+        uint64_t mark = c->arena.mark();
+        uint8_t* ord0 = (uint8_t*)c->arena.perm(std::max<uint64_t>(m, 8));
+        uint64_t nbig = 0;
+        BigCount* big = nullptr;
+        uint64_t* h = (uint64_t*)c->h_pinned;
+        std::vector<uint64_t> hist;                      // (count, frequency) pairs, ascending
+        if (m)
+        {
+            uint64_t* slot = (uint64_t*)c->arena.temp((m + 1) * 8);
+            hipLaunchKernelGGL(vba_ord0_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, ord0, slot);
+            HIP_TRY(hipMemsetAsync(slot + m, 0, 8, c->stream));
+            exclusive_scan_u64(c, slot, m + 1);
+            HIP_TRY(hipMemcpyAsync(h, slot + m, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            nbig = h[0];
+            big = (BigCount*)c->arena.perm(std::max<uint64_t>(nbig * sizeof(BigCount), 16));
+            if (nbig)
+                hipLaunchKernelGGL(vba_big_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, (const uint64_t*)slot,
+                                   first_index, big);
+            // histogram of this range's counts: sort them as keys, run-length them
+            Key1* ka = (Key1*)c->arena.temp(m * 8);
+            Key1* kb = (Key1*)c->arena.temp(m * 8);
+            hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, counts, m, ka);
+            const bool mute = c->mute_timing; c->mute_timing = true;
+            const bool in_b = radix_sort<Key1, false>(c, ka, kb, nullptr, nullptr, m, 4);
+            c->mute_timing = mute;
+            const Key1* sorted = in_b ? kb : ka;
+            Key1* distinct = in_b ? ka : kb;
+            const uint64_t ntiles = (m + kRedTile - 1) / kRedTile;
+            uint64_t* tile_counts = (uint64_t*)c->arena.temp((ntiles + 1) * 8);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_count_kernel<Key1>), dim3(grid_for(m, kRedTile)), dim3(kTB), 0, c->stream,
+                               sorted, m, tile_counts);
+            HIP_TRY(hipMemsetAsync(tile_counts + ntiles, 0, 8, c->stream));
+            exclusive_scan_u64(c, tile_counts, ntiles + 1);
+            HIP_TRY(hipMemcpyAsync(h, tile_counts + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint64_t nv = h[0];
+            uint64_t* starts = (uint64_t*)c->arena.temp(std::max<uint64_t>(nv, 1) * 8);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(heads_write_kernel<Key1>), dim3(grid_for(m, kRedTile)), dim3(kTB), 0, c->stream,
+                               sorted, m, (const uint64_t*)tile_counts, distinct, starts);
+            std::vector<uint64_t> hv(nv), hs(nv);
+            HIP_TRY(hipMemcpyAsync(hv.data(), distinct, nv * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(hs.data(), starts, nv * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (uint64_t i = 0; i < nv; ++i) { hist.push_back(hv[i]); hist.push_back((i + 1 < nv ? hs[i + 1] : m) - hs[i]); }
+        }
+        { OutFile f; f.suffix = "-counts.ord0"; f.size = m; f.dev = ord0; c->files.push_back(std::move(f)); }
+        { OutFile f; f.suffix = ".part.big"; f.size = nbig * sizeof(BigCount); f.dev = (const uint8_t*)big; if (!big) f.host.clear(); c->files.push_back(std::move(f)); }
+        add_host_file(c, ".part.hist", hist.data(), hist.size() * 8);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+    }
+    t.stop();
+    uint32_t* hf = (uint32_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hf, c->d_flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hf[0]) throw StatusError{GOSS_ERR_TOO_LARGE, "SparseArray::push_back: high bits do not fit 64 bits"};
+    (void)total;
+}
+
+// Distributed emission, the assembling side (goss_gpu_emit_assemble): everything that needs all ranges.
+void emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uint64_t total, uint64_t estimate,
+                   const BigCount* big, uint64_t nbig, const uint64_t* hist, uint64_t nhist)
+{
+    PhaseTimer t(c, GOSS_T_EMIT, total);
+    uint64_t nlo, nhi; std::string base;
+    object_universe(c, &nlo, &nhi, &base);
+    const uint32_t D = (uint32_t)sparse_d(nlo, nhi, estimate);
+    const uint64_t nd = sparse_nd(D, nlo, nhi);
+    // the high parts as one-word keys with D = 0: position of one i is (key_i >> 0) + i, as in a whole build
+    uint64_t mark = c->arena.mark();
+    const Key1* hk = (const Key1*)d_high;
+    if (high_bytes == 4 && total)
+    {
+        Key1* wide = (Key1*)c->arena.temp(total * 8);
+        hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, (const uint32_t*)d_high, total, wide);
+        hk = wide;
+    }
+    if (c->mode == GOSS_MODE_KMER_SET)
+    {
+        emit_sparse_header(c, D, nlo, nhi, total, base);
+        emit_sparse_index<Key1>(c, hk, total, 0, nd, base);
+        uint64_t hdr[3] = {2011101701ULL, c->k, total};
+        add_host_file(c, ".header", hdr, sizeof hdr);
+    }
+    else
+    {
+        uint64_t hdr[3] = {2011101014ULL, c->k, 0};
+        add_host_file(c, ".header", hdr, sizeof hdr);
+        emit_sparse_header(c, D, nlo, nhi, total, base);
+        emit_sparse_index<Key1>(c, hk, total, 0, nd, base);
+        // VariableByteArray continuation arrays from the entries with count > 255 (VariableByteArray.hh:76-118):
+        // ord1p marks their global positions, ord1 holds bits 8..15; ord2p marks, among those, the ones with
+        // count > 65535 by their index in ord1, ord2 holds bits 16..31
+        std::vector<uint64_t> pos1(nbig), pos2;
+        std::vector<uint8_t> ord1(nbig);
+        std::vector<uint16_t> ord2;
+        for (uint64_t i = 0; i < nbig; ++i)
+        {
+            pos1[i] = big[i].index;
+            ord1[i] = (uint8_t)((big[i].count >> 8) & 0xFF);
+            if (big[i].count >> 16) { pos2.push_back(i); ord2.push_back((uint16_t)(big[i].count >> 16)); }
+        }
+        const uint64_t mest = (uint64_t)((double)estimate * 0.001);
+        Key1* d1 = (Key1*)c->arena.temp(std::max<uint64_t>(nbig, 1) * 8);
+        Key1* d2 = (Key1*)c->arena.temp(std::max<uint64_t>(pos2.size(), 1) * 8);
+        if (nbig) HIP_TRY(hipMemcpyAsync(d1, pos1.data(), nbig * 8, hipMemcpyHostToDevice, c->stream));
+        if (!pos2.empty()) HIP_TRY(hipMemcpyAsync(d2, pos2.data(), pos2.size() * 8, hipMemcpyHostToDevice, c->stream));
+        emit_sparse_array<Key1>(c, d1, nbig, estimate, 0, mest, total, 0, "-counts.ord1p");
+        add_host_file(c, "-counts.ord1", ord1.data(), ord1.size());
+        emit_sparse_array<Key1>(c, d2, pos2.size(), estimate, 0, mest, nbig, 0, "-counts.ord2p");
+        add_host_file(c, "-counts.ord2", ord2.data(), ord2.size() * 2);
+        // histogram: the ranges' (count, frequency) pairs added up (Graph.cc:131-150 writes them ascending)
+        std::map<uint64_t, uint64_t> all;
+        for (uint64_t i = 0; i < nhist; ++i) all[hist[2 * i]] += hist[2 * i + 1];
+        std::string text;
+        char line[64];
+        for (auto& kv : all)
+        {
+            int l = snprintf(line, sizeof line, "%llu\t%llu\n", (unsigned long long)kv.first, (unsigned long long)kv.second);
+            text.append(line, (size_t)l);
+        }
+        add_host_file(c, "-counts-hist.txt", text.data(), text.size());
+    }
+    t.stop();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+}
+
 template <class F>
 int guarded(goss_gpu_ctx* c, F&& f)
 {
@@ -2167,6 +2335,53 @@ int goss_gpu_emit(goss_gpu_ctx* c)
     });
     if (rc == GOSS_OK) c->emitted = true;
     return rc;
+}
+
+int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished || c->emitted) { c->last_error = "emit_part needs exactly one finish before it"; return GOSS_ERR_STATE; }
+    if (first_index + c->M > total) { c->last_error = "emit_part: the range does not fit the total"; return GOSS_ERR_INVALID_ARG; }
+    int rc = guarded(c, [&]() {
+        c->files.clear();
+        {
+            const uint64_t need = c->M * 48 + (256ULL << 20);
+            if (c->arena.avail() < need) grow_arena(c, need);
+        }
+        const uint64_t est = estimate ? estimate : total;
+        if (c->words == 1) emit_part<Key1>(c, first_index, total, est); else emit_part<Key2>(c, first_index, total, est);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+    if (rc == GOSS_OK) c->emitted = true;
+    return rc;
+}
+
+int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uint64_t total, uint64_t estimate,
+                           const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist)
+{
+    if (!c || (high_bytes != 4 && high_bytes != 8) || (total && !d_high) || (nbig && !h_big) || (nhist && !h_hist))
+        return GOSS_ERR_INVALID_ARG;
+    if (!c->finished && (!c->runs.empty() || c->stage_fill))
+    {
+        c->last_error = "emit_assemble while a count is in progress";
+        return GOSS_ERR_STATE;
+    }
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        {
+            const uint64_t need = total * 12 + (256ULL << 20);
+            if (c->arena.avail() < need) grow_arena(c, need);
+        }
+        emit_assemble(c, d_high, high_bytes, total, estimate ? estimate : total, (const BigCount*)h_big, nbig, h_hist, nhist);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
+int goss_gpu_file_device(goss_gpu_ctx* c, uint32_t i, const void** d_ptr)
+{
+    if (!c || !d_ptr || i >= c->files.size()) return GOSS_ERR_INVALID_ARG;
+    *d_ptr = c->files[i].dev;          // NULL for a file built on the host
+    return GOSS_OK;
 }
 
 int goss_gpu_emit_sparse_array(goss_gpu_ctx* c, const void* d_positions, uint32_t key_words, uint64_t n,

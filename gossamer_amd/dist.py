@@ -307,17 +307,91 @@ def _assemble_on_root(ctx, keys, counts, ms, M, device, group):
         ctx.emit_device()
 
 
-def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True, splitters="sampled"):
+def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
+    """Every rank emits its own span of the object, rank 0 the parts that need all ranges.
+
+    On every rank (goss_gpu_emit_part): its slice of the low-bits column files (and, for graphs, of the
+    ord0 byte file) -- they belong at element offset `first_index` of the whole file and stay in the
+    rank's HBM for its own writer.  Only key >> D of every key (4 bytes per key when N >> D < 2^32) and the
+    few records of counts > 255 / the count histogram travel to rank 0, which builds the header, the
+    high-bits bitmap, -d0 / -d1 and, for graphs, ord1 / ord2 with their presence arrays and the histogram
+    text (goss_gpu_emit_assemble).  Returns {suffix: (size, device address)} of this rank's files."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ctx.emit_part(first_index, total, estimate)
+    files = {name: (size, ptr) for name, size, ptr in ctx.file_list()}
+    high = [n for n in files if n.startswith(".part.high")][0]
+    high_bytes = 4 if high.endswith("32") else 8
+    size, ptr = files[high]
+    xdev = _exchange_device(device, group)
+    mine = device_view(ptr, size, torch.uint8, device).to(xdev) if size else torch.empty(0, dtype=torch.uint8, device=xdev)
+    # sizes of every rank's parts: one small all-gather
+    small = b""
+    if ".part.big" in files:
+        small = ctx.read_file(".part.big")
+    hist = ctx.read_file(".part.hist") if ".part.hist" in files else b""
+    meta = torch.tensor([size, len(small), len(hist)], dtype=torch.int64, device=xdev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = torch.stack(metas).cpu().tolist()
+    # high parts -> rank 0 (an all-to-all in which only rank 0 receives)
+    recv = [int(r[0]) for r in metas] if rank == 0 else [0] * world
+    send = [size] + [0] * (world - 1)
+    allhigh = torch.empty(max(1, sum(recv)), dtype=torch.uint8, device=xdev)
+    dist.all_to_all_single(allhigh[:sum(recv)], mine, recv, send, group=group)
+    # the small records: padded to the longest, gathered through the same kind of collective
+    rec = torch.frombuffer(bytearray(small + hist), dtype=torch.uint8).to(xdev) if small or hist else torch.empty(0, dtype=torch.uint8, device=xdev)
+    recv2 = [int(r[1] + r[2]) for r in metas] if rank == 0 else [0] * world
+    send2 = [int(rec.numel())] + [0] * (world - 1)
+    allrec = torch.empty(max(1, sum(recv2)), dtype=torch.uint8, device=xdev)
+    dist.all_to_all_single(allrec[:sum(recv2)], rec, recv2, send2, group=group)
+    _sync(device)
+    if rank == 0:
+        big, hst = b"", b""
+        raw = bytes(allrec[:sum(recv2)].cpu().numpy().tobytes())
+        at = 0
+        for r in metas:
+            big += raw[at:at + int(r[1])]
+            hst += raw[at + int(r[1]):at + int(r[1]) + int(r[2])]
+            at += int(r[1]) + int(r[2])
+        hp = allhigh.to(device) if allhigh.device.type != "cuda" else allhigh
+        ctx.emit_assemble(hp.data_ptr(), high_bytes, total, estimate, big, hst)
+        del hp
+    return {name: (size, ptr) for name, size, ptr in ctx.file_list()}
+
+
+def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True, splitters="sampled",
+                      emission="distributed"):
     """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
-    local count -> exchange -> merge own range -> all-gather M -> (root) assemble + emit.
-    Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>)."""
+    local count -> exchange -> merge own range -> all-gather M -> emit.  emission = "distributed": every
+    rank emits its span, rank 0 the index (emit_distributed); "root": the ranges are gathered on rank 0,
+    which builds every file (the first form of this path, kept for comparison).
+    Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>, ranges, first)."""
     windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters)
     m_range = ctx.counts.distinct
-    ms, M, _ = gather_counts(m_range, device, group)
-    out = {"windows": windows, "M": M, "m_range": m_range, "ranges": ms}
+    ms, M, first = gather_counts(m_range, device, group)
+    out = {"windows": windows, "M": M, "m_range": m_range, "ranges": ms, "first": first}
     if emit_on_root:
-        keys, counts = result_views(ctx, words, device)
-        _assemble_on_root(ctx, keys, counts, ms, M, device, group)
+        if emission == "distributed":
+            out["files"] = emit_distributed(ctx, device, first, M, group)
+        else:
+            keys, counts = result_views(ctx, words, device)
+            _assemble_on_root(ctx, keys, counts, ms, M, device, group)
+    return out
+
+
+def assemble_files(per_rank_files):
+    """{suffix: bytes} of the whole object from every rank's {suffix: bytes} in rank order: the slices
+    (low-bits columns, ord0) concatenate; everything else comes from rank 0; the .part.* transport files
+    are dropped.  What a set of per-rank writers produces by writing each slice at its element offset."""
+    out = {}
+    for name, data in per_rank_files[0].items():
+        if name.startswith(".part."):
+            continue
+        if ".low-bits" in name and ".ord" not in name or name == "-counts.ord0":
+            out[name] = b"".join(f.get(name, b"") for f in per_rank_files)
+        else:
+            out[name] = data
     return out
 
 
@@ -358,10 +432,8 @@ def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_
         ctx.push_run(keys.data_ptr(), w.data_ptr(), keys.shape[0])
     ctx.finish()
     ctx.select_counts(keep, keep)
-    keys, _ = result_views(ctx, words, device)
-    m = int(keys.shape[0])
-    ms, M, _ = gather_counts(m, device, group)
+    m = int(ctx.result_ptrs()[2])
+    ms, M, first = gather_counts(m, device, group)
     if emit_on_root:
-        counts = torch.ones(m, dtype=torch.int32, device=device)
-        _assemble_on_root(ctx, keys, counts, ms, M, device, group)
+        emit_distributed(ctx, device, first, M, group)
     return {"sizes": sizes, "M": M}

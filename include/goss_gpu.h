@@ -262,6 +262,35 @@ typedef struct {
 int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, goss_gpu_index_report* out);
 
 /*
+ * Distributed emission (one context per GPU, each holding one range of the globally sorted result; no
+ * reference counterpart -- the reference is single-node; the files are those of SparseArray::Builder
+ * (SparseArray.hh:87-118, SparseArray.cc:47-131) and VariableByteArray::Builder (VariableByteArray.hh:76-118)
+ * fed the concatenation of the ranges).
+ *
+ * goss_gpu_emit_part, after finish, on every range's owner: builds what the range alone determines --
+ *   "<base>.low-bits*"   this range's slice of every low-bits column file (base ".kmers" / "-edges"),
+ *   "-counts.ord0"        (graph) this range's slice of the ord0 byte file,
+ *   ".part.high32|64"     key >> D of every key (u32 when N >> D < 2^32, else u64), for the assembler,
+ *   ".part.big"           (graph) the entries with count > 255: {u64 global index, u32 count, u32 0},
+ *   ".part.hist"          (graph) {u64 count, u64 frequency} pairs of this range, ascending.
+ * first_index = number of result items in the ranges below this one, total = items in all ranges,
+ * estimate = the SparseArray estimate M (0 = total: the single-pass build).  The slices of range p belong at
+ * element offset first_index of the whole file.
+ *
+ * goss_gpu_emit_assemble, on one context of the same (k, mode): from the concatenation (in range order)
+ * of every ".part.high*" on the device and of the ".part.big" / ".part.hist" records in host memory, builds
+ * the files that need all ranges: ".header", "<base>.header", "<base>.high-bits", "<base>-d0", "<base>-d1"
+ * and for graphs "-counts.ord1p.*", "-counts.ord1", "-counts.ord2p.*", "-counts.ord2", "-counts-hist.txt".
+ * The files are appended to the context's list (a context may hold its own part and the assembly).
+ */
+int goss_gpu_emit_part(goss_gpu_ctx* ctx, uint64_t first_index, uint64_t total, uint64_t estimate);
+int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_high, uint32_t high_bytes, uint64_t total,
+                           uint64_t estimate, const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist);
+/* Device address of file i's image (NULL when the file was built on the host): for moving slices
+ * between GPUs without a host copy.  Valid until the next emit, reset, push or destroy. */
+int goss_gpu_file_device(goss_gpu_ctx* ctx, uint32_t i, const void** d_ptr);
+
+/*
  * Let the context's HBM arena grow beyond hbm_budget, up to max_bytes (0 = fixed, the default):
  * mapping HBM costs time, so a caller may start small and let inputs with little duplication --
  * whose sorted runs do not shrink (the case the reference spills to disk for, AsyncMerge.tcc) --

@@ -58,8 +58,15 @@ def _worker(rank, world, port, cases, q):
                     bufs = [torch.frombuffer(bytearray(s[rank]), dtype=torch.uint8).to(dev) for s in case["sets"]]
                     r = gd.set_algebra_distributed(ctx, [(b.data_ptr(), b.numel()) for b in bufs], key_bits, kind, dev)
                     assert r["sizes"] == case["sizes"], (name, r["sizes"], case["sizes"])
+                # every rank holds its span of the object: the test plays the per-rank writers
+                mine = ctx.files()
+                parts = [None] * world
+                dist.all_gather_object(parts, mine)
                 if rank == 0:
-                    got = ctx.files()
+                    assert any(n.startswith(".part.") for n in mine)
+                    for other in parts[1:]:
+                        assert all(".low-bits" in n or n == "-counts.ord0" or n.startswith(".part.") for n in other), sorted(other)
+                    got = gd.assemble_files(parts)
                     exp = case["expect"]
                     assert sorted(got) == sorted(exp), (name, sorted(got), sorted(exp))
                     for f in exp:

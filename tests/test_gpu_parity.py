@@ -362,7 +362,10 @@ def test_distributed_path_world1(oracle, nccl_world1, k, graph):
     buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
     with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
         r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0))
-        got = ctx.files()
+        got = gd.assemble_files([ctx.files()])
+        # the first form of the path (ranges gathered on rank 0, which builds everything) gives the same files
+        gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), emission="root")
+        assert ctx.files() == got
     assert r["windows"] == nwin
     assert sorted(got) == sorted(exp)
     for name in exp:
@@ -396,7 +399,7 @@ def test_distributed_set_algebra_world1(oracle, nccl_world1, k):
             else:
                 exp = oracle.subtract_kmer_set(files, names[sel[0]], names[sel[1]], "out")
             r = gd.set_algebra_distributed(ctx, [ins[j] for j in sel], 2 * k, op, dev)
-            got = ctx.files()
+            got = gd.assemble_files([ctx.files()])
             exp = _suffix_map(exp, "out")
             assert sorted(got) == sorted(exp), (sel, op)
             for name in exp:
