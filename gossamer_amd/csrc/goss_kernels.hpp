@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     // the tile's keys and the keys carried in: first the parts stored now, bucket after bucket
     // (each a multiple of 8), then the parts carried out
     __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry];
-    __shared__ uint32_t dh[256];                 // new keys of this tile per digit (rank counter)
+    __shared__ uint32_t dh[256 + 32];            // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
     // per bucket: x = first slot in `sorted` of the stored part | its length << 16,
     //             y = first slot of the part carried out | keys carried in << 13 | stored keys that fit the current block << 16
     __shared__ uint2 t_lay[256];
@@ -870,14 +870,18 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         }
 
         // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
+        // Written without branches around the LDS operations: a window that is not valid still gets a
+        // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
+        // of a thread are issued back to back and waited for once, not one round trip after the other.
         Key1 kreg[NK];
-        uint16_t rk[NK];
+        uint32_t rk[NK];
         uint32_t vm;
         {
             const uint32_t q0 = tid * P + mis;
             const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
             const uint64_t p0 = tile_base + (uint64_t)tid * P;
             uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+            uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
             const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
             uint32_t m = 0;
 #pragma unroll
@@ -888,47 +892,45 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             }
             vm = m;
             nvalid += __popc(m);
-            if (m)
-            {
-                uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
-                uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
-                const uint32_t s2 = 2 * sh;
-                const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-                const uint64_t bhi = hi >> s2;
-                // forward key f and reverse complement r of window 0, then one base rolled in per window
-                uint64_t f = rev64(blo & kmask) >> (64 - bits);
-                uint64_t r = (~blo) & kmask;
-                const uint32_t top = bits - 2;
+            const uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+            const uint32_t s2 = 2 * sh;
+            const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            const uint64_t bhi = hi >> s2;
+            // forward key f and reverse complement r of window 0, then one base rolled in per window
+            uint64_t f = rev64(blo & kmask) >> (64 - bits);
+            uint64_t r = (~blo) & kmask;
+            const uint32_t top = bits - 2;
+            const uint32_t spare = 256u + (tid & 31u);          // counters nobody reads
+            uint32_t bin[NK];
 #pragma unroll
-                for (int i = 0; i < P; ++i)
+            for (int i = 0; i < P; ++i)
+            {
+                if (i)
                 {
-                    if (i)
-                    {
-                        const uint32_t pos = 2 * (i + len - 1);
-                        const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
-                        f = ((f << 2) | nb) & kmask;
-                        r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
-                    }
-                    if ((m >> i) & 1u)
-                    {
-                        const Key1 fk{f}, rck{r};
-                        if (MODE == 0)
-                        {
-                            // odd length: the central base decides (its low bit differs between the strands)
-                            const Key1 k = ODD ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
-                            kreg[i] = k;
-                            rk[i] = (uint16_t)atomicAdd(&dh[(uint32_t)(k.lo >> shift) & 0xFFu], 1u);
-                        }
-                        else
-                        {
-                            kreg[i * 2] = fk;
-                            rk[i * 2] = (uint16_t)atomicAdd(&dh[(uint32_t)(fk.lo >> shift) & 0xFFu], 1u);
-                            kreg[i * 2 + 1] = rck;
-                            rk[i * 2 + 1] = (uint16_t)atomicAdd(&dh[(uint32_t)(rck.lo >> shift) & 0xFFu], 1u);
-                        }
-                    }
+                    const uint32_t pos = 2 * (i + len - 1);
+                    const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                    f = ((f << 2) | nb) & kmask;
+                    r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
+                }
+                const bool ok = (m >> i) & 1u;
+                const Key1 fk{f}, rck{r};
+                if (MODE == 0)
+                {
+                    // odd length: the central base decides (its low bit differs between the strands)
+                    const Key1 k = ODD ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
+                    kreg[i] = k;
+                    bin[i] = ok ? ((uint32_t)(k.lo >> shift) & 0xFFu) : spare;
+                }
+                else
+                {
+                    kreg[i * 2] = fk;
+                    bin[i * 2] = ok ? ((uint32_t)(fk.lo >> shift) & 0xFFu) : spare;
+                    kreg[i * 2 + 1] = rck;
+                    bin[i * 2 + 1] = ok ? ((uint32_t)(rck.lo >> shift) & 0xFFu) : spare;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
         }
         __syncthreads();
 
@@ -967,24 +969,24 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             ccnt = rem;
         }
         __syncthreads();
-        // new keys to their place: position ccnt_in + rank of the bucket's stream
+        // new keys to their place: position ccnt_in + rank of the bucket's stream (the table reads of
+        // all sixteen keys first, then the writes: no round trip per key)
+        {
+            uint2 tl[NK];
 #pragma unroll
-        for (int i = 0; i < P; ++i)
-            if ((vm >> i) & 1u)
-            {
+            for (int i = 0; i < NK; ++i) tl[i] = t_lay[(uint32_t)(kreg[i].lo >> shift) & 0xFFu];
 #pragma unroll
-                for (int q = 0; q < S; ++q)
+            for (int i = 0; i < NK; ++i)
+                if ((vm >> (i / S)) & 1u)
                 {
-                    const Key1 k = kreg[i * S + q];
-                    const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
-                    const uint2 tl = t_lay[d];
-                    const uint32_t p = ((tl.y >> 13) & 7u) + rk[i * S + q];
-                    const uint32_t fl = tl.x >> 16;
-                    sorted[p < fl ? (tl.x & 0xFFFFu) + p : (tl.y & 0x1FFFu) + (p - fl)] = k;
+                    const Key1 k = kreg[i];
+                    const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
+                    const uint32_t fl = tl[i].x >> 16;
+                    sorted[p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl)] = k;
                     if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
                     if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
                 }
-            }
+        }
         if (more)
         {
             encode(q0, c0, b0);
@@ -994,15 +996,31 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
 
         // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------
         if (sh_ovf == 0)
-            for (uint32_t i = tid; i < total_store; i += kTB)
+            for (uint32_t i0 = tid; i0 < total_store; i0 += 4 * kTB)
             {
-                const Key1 k = sorted[i];
-                const uint32_t d = (uint32_t)(k.lo >> shift) & 0xFFu;
-                const uint2 tl = t_lay[d], tb = t_base[d];
-                const uint32_t p = i - (tl.x & 0xFFFFu);
-                const uint32_t thr = tl.y >> 16;
-                const uint64_t o = p < thr ? ((uint64_t)tb.x << 3) + p : ((uint64_t)tb.y << 3) + (p - thr);
-                out[o] = k;
+                // four keys at a time: their LDS reads, then their table reads, then their stores
+                Key1 kk[4];
+                uint2 tl[4], tb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kk[u] = sorted[min(i0 + u * kTB, (uint32_t)(T * S + 256 * kCarry - 1))];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t d = (uint32_t)(kk[u].lo >> shift) & 0xFFu;
+                    tl[u] = t_lay[d]; tb[u] = t_base[d];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t i = i0 + u * kTB;
+                    if (i < total_store)
+                    {
+                        const uint32_t p = i - (tl[u].x & 0xFFFFu);
+                        const uint32_t thr = tl[u].y >> 16;
+                        const uint64_t o = p < thr ? ((uint64_t)tb[u].x << 3) + p : ((uint64_t)tb[u].y << 3) + (p - thr);
+                        out[o] = kk[u];
+                    }
+                }
             }
         // what bucket tid carries out, back into registers
         {
