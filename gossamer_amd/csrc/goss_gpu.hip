@@ -117,10 +117,12 @@ struct goss_gpu_ctx {
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
+    bool wide_table = true;             // GOSS_GPU_NO_WIDE_TABLE=1: never count two-word keys in the 6144-slot table
     bool big_table = true;              // GOSS_GPU_NO_BIG_TABLE=1: never count 16-bit segments in the 8192-slot table
     int big_rounds_max = 2;             // GOSS_GPU_BIG_ROUNDS=<r>: at most 2^r workgroups share a segment of that form
     int big_rounds_min = 0;             // GOSS_GPU_BIG_ROUNDS_MIN=<r>: at least 2^r (tests)
     uint32_t big_table_chunks = 0;      // chunks counted that way
+    uint32_t wide_table_chunks = 0;     // ... of them, two-word keys in the 6144-slot table
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
     uint64_t budget = 0;
@@ -594,7 +596,11 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, co
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
                             SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
-    if (big)
+    // big: -1 = the 6144-slot table, one workgroup per segment; 1 + r = the 4096-slot table, 2^r workgroups per segment
+    if (big < 0)
+        hipLaunchKernelGGL(seg_hash_reduce2_wide_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
+                           seg_pos, seg_cnt, sk, sc, rem_bits);
+    else if (big)
         hipLaunchKernelGGL(seg_hash_reduce2_big_kernel, unit_grid((uint64_t)nseg << (big - 1)), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
                            seg_pos, seg_cnt, sk, sc, rem_bits, (uint32_t)(big - 1));
     else
@@ -964,7 +970,11 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // keys costs more than one over 8-byte keys)
     if (!kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits)
         for (int r = std::max(0, c->big_rounds_min); r <= std::min(1, c->big_rounds_max); ++r)
+        {
             if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit2 * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
+            // between the two: the 6144-slot table, still one workgroup (and one read) per segment
+            if (r == 0 && c->wide_table && (m_est >> kSegBits) <= (uint64_t)kSegWideLimit2 * 3 / 4) { segbits = kSegBits; big_table = -1; break; }
+        }
     if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
@@ -1205,11 +1215,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if (rc != 0)
         {
             c->segment_retries++;
-            if (big_table) c->big_table = false;           // this input is too skewed for it: three digits from now on
+            // this input is too skewed for it: the next smaller form from now on
+            if (big_table < 0) c->wide_table = false;
+            else if (big_table) c->big_table = false;
             return decline("a segment table overflowed");
         }
         c->fused_msd_chunks++;
         if (big_table) c->big_table_chunks++;
+        if (big_table < 0) c->wide_table_chunks++;
     }
     else
     {
@@ -2154,6 +2167,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_WIDE_TABLE"); if (e && *e && *e != '0') c->wide_table = false; }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS_MIN"); if (e && *e) c->big_rounds_min = std::min(3, std::max(0, std::atoi(e))); }
     { const char* e = std::getenv("GOSS_GPU_NO_VALID_SIZING"); if (e && *e && *e != '0') c->size_by_valid = false; }
@@ -2721,6 +2735,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;
+    else if (n == "wide_table_chunks") *value = c->wide_table_chunks;
     else if (n == "valid_sized_chunks") *value = c->valid_sized_chunks;
     else if (n == "valid_resizes") *value = c->valid_resizes;
     else if (n == "seg_merges") *value = c->seg_merges;

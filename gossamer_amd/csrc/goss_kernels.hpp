@@ -2433,8 +2433,12 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     // round_bits > 0: unit (segment, r) as in seg_hash_reduce_body -- 2^round_bits workgroups stream
     // the segment, each counting the keys whose next round_bits bits equal r
     constexpr int kLimit = SLOTS / 4 * 3;
-    constexpr int kSlotBits = SLOTS == 2048 ? 11 : SLOTS == 4096 ? 12 : -1;
+    // SLOTS is a power of two, or 6144 (the largest table of two-word keys that fits a CU's LDS:
+    // slot = high half of hash * SLOTS instead of the hash's top bits, wrap-around by comparison)
+    constexpr bool kPow2 = (SLOTS & (SLOTS - 1)) == 0;
+    constexpr int kSlotBits = SLOTS == 2048 ? 11 : SLOTS == 4096 ? 12 : SLOTS == 6144 ? 13 : -1;
     static_assert(kSlotBits > 0 && SLOTS % NT == 0, "table size");
+    auto next_slot = [](uint32_t a) { return kPow2 ? ((a + 1) & (uint32_t)(SLOTS - 1)) : (a + 1 == (uint32_t)SLOTS ? 0u : a + 1); };
     __shared__ unsigned long long tlo[SLOTS];
     __shared__ unsigned long long thi[SLOTS];
     __shared__ uint32_t st[SLOTS];
@@ -2506,7 +2510,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
                 const uint32_t w0 = (uint32_t)kv[u].lo, w1 = (uint32_t)(kv[u].lo >> 32);
                 const uint32_t w2 = (uint32_t)kv[u].hi, w3 = (uint32_t)(kv[u].hi >> 32);
                 const uint32_t f = w0 ^ __builtin_rotateleft32(w1, 15) ^ __builtin_rotateleft32(w2, 7) ^ __builtin_rotateleft32(w3, 23);
-                slots[u] = (f * 0x9E3779B1u) >> (32 - kSlotBits);
+                slots[u] = kPow2 ? (f * 0x9E3779B1u) >> (32 - kSlotBits) : __umulhi(f * 0x9E3779B1u, (uint32_t)SLOTS);
             }
         }
         // fast path: the home slots of the whole batch are read together (plain LDS loads, the
@@ -2531,14 +2535,14 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
                 {
-                    const uint32_t a = slots[h * kQ + j], b2 = (a + 1) & (SLOTS - 1);
+                    const uint32_t a = slots[h * kQ + j], b2 = next_slot(a);
                     fs[j] = pst[a]; gs[j] = pst[b2];
                 }
                 asm volatile("" ::: "memory");       // the compiler keeps the states ahead of the keys; the LDS runs a wave's operations in order
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
                 {
-                    const uint32_t a = slots[h * kQ + j], b2 = (a + 1) & (SLOTS - 1);
+                    const uint32_t a = slots[h * kQ + j], b2 = next_slot(a);
                     fl[j] = plo[a]; fh[j] = phi[a]; gl[j] = plo[b2]; gh[j] = phi[b2];
                 }
 #pragma unroll
@@ -2549,7 +2553,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
                     const bool at0 = fs[j] != 0u && fs[j] != kSegLock && fl[j] == kv[u].lo && fh[j] == kv[u].hi;
                     const bool at1 = gs[j] != 0u && gs[j] != kSegLock && gl[j] == kv[u].lo && gh[j] == kv[u].hi;
                     if (at0) atomicAdd(&st[slots[u]], 1u);
-                    else if (at1) atomicAdd(&st[(slots[u] + 1) & (SLOTS - 1)], 1u);
+                    else if (at1) atomicAdd(&st[next_slot(slots[u])], 1u);
                     else pend |= 1u << u;
                 }
             }
@@ -2589,7 +2593,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
                 else if (state != kSegLock)
                 {
                     if (vlo[slot] == key.lo && vhi[slot] == key.hi) { atomicAdd(&st[slot], 1u); have = false; }
-                    else slot = (slot + 1) & (SLOTS - 1);
+                    else slot = next_slot(slot);
                 }
             }
             if (*vovf) break;
@@ -2608,7 +2612,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     // bucket sizes, scatter, insertion sort of every bucket -- and only a bucket above 24 keys (skewed
     // bits) sends the compacted entries through the bitonic network (66 barriers for 2048 of them).
     constexpr int kPer2 = SLOTS / NT;
-    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kSlotBits - 2;
+    constexpr int kBins = kPow2 ? SLOTS / 4 : 2048, kBinsPer = kBins / NT, kBinBits = kPow2 ? kSlotBits - 2 : 11;
     static_assert(kBins % NT == 0, "bins per thread");
     __shared__ uint32_t bins[kBins];
     __shared__ uint32_t sh_scan2[NT / 64 + 1];
@@ -2677,6 +2681,13 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     {
         uint32_t nsort = 64;
         while (nsort < tot_occ) nsort <<= 1;
+        if (nsort > (uint32_t)SLOTS)
+        {
+            // (6144-slot table only) more entries than the largest network the arrays hold: the host retries
+            // with more partition bits
+            if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+            return;
+        }
         for (uint32_t i = tot_occ + tid; i < nsort; i += NT) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
         __syncthreads();
         // empty slots sort last: hi = all ones is never a key (2*len <= 126 bits)
@@ -2732,6 +2743,19 @@ __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __res
 // distinct two-word keys keep the two-level form (see seg_hash_reduce_big_kernel).
 constexpr int kSegBigSlots2 = 4096;
 constexpr int kSegBigLimit2 = kSegBigSlots2 / 4 * 3;
+// ... and with the largest table a CU's LDS holds for two-word keys (6144 slots of 20 bytes + the sort's
+// bins = 128 KB): up to 4608 distinct keys per segment counted by ONE workgroup, where the 4096-slot table
+// needs two that each read the whole segment
+constexpr int kSegWideSlots2 = 6144;
+constexpr int kSegWideLimit2 = kSegWideSlots2 / 4 * 3;
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce2_wide_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                               uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                               Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                               uint32_t rem_bits)
+{
+    seg_hash_reduce2_body<kSegBigThreads, kSegWideSlots2>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, 0u);
+}
 __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce2_big_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                                               const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                               uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,

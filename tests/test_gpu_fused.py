@@ -307,6 +307,47 @@ def test_big_counting_table_two_word_keys():
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
+def test_wide_counting_table_two_word_keys():
+    """k = 45, ~1.8e8 distinct two-word k-mers in one chunk (2 800 per 16-bit segment): too many for the
+    4096-slot table with margin, few enough for the 6144-slot one -- one workgroup and one read per
+    segment (seg_hash_reduce2_wide_kernel) against two workgroups sharing every segment of the 4096-slot
+    table: same keys and counts."""
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 100 * (1 << 30):
+        pytest.skip("needs ~50 GB of HBM")
+    n, L, G = 6_000_000, 150, 190_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for env in ({}, {"GOSS_GPU_NO_WIDE_TABLE": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(45, g.MODE_KMER_SET, hbm_budget=48 << 30)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=57)
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert c.key_words == 2
+        assert ctx.stat("fused_chunks") == 1 and ctx.stat("segment_retries") == 0
+        assert ctx.stat("big_table_chunks") == 1 and ctx.stat("wide_table_chunks") == (0 if env else 1)
+        kp, cp, m = ctx.result_ptrs()
+        assert 170_000_000 < m < 190_000_000
+        res.append((gd.key_view(kp, m, 2, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
+
+
 def test_segment_sort_skewed_low_bits(oracle):
     """Keys of one segment that also agree on the ten bits below the segment bits overflow the
     bucket sort's insertion-sort limit: the bitonic fallback of seg_hash_reduce_kernel must give
