@@ -117,6 +117,8 @@ struct goss_gpu_ctx {
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
+    bool table96 = true;                // GOSS_GPU_NO_TABLE96=1: never count two-word keys as 96-bit remainders in 16-byte slots
+    uint32_t table96_chunks = 0;
     bool wide_table = true;             // GOSS_GPU_NO_WIDE_TABLE=1: never count two-word keys in the 6144-slot table
     bool big_table = true;              // GOSS_GPU_NO_BIG_TABLE=1: never count 16-bit segments in the 8192-slot table
     int big_rounds_max = 2;             // GOSS_GPU_BIG_ROUNDS=<r>: at most 2^r workgroups share a segment of that form
@@ -596,8 +598,12 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key1* keys, co
 inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, const uint64_t* seg_off, const uint64_t* seg_end,
                             SegOut* so, uint64_t* seg_pos, uint64_t* seg_cnt, Key2* sk, uint32_t* sc, uint32_t rem_bits, int big)
 {
-    // big: -1 = the 6144-slot table, one workgroup per segment; 1 + r = the 4096-slot table, 2^r workgroups per segment
-    if (big < 0)
+    // big: -2 = the 8192-slot table of 96-bit remainders, -1 = the 6144-slot table, one workgroup per segment each;
+    // 1 + r = the 4096-slot table, 2^r workgroups per segment
+    if (big == -2)
+        hipLaunchKernelGGL(seg_hash_reduce96_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
+                           seg_pos, seg_cnt, sk, sc, rem_bits);
+    else if (big < 0)
         hipLaunchKernelGGL(seg_hash_reduce2_wide_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
                            seg_pos, seg_cnt, sk, sc, rem_bits);
     else if (big)
@@ -968,7 +974,11 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
     // two-word keys: the 4096-slot table, up to two workgroups per segment (a pass over 16-byte
     // keys costs more than one over 8-byte keys)
-    if (!kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits)
+    // two-word keys whose bits below a 16-bit prefix fit 96: 16-byte slots, 8192 of them
+    if (!kOne && c->fused_msd && c->big_table && c->table96 && segbits > (uint32_t)kSegBits && keybits - kSegBits <= 96 &&
+        c->big_rounds_min == 0 && (m_est >> kSegBits) <= (uint64_t)kSeg96Limit * 3 / 4)
+    { segbits = kSegBits; big_table = -2; }
+    if (!kOne && !big_table && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits)
         for (int r = std::max(0, c->big_rounds_min); r <= std::min(1, c->big_rounds_max); ++r)
         {
             if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit2 * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
@@ -1216,13 +1226,15 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             c->segment_retries++;
             // this input is too skewed for it: the next smaller form from now on
-            if (big_table < 0) c->wide_table = false;
+            if (big_table == -2) c->table96 = false;
+            else if (big_table < 0) c->wide_table = false;
             else if (big_table) c->big_table = false;
             return decline("a segment table overflowed");
         }
         c->fused_msd_chunks++;
         if (big_table) c->big_table_chunks++;
-        if (big_table < 0) c->wide_table_chunks++;
+        if (big_table == -1) c->wide_table_chunks++;
+        if (big_table == -2) c->table96_chunks++;
     }
     else
     {
@@ -2167,6 +2179,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_TABLE96"); if (e && *e && *e != '0') c->table96 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_WIDE_TABLE"); if (e && *e && *e != '0') c->wide_table = false; }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS_MIN"); if (e && *e) c->big_rounds_min = std::min(3, std::max(0, std::atoi(e))); }
@@ -2736,6 +2749,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;
     else if (n == "wide_table_chunks") *value = c->wide_table_chunks;
+    else if (n == "table96_chunks") *value = c->table96_chunks;
     else if (n == "valid_sized_chunks") *value = c->valid_sized_chunks;
     else if (n == "valid_resizes") *value = c->valid_resizes;
     else if (n == "seg_merges") *value = c->seg_merges;

@@ -2730,6 +2730,275 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     }
 }
 
+// The same for two-word keys whose bits below the segment prefix fit 96 bits (2*len <= 112 with 16-bit
+// segments: every build-graph k <= 55, every k-mer set k <= 56).  Inside a segment all keys share the
+// prefix, so a slot holds the 96-bit REMAINDER and the count in 16 bytes: a probe is one ds_read_b128
+// instead of three reads from three arrays, and 8192 slots fit a CU's LDS (128 KB) -- up to 6144
+// distinct keys per segment counted by one workgroup.  Slot word w: 0 = empty, kSegLock = being
+// written, otherwise the count of a published key (the protocol of seg_hash_reduce2_body).
+struct __attribute__((aligned(16))) Slot96 { uint32_t r0, r1, r2, w; };
+__device__ __forceinline__ uint4 tbl4(const Slot96* t, uint32_t i) { return reinterpret_cast<const uint4*>(t)[i]; }
+
+template <int NT, int SLOTS>
+__device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                       const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
+                                                       uint64_t* __restrict__ seg_cnt,
+                                                       Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                       uint32_t rem_bits)
+{
+    constexpr int kLimit = SLOTS / 4 * 3;
+    constexpr int kSlotBits = SLOTS == 4096 ? 12 : SLOTS == 8192 ? 13 : -1;
+    static_assert(kSlotBits > 0 && SLOTS % NT == 0, "table size");
+    __shared__ Slot96 tbl[SLOTS];
+    __shared__ uint32_t ndist;
+    __shared__ uint32_t ovf;
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = unit_block(), tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_end[s];
+    if (b == e)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    if (e - b > 0xFFFFFFFFULL)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tbl);
+    for (uint32_t i = tid; i < SLOTS; i += NT) tw[4 * i + 3] = 0;
+    if (tid == 0) { ndist = 0; ovf = 0; }
+    __syncthreads();
+    // remainder of a key: its low rem_bits bits (64 <= rem_bits <= 96, or fewer: then r2 = 0)
+    const uint32_t hbits = rem_bits > 64 ? rem_bits - 64 : 0;
+    const uint32_t hmask = hbits >= 32 ? 0xFFFFFFFFu : ((1u << hbits) - 1u);
+    const uint64_t lmask64 = rem_bits >= 64 ? ~0ULL : ((1ULL << rem_bits) - 1ULL);
+
+    lds_vu32 vovf = (lds_vu32)&ovf;
+    lds_vu32 vt = (lds_vu32)tw;
+    constexpr int kU = 8;
+    Key2 nxt[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+    {
+        uint64_t i = b + (uint64_t)u * NT + tid;
+        nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+    }
+    for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kU)
+    {
+        uint32_t r0[kU], r1[kU], r2[kU], slots[kU];
+        uint32_t pend = 0, live = 0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+            const Key2 kv = nxt[u];
+            if (kv.hi != ~0ULL) live |= 1u << u;
+            const uint64_t lo = kv.lo & lmask64;
+            r0[u] = (uint32_t)lo; r1[u] = (uint32_t)(lo >> 32); r2[u] = (uint32_t)kv.hi & hmask;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+            uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
+            nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+            const uint32_t f = r0[u] ^ __builtin_rotateleft32(r1[u], 15) ^ __builtin_rotateleft32(r2[u], 7);
+            slots[u] = (f * 0x9E3779B1u) >> (32 - kSlotBits);
+        }
+        // fast path: home slot and its neighbour of the whole batch read together (plain 16-byte LDS
+        // loads: a slot whose word shows a count was published with its key, and keys never change)
+        {
+            constexpr int kQ = 4;
+            static_assert(kU % kQ == 0, "quarter batches");
+#pragma unroll
+            for (int h = 0; h < kU / kQ; ++h)
+            {
+                uint4 fa[kQ], fb[kQ];
+#pragma unroll
+                for (int j = 0; j < kQ; ++j)
+                {
+                    fa[j] = tbl4(tbl, slots[h * kQ + j]);
+                    fb[j] = tbl4(tbl, (slots[h * kQ + j] + 1) & (SLOTS - 1));
+                }
+#pragma unroll
+                for (int j = 0; j < kQ; ++j)
+                {
+                    const int u = h * kQ + j;
+                    if (!((live >> u) & 1u)) continue;
+                    const bool at0 = fa[j].w != 0u && fa[j].w != kSegLock && fa[j].x == r0[u] && fa[j].y == r1[u] && fa[j].z == r2[u];
+                    const bool at1 = fb[j].w != 0u && fb[j].w != kSegLock && fb[j].x == r0[u] && fb[j].y == r1[u] && fb[j].z == r2[u];
+                    if (at0) atomicAdd(&tw[4 * slots[u] + 3], 1u);
+                    else if (at1) atomicAdd(&tw[4 * ((slots[u] + 1) & (SLOTS - 1)) + 3], 1u);
+                    else pend |= 1u << u;
+                }
+            }
+        }
+        uint32_t k0 = 0, k1 = 0, k2 = 0, slot = 0;
+        bool have = false;
+        for (;;)
+        {
+            if (!have && pend)
+            {
+                const uint32_t u = __ffs(pend) - 1;
+                pend &= pend - 1;
+#pragma unroll
+                for (int uu = 0; uu < kU; ++uu)
+                    if (u == (uint32_t)uu) { k0 = r0[uu]; k1 = r1[uu]; k2 = r2[uu]; slot = slots[uu]; }
+                have = true;
+            }
+            if (!__ballot(have)) break;
+            if (have)
+            {
+                const uint32_t state = vt[4 * slot + 3];
+                if (state == 0)
+                {
+                    const uint32_t old = atomicCAS(&tw[4 * slot + 3], 0u, kSegLock);
+                    if (old == 0)
+                    {
+                        vt[4 * slot] = k0; vt[4 * slot + 1] = k1; vt[4 * slot + 2] = k2;
+                        vt[4 * slot + 3] = 1u;               // publish (LDS ops of a lane are in order)
+                        const uint32_t nd = atomicAdd(&ndist, 1u);
+                        if (nd + 1 > kLimit) *vovf = 1;
+                        have = false;
+                    }
+                }
+                else if (state != kSegLock)
+                {
+                    if (vt[4 * slot] == k0 && vt[4 * slot + 1] == k1 && vt[4 * slot + 2] == k2) { atomicAdd(&tw[4 * slot + 3], 1u); have = false; }
+                    else slot = (slot + 1) & (SLOTS - 1);
+                }
+            }
+            if (*vovf) break;
+        }
+        if (*vovf) break;
+    }
+    __syncthreads();
+    if (ovf)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    // order the occupied slots by remainder (= by key: the prefix is common): registers, bucket sort on
+    // the top remainder bits, insertion sort inside the buckets; bitonic network only for skewed bits
+    constexpr int kPer = SLOTS / NT;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kSlotBits - 2;
+    static_assert(kBins % NT == 0, "bins per thread");
+    __shared__ uint32_t bins[kBins];
+    __shared__ uint32_t sh_scan2[NT / 64 + 1];
+    __shared__ uint32_t big;
+    uint4 c[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) c[j] = tbl4(tbl, tid * kPer + j);
+    for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
+    if (tid == 0) big = 0;
+    __syncthreads();
+    const uint32_t bsh = rem_bits > (uint32_t)kBinBits ? rem_bits - kBinBits : 0;
+    auto rem_shr = [](const uint4& v, uint32_t sh) -> uint32_t {      // bits [sh, sh + 32) of the 96-bit remainder
+        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        if (sh == 0) return (uint32_t)lo;
+        if (sh < 64) return (uint32_t)((lo >> sh) | ((uint64_t)v.z << (64 - sh)));
+        return sh >= 96 ? 0u : (v.z >> (sh - 64));
+    };
+    auto rem_less = [](const uint4& a, const uint4& b2) { return a.z < b2.z || (a.z == b2.z && (a.y < b2.y || (a.y == b2.y && a.x < b2.x))); };
+    uint32_t rnk[kPer], bin[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (c[j].w != 0)
+        {
+            bin[j] = rem_shr(c[j], bsh) & (kBins - 1);
+            rnk[j] = atomicAdd(&bins[bin[j]], 1u);
+        }
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
+    lds_vu32 vbig = (lds_vu32)&big;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        if (bn[q] > 24) *vbig = 1;
+    }
+    __syncthreads();
+    uint4* t4 = reinterpret_cast<uint4*>(tbl);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (c[j].w != 0) t4[bins[bin[j]] + rnk[j]] = c[j];
+    __syncthreads();
+    if (!big)
+    {
+#pragma unroll
+        for (int q = 0; q < kBinsPer; ++q)
+            for (uint32_t i = 1; i < bn[q]; ++i)
+            {
+                const uint4 v = t4[bs[q] + i];
+                uint32_t j = i;
+                while (j > 0 && rem_less(v, t4[bs[q] + j - 1])) { t4[bs[q] + j] = t4[bs[q] + j - 1]; --j; }
+                t4[bs[q] + j] = v;
+            }
+        __syncthreads();
+    }
+    else
+    {
+        uint32_t nsort = 64;
+        while (nsort < tot_occ) nsort <<= 1;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += NT) t4[i] = make_uint4(~0u, ~0u, ~0u, 0u);     // sorts last
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+        {
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += NT)
+                {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t p = i + j;
+                    const bool up = (i & k2) == 0;
+                    const uint4 a = t4[i], b2 = t4[p];
+                    const bool gt = rem_less(b2, a);
+                    if (gt == up) { t4[i] = b2; t4[p] = a; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const uint32_t d = ndist;
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
+    // the full key again: remainder | segment number << rem_bits
+    const unsigned __int128 prefix = (unsigned __int128)s << rem_bits;
+    for (uint32_t i = tid; i < d; i += NT)
+    {
+        const uint4 v = t4[i];
+        const unsigned __int128 full = prefix | ((unsigned __int128)v.z << 64) | ((uint64_t)v.x | ((uint64_t)v.y << 32));
+        stage_keys[ob + i] = Key2{(uint64_t)full, (uint64_t)(full >> 64)};
+        stage_counts[ob + i] = v.w;
+    }
+}
+
+constexpr int kSeg96Slots = 8192;
+constexpr int kSeg96Limit = kSeg96Slots / 4 * 3;
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce96_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                           const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                           uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                           Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                           uint32_t rem_bits)
+{
+    seg_hash_reduce96_body<kSegBigThreads, kSeg96Slots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+}
+
 __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                                const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                                uint64_t* __restrict__ seg_cnt,

@@ -276,7 +276,7 @@ def test_big_counting_table_two_word_keys():
     n, L, G = 4_600_000, 150, 110_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
-    for env in ({}, {"GOSS_GPU_NO_BIG_TABLE": "1"}, {"GOSS_GPU_BIG_ROUNDS_MIN": "1"}):
+    for env in ({"GOSS_GPU_NO_TABLE96": "1"}, {"GOSS_GPU_NO_BIG_TABLE": "1"}, {"GOSS_GPU_BIG_ROUNDS_MIN": "1"}, {}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -297,6 +297,7 @@ def test_big_counting_table_two_word_keys():
         plain = "GOSS_GPU_NO_BIG_TABLE" in env
         assert ctx.stat("big_table_chunks") == (0 if plain else 1)
         assert ctx.stat("fused_msd_chunks") == (0 if plain else 1)
+        assert ctx.stat("table96_chunks") == (0 if env else 1)       # k = 45: 90 - 16 = 74 remainder bits, 16-byte slots
         kp, cp, m = ctx.result_ptrs()
         assert 100_000_000 < m < 110_000_000
         res.append((gd.key_view(kp, m, 2, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
@@ -320,7 +321,7 @@ def test_wide_counting_table_two_word_keys():
     n, L, G = 6_000_000, 150, 190_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
-    for env in ({}, {"GOSS_GPU_NO_WIDE_TABLE": "1"}):
+    for env in ({"GOSS_GPU_NO_TABLE96": "1"}, {"GOSS_GPU_NO_TABLE96": "1", "GOSS_GPU_NO_WIDE_TABLE": "1"}, {}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -338,13 +339,15 @@ def test_wide_counting_table_two_word_keys():
         c = ctx.finish()
         assert c.key_words == 2
         assert ctx.stat("fused_chunks") == 1 and ctx.stat("segment_retries") == 0
-        assert ctx.stat("big_table_chunks") == 1 and ctx.stat("wide_table_chunks") == (0 if env else 1)
+        assert ctx.stat("big_table_chunks") == 1 and ctx.stat("wide_table_chunks") == (1 if len(env) == 1 else 0)
+        assert ctx.stat("table96_chunks") == (0 if env else 1)
         kp, cp, m = ctx.result_ptrs()
         assert 170_000_000 < m < 190_000_000
         res.append((gd.key_view(kp, m, 2, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
         ctx.close()
-    assert res[0][2] == res[1][2]
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert res[0][2] == other[2]
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
