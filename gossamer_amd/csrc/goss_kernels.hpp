@@ -2142,8 +2142,10 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
 #pragma unroll
     for (int u = 0; u < kSegUnroll; ++u)
     {
-        uint64_t i = b + (uint64_t)u * NT + tid;
-        nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+        // (clamped index and a select instead of a branch around the load)
+        const uint64_t i = b + (uint64_t)u * NT + tid;
+        const unsigned long long v = __builtin_nontemporal_load(&keys[i < e ? i : e - 1].lo);
+        nxt[u] = i < e ? v : kEmpty;
     }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kSegUnroll)
     {
@@ -2154,8 +2156,9 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
 #pragma unroll
         for (int u = 0; u < kSegUnroll; ++u)
         {
-            uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * NT + tid;
-            nxt[u] = i < e ? __builtin_nontemporal_load(&keys[i].lo) : kEmpty;
+            const uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * NT + tid;
+            const unsigned long long v = __builtin_nontemporal_load(&keys[i < e ? i : e - 1].lo);
+            nxt[u] = i < e ? v : kEmpty;
         }
         // The table is probed in buckets of two adjacent slots (one 16-byte LDS read): at a load
         // of ~0.4 a present key is almost always in its home bucket.
@@ -2194,26 +2197,19 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
             {
                 const int u = h * kHalf + j;
                 const unsigned long long s0 = q[j].x, s1 = q[j].y;
-                if (FILTER)
-                {
-                    // most keys belong to another workgroup: one predicated atomic for a hit, one
-                    // bit for a miss (the slow path reads the home bucket again) -- measured faster
-                    // here, slower where every key is live
-                    const bool live = kv[u] != kEmpty, h0 = s0 == kv[u], h1 = s1 == kv[u];
-                    if (live && (h0 || h1)) atomicAdd(&cnt[2 * bkt[u] + (h1 ? 1u : 0u)], 1u);
-                    pend |= (live && !(h0 || h1)) ? (1u << u) : 0u;
-                }
-                else if (kv[u] != kEmpty)
-                {
-                    if (s0 == kv[u]) atomicAdd(&cnt[2 * bkt[u]], 1u);
-                    else if (s1 == kv[u]) atomicAdd(&cnt[2 * bkt[u] + 1], 1u);
-                    else
-                    {
-                        pend |= 1u << u;
-                        // a full home bucket cannot take the key: start at the next one
-                        if (s0 != kEmpty && s1 != kEmpty) bkt[u] = (bkt[u] + 1) & (SLOTS / 2 - 1);
-                    }
-                }
+                // No branch per key: the count of the slot that holds the key (or of slot 0 of the bucket,
+                // by 0) is bumped unconditionally, a miss sets a bit.  Written with && / if-else chains the
+                // compiler emits a branch per term, and the scalar exec-mask bookkeeping then costs more
+                // issue slots than the vector work.
+                const uint32_t live = kv[u] != kEmpty ? 1u : 0u;
+                const uint32_t h0 = s0 == kv[u] ? 1u : 0u, h1 = s1 == kv[u] ? 1u : 0u;
+                const uint32_t hit = (h0 | h1) & live;
+                atomicAdd(&cnt[2 * bkt[u] + h1], hit);
+                const uint32_t miss = live & (hit ^ 1u);
+                pend |= miss << u;
+                // a full home bucket cannot take the key: the slow path starts at the next one
+                const uint32_t full = (s0 != kEmpty ? 1u : 0u) & (s1 != kEmpty ? 1u : 0u) & miss;
+                bkt[u] = (bkt[u] + full) & (SLOTS / 2 - 1);
             }
         }
         // slow path (key absent from its home bucket): every lane walks its OWN queue of
@@ -2781,8 +2777,10 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
 #pragma unroll
     for (int u = 0; u < kU; ++u)
     {
-        uint64_t i = b + (uint64_t)u * NT + tid;
-        nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+        // (clamped index and a select instead of a branch around the load)
+        const uint64_t i = b + (uint64_t)u * NT + tid;
+        nxt[u] = keys[i < e ? i : e - 1];
+        nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
     }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kU)
     {
@@ -2799,8 +2797,9 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kU; ++u)
         {
-            uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
-            nxt[u] = i < e ? keys[i] : Key2{~0ULL, ~0ULL};
+            const uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
+            nxt[u] = keys[i < e ? i : e - 1];
+            nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -2808,31 +2807,41 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
             const uint32_t f = r0[u] ^ __builtin_rotateleft32(r1[u], 15) ^ __builtin_rotateleft32(r2[u], 7);
             slots[u] = (f * 0x9E3779B1u) >> (32 - kSlotBits);
         }
-        // fast path: home slot and its neighbour of the whole batch read together (plain 16-byte LDS
-        // loads: a slot whose word shows a count was published with its key, and keys never change)
+        // fast path: the home slot and the three behind it, two keys at a time (plain 16-byte LDS loads: a
+        // slot whose word shows a count was published with its key, and keys never change).  Once a segment's
+        // keys are in the table -- after its first few batches -- nearly every key is found here (at a load
+        // of 0.37 about 1 % sit further from home); what is not goes through the state machine below, whose
+        // wave-wide loop costs every lane of the wave its iterations.
         {
-            constexpr int kQ = 4;
-            static_assert(kU % kQ == 0, "quarter batches");
+            constexpr int kQ = 2;
+            static_assert(kU % kQ == 0, "pairs");
 #pragma unroll
             for (int h = 0; h < kU / kQ; ++h)
             {
-                uint4 fa[kQ], fb[kQ];
+                uint4 f[kQ][4];
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
-                {
-                    fa[j] = tbl4(tbl, slots[h * kQ + j]);
-                    fb[j] = tbl4(tbl, (slots[h * kQ + j] + 1) & (SLOTS - 1));
-                }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f[j][q] = tbl4(tbl, (slots[h * kQ + j] + q) & (SLOTS - 1));
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
                 {
                     const int u = h * kQ + j;
-                    if (!((live >> u) & 1u)) continue;
-                    const bool at0 = fa[j].w != 0u && fa[j].w != kSegLock && fa[j].x == r0[u] && fa[j].y == r1[u] && fa[j].z == r2[u];
-                    const bool at1 = fb[j].w != 0u && fb[j].w != kSegLock && fb[j].x == r0[u] && fb[j].y == r1[u] && fb[j].z == r2[u];
-                    if (at0) atomicAdd(&tw[4 * slots[u] + 3], 1u);
-                    else if (at1) atomicAdd(&tw[4 * ((slots[u] + 1) & (SLOTS - 1)) + 3], 1u);
-                    else pend |= 1u << u;
+                    // (integer arithmetic, no && chains: the compiler turns those into a branch per term, and
+                    // the scalar instructions of exec-mask bookkeeping then outnumber the vector ones)
+                    uint32_t off = 4;
+#pragma unroll
+                    for (int q = 3; q >= 0; --q)
+                    {
+                        const uint32_t diff = (f[j][q].x ^ r0[u]) | (f[j][q].y ^ r1[u]) | (f[j][q].z ^ r2[u]);
+                        // a published slot: 1 <= w < kSegLock
+                        const uint32_t bad = diff | (uint32_t)((f[j][q].w - 1u) >= (kSegLock - 1u));
+                        off = bad ? off : (uint32_t)q;
+                    }
+                    const uint32_t is_live = (live >> u) & 1u;
+                    const uint32_t hit = (off < 4u ? 1u : 0u) & is_live;
+                    if (hit) atomicAdd(&tw[4 * ((slots[u] + off) & (SLOTS - 1)) + 3], 1u);
+                    pend |= (is_live & (hit ^ 1u)) << u;
                 }
             }
         }
