@@ -755,7 +755,7 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
 // The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
 template <int MODE, int NH, bool ODD>
-__global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+__global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
                                                             const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
@@ -771,7 +771,10 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
     constexpr int kCarry = 7;
     // the tile's keys and the keys carried in: first the parts stored now, bucket after bucket
     // (each a multiple of 8), then the parts carried out
-    __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry];
+    // (+ 64 slots nobody reads: LDS writes that do not apply go there instead of under a branch, whose
+    // exec-mask bookkeeping costs scalar issue slots; reads past the live part land there too)
+    constexpr uint32_t kSpare = T * S + 256 * kCarry;
+    __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry + 64];
     __shared__ uint32_t dh[256 + 32];            // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
     // per bucket: x = first slot in `sorted` of the stored part | its length << 16,
     //             y = first slot of the part carried out | keys carried in << 13 | stored keys that fit the current block << 16
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             // the keys carried in go first (phase A's arrays in `sorted` are dead: every thread is past phase B)
 #pragma unroll
             for (int j = 0; j < kCarry; ++j)
-                if ((uint32_t)j < ccnt) sorted[(uint32_t)j < fl ? f_at + j : l_at + j] = kc[j];
+                sorted[(uint32_t)j < ccnt ? ((uint32_t)j < fl ? f_at + j : l_at + j) : kSpare + (tid & 63u)] = kc[j];
             ccnt = rem;
         }
         __syncthreads();
@@ -977,15 +980,16 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
             for (int i = 0; i < NK; ++i) tl[i] = t_lay[(uint32_t)(kreg[i].lo >> shift) & 0xFFu];
 #pragma unroll
             for (int i = 0; i < NK; ++i)
-                if ((vm >> (i / S)) & 1u)
-                {
-                    const Key1 k = kreg[i];
-                    const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
-                    const uint32_t fl = tl[i].x >> 16;
-                    sorted[p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl)] = k;
-                    if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], 1u);
-                    if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], 1u);
-                }
+            {
+                const bool ok = (vm >> (i / S)) & 1u;
+                const Key1 k = kreg[i];
+                const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
+                const uint32_t fl = tl[i].x >> 16;
+                const uint32_t at = p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl);
+                sorted[ok ? at : kSpare + (tid & 63u)] = k;
+                if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], ok ? 1u : 0u);
+                if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], ok ? 1u : 0u);
+            }
         }
         if (more)
         {
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
                 Key1 kk[4];
                 uint2 tl[4], tb[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kk[u] = sorted[min(i0 + u * kTB, (uint32_t)(T * S + 256 * kCarry - 1))];
+                for (int u = 0; u < 4; ++u) kk[u] = sorted[min(i0 + u * kTB, kSpare)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                 {
@@ -1026,8 +1030,7 @@ __global__ __launch_bounds__(kTB) void extract1_part_kernel(const uint8_t* __res
         {
             const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
 #pragma unroll
-            for (int j = 0; j < kCarry; ++j)
-                if ((uint32_t)j < ccnt) kc[j] = sorted[l_at + j];
+            for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];       // (those beyond ccnt are never used)
         }
         __syncthreads();
     }
