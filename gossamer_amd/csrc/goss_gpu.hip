@@ -839,7 +839,41 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
     HIP_TRY(hipMemcpyAsync(va, r.counts, m * 4, hipMemcpyDeviceToDevice, c->stream));
     const bool mute = c->mute_timing;
     c->mute_timing = true;                  // the sort's passes belong to this phase, not to the partition classes
-    const bool in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, key_digits(c));
+    bool in_b = false, ordered = false;
+    const uint32_t keybits = 2 * c->len;
+    if constexpr (std::is_same<K, Key1>::value)
+    {
+        // canonical forms are uniform on their leading bits: two radix passes group the pairs by their top
+        // 16 bits, then every group (m / 65536 pairs) is ordered in LDS -- three passes over the pairs instead
+        // of one per key byte
+        if (keybits >= 26 && m >= (1u << 20) && m <= 65536ULL * 2400)
+        {
+            in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, 2, keybits - 16);
+            K* sk = in_b ? kb : ka;
+            uint32_t* sv = in_b ? vb : va;
+            uint64_t m2 = c->arena.mark();
+            uint64_t* soff = (uint64_t*)c->arena.temp(65537 * 8);
+            uint32_t* flag = (uint32_t*)c->arena.temp(16);
+            HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(65536 / 256 + 1), dim3(256), 0, c->stream,
+                               (const K*)sk, m, keybits - 16, 65536u, soff);
+            hipLaunchKernelGGL(seg_sort_pairs_kernel, unit_grid(65536), dim3(kTB), 0, c->stream, sk, sv, (const uint64_t*)soff,
+                               keybits - 16, flag);
+            uint32_t* hf = (uint32_t*)c->h_pinned;
+            HIP_TRY(hipMemcpyAsync(hf, flag, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            ordered = hf[0] == 0;
+            c->arena.release(m2);
+            if (!ordered)
+            {
+                // skewed bits: order everything by the remaining digits as well (the top 16 bits are in place,
+                // a full stable sort from the current buffer is simply the general answer)
+                if (in_b) { std::swap(ka, kb); std::swap(va, vb); }
+                in_b = false;
+            }
+        }
+    }
+    if (!ordered) in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, key_digits(c));
     c->mute_timing = mute;
     HIP_TRY(hipMemcpyAsync(r.keys, in_b ? kb : ka, m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(r.counts, in_b ? vb : va, m * 4, hipMemcpyDeviceToDevice, c->stream));

@@ -3190,6 +3190,83 @@ __global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ ke
     }
 }
 
+// Order the (key,count) pairs of every segment in place: the pairs are already grouped by their top
+// bits (segment s = [seg_off[s], seg_off[s+1])), at most kSortCap per segment.  One workgroup per
+// segment: pairs into registers, bucket sort through LDS on the 10 bits below the segment prefix (rank
+// by LDS atomic, scan, scatter, insertion sort of the ~1.5-pair buckets), coalesced write-back.  A
+// segment above kSortCap or a bucket above 24 pairs (skewed bits) raises *fallback: the host orders the
+// array by a full radix sort instead.  Used by canonicalize_run after two radix passes on the top 16 bits.
+constexpr int kSortCap = 4096;
+__global__ __launch_bounds__(kTB) void seg_sort_pairs_kernel(Key1* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                             const uint64_t* __restrict__ seg_off, uint32_t rem_bits,
+                                                             uint32_t* __restrict__ fallback)
+{
+    constexpr int kPer = kSortCap / kTB;          // 16
+    constexpr int kBins = 1024, kBinsPer = kBins / kTB;
+    __shared__ unsigned long long tab[kSortCap];
+    __shared__ uint32_t cnt[kSortCap];
+    __shared__ uint32_t bins[kBins];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    const uint32_t s = unit_block(), tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_off[s + 1];
+    const uint32_t n = (uint32_t)(e - b);
+    if (e - b > (uint64_t)kSortCap) { if (tid == 0) atomicOr(fallback, 1u); return; }
+    if (n < 2) return;
+    unsigned long long ck[kPer];
+    uint32_t cc[kPer], rnk[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+    {
+        const uint32_t i = tid + j * kTB;
+        ck[j] = i < n ? keys[b + i].lo : ~0ULL;
+        cc[j] = i < n ? vals[b + i] : 0u;
+    }
+    for (uint32_t i = tid; i < kBins; i += kTB) bins[i] = 0;
+    __syncthreads();
+    const uint32_t bsh = rem_bits > 10 ? rem_bits - 10 : 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (tid + j * kTB < n) rnk[j] = atomicAdd(&bins[(uint32_t)(ck[j] >> bsh) & (kBins - 1)], 1u);
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot;
+    uint32_t at = block_excl_scan<uint32_t>(mine, sh_scan, &tot);
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        big |= bn[q] > 24;
+    }
+    if (__syncthreads_or(big)) { if (tid == 0) atomicOr(fallback, 1u); return; }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (tid + j * kTB < n)
+        {
+            const uint32_t pos = bins[(uint32_t)(ck[j] >> bsh) & (kBins - 1)] + rnk[j];
+            tab[pos] = ck[j]; cnt[pos] = cc[j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+        for (uint32_t i = 1; i < bn[q]; ++i)
+        {
+            const unsigned long long kk = tab[bs[q] + i];
+            const uint32_t vv = cnt[bs[q] + i];
+            uint32_t j = i;
+            while (j > 0 && tab[bs[q] + j - 1] > kk)
+            {
+                tab[bs[q] + j] = tab[bs[q] + j - 1]; cnt[bs[q] + j] = cnt[bs[q] + j - 1];
+                --j;
+            }
+            tab[bs[q] + j] = kk; cnt[bs[q] + j] = vv;
+        }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kTB) { keys[b + i].lo = tab[i]; vals[b + i] = cnt[i]; }
+}
+
 // Restore segment order: out[seg_dst[s] + i] = stage[seg_pos[s] + i].
 template <class K>
 __global__ __launch_bounds__(kTB) void seg_gather_kernel(const K* __restrict__ stage_keys, const uint32_t* __restrict__ stage_counts,
