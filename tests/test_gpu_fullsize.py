@@ -102,3 +102,74 @@ def test_c4_full_size_properties():
         assert irep["select"] == 0 and irep["rank"] == 0 and irep["access"] == 0 and irep["failures"] == 0, irep
         hist = files["-counts-hist.txt"].decode().split("\n")
         assert sum(int(l.split("\t")[1]) for l in hist if l) == m
+
+
+def test_c5_full_size_properties():
+    """BASELINE config C5 at full size on one GPU: two k-mer sets of 50 M x 150 bp reads each (genomes
+    sharing half of their sequence), intersect / subtract through the library's set algebra on weighted
+    runs (what the commands and the multi-GPU path do range by range).  Size-independent properties:
+    |A n B| + |A \\ B| = |A|, |A n B| + |B \\ A| = |B|, commutativity of the intersection (same keys), the
+    three parts are disjoint and their union is the merge, and the emitted intersection passes its own
+    index check."""
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 250 * (1 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    n, L, G = 50_000_000, 150, 100_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    budget = int((free_b - buf.numel()) * 0.80)
+    sets = []
+    with g.Context(25, g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+        # two "genomes" of 200 Mbp that share one half: A = reads of sequence 1 and of sequence 3, B = reads of
+        # sequence 1 (other reads) and of sequence 2 -- the generator's sequences of different seeds are unrelated
+        half = n // 2
+        for seeds, first in (((1, 3), 0), ((1, 2), half)):
+            ctx.reset()
+            ctx.synth_reads(buf.data_ptr(), half, L, G, seed=seeds[0], first_read=first)
+            ctx.synth_reads(buf.data_ptr() + half * (L + 1), n - half, L, G, seed=seeds[1], first_read=0)
+            torch.cuda.synchronize()
+            ctx.push_device(buf.data_ptr(), buf.numel())
+            c = ctx.finish()
+            kp, cp, m = ctx.result_ptrs()
+            sets.append(gd.device_view(kp, m, torch.int64, "cuda").clone())
+            assert bool((sets[-1][1:] > sets[-1][:-1]).all().item())
+        a, b = sets
+        na, nb = int(a.numel()), int(b.numel())
+        assert 190_000_000 < na < 200_000_001 and 190_000_000 < nb < 200_000_001
+
+        def algebra(x, wx, y, wy, lo, hi):
+            ctx.reset()
+            ones = torch.full((max(x.numel(), y.numel()),), 1, dtype=torch.int32, device="cuda")
+            twos = ones * 2
+            torch.cuda.synchronize()
+            ctx.push_run(x.data_ptr(), (ones if wx == 1 else twos).data_ptr(), x.numel())
+            ctx.push_run(y.data_ptr(), (ones if wy == 1 else twos).data_ptr(), y.numel())
+            ctx.finish()
+            ctx.select_counts(lo, hi)
+            kp, cp, m = ctx.result_ptrs()
+            return gd.device_view(kp, m, torch.int64, "cuda").clone()
+
+        ab = algebra(a, 1, b, 1, 2, 2)            # intersect: count == number of sets
+        ba = algebra(b, 1, a, 1, 2, 2)
+        a_b = algebra(a, 1, b, 2, 1, 1)           # subtract: weights 1 and 2, keep count == 1
+        b_a = algebra(b, 1, a, 2, 1, 1)
+        union = algebra(a, 1, b, 1, 1, 2)
+        assert torch.equal(ab, ba)
+        assert 90_000_000 < ab.numel() < 100_000_001          # the shared sequence
+        assert ab.numel() + a_b.numel() == na and ab.numel() + b_a.numel() == nb
+        assert union.numel() == na + nb - ab.numel()
+        # the intersection is inside both sets (membership by binary search), the differences are not in the other
+        assert bool((a[torch.searchsorted(a, ab).clamp(max=na - 1)] == ab).all().item())
+        assert bool((b[torch.searchsorted(b, ab).clamp(max=nb - 1)] == ab).all().item())
+        assert not bool((b[torch.searchsorted(b, a_b).clamp(max=nb - 1)] == a_b).any().item())
+        # emit the intersection and let the device reader walk its own index
+        ctx.reset()
+        ones = torch.ones(ab.numel(), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.push_run(ab.data_ptr(), ones.data_ptr(), ab.numel())
+        ctx.finish()
+        files = ctx.emit()
+        assert struct.unpack("<QQQ", files[".header"]) == (2011101701, 25, ab.numel())
+        rep = ctx.check_index({k[len(".kmers"):]: v for k, v in files.items() if k.startswith(".kmers")})
+        assert rep["select"] == 0 and rep["rank"] == 0 and rep["access"] == 0 and rep["failures"] == 0, rep
