@@ -23,7 +23,7 @@ SYMBOLS = [
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
-    "goss_gpu_file_device",
+    "goss_gpu_file_device", "goss_gpu_big_counts",
 ]
 
 
@@ -219,6 +219,15 @@ class Context:
         else:
             ks = [int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64) for i in range(m)]
         return ks, cnts
+
+    def big_counts(self):
+        """{key: exact count} of the keys that occurred 2^32 - 1 times or more (goss_gpu_big_counts)."""
+        self._L.goss_gpu_big_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
+        n = C.c_uint32()
+        keys = (C.c_uint64 * 512)()
+        counts = (C.c_uint64 * 256)()
+        self._check(self._L.goss_gpu_big_counts(self._h, keys, counts, 256, C.byref(n)))
+        return {int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64): int(counts[i]) for i in range(min(n.value, 256))}
 
     def select_counts(self, lo, hi):
         """Between finish and emit: keep the result items whose count lies in [lo, hi]

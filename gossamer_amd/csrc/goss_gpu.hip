@@ -70,7 +70,8 @@ struct OutFile {
     std::vector<uint8_t> host;         // host-built bytes
 };
 
-struct Run { void* keys; uint32_t* counts; uint64_t m; };
+typedef std::map<std::pair<uint64_t, uint64_t>, uint64_t> BigMap;     // key (hi, lo) -> count that does not fit 32 bits
+struct Run { void* keys; uint32_t* counts; uint64_t m; int big = -1; };      // big: index into ctx.big_maps, or -1
 
 struct PhaseEvents { hipEvent_t a, b; int phase; uint64_t units; };
 
@@ -133,6 +134,8 @@ struct goss_gpu_ctx {
     std::string last_error;
     Arena arena;
     std::vector<Run> runs;
+    std::vector<BigMap> big_maps;       // per run that has them: the counts >= 2^32 - 1 (graph mode; marker 0xFFFFFFFF in the run)
+    BigMap res_big;                     // ... of the result (its u32 counts hold the value modulo 2^32, as the reference stores it)
     uint64_t windows = 0, keys_total = 0;
     bool finished = false, emitted = false;
     void* res_keys = nullptr;
@@ -416,12 +419,75 @@ bool radix_sort(goss_gpu_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, uint6
     return in_b;
 }
 
+// ---- counts beyond 32 bits (graph mode) ----------------------------------------------------
+// After a step that summed counts into `out` (run lengths, run sums, segment merge) and raised the
+// overflow flag: the entries of `out` that carry the marker get their exact u64 count from the inputs
+// the step read (`keys`/`vals` in `nruns` sorted pieces; vals == nullptr: raw keys, each worth 1) plus
+// what the input runs' own big maps hold for the key.  A k-mer set stores no counts: nothing to do.
+constexpr uint32_t kMaxBig = 256;
+template <class K>
+void resolve_big_counts(goss_gpu_ctx* c, Run& out, const K* keys, const uint32_t* vals, const std::vector<uint64_t>& run_off,
+                        const std::vector<int>& in_bigs)
+{
+    if (c->mode != GOSS_MODE_GRAPH || out.m == 0) return;
+    uint32_t* hf = (uint32_t*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hf, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!hf[0]) return;
+    uint64_t mark = c->arena.mark();
+    unsigned long long* found = (unsigned long long*)c->arena.temp((kMaxBig + 1) * 8);
+    HIP_TRY(hipMemsetAsync(found, 0, 8, c->stream));
+    hipLaunchKernelGGL(find_saturated_kernel, dim3(grid_for(out.m, 256)), dim3(256), 0, c->stream, (const uint32_t*)out.counts, out.m, found, kMaxBig);
+    std::vector<unsigned long long> hfound(kMaxBig + 1);
+    HIP_TRY(hipMemcpyAsync(hfound.data(), found, (kMaxBig + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t nq = (uint32_t)hfound[0];
+    if (nq > kMaxBig) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "more than 256 keys occurred 2^32 times or more"};
+    const uint32_t nruns = (uint32_t)run_off.size() - 1;
+    if (nruns > 1024) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "a key occurred 2^32 times or more in a merge of more than 1024 runs"};
+    if (nq)
+    {
+        K* dq = (K*)c->arena.temp(nq * sizeof(K));
+        uint64_t* doff = (uint64_t*)c->arena.temp((nruns + 1) * 8);
+        unsigned long long* dsum = (unsigned long long*)c->arena.temp(2 * nq * 8);
+        for (uint32_t q = 0; q < nq; ++q)
+            HIP_TRY(hipMemcpyAsync(dq + q, (const K*)out.keys + hfound[1 + q], sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(doff, run_off.data(), (nruns + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(dsum, 0, 2 * nq * 8, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum_equal_kernel<K>), dim3(nq), dim3(std::max<uint32_t>(64, (nruns + 63) / 64 * 64)), 0, c->stream,
+                           keys, vals, (const uint64_t*)doff, nruns, (const K*)dq, nq, dsum, dsum + nq);
+        std::vector<K> hq(nq);
+        std::vector<unsigned long long> hs(2 * nq);
+        HIP_TRY(hipMemcpyAsync(hq.data(), dq, nq * sizeof(K), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hs.data(), dsum, 2 * nq * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        BigMap bm;
+        for (uint32_t q = 0; q < nq; ++q)
+        {
+            const std::pair<uint64_t, uint64_t> kk(key_hi_word(hq[q]), key_lo_word(hq[q]));
+            uint64_t exact = hs[q], markers = 0;
+            for (int b : in_bigs)
+                if (b >= 0)
+                {
+                    auto it = c->big_maps[b].find(kk);
+                    if (it != c->big_maps[b].end()) { exact += it->second; ++markers; }
+                }
+            if (markers != hs[nq + q]) throw StatusError{GOSS_ERR_HIP, "count bookkeeping: a saturated entry without its exact count"};
+            bm[kk] = exact;
+        }
+        c->big_maps.push_back(std::move(bm));
+        out.big = (int)c->big_maps.size() - 1;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, 4, c->stream));
+    c->arena.release(mark);
+}
+
 // ---- run compaction ---------------------------------------------------------------------
 // keys sorted (n).  Produces a permanent Run (distinct keys + u32 counts).  If vals != null
 // the counts are sums of vals over each run, else run lengths.  `scratch_keys` is a buffer
 // of >= n keys that may be clobbered (the free half of the sort ping-pong).
 template <class K>
-Run reduce_runs(goss_gpu_ctx* c, const K* keys, const uint32_t* vals, uint64_t n, K* scratch_keys)
+Run reduce_runs(goss_gpu_ctx* c, const K* keys, const uint32_t* vals, uint64_t n, K* scratch_keys, const std::vector<int>* in_bigs = nullptr)
 {
     Run r{nullptr, nullptr, 0};
     if (n == 0) return r;
@@ -452,6 +518,7 @@ Run reduce_runs(goss_gpu_ctx* c, const K* keys, const uint32_t* vals, uint64_t n
         hipLaunchKernelGGL(run_lengths_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream,
                            (const uint64_t*)starts, m, n, r.counts, c->d_flags);
     HIP_TRY(hipStreamSynchronize(c->stream));   // temporaries are released below
+    resolve_big_counts<K>(c, r, keys, vals, std::vector<uint64_t>{0, n}, in_bigs ? *in_bigs : std::vector<int>());
     c->arena.release(mark);
     return r;
 }
@@ -1437,6 +1504,8 @@ void merge_runs(goss_gpu_ctx* c)
         run_off.push_back(o);
     }
     const uint32_t nruns = (uint32_t)c->runs.size();
+    std::vector<int> in_bigs;                       // the inputs' counts beyond 32 bits (graph mode)
+    for (auto& r : c->runs) in_bigs.push_back(r.big);
     // the old runs' permanent storage is dead now: rewind the permanent end to the first run
     c->arena.lo = (uint64_t)((uint8_t*)c->runs.front().keys - c->arena.base);
     c->runs.clear();
@@ -1493,6 +1562,7 @@ void merge_runs(goss_gpu_ctx* c)
                                (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)r.keys, r.counts);
             t.stop();
             HIP_TRY(hipStreamSynchronize(c->stream));
+            resolve_big_counts<K>(c, r, ka, va, run_off, in_bigs);
             c->runs.push_back(r);
             c->seg_merges++;
             c->arena.release(mark);
@@ -1501,7 +1571,7 @@ void merge_runs(goss_gpu_ctx* c)
     }
     bool in_b = radix_sort<K, true>(c, ka, kb, va, vb, total, key_digits(c));
     PhaseTimer t(c, GOSS_T_REDUCE, total);
-    Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb);
+    Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb, &in_bigs);
     t.stop();
     c->runs.push_back(r);
     c->arena.release(mark);
@@ -1913,11 +1983,21 @@ void emit_counts(goss_gpu_ctx* c, const uint32_t* counts, uint64_t m, uint64_t n
         HIP_TRY(hipMemcpyAsync(hv.data(), distinct, nd * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(hs.data(), starts, nd * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::map<uint64_t, uint64_t> hist;
+        for (uint64_t i = 0; i < nd; ++i) hist[hv[i]] = (i + 1 < nd ? hs[i + 1] : m) - hs[i];
+        // the result's counts beyond 32 bits sit in the array modulo 2^32; the histogram is keyed by the count
+        // itself (Graph.hh:101-106: mHist[count]++ on the u64 before it is narrowed)
+        if (counts == c->res_counts)
+            for (auto& kv : c->res_big)
+            {
+                auto it = hist.find(kv.second & 0xFFFFFFFFULL);
+                if (it != hist.end() && --it->second == 0) hist.erase(it);
+                hist[kv.second] += 1;
+            }
         char line[64];
-        for (uint64_t i = 0; i < nd; ++i)
+        for (auto& kv : hist)
         {
-            uint64_t e = i + 1 < nd ? hs[i + 1] : m;
-            int l = snprintf(line, sizeof line, "%llu\t%llu\n", (unsigned long long)hv[i], (unsigned long long)(e - hs[i]));
+            int l = snprintf(line, sizeof line, "%llu\t%llu\n", (unsigned long long)kv.first, (unsigned long long)kv.second);
             text.append(line, (size_t)l);
         }
     }
@@ -2039,7 +2119,15 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
             HIP_TRY(hipMemcpyAsync(hv.data(), distinct, nv * 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(hs.data(), starts, nv * 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            for (uint64_t i = 0; i < nv; ++i) { hist.push_back(hv[i]); hist.push_back((i + 1 < nv ? hs[i + 1] : m) - hs[i]); }
+            std::map<uint64_t, uint64_t> hm;
+            for (uint64_t i = 0; i < nv; ++i) hm[hv[i]] = (i + 1 < nv ? hs[i + 1] : m) - hs[i];
+            for (auto& kv : c->res_big)              // counts beyond 32 bits: keyed by the count itself (see emit_counts)
+            {
+                auto it = hm.find(kv.second & 0xFFFFFFFFULL);
+                if (it != hm.end() && --it->second == 0) hm.erase(it);
+                hm[kv.second] += 1;
+            }
+            for (auto& kv : hm) { hist.push_back(kv.first); hist.push_back(kv.second); }
         }
         { OutFile f; f.suffix = "-counts.ord0"; f.size = m; f.dev = ord0; c->files.push_back(std::move(f)); }
         { OutFile f; f.suffix = ".part.big"; f.size = nbig * sizeof(BigCount); f.dev = (const uint8_t*)big; if (!big) f.host.clear(); c->files.push_back(std::move(f)); }
@@ -2344,9 +2432,45 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
         uint32_t* hf = (uint32_t*)c->h_pinned;
         HIP_TRY(hipMemcpyAsync(hf, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        // counts saturate at 2^32-1.  A k-mer set does not store counts, so only a graph cares
-        // (the reference would write the count modulo 2^32 there: VariableByteArray.hh:93-118)
-        if (hf[0] && c->mode == GOSS_MODE_GRAPH) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "a key occurred 2^32 times or more"};
+        // u32 counts saturate at 2^32-1.  A k-mer set does not store counts.  A graph keeps the exact u64 counts
+        // of such keys beside the run (resolve_big_counts); its u32 count becomes the value modulo 2^32, which is
+        // what the reference stores (Graph::Builder::push_back hands a u64 to VariableByteArray's u32 value_type,
+        // Graph.hh:101-106, VariableByteArray.hh:72,81), and its histogram is keyed by the exact count.
+        c->res_big.clear();
+        if (c->mode == GOSS_MODE_GRAPH)
+        {
+            if (hf[0]) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "a key occurred 2^32 times or more (unresolved)"};
+            if (!c->runs.empty() && c->runs[0].big >= 0 && !c->big_maps[c->runs[0].big].empty())
+            {
+                c->res_big = c->big_maps[c->runs[0].big];
+                uint64_t mark = c->arena.mark();
+                unsigned long long* found = (unsigned long long*)c->arena.temp((kMaxBig + 1) * 8);
+                HIP_TRY(hipMemsetAsync(found, 0, 8, c->stream));
+                hipLaunchKernelGGL(find_saturated_kernel, dim3(grid_for(c->M, 256)), dim3(256), 0, c->stream, (const uint32_t*)c->res_counts, c->M, found, kMaxBig);
+                std::vector<unsigned long long> hfound(kMaxBig + 1);
+                HIP_TRY(hipMemcpyAsync(hfound.data(), found, (kMaxBig + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                const uint32_t nq = (uint32_t)std::min<unsigned long long>(hfound[0], kMaxBig);
+                std::vector<uint32_t> vals(nq);
+                for (uint32_t q = 0; q < nq; ++q)
+                {
+                    uint64_t kw[2] = {0, 0};
+                    HIP_TRY(hipMemcpy(kw, (const uint8_t*)c->res_keys + hfound[1 + q] * c->words * 8, c->words * 8, hipMemcpyDeviceToHost));
+                    auto it = c->res_big.find(std::make_pair(c->words == 2 ? kw[1] : 0ULL, kw[0]));
+                    if (it == c->res_big.end()) throw StatusError{GOSS_ERR_HIP, "count bookkeeping: a saturated result entry without its exact count"};
+                    vals[q] = (uint32_t)(it->second & 0xFFFFFFFFULL);
+                }
+                if (nq)
+                {
+                    uint32_t* dv = (uint32_t*)c->arena.temp(nq * 4);
+                    HIP_TRY(hipMemcpyAsync(dv, vals.data(), nq * 4, hipMemcpyHostToDevice, c->stream));
+                    hipLaunchKernelGGL(patch_counts_kernel, dim3(grid_for(nq, 64)), dim3(64), 0, c->stream, c->res_counts,
+                                       (const unsigned long long*)(found + 1), (const uint32_t*)dv, nq);
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
+                c->arena.release(mark);
+            }
+        }
         c->finished = true;
     });
     if (rc == GOSS_OK && out)
@@ -2396,6 +2520,22 @@ int goss_gpu_emit(goss_gpu_ctx* c)
     });
     if (rc == GOSS_OK) c->emitted = true;
     return rc;
+}
+
+int goss_gpu_big_counts(goss_gpu_ctx* c, uint64_t* keys, uint64_t* counts, uint32_t cap, uint32_t* n)
+{
+    if (!c || !n) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished) { c->last_error = "big_counts before finish"; return GOSS_ERR_STATE; }
+    *n = (uint32_t)c->res_big.size();
+    uint32_t i = 0;
+    for (auto& kv : c->res_big)
+    {
+        if (i >= cap) break;
+        if (keys) { keys[2 * i] = kv.first.second; keys[2 * i + 1] = kv.first.first; }
+        if (counts) counts[i] = kv.second;
+        ++i;
+    }
+    return GOSS_OK;
 }
 
 int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
@@ -2542,6 +2682,8 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         if (c->arena_thread.joinable()) ensure_arena(c);      // a background mapping (goss_gpu_prepare) ends first
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->runs.clear();
+        c->big_maps.clear();
+        c->res_big.clear();
         c->files.clear();
         c->windows = c->keys_total = 0;
         c->finished = c->emitted = false;

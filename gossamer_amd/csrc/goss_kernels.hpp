@@ -1818,7 +1818,7 @@ __global__ void run_lengths_kernel(const uint64_t* __restrict__ starts, uint64_t
     if (j >= m) return;
     uint64_t e = j + 1 < m ? starts[j + 1] : n;
     uint64_t c = e - starts[j];
-    if (c > 0xFFFFFFFFULL) { atomicOr(overflow, 1u); c = 0xFFFFFFFFULL; }
+    if (c >= 0xFFFFFFFFULL) { atomicOr(overflow, 1u); c = 0xFFFFFFFFULL; }       // 0xFFFFFFFF is the marker of a count kept elsewhere
     counts[j] = (uint32_t)c;
 }
 
@@ -1833,8 +1833,53 @@ __global__ void run_sums_kernel(const uint64_t* __restrict__ starts, uint64_t m,
     uint64_t e = j + 1 < m ? starts[j + 1] : n;
     uint64_t s = 0;
     for (uint64_t i = starts[j]; i < e; ++i) s += vals[i];
-    if (s > 0xFFFFFFFFULL) { atomicOr(overflow, 1u); s = 0xFFFFFFFFULL; }
+    if (s >= 0xFFFFFFFFULL) { atomicOr(overflow, 1u); s = 0xFFFFFFFFULL; }       // (also a single marker entry: its exact count moves on)
     counts[j] = (uint32_t)s;
+}
+
+// Counts that do not fit 32 bits (graph mode keeps them: the reference's histogram key is the u64 count,
+// Graph.hh:101-106).  A saturated count is the marker 0xFFFFFFFF; the host resolves the few keys that
+// carry it with these two kernels: where they are, and what their entries in the merged inputs add up to.
+__global__ void find_saturated_kernel(const uint32_t* __restrict__ counts, uint64_t m, unsigned long long* __restrict__ out, uint32_t cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || counts[i] != 0xFFFFFFFFu) return;
+    const unsigned long long at = atomicAdd(&out[0], 1ULL);
+    if (at < cap) out[1 + at] = i;
+}
+// For query q: over every input run r (entries [run_off[r], run_off[r+1]) sorted by key, equal keys
+// adjacent) the sum of the values of the entries equal to it -- their number when vals is NULL (raw
+// keys) -- leaving out marker values, which are counted in markers[q] instead.
+template <class K>
+__global__ void sum_equal_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ vals, const uint64_t* __restrict__ run_off,
+                                 uint32_t nruns, const K* __restrict__ queries, uint32_t nq,
+                                 unsigned long long* __restrict__ sums, unsigned long long* __restrict__ markers)
+{
+    const uint32_t q = blockIdx.x, r = threadIdx.x;
+    if (q >= nq || r >= nruns) return;
+    const K key = queries[q];
+    uint64_t a = run_off[r], b = run_off[r + 1];
+    const uint64_t end = b;
+    while (a < b) { const uint64_t mid = a + ((b - a) >> 1); if (keys[mid] < key) a = mid + 1; else b = mid; }
+    unsigned long long s = 0, mk = 0;
+    uint64_t hi = a, top = end;
+    // upper bound
+    while (hi < top) { const uint64_t mid = hi + ((top - hi) >> 1); if (key < keys[mid]) top = mid; else hi = mid + 1; }
+    if (!vals) s = hi - a;
+    else
+        for (uint64_t i = a; i < hi; ++i)
+        {
+            const uint32_t v = vals[i];
+            if (v == 0xFFFFFFFFu) ++mk; else s += v;
+        }
+    if (s) atomicAdd(&sums[q], s);
+    if (mk) atomicAdd(&markers[q], mk);
+}
+__global__ void patch_counts_kernel(uint32_t* __restrict__ counts, const unsigned long long* __restrict__ idx,
+                                    const uint32_t* __restrict__ values, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[idx[i]] = values[i];
 }
 
 // graph-to-kmer-set (GossCmdGraphToKmerSet.cc:40-55): an edge stays when it is its own canonical
@@ -3182,7 +3227,7 @@ __global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ ke
         {
             uint64_t sum = 0;
             for (uint32_t j = i; j < n && lk[j] == lk[i]; ++j) sum += lc[j];
-            if (sum > 0xFFFFFFFFULL) { atomicOr(count_overflow, 1u); sum = 0xFFFFFFFFULL; }
+            if (sum >= 0xFFFFFFFFULL) { atomicOr(count_overflow, 1u); sum = 0xFFFFFFFFULL; }
             stage_keys[ob + done + before] = lk[i];
             stage_counts[ob + done + before] = (uint32_t)sum;
         }

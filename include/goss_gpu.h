@@ -31,7 +31,8 @@ typedef enum {
     GOSS_ERR_HIP          = -4,   /* a HIP call failed; see goss_gpu_last_error */
     GOSS_ERR_STATE        = -5,   /* call out of order (e.g. push after finish) */
     GOSS_ERR_K_RANGE      = -6,   /* "unable to build a graph with k=<K>" (KmerSet.hh:89-95, Graph.cc:152-158) */
-    GOSS_ERR_COUNT_OVERFLOW = -7, /* a key occurred >= 2^32 times */
+    GOSS_ERR_COUNT_OVERFLOW = -7, /* graph mode: more than 256 keys occurred >= 2^32 - 1 times each (up to that many are
+                                     kept exactly, goss_gpu_big_counts) */
     GOSS_ERR_TOO_LARGE    = -8    /* high-bits value does not fit 64 bits (SparseArray.hh:91-95) */
 } goss_status;
 
@@ -113,6 +114,16 @@ int goss_gpu_finish(goss_gpu_ctx* ctx, goss_gpu_counts* out);
  * recycles the memory).  Either pointer may be NULL. */
 int goss_gpu_result(goss_gpu_ctx* ctx, const void** d_keys, const uint32_t** d_counts,
                     uint64_t* distinct);
+
+/*
+ * Graph mode: the keys whose count does not fit the u32 array (2^32 - 1 occurrences or more), with their
+ * exact counts.  In the result (and in the emitted VariableByteArray) such a key carries its count modulo
+ * 2^32 -- what the reference stores when Graph::Builder::push_back narrows its u64 count
+ * (Graph.hh:101-106, VariableByteArray.hh:72,81) -- while "-counts-hist.txt" is keyed by the exact count,
+ * as the reference's histogram is.  keys: 2 u64 (lo, hi) per entry; at most `cap` entries are written,
+ * *n = how many there are.  Always 0 for a k-mer set (no counts are stored).
+ */
+int goss_gpu_big_counts(goss_gpu_ctx* ctx, uint64_t* keys, uint64_t* counts, uint32_t cap, uint32_t* n);
 
 /* Copy a slice [first, first+n) of the result to host memory (keys: n*key_words u64). */
 int goss_gpu_result_copy(goss_gpu_ctx* ctx, uint64_t first, uint64_t n,

@@ -459,6 +459,28 @@ def test_extreme_skew_one_kmer_five_billion_times():
         keys, counts = ctx.result()
         assert c.distinct == 2 and keys == [0, 4 ** 28 - 1]
         assert counts[0] == counts[1] == m + 1 - 27
+        assert ctx.big_counts() == {}
+    # the whole string as a graph: both edges occur n - 27 = 4 599 999 973 times, more than a u32 holds.  The
+    # reference keeps the u64 count as the histogram key and stores it narrowed to 32 bits in the
+    # VariableByteArray (Graph.hh:101-106, VariableByteArray.hh:72,81); first-principles expectation, both
+    # with the string counted in chunks (the counts meet 2^32 in a merge) and in as few as fit
+    for budget in (48 << 30, 200 << 30):
+        with g.Context(27, g.MODE_GRAPH, hbm_budget=budget) as ctx:
+            ctx.push_device(buf.data_ptr(), buf.numel())
+            c = ctx.finish()
+            want = n - 27
+            assert c.windows == want and c.distinct == 2 and c.keys == 2 * want
+            keys, counts = ctx.result()
+            assert keys == [0, 4 ** 28 - 1]
+            assert [int(x) for x in counts] == [want & 0xFFFFFFFF] * 2
+            assert ctx.big_counts() == {0: want, 4 ** 28 - 1: want}
+            files = ctx.emit()
+            assert files["-counts-hist.txt"] == b"%d\t2\n" % want
+            # the VariableByteArray holds the narrowed value: ord0 = low byte, ord1 = next byte, ord2 = the high half
+            v = want & 0xFFFFFFFF
+            assert files["-counts.ord0"] == bytes([v & 0xFF] * 2)
+            assert files["-counts.ord1"] == bytes([(v >> 8) & 0xFF] * 2)
+            assert files["-counts.ord2"] == struct.pack("<HH", v >> 16, v >> 16)
 
 
 @pytest.mark.parametrize("k,mode,form", [(13, "kmer", "msd"), (16, "kmer", "lsd"), (25, "kmer", "msd"), (31, "kmer", "lsd"),
