@@ -420,6 +420,37 @@ def test_one_segment_with_more_keys_than_any_table(oracle):
         _same(got, _suffix_map(exp, "gr"))
 
 
+def test_segments_of_24_bits_succeed_after_16_and_20_overflow(oracle):
+    """One-word keys that need the third width of the segment stage and get through it: build-graph
+    k = 27 on 28-base reads (one edge each) that share their first 10 bases (20 key bits), take all
+    16 values of the next two bases and 3 000 distinct tails under each -- 48 000 distinct forward
+    edges in one 16-bit and one 20-bit segment (the 4096-slot table holds 3 072), 3 000 in each of
+    16 segments of 24 bits.  Exactly two retries, the result from the counting kernel (no full sort),
+    files equal to the oracle's."""
+    import random
+    rng = random.Random(77)
+    prefix = "GATTACAGAT"
+    reads = []
+    for a in "ACGT":
+        for b in "ACGT":
+            tails = set()
+            while len(tails) < 3000:
+                tails.add("".join(rng.choice("ACGT") for _ in range(16)))
+            for t in tails:
+                reads += [prefix + a + b + t] * 4
+    rng.shuffle(reads)
+    txt = "\n".join(reads) + "\n"
+    exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], 27, out="gr")
+    assert nwin == len(reads) == 192000
+    with g.Context(27, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
+        ctx.push_host(txt.encode())
+        c = ctx.finish()
+        assert c.windows == nwin and c.distinct == 2 * 48000
+        assert ctx.stat("segment_retries") == 2, ctx.stat("segment_retries")
+        got = ctx.emit()
+    _same(got, _suffix_map(exp, "gr"))
+
+
 def test_fused_path_declines_unique_input(oracle):
     """No duplication (every k-mer once): the sample says so and the plain sequence runs."""
     import numpy as np
