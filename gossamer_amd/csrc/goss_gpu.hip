@@ -113,6 +113,8 @@ struct goss_gpu_ctx {
     uint32_t fused_grid = 0;            // GOSS_GPU_FUSED_GRID: workgroups of the fused extraction kernel (0 = 1024)
     bool seg_merge = true;              // GOSS_GPU_NO_SEG_MERGE=1: merge runs by sorting their concatenation
     uint32_t seg_merges = 0;            // merges done by segments
+    uint32_t hash_merges = 0;           // ... of them through the counting table (seg_hash_merge96_kernel)
+    uint64_t hash_merge_min = 1u << 20; // GOSS_GPU_HASH_MERGE_MIN=<entries>: smallest merge that goes that way (65 536 workgroups)
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
@@ -1510,6 +1512,61 @@ void merge_runs(goss_gpu_ctx* c)
     c->arena.lo = (uint64_t)((uint8_t*)c->runs.front().keys - c->arena.base);
     c->runs.clear();
 
+    // Two-word keys with at most 96 bits below a 16-bit prefix: the runs' entries are counted into the LDS table
+    // of the counting kernel, segment by segment (seg_hash_merge96_kernel).  The runs of a high-coverage build all
+    // hold the same keys, so 65 536 tables of 8192 slots take them; a segment with more than 6144 distinct keys, or
+    // a count that reaches 2^31, sends the merge down the general path below.
+    if constexpr (std::is_same<K, Key2>::value)
+    {
+        const uint32_t keybits = 2 * c->len;
+        if (c->seg_merge && c->table96 && keybits >= 16 + 8 && keybits - 16 <= 96 && nruns <= (uint32_t)kMergeRuns && total >= c->hash_merge_min)
+        {
+            const uint32_t nseg = 65536, shift = keybits - 16;
+            uint64_t m2 = c->arena.mark();
+            uint64_t* bounds = (uint64_t*)c->arena.temp((uint64_t)nruns * (nseg + 1) * 8);
+            uint64_t* d_off = (uint64_t*)c->arena.temp((nruns + 1) * 8);
+            uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
+            uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+            uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+            SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
+            SegOut hso{};
+            hso.stage_cap = total;
+            HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_off, run_off.data(), (nruns + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            PhaseTimer t(c, GOSS_T_REDUCE, total);
+            for (uint32_t r = 0; r < nruns; ++r)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
+                                   (const K*)(ka + run_off[r]), run_off[r + 1] - run_off[r], shift, nseg,
+                                   bounds + (uint64_t)r * (nseg + 1));
+            hipLaunchKernelGGL(seg_hash_merge96_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, (const Key2*)ka, (const uint32_t*)va,
+                               (const uint64_t*)d_off, (const uint64_t*)bounds, nruns, so, seg_pos, seg_cnt, (Key2*)kb, vb, shift);
+            SegOut* h = (SegOut*)c->h_pinned;
+            HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!h->overflow)
+            {
+                const uint64_t m = h->cursor;
+                HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nseg * 8, hipMemcpyDeviceToDevice, c->stream));
+                exclusive_scan_u64(c, seg_dst, nseg);
+                Run r{nullptr, nullptr, m};
+                r.keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(K));
+                r.counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<K>), unit_grid(nseg), dim3(kTB), 0, c->stream,
+                                   (const K*)kb, (const uint32_t*)vb, (const uint64_t*)seg_pos,
+                                   (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)r.keys, r.counts);
+                t.stop();
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->runs.push_back(r);
+                c->seg_merges++;
+                c->hash_merges++;
+                c->arena.release(mark);
+                return;
+            }
+            t.stop();
+            c->arena.release(m2);
+        }
+    }
+
     // Merge by segments (seg_merge_kernel): every entry read once, written once.  Needs every
     // segment's entries of all runs to fit kMergeCap; else the concatenation is sorted again.
     if (c->seg_merge && nruns <= (uint32_t)kMergeRuns && total >= 1024)
@@ -2301,6 +2358,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
+    { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_TABLE96"); if (e && *e && *e != '0') c->table96 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_WIDE_TABLE"); if (e && *e && *e != '0') c->wide_table = false; }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }
@@ -2929,6 +2987,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "valid_sized_chunks") *value = c->valid_sized_chunks;
     else if (n == "valid_resizes") *value = c->valid_resizes;
     else if (n == "seg_merges") *value = c->seg_merges;
+    else if (n == "hash_merges") *value = c->hash_merges;
     else if (n == "segment_retries") *value = c->segment_retries;
     else if (n == "lookback_failures") *value = c->lookback_failures;
     else if (n == "runs") *value = c->runs.size();

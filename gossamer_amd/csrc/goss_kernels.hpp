@@ -2783,12 +2783,19 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
 struct __attribute__((aligned(16))) Slot96 { uint32_t r0, r1, r2, w; };
 __device__ __forceinline__ uint4 tbl4(const Slot96* t, uint32_t i) { return reinterpret_cast<const uint4*>(t)[i]; }
 
-template <int NT, int SLOTS>
+// MERGE: the input is not one slice of raw keys but the segment's slice of each of `nruns` sorted (key,count)
+// runs (run r = entries [run_off[r], run_off[r+1]) of keys / vals, its segment bounds in bounds[r * 65537 ..]):
+// every entry adds its count.  That is the k-way merge of the chunk runs of a large build -- the runs of a
+// high-coverage input all hold the same keys, so the table stays small -- done as hash inserts instead of
+// ordering networks and binary searches.  A count that would reach 2^31 (the lock bit of the slot word)
+// makes the kernel give up; the host then merges the general way.
+template <int NT, int SLOTS, bool MERGE = false>
 __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                        const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                        uint64_t* __restrict__ seg_cnt,
                                                        Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                       uint32_t rem_bits)
+                                                       uint32_t rem_bits, const uint32_t* __restrict__ vals = nullptr,
+                                                       const uint64_t* __restrict__ run_off = nullptr, uint32_t nruns = 1)
 {
     constexpr int kLimit = SLOTS / 4 * 3;
     constexpr int kSlotBits = SLOTS == 4096 ? 12 : SLOTS == 8192 ? 13 : -1;
@@ -2798,16 +2805,19 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
     __shared__ uint32_t ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = unit_block(), tid = threadIdx.x;
-    const uint64_t b = seg_off[s], e = seg_end[s];
-    if (b == e)
+    if (!MERGE)
     {
-        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
-        return;
-    }
-    if (e - b > 0xFFFFFFFFULL)
-    {
-        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
-        return;
+        const uint64_t b = seg_off[s], e = seg_end[s];
+        if (b == e)
+        {
+            if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+            return;
+        }
+        if (e - b > 0xFFFFFFFFULL)
+        {
+            if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+            return;
+        }
     }
     uint32_t* tw = reinterpret_cast<uint32_t*>(tbl);
     for (uint32_t i = tid; i < SLOTS; i += NT) tw[4 * i + 3] = 0;
@@ -2821,7 +2831,14 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
     lds_vu32 vovf = (lds_vu32)&ovf;
     lds_vu32 vt = (lds_vu32)tw;
     constexpr int kU = 8;
+    for (uint32_t run = 0; run < (MERGE ? nruns : 1u); ++run)
+    {
+    // this run's slice of the segment (MERGE), or the segment itself
+    const uint64_t b = MERGE ? run_off[run] + seg_off[(uint64_t)run * 65537u + s] : seg_off[s];
+    const uint64_t e = MERGE ? run_off[run] + seg_off[(uint64_t)run * 65537u + s + 1] : seg_end[s];
+    if (b >= e) continue;
     Key2 nxt[kU];
+    uint32_t nwt[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u)
     {
@@ -2829,10 +2846,11 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
         const uint64_t i = b + (uint64_t)u * NT + tid;
         nxt[u] = keys[i < e ? i : e - 1];
         nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
+        nwt[u] = MERGE ? vals[i < e ? i : e - 1] : 1u;
     }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kU)
     {
-        uint32_t r0[kU], r1[kU], r2[kU], slots[kU];
+        uint32_t r0[kU], r1[kU], r2[kU], slots[kU], wt[kU];
         uint32_t pend = 0, live = 0;
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -2841,6 +2859,9 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
             if (kv.hi != ~0ULL) live |= 1u << u;
             const uint64_t lo = kv.lo & lmask64;
             r0[u] = (uint32_t)lo; r1[u] = (uint32_t)(lo >> 32); r2[u] = (uint32_t)kv.hi & hmask;
+            wt[u] = nwt[u];
+            // a weight that alone reaches the lock bit (or is the marker of a count kept elsewhere): not here
+            if (MERGE && (live >> u & 1u) && wt[u] >= kSegLock) *vovf = 1;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -2848,6 +2869,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
             const uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
             nxt[u] = keys[i < e ? i : e - 1];
             nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
+            nwt[u] = MERGE ? vals[i < e ? i : e - 1] : 1u;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -2888,12 +2910,16 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
                     }
                     const uint32_t is_live = (live >> u) & 1u;
                     const uint32_t hit = (off < 4u ? 1u : 0u) & is_live;
-                    if (hit) atomicAdd(&tw[4 * ((slots[u] + off) & (SLOTS - 1)) + 3], 1u);
+                    if (hit)
+                    {
+                        const uint32_t old = atomicAdd(&tw[4 * ((slots[u] + off) & (SLOTS - 1)) + 3], wt[u]);
+                        if (MERGE && old + wt[u] >= kSegLock) *vovf = 1;
+                    }
                     pend |= (is_live & (hit ^ 1u)) << u;
                 }
             }
         }
-        uint32_t k0 = 0, k1 = 0, k2 = 0, slot = 0;
+        uint32_t k0 = 0, k1 = 0, k2 = 0, slot = 0, kw = 1;
         bool have = false;
         for (;;)
         {
@@ -2903,7 +2929,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
                 pend &= pend - 1;
 #pragma unroll
                 for (int uu = 0; uu < kU; ++uu)
-                    if (u == (uint32_t)uu) { k0 = r0[uu]; k1 = r1[uu]; k2 = r2[uu]; slot = slots[uu]; }
+                    if (u == (uint32_t)uu) { k0 = r0[uu]; k1 = r1[uu]; k2 = r2[uu]; slot = slots[uu]; kw = wt[uu]; }
                 have = true;
             }
             if (!__ballot(have)) break;
@@ -2916,7 +2942,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
                     if (old == 0)
                     {
                         vt[4 * slot] = k0; vt[4 * slot + 1] = k1; vt[4 * slot + 2] = k2;
-                        vt[4 * slot + 3] = 1u;               // publish (LDS ops of a lane are in order)
+                        vt[4 * slot + 3] = kw;               // publish (LDS ops of a lane are in order)
                         const uint32_t nd = atomicAdd(&ndist, 1u);
                         if (nd + 1 > kLimit) *vovf = 1;
                         have = false;
@@ -2924,7 +2950,12 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
                 }
                 else if (state != kSegLock)
                 {
-                    if (vt[4 * slot] == k0 && vt[4 * slot + 1] == k1 && vt[4 * slot + 2] == k2) { atomicAdd(&tw[4 * slot + 3], 1u); have = false; }
+                    if (vt[4 * slot] == k0 && vt[4 * slot + 1] == k1 && vt[4 * slot + 2] == k2)
+                    {
+                        const uint32_t old = atomicAdd(&tw[4 * slot + 3], kw);
+                        if (MERGE && old + kw >= kSegLock) *vovf = 1;
+                        have = false;
+                    }
                     else slot = (slot + 1) & (SLOTS - 1);
                 }
             }
@@ -2932,6 +2963,8 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
         }
         if (*vovf) break;
     }
+    if (*vovf) break;
+    }   // runs
     __syncthreads();
     if (ovf)
     {
@@ -3054,6 +3087,17 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce96_kernel(const
                                                                            uint32_t rem_bits)
 {
     seg_hash_reduce96_body<kSegBigThreads, kSeg96Slots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+}
+// merge of sorted (key,count) runs by 16-bit segments through the same table (bounds: [nruns][65537] from seg_bounds_kernel)
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_merge96_kernel(const Key2* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                          const uint64_t* __restrict__ run_off, const uint64_t* __restrict__ bounds,
+                                                                          uint32_t nruns, SegOut* __restrict__ so,
+                                                                          uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                          Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                          uint32_t rem_bits)
+{
+    seg_hash_reduce96_body<kSegBigThreads, kSeg96Slots, true>(keys, bounds, nullptr, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits,
+                                                              vals, run_off, nruns);
 }
 
 __global__ __launch_bounds__(kTB) void seg_hash_reduce2_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,

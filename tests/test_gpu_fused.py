@@ -420,6 +420,46 @@ def test_one_segment_with_more_keys_than_any_table(oracle):
         _same(got, _suffix_map(exp, "gr"))
 
 
+def test_runs_of_two_word_keys_merged_through_the_counting_table(oracle):
+    """build-graph k = 55 in five pushes (five runs of mostly the same 112-bit edges): the runs are merged by
+    hash inserts into the 96-bit-remainder table, segment by segment (seg_hash_merge96_kernel) -- files equal
+    to the oracle's; the same with the general merge (GOSS_GPU_NO_TABLE96), and k = 62 (126-bit keys: too wide
+    for the remainder table, general merge)."""
+    reads = g.synth_reads_host(6000, 150, 60000, seed=44)
+    lines = reads.split(b"\n")[:-1]
+    pieces = [b"".join(l + b"\n" for l in lines[i::5]) for i in range(5)]
+    for k, env, want in ((55, {"GOSS_GPU_HASH_MERGE_MIN": "1"}, 1), (55, {"GOSS_GPU_NO_TABLE96": "1"}, 0), (62, {"GOSS_GPU_HASH_MERGE_MIN": "1"}, 0)):
+        exp, nwin = oracle.build_graph([(oracle.LINE, "reads", reads)], k, out="gr")
+        old = {n: os.environ.get(n) for n in env}
+        os.environ.update(env)
+        try:
+            import torch
+            from gossamer_amd import dist as gd
+            with g.Context(k, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
+                runs, windows = [], 0
+                for p in pieces:                       # every piece counted on its own: five sorted runs
+                    ctx.reset()
+                    ctx.push_host(p)
+                    c = ctx.finish()
+                    windows += c.windows
+                    kp, cp, m = ctx.result_ptrs()
+                    runs.append((gd.key_view(kp, m, 2, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone()))
+                ctx.reset()
+                for keys, counts in runs:
+                    ctx.push_run(keys.data_ptr(), counts.data_ptr(), keys.shape[0])
+                ctx.finish()
+                assert ctx.stat("runs") == 1 and ctx.stat("hash_merges") == want, (k, env, ctx.stat("hash_merges"))
+                got = ctx.emit()
+        finally:
+            for n, v in old.items():
+                if v is None:
+                    del os.environ[n]
+                else:
+                    os.environ[n] = v
+        assert windows == nwin
+        _same(got, _suffix_map(exp, "gr"))
+
+
 def test_segments_of_24_bits_succeed_after_16_and_20_overflow(oracle):
     """One-word keys that need the third width of the segment stage and get through it: build-graph
     k = 27 on 28-base reads (one edge each) that share their first 10 bases (20 key bits), take all
