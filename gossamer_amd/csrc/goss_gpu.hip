@@ -669,7 +669,10 @@ inline void launch_seg_hash(goss_gpu_ctx* c, uint32_t nseg, const Key2* keys, co
 {
     // big: -2 = the 8192-slot table of 96-bit remainders, -1 = the 6144-slot table, one workgroup per segment each;
     // 1 + r = the 4096-slot table, 2^r workgroups per segment
-    if (big == -2)
+    if (big == -3)      // the 96-bit-remainder table fed 12-byte records by the second level
+        hipLaunchKernelGGL(seg_hash_reduce96p_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
+                           seg_pos, seg_cnt, sk, sc, rem_bits);
+    else if (big == -2)
         hipLaunchKernelGGL(seg_hash_reduce96_kernel, unit_grid(nseg), dim3(kSegBigThreads), 0, c->stream, keys, seg_off, seg_end, so,
                            seg_pos, seg_cnt, sk, sc, rem_bits);
     else if (big < 0)
@@ -1315,7 +1318,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)tiles), dim3(kTB), 0,
                                c->stream, (const K*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, ctl, cur2,
-                               (const GapTable*)dgt, (const SubTable*)dsub);
+                               (const GapTable*)dgt, (const SubTable*)dsub, big_table == -2 ? 1u : 0u);
             t.stop();
         }
         hipLaunchKernelGGL(sub_bounds_kernel, dim3(256), dim3(256), 0, c->stream, (const SubTable*)dsub,
@@ -1324,7 +1327,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
         lap("second level");
-        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end, big_table);
+        // (-3: the second level wrote 12-byte remainders for the 96-bit table)
+        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end, big_table == -2 ? -3 : big_table);
         if (rc != 0)
         {
             c->segment_retries++;

@@ -201,6 +201,7 @@ __device__ __forceinline__ Key1 strand_rep(const Key1& f, const Key1& rc, uint32
     return rot_half(rc.lo, len, lmask) < rot_half(f.lo, len, lmask) ? rc : f;
 }
 
+struct Rem96 { uint32_t r0, r1, r2; };           // the low 96 bits of a two-word key, packed (12-byte records)
 __device__ __forceinline__ bool is_pad_key(const Key1& k) { return k.lo == ~0ULL; }
 __device__ __forceinline__ bool is_pad_key(const Key2& k) { return (k.lo & k.hi) == ~0ULL; }
 
@@ -1483,8 +1484,12 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
                                                              LookbackCtl* __restrict__ ctl,
                                                              unsigned long long* __restrict__ cursors,
                                                              const GapTable* __restrict__ gt = nullptr,
-                                                             const SubTable* __restrict__ sub = nullptr)
+                                                             const SubTable* __restrict__ sub = nullptr,
+                                                             uint32_t rem_out = 0)
 {
+    // rem_out (two-word keys, sub-region mode): slot o of keys_out is a 12-byte record holding the key's low
+    // `digit` bits -- what is left below the 16-bit segment prefix, which the slot's sub-region implies; the
+    // counting kernel of 96-bit remainders reads those (a quarter less to write here and to read there)
     constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
     constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
     __shared__ uint32_t wave_hist[kWaves][256];
@@ -1715,6 +1720,24 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 
     if (GAPPED && sh_skip) return;
     const uint32_t tile_keys = GAPPED ? sh_total : tile_n;      // padding slots hold no key
+    if constexpr (sizeof(K) == 16)
+    {
+        if (rem_out)
+        {
+            const uint32_t hb = digit > 64 ? digit - 64 : 0;
+            const uint32_t hmask = hb >= 32 ? 0xFFFFFFFFu : ((1u << hb) - 1u);
+            const uint64_t lmask64 = digit >= 64 ? ~0ULL : ((1ULL << digit) - 1ULL);
+            Rem96* out96 = reinterpret_cast<Rem96*>(keys_out);
+            for (uint32_t i = tid; i < tile_keys; i += kTB)
+            {
+                const K k = stage[i];
+                const uint64_t o = global_base[key_digit(k, digit)] + i;
+                const uint64_t lo = key_lo_word(k) & lmask64;
+                out96[o] = Rem96{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)key_hi_word(k) & hmask};
+            }
+            return;
+        }
+    }
     for (uint32_t i = tid; i < tile_keys; i += kTB)
     {
         K k = stage[i];
@@ -2789,7 +2812,8 @@ __device__ __forceinline__ uint4 tbl4(const Slot96* t, uint32_t i) { return rein
 // high-coverage input all hold the same keys, so the table stays small -- done as hash inserts instead of
 // ordering networks and binary searches.  A count that would reach 2^31 (the lock bit of the slot word)
 // makes the kernel give up; the host then merges the general way.
-template <int NT, int SLOTS, bool MERGE = false>
+// PACKED: `keys` is an array of 12-byte Rem96 records (the second partition level wrote remainders).
+template <int NT, int SLOTS, bool MERGE = false, bool PACKED = false>
 __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
                                                        const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so, uint64_t* __restrict__ seg_pos,
                                                        uint64_t* __restrict__ seg_cnt,
@@ -2839,13 +2863,25 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
     if (b >= e) continue;
     Key2 nxt[kU];
     uint32_t nwt[kU];
+    const Rem96* packed = reinterpret_cast<const Rem96*>(keys);
+    // key i of the input as (lo, hi) with hi = all ones for "no key" (an index beyond the slice)
+    auto load = [&](uint64_t i) -> Key2 {
+        Key2 v;
+        if (PACKED)
+        {
+            const Rem96 r = packed[i < e ? i : e - 1];
+            v.lo = (uint64_t)r.r0 | ((uint64_t)r.r1 << 32); v.hi = r.r2;
+        }
+        else v = keys[i < e ? i : e - 1];
+        v.hi = i < e ? v.hi : ~0ULL;
+        return v;
+    };
 #pragma unroll
     for (int u = 0; u < kU; ++u)
     {
         // (clamped index and a select instead of a branch around the load)
         const uint64_t i = b + (uint64_t)u * NT + tid;
-        nxt[u] = keys[i < e ? i : e - 1];
-        nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
+        nxt[u] = load(i);
         nwt[u] = MERGE ? vals[i < e ? i : e - 1] : 1u;
     }
     for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kU)
@@ -2867,8 +2903,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
         for (int u = 0; u < kU; ++u)
         {
             const uint64_t i = i0 + (uint64_t)(kU + u) * NT + tid;
-            nxt[u] = keys[i < e ? i : e - 1];
-            nxt[u].hi = i < e ? nxt[u].hi : ~0ULL;
+            nxt[u] = load(i);
             nwt[u] = MERGE ? vals[i < e ? i : e - 1] : 1u;
         }
 #pragma unroll
@@ -3087,6 +3122,15 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce96_kernel(const
                                                                            uint32_t rem_bits)
 {
     seg_hash_reduce96_body<kSegBigThreads, kSeg96Slots>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
+}
+// the same reading 12-byte remainder records (the second level's rem_out form)
+__global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce96p_kernel(const Key2* __restrict__ keys, const uint64_t* __restrict__ seg_off,
+                                                                            const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                            uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                            Key2* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                            uint32_t rem_bits)
+{
+    seg_hash_reduce96_body<kSegBigThreads, kSeg96Slots, false, true>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits);
 }
 // merge of sorted (key,count) runs by 16-bit segments through the same table (bounds: [nruns][65537] from seg_bounds_kernel)
 __global__ __launch_bounds__(kSegBigThreads) void seg_hash_merge96_kernel(const Key2* __restrict__ keys, const uint32_t* __restrict__ vals,
