@@ -959,6 +959,10 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
 // buffers of one key per window start).
 enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2 };
 constexpr uint32_t kFusedGrid = 768;                         // workgroups of extract1_part_kernel: 3 per CU (52 KB of LDS each)
+#ifndef GOSS_FUSED_NKEYS2
+#define GOSS_FUSED_NKEYS2 14          // keys per thread of extract2_part_kernel (tile of 3584 keys + carry = 70 KB of LDS)
+#endif
+constexpr uint32_t kFusedGrid2 = 512;                        // ... of extract2_part_kernel: 2 per CU (75 KB)
 constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
 constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
 
@@ -1167,20 +1171,22 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // bucket regions of the first buffer: expected size of every bucket plus five standard
     // deviations of the sample count; whatever room the key buffer has beyond that (up to 25 %)
     // is handed out proportionally, so that a mildly non-stationary input still fits
-    // One-word keys: every workgroup of the fused kernel appends to a private block of B slots per
-    // bucket and pads the unused tail of its last blocks, so a region also needs one block per
-    // workgroup; B is the largest power of two (8 .. 256) that keeps that padding near 1 % of the keys.
-    // (up to 3 % of the keys in all: a small chunk gets fewer workgroups, then smaller blocks)
-    const uint64_t kSuperOne = (uint64_t)kTB * (graph_mode ? 8 : 16);
+    // Every workgroup of the fused kernel appends to a private block of B slots per bucket and pads the
+    // unused tail of its last blocks, so a region also needs one block per workgroup; B is the largest
+    // power of two (one 64-byte granule .. 256 slots) that keeps that padding within 3 % of the keys: a small
+    // chunk gets fewer workgroups, then smaller blocks.  Workgroups per CU: 3 for one-word keys (52 KB of
+    // LDS each), 2 for two-word keys (75 KB).
+    const uint32_t kGranule = kOne ? 8 : 4;                       // keys per 64 bytes
+    const uint64_t kSuperFused = kOne ? (uint64_t)kTB * (graph_mode ? 8 : 16)
+                                      : (uint64_t)kTB * (graph_mode ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
     const double pad_budget = 0.03 * (double)n_exp;
-    uint32_t fgrid = (uint32_t)std::min<uint64_t>((nstarts + kSuperOne - 1) / kSuperOne, (uint64_t)kFusedGrid);
+    uint32_t fgrid = (uint32_t)std::min<uint64_t>((nstarts + kSuperFused - 1) / kSuperFused, (uint64_t)(kOne ? kFusedGrid : kFusedGrid2));
     if (c->fused_grid) fgrid = std::min(fgrid, c->fused_grid);
-    if (kOne) fgrid = (uint32_t)std::max(16.0, std::min((double)fgrid, pad_budget / (256.0 * 8.0)));
-    uint32_t blk_log2 = 3;
-    if (kOne)
-        while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
-    const uint64_t B = kOne ? (1ULL << blk_log2) : 16;
-    const double blk_extra = kOne ? (double)fgrid * (double)B : 0.0;
+    fgrid = (uint32_t)std::max(16.0, std::min((double)fgrid, pad_budget / (256.0 * kGranule)));
+    uint32_t blk_log2 = kOne ? 3 : 2;
+    while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
+    const uint64_t B = 1ULL << blk_log2;
+    const double blk_extra = (double)fgrid * (double)B;
     GapTable gt{};
     double base[256], base_sum = 0;
     for (int d = 0; d < 256; ++d)
@@ -1218,15 +1224,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 #define GOSS_FUSED_G 1
 #endif
         const bool graph = c->mode == GOSS_MODE_GRAPH;
-#ifndef GOSS_FUSED_NKEYS2
-#define GOSS_FUSED_NKEYS2 16
-#endif
         const uint64_t kSuper = kOne ? (uint64_t)kTB * (graph ? 8 : 16)
                                      : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
         uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);
         if (c->fused_grid) grid = std::min(grid, c->fused_grid);      // experiments: leave room for a second context's kernels
-        if (kOne) grid = fgrid;                                        // the regions were sized for this many workgroups
+        grid = fgrid;                                                  // the regions were sized for this many workgroups
         const int nh = msd ? 0 : (npass > 2 ? 2 : 1);
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         if constexpr (kOne)
@@ -1260,7 +1263,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
 #define GOSS_LAUNCH_E2P(MODE, NH, NBH)                                                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
-                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper)
+                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2)
 #define GOSS_LAUNCH_E2N(MODE, NBH)                                                                                    \
     do { if (nh == 0) GOSS_LAUNCH_E2P(MODE, 0, NBH); else if (nh == 1) GOSS_LAUNCH_E2P(MODE, 1, NBH); else GOSS_LAUNCH_E2P(MODE, 2, NBH); } while (0)
             if (graph) GOSS_LAUNCH_E2N(1, 8);
@@ -1296,7 +1299,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         sum += gt.cnt[d];
     }
     gt.tile_first[256] = tiles;
-    if (kOne ? (sum < n || sum > n + (uint64_t)fgrid * 256 * (B + 8)) : sum != n)
+    if (sum < n || sum > n + (uint64_t)fgrid * 256 * (B + 8))
         throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
     HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
 

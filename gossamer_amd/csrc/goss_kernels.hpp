@@ -1086,90 +1086,128 @@ __global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* __restrict_
 }
 
 // The same fusion for two-word keys (32 <= len <= 63): windows out of a 192-bit register buffer
-// (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`.
-// Only the one-level form uses it (two-word keys need more than two partition digits at the
-// sizes where fusing pays).
+// (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`,
+// in the form of extract1_part_kernel: private blocks of B slots per workgroup and bucket (a cursor is
+// touched once per block), whole 64-byte granules (4 keys) stored from 4 aligned lanes, the remainder of a
+// bucket (<= 3 keys) carried in the registers of the thread that owns it, kPadKey pairs behind the last
+// keys of every last block, the next tile's bytes fetched one tile ahead.  MODE 0 still computes gossamer's
+// canonical form in the kernel (two FNV chains over 16 bytes).
 template <int MODE, int NH, int NKEYS, int NBH = 8>
-__global__ __launch_bounds__(kTB) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
-                                                            uint64_t nstarts, uint64_t navail, uint32_t len,
-                                                            Key2* __restrict__ out, PartCounters* __restrict__ pc,
-                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper)
+__global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                               uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                               Key2* __restrict__ out, PartCounters* __restrict__ pc,
+                                                               const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
+                                                               uint32_t blk_log2)
 {
     constexpr int S = MODE == 1 ? 2 : 1;
     constexpr int P = NKEYS / S;                 // windows per thread; NKEYS keys per thread
     constexpr int T = kTB * P;
     constexpr int NVEC = T / 16 + 6;
     constexpr int NK = P * S;
-    __shared__ uint32_t pk[NVEC];
-    __shared__ uint32_t iv[NVEC];
-    __shared__ Key2 sorted[T * S];
-    __shared__ uint32_t dh[256];
-    __shared__ uint64_t gbase[256];
+    constexpr int kCarry = 3;                    // keys of a bucket below a granule of 4
+    constexpr uint32_t kSpare = T * S + 256 * kCarry;
+    __shared__ __attribute__((aligned(64))) Key2 sorted[T * S + 256 * kCarry + 64];
+    __shared__ uint32_t dh[256 + 32];
+    __shared__ uint2 t_lay[256];                 // x = first slot of the stored part | its length << 16; y = first slot of the carried part | keys carried in << 13 | stored keys that fit the current block << 16
+    __shared__ uint2 t_base[256];                // slot / 4 of the current block's write position (x) and of the new block(s) (y)
     __shared__ uint32_t lh[NH ? 256 * NH : 1];
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ uint32_t sh_ovf;
+    uint32_t* pk = reinterpret_cast<uint32_t*>(sorted);
+    uint32_t* iv = pk + NVEC;
 
     const uint32_t tid = threadIdx.x;
     if (NH > 0) lh[tid] = 0;
     if (NH > 1) lh[tid + 256] = 0;
     dh[tid] = 0;
+    if (tid < 32) dh[256 + tid] = 0;
     if (tid == 0) sh_ovf = 0;
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t B = 1u << blk_log2;
     const uint32_t bits = 2 * len;                                       // 64..126
     const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
     const uint64_t lmask = (1ULL << len) - 1;
     unsigned long long nvalid = 0;
+    uint64_t wpos = 0;
+    uint32_t ccnt = 0;
+    Key2 kc[kCarry];
+#pragma unroll
+    for (int j = 0; j < kCarry; ++j) kc[j] = Key2{0, 0};
+
+    auto fetch = [&](uint64_t byte0, uint4& q) {
+        if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return; }
+        q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        if (byte0 < navail + mis)
+        {
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        codes = 0; bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+    };
+    constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..5 also vector NV0 + tid
+    static_assert(NVEC == NV0 + 6 && NV0 <= kTB, "one vector per thread and six more");
+    uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
+    if (blockIdx.x < nsuper)
+    {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const uint64_t tb = (uint64_t)blockIdx.x * T;
+        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+        if (tid < 6) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        encode(q0, c0, b0);
+        if (tid < 6) encode(q1, c1, b1);
+    }
 
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
     {
         const uint64_t tile_base = st * (uint64_t)T;
-        for (uint32_t v = tid; v < NVEC; v += kTB)
-        {
-            uint64_t byte0 = tile_base + (uint64_t)v * 16;
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-            if (byte0 + 16 <= navail + mis)
-            {
-                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            }
-            else if (byte0 < navail + mis)
-            {
-                for (int j = 0; j < 16; ++j)
-                {
-                    uint64_t b = byte0 + j;
-                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
-                }
-            }
-            uint32_t codes = 0, bads = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                uint32_t l = w[i] | 0x20202020u;
-                uint32_t x = (l >> 1) & 0x03030303u;
-                x ^= (x >> 1) & 0x01010101u;
-                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-                uint32_t b1 = bad >> 7;
-                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-                codes |= c8 << (8 * i);
-                bads |= b4 << (4 * i);
-            }
-            pk[v] = codes;
-            iv[v] = bads;
-        }
+        if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
+        if (tid < 6) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
         __syncthreads();
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const bool more = st + gridDim.x < nsuper;
+        if (more)
+        {
+            const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
+            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+            if (tid < 6) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        }
 
+        // ---- windows out of registers, keys, rank inside their digit (no branch around the LDS atomics) ----
         Key2 kreg[NK];
-        uint16_t rk[NK];
+        uint32_t rk[NK];
         uint32_t vm = 0;
         {
-            const uint32_t q0 = tid * P + mis;
-            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint32_t q0i = tid * P + mis;
+            const uint32_t v0 = q0i >> 4, sh = q0i & 15u;
             const uint64_t p0 = tile_base + (uint64_t)tid * P;
             const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
             const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+            const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
+            const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
+            const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
 #pragma unroll
             for (int i = 0; i < P; ++i)
             {
@@ -1179,89 +1217,171 @@ __global__ __launch_bounds__(kTB) void extract2_part_kernel(const uint8_t* __res
                 vm |= ok ? (1u << i) : 0u;
             }
             nvalid += __popc(vm);
-            if (vm)
-            {
-                const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
-                const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
-                const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
-                Key2 f{0, 0};
+            const uint32_t spare = 256u + (tid & 31u);
+            uint32_t bin[NK];
+            Key2 f{0, 0};
 #pragma unroll
-                for (int i = 0; i < P; ++i)
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t t2 = 2 * (sh + i);
+                Key2 e;
+                e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
+                if (i == 0)
                 {
-                    const uint32_t t2 = 2 * (sh + i);
-                    Key2 e;
-                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
-                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
-                    if (i == 0)
-                    {
-                        const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
-                        const uint32_t sft = 128 - bits;
-                        if (sft == 64) { f.lo = rhi; f.hi = 0; }
-                        else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
-                    }
-                    else
-                    {
-                        const uint32_t pos = 2 * (sh + i + len - 1);
-                        const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
-                        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
-                        f.lo = (f.lo << 2) | nb;
-                    }
-                    if ((vm >> i) & 1u)
-                    {
-                        const Key2 rck{~e.lo, (~e.hi) & mask_hi};
-                        if (MODE == 0)
-                        {
-                            const Key2 k = canonical_tail<NBH>(f, rck);
-                            kreg[i] = k;
-                            rk[i] = (uint16_t)atomicAdd(&dh[key_digit(k, shift)], 1u);
-                        }
-                        else
-                        {
-                            kreg[2 * i] = f;
-                            rk[2 * i] = (uint16_t)atomicAdd(&dh[key_digit(f, shift)], 1u);
-                            kreg[2 * i + 1] = rck;
-                            rk[2 * i + 1] = (uint16_t)atomicAdd(&dh[key_digit(rck, shift)], 1u);
-                        }
-                    }
+                    const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
+                    const uint32_t sft = 128 - bits;
+                    if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                    else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                }
+                else
+                {
+                    const uint32_t pos = 2 * (sh + i + len - 1);
+                    const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
+                    f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+                    f.lo = (f.lo << 2) | nb;
+                }
+                const bool ok = (vm >> i) & 1u;
+                const Key2 rck{~e.lo, (~e.hi) & mask_hi};
+                if (MODE == 0)
+                {
+                    const Key2 k = canonical_tail<NBH>(f, rck);
+                    kreg[i] = k;
+                    bin[i] = ok ? key_digit(k, shift) : spare;
+                }
+                else
+                {
+                    kreg[2 * i] = f;
+                    bin[2 * i] = ok ? key_digit(f, shift) : spare;
+                    kreg[2 * i + 1] = rck;
+                    bin[2 * i + 1] = ok ? key_digit(rck, shift) : spare;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
         }
         __syncthreads();
 
-        uint32_t total;
+        // ---- bookkeeping of bucket tid: what is stored now, where, what is carried out ----
+        uint32_t total_store;
         {
             const uint32_t cnt = dh[tid];
-            const uint32_t start = block_excl_scan<uint32_t>(cnt, sh_scan, &total);
-            dh[tid] = start;
-            unsigned long long at = cnt ? atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)cnt) : 0ULL;
-            gbase[tid] = my_start + at - start;
-            if (cnt && at + cnt > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+            const uint32_t tot = ccnt + cnt;
+            const uint32_t fl = tot & ~3u, rem = tot & 3u;
+            uint32_t sums;
+            const uint32_t pre = block_excl_scan<uint32_t>(fl | (rem << 16), sh_scan, &sums);
+            total_store = sums & 0xFFFFu;
+            const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
+            dh[tid] = 0;
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            uint32_t thr = fl;
+            uint2 tb = make_uint2((uint32_t)(wpos >> 2), 0u);
+            if (fl > room)
+            {
+                thr = room;
+                const uint32_t need = fl - room;
+                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+                tb.y = (uint32_t)((my_start + at) >> 2);
+                wpos = my_start + at + need;
+            }
+            else wpos += fl;
+            t_base[tid] = tb;
+            t_lay[tid] = make_uint2(f_at | (fl << 16), l_at | (ccnt << 13) | (thr << 16));
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                sorted[(uint32_t)j < ccnt ? ((uint32_t)j < fl ? f_at + j : l_at + j) : kSpare + (tid & 63u)] = kc[j];
+            ccnt = rem;
         }
         __syncthreads();
+        {
+            uint2 tl[NK];
 #pragma unroll
-        for (int i = 0; i < P; ++i)
-            if ((vm >> i) & 1u)
+            for (int i = 0; i < NK; ++i) tl[i] = t_lay[key_digit(kreg[i], shift)];
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
             {
+                const bool ok = (vm >> (i / S)) & 1u;
+                const Key2 k = kreg[i];
+                const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
+                const uint32_t fl = tl[i].x >> 16;
+                const uint32_t at = p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl);
+                sorted[ok ? at : kSpare + (tid & 63u)] = k;
+                if (NH > 0) atomicAdd(&lh[key_digit(k, shift + 8)], ok ? 1u : 0u);
+                if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], ok ? 1u : 0u);
+            }
+        }
+        if (more)
+        {
+            encode(q0, c0, b0);
+            if (tid < 6) encode(q1, c1, b1);
+        }
+        __syncthreads();
+
+        // ---- whole granules to the bucket blocks; every 4 aligned lanes store one ----
+        if (sh_ovf == 0)
+            for (uint32_t i0 = tid; i0 < total_store; i0 += 2 * kTB)
+            {
+                Key2 kk[2];
+                uint2 tl[2], tb[2];
 #pragma unroll
-                for (int q = 0; q < S; ++q)
+                for (int u = 0; u < 2; ++u) kk[u] = sorted[min(i0 + u * kTB, kSpare)];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
                 {
-                    const Key2 k = kreg[i * S + q];
-                    sorted[dh[key_digit(k, shift)] + rk[i * S + q]] = k;
+                    const uint32_t d = key_digit(kk[u], shift);
+                    tl[u] = t_lay[d]; tb[u] = t_base[d];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t i = i0 + u * kTB;
+                    if (i < total_store)
+                    {
+                        const uint32_t p = i - (tl[u].x & 0xFFFFu);
+                        const uint32_t thr = tl[u].y >> 16;
+                        const uint64_t o = p < thr ? ((uint64_t)tb[u].x << 2) + p : ((uint64_t)tb[u].y << 2) + (p - thr);
+                        out[o] = kk[u];
+                    }
                 }
             }
-        __syncthreads();
-        dh[tid] = 0;
-        if (!sh_ovf)
         {
-            for (uint32_t i = tid; i < total; i += kTB)
-            {
-                const Key2 k = sorted[i];
-                out[gbase[key_digit(k, shift)] + i] = k;
-                if (NH > 0) atomicAdd(&lh[key_digit(k, shift + 8)], 1u);
-                if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], 1u);
-            }
+            const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];
         }
         __syncthreads();
+    }
+
+    // ---- the end: carried keys and the unused tail of every open block ----
+    if (sh_ovf == 0)
+    {
+        if (ccnt)
+        {
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            if (room == 0)
+            {
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
+                else wpos = my_start + at;
+            }
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) out[wpos + j] = kc[j];
+            wpos += ccnt;
+        }
+        const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+        __syncthreads();
+        t_base[tid].x = tail;
+        reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        __syncthreads();
+        for (uint32_t d = 0; d < 256; ++d)
+        {
+            const uint32_t n = t_base[d].x;
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key2{~0ULL, ~0ULL};
+        }
     }
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
     if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
