@@ -120,6 +120,7 @@ struct goss_gpu_ctx {
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
+    uint32_t blk_log2_max = 0;          // GOSS_GPU_BLK_LOG2=<b>: blocks of the fused extraction of at most 2^b slots (experiments)
     bool table96 = true;                // GOSS_GPU_NO_TABLE96=1: never count two-word keys as 96-bit remainders in 16-byte slots
     uint32_t table96_chunks = 0;
     bool wide_table = true;             // GOSS_GPU_NO_WIDE_TABLE=1: never count two-word keys in the 6144-slot table
@@ -962,7 +963,10 @@ constexpr uint32_t kFusedGrid = 768;                         // workgroups of ex
 #ifndef GOSS_FUSED_NKEYS2
 #define GOSS_FUSED_NKEYS2 14          // keys per thread of extract2_part_kernel (tile of 3584 keys + carry = 70 KB of LDS)
 #endif
-constexpr uint32_t kFusedGrid2 = 512;                        // ... of extract2_part_kernel: 2 per CU (75 KB)
+#ifndef GOSS_FUSED_GRID2
+#define GOSS_FUSED_GRID2 512
+#endif
+constexpr uint32_t kFusedGrid2 = GOSS_FUSED_GRID2;                        // ... of extract2_part_kernel: 2 per CU (75 KB)
 constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
 constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
 
@@ -1185,6 +1189,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     fgrid = (uint32_t)std::max(16.0, std::min((double)fgrid, pad_budget / (256.0 * kGranule)));
     uint32_t blk_log2 = kOne ? 3 : 2;
     while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
+    if (c->blk_log2_max) blk_log2 = std::min(blk_log2, std::max(c->blk_log2_max, kOne ? 3u : 2u));
     const uint64_t B = 1ULL << blk_log2;
     const double blk_extra = (double)fgrid * (double)B;
     GapTable gt{};
@@ -2366,6 +2371,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
+    { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_TABLE96"); if (e && *e && *e != '0') c->table96 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_WIDE_TABLE"); if (e && *e && *e != '0') c->wide_table = false; }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }

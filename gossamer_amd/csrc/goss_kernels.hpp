@@ -1219,20 +1219,24 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             nvalid += __popc(vm);
             const uint32_t spare = 256u + (tid & 31u);
             uint32_t bin[NK];
-            Key2 f{0, 0};
+            // forward key f and reverse complement r of window 0 from the register buffer, then one base
+            // rolled into both per window
+            Key2 f{0, 0}, r{0, 0};
+            const uint32_t top = bits - 2;                  // position of a key's first base (>= 62)
 #pragma unroll
             for (int i = 0; i < P; ++i)
             {
-                const uint32_t t2 = 2 * (sh + i);
-                Key2 e;
-                e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
-                e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
                 if (i == 0)
                 {
+                    const uint32_t t2 = 2 * sh;
+                    Key2 e;
+                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
                     const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
                     const uint32_t sft = 128 - bits;
                     if (sft == 64) { f.lo = rhi; f.hi = 0; }
                     else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                    r.lo = ~e.lo; r.hi = (~e.hi) & mask_hi;
                 }
                 else
                 {
@@ -1240,9 +1244,13 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                     const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
                     f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
                     f.lo = (f.lo << 2) | nb;
+                    const uint64_t cb = nb ^ 3u;
+                    r.lo = (r.lo >> 2) | (r.hi << 62);
+                    r.hi = (r.hi >> 2) | (top >= 64 ? cb << (top - 64) : 0ULL);
+                    if (top < 64) r.lo |= cb << top;
                 }
                 const bool ok = (vm >> i) & 1u;
-                const Key2 rck{~e.lo, (~e.hi) & mask_hi};
+                const Key2 rck = r;
                 if (MODE == 0)
                 {
                     const Key2 k = canonical_tail<NBH>(f, rck);
