@@ -2808,9 +2808,42 @@ int goss_gpu_push_run_host(goss_gpu_ctx* c, const uint64_t* keys, const uint32_t
     });
 }
 
+extern "C++" {
+// SparseArray in its on-disk form (host pointers) -> m decoded positions on the device
+// (SparseArray::LazyIterator, SparseArray.hh:185-224).  Temporaries above `out` in the arena are the caller's to release.
+template <class K>
+static void decode_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s, K* out)
+{
+    const uint64_t m = s->count;
+    uint64_t* words = (uint64_t*)c->arena.temp(std::max<uint64_t>(s->high_words, 1) * 8);
+    uint64_t* prefix = (uint64_t*)c->arena.temp(std::max<uint64_t>(s->high_words, 1) * 8);
+    HIP_TRY(hipMemcpyAsync(words, s->high_bits, s->high_words * 8, hipMemcpyHostToDevice, c->stream));
+    EfColumnsIn cols{};
+    cols.n = s->ncols;
+    for (uint32_t i = 0; i < s->ncols; ++i)
+    {
+        uint8_t* d = (uint8_t*)c->arena.temp(m * s->col_bytes[i] + 16);
+        HIP_TRY(hipMemcpyAsync(d, s->col[i], m * s->col_bytes[i], hipMemcpyHostToDevice, c->stream));
+        cols.src[i] = d; cols.bytes[i] = s->col_bytes[i]; cols.shift[i] = s->col_shift[i];
+    }
+    hipLaunchKernelGGL(popc_words_kernel, dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
+                       (const uint64_t*)words, s->high_words, prefix);
+    exclusive_scan_u64(c, prefix, s->high_words);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<K>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
+                       (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, out);
+}
+static bool sparse_run_ok(const goss_gpu_sparse_run* s) { return s && s->ncols >= 1 && s->ncols <= 4 && (!s->count || s->high_bits); }
+static uint64_t sparse_run_need(const goss_gpu_sparse_run* s)
+{
+    uint64_t need = s->high_words * 16 + 4096;
+    for (uint32_t i = 0; i < s->ncols; ++i) need += s->count * s->col_bytes[i] + 256;
+    return need;
+}
+}  // extern "C++"
+
 int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
 {
-    if (!c || !s || s->ncols == 0 || s->ncols > 4 || (s->count && !s->high_bits)) return GOSS_ERR_INVALID_ARG;
+    if (!c || !sparse_run_ok(s)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
     if (s->count == 0) return GOSS_OK;
     return guarded(c, [&]() {
@@ -2818,36 +2851,68 @@ int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
         flush_staging(c);
         const uint64_t m = s->count, ksz = c->words * 8;
         {
-            uint64_t need = m * (ksz + 4) + s->high_words * 16 + (64u << 20);
-            for (uint32_t i = 0; i < s->ncols; ++i) need += m * s->col_bytes[i] + 256;
+            const uint64_t need = m * (ksz + 4) + sparse_run_need(s) + (64u << 20);
             if (c->arena.avail() < need) grow_arena(c, need);
         }
         Run r{nullptr, nullptr, m};
         r.keys = c->arena.perm(m * ksz);
         r.counts = (uint32_t*)c->arena.perm(m * 4);
         uint64_t mark = c->arena.mark();
-        uint64_t* words = (uint64_t*)c->arena.temp(s->high_words * 8);
-        uint64_t* prefix = (uint64_t*)c->arena.temp(s->high_words * 8);
-        HIP_TRY(hipMemcpyAsync(words, s->high_bits, s->high_words * 8, hipMemcpyHostToDevice, c->stream));
-        EfColumnsIn cols{};
-        cols.n = s->ncols;
-        for (uint32_t i = 0; i < s->ncols; ++i)
-        {
-            uint8_t* d = (uint8_t*)c->arena.temp(m * s->col_bytes[i] + 16);
-            HIP_TRY(hipMemcpyAsync(d, s->col[i], m * s->col_bytes[i], hipMemcpyHostToDevice, c->stream));
-            cols.src[i] = d; cols.bytes[i] = s->col_bytes[i]; cols.shift[i] = s->col_shift[i];
-        }
-        hipLaunchKernelGGL(popc_words_kernel, dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
-                           (const uint64_t*)words, s->high_words, prefix);
-        exclusive_scan_u64(c, prefix, s->high_words);
-        if (c->words == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<Key1>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
-                               (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, (Key1*)r.keys);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_decode_kernel<Key2>), dim3(grid_for(s->high_words, 256)), dim3(256), 0, c->stream,
-                               (const uint64_t*)words, s->high_words, (const uint64_t*)prefix, (uint32_t)s->D, cols, m, (Key2*)r.keys);
+        if (c->words == 1) decode_sparse<Key1>(c, s, (Key1*)r.keys); else decode_sparse<Key2>(c, s, (Key2*)r.keys);
         if (s->counts) HIP_TRY(hipMemcpyAsync(r.counts, s->counts, m * 4, hipMemcpyHostToDevice, c->stream));
         else hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, r.counts, m, s->weight ? s->weight : 1u);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+        c->runs.push_back(r);
+    });
+}
+
+int goss_gpu_push_run_graph(goss_gpu_ctx* c, const goss_gpu_sparse_run* edges, const goss_gpu_vba* v)
+{
+    if (!c || !sparse_run_ok(edges) || !v || !sparse_run_ok(&v->ord1p) || !sparse_run_ok(&v->ord2p)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    const uint64_t m = edges->count, n1 = v->ord1p.count, n2 = v->ord2p.count;
+    if (m == 0) return GOSS_OK;
+    if (v->ord0_bytes < m || v->ord1_bytes < n1 || v->ord2_bytes < 2 * n2 || (m && !v->ord0) || (n1 && !v->ord1) || (n2 && !v->ord2))
+    {
+        c->last_error = "VariableByteArray files shorter than their presence arrays say";
+        return GOSS_ERR_INVALID_ARG;
+    }
+    return guarded(c, [&]() {
+        ensure_arena(c);
+        flush_staging(c);
+        const uint64_t ksz = c->words * 8;
+        {
+            const uint64_t need = m * (ksz + 5) + sparse_run_need(edges) + sparse_run_need(&v->ord1p) + sparse_run_need(&v->ord2p)
+                                  + n1 * 9 + n2 * 10 + (64u << 20);
+            if (c->arena.avail() < need) grow_arena(c, need);
+        }
+        Run r{nullptr, nullptr, m};
+        r.keys = c->arena.perm(m * ksz);
+        r.counts = (uint32_t*)c->arena.perm(m * 4);
+        uint64_t mark = c->arena.mark();
+        if (c->words == 1) decode_sparse<Key1>(c, edges, (Key1*)r.keys); else decode_sparse<Key2>(c, edges, (Key2*)r.keys);
+        // the multiplicities: VariableByteArray read on the device
+        uint8_t* d0 = (uint8_t*)c->arena.temp(m + 16);
+        HIP_TRY(hipMemcpyAsync(d0, v->ord0, m, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(vba_read0_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, (const uint8_t*)d0, m, r.counts);
+        if (n1)
+        {
+            Key1* p1 = (Key1*)c->arena.temp(n1 * 8);
+            uint8_t* d1 = (uint8_t*)c->arena.temp(n1 + 16);
+            decode_sparse<Key1>(c, &v->ord1p, p1);
+            HIP_TRY(hipMemcpyAsync(d1, v->ord1, n1, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(vba_read1_kernel, dim3(grid_for(n1, 256)), dim3(256), 0, c->stream, (const Key1*)p1, (const uint8_t*)d1, n1, m, r.counts);
+            if (n2)
+            {
+                Key1* p2 = (Key1*)c->arena.temp(n2 * 8);
+                uint16_t* d2 = (uint16_t*)c->arena.temp(n2 * 2 + 16);
+                decode_sparse<Key1>(c, &v->ord2p, p2);
+                HIP_TRY(hipMemcpyAsync(d2, v->ord2, n2 * 2, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(vba_read2_kernel, dim3(grid_for(n2, 256)), dim3(256), 0, c->stream, (const Key1*)p2, (const uint16_t*)d2, n2,
+                                   (const Key1*)p1, n1, m, r.counts);
+            }
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->arena.release(mark);
         c->runs.push_back(r);

@@ -3829,6 +3829,29 @@ __global__ void widen_counts_kernel(const uint32_t* __restrict__ counts, uint64_
     if (i < m) out[i].lo = counts[i];
 }
 
+// VariableByteArray read side (VariableByteArray::operator[] / GeneralIterator, VariableByteArray.hh:120-247) as
+// three passes over the whole array: byte 0 of every value from ord0; the items listed in the ord1p presence
+// array get bits 8..15 from ord1; the entries of that list which ord2p names get bits 16..31 from ord2.
+__global__ void vba_read0_kernel(const uint8_t* __restrict__ ord0, uint64_t m, uint32_t* __restrict__ counts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) counts[i] = ord0[i];
+}
+__global__ void vba_read1_kernel(const Key1* __restrict__ pos1, const uint8_t* __restrict__ ord1, uint64_t n1, uint64_t m,
+                                 uint32_t* __restrict__ counts)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n1 && pos1[j].lo < m) counts[pos1[j].lo] |= (uint32_t)ord1[j] << 8;
+}
+__global__ void vba_read2_kernel(const Key1* __restrict__ pos2, const uint16_t* __restrict__ ord2, uint64_t n2,
+                                 const Key1* __restrict__ pos1, uint64_t n1, uint64_t m, uint32_t* __restrict__ counts)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n2 || pos2[t].lo >= n1) return;
+    const uint64_t i = pos1[pos2[t].lo].lo;
+    if (i < m) counts[i] |= (uint32_t)ord2[t] << 16;
+}
+
 // --------------------------------------------------------------------------------------
 // SparseArray decode (SparseArray::LazyIterator, SparseArray.hh:185-224): the i-th one of the
 // high-bits bitmap at position p gives the key ((p - i) << D) + low[i].  Used to read existing

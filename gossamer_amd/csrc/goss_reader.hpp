@@ -72,47 +72,53 @@ __device__ inline uint64_t rd_u(const uint8_t* p, uint32_t bytes, uint64_t i)
     }
 }
 
-// DenseSelect::select(i) (DenseArray.cc:185-258) with lookupSubBlock (DenseArray.cc:134-182)
-__device__ inline bool rd_dense_select(const RdDenseSelect& d, const RdBits& bits, uint64_t i, uint64_t* out)
+// DenseSelect::select(i): the format (DenseArray.hh:98-169; written here by ds_classify_kernel /
+// ds_fill_kernel) is a two-level directory.  Per block of 8192 indexed positions: a start position
+// (rank array) and a 64-bit reference (index array); a reference, at either level, is a byte offset
+// with the kind of what it points at in its low three bits.  Three shapes exist:
+//   * "scan"      -- only sample positions are stored (one per 64 indexed positions); the answer is
+//                    found by walking the bit vector from the sample;
+//   * "explicit"  -- every position is stored, as 8/16/32-bit offsets from a base or as absolute u64;
+//   * "two-level" -- per sample a 32-bit offset and a 16-bit reference to a scan or explicit table of
+//                    its own.
+// The reference walks this in DenseSelect::select + lookupSubBlock (DenseArray.cc:134-258).
+struct RdRef { const uint8_t* at; uint32_t kind; };
+__device__ inline RdRef rd_ref(const uint8_t* origin, uint64_t word)
 {
-    const uint64_t blockNum = i >> d.logBlockSize;
-    if (blockNum >= d.numBlocks) return false;
-    const uint64_t* index = reinterpret_cast<const uint64_t*>(d.data + d.indexArrayOffset);
-    const uint64_t* rank = reinterpret_cast<const uint64_t*>(d.data + d.rankArrayOffset);
-    uint64_t startRank = rank[blockNum];
-    const uint64_t il = index[blockNum];
-    const uint8_t* block = d.data + (il & ~kRdTypeMask);
-    const uint64_t inBlock = i & (d.blockSize - 1);
-    const uint64_t sub = inBlock >> d.logSampleRate;
-    const bool invert = d.flags & 1;
-    switch (il & kRdTypeMask)
+    return RdRef{origin + (word & ~(uint64_t)kRdTypeMask), (uint32_t)(word & kRdTypeMask)};
+}
+// entry j of an explicit table, relative to `base` (absolute for 64-bit entries)
+__device__ inline bool rd_explicit(const RdRef& t, uint64_t base, uint64_t j, uint64_t* out)
+{
+    switch (t.kind)
     {
-        case kRdSmall:
-            startRank += reinterpret_cast<const uint16_t*>(block)[sub];
-            return rd_bits_select(bits, invert, startRank, i & (d.sampleRate - 1), out);
-        case kRdFull64: *out = reinterpret_cast<const uint64_t*>(block)[inBlock]; return true;
-        case kRdFull32: *out = startRank + reinterpret_cast<const uint32_t*>(block)[inBlock]; return true;
-        case kRdFull16: *out = startRank + reinterpret_cast<const uint16_t*>(block)[inBlock]; return true;
-        case kRdFull8:  *out = startRank + block[inBlock]; return true;
-        case kRdIntermediate:
-        {
-            const uint32_t* b = reinterpret_cast<const uint32_t*>(block);
-            const uint16_t* sbs = reinterpret_cast<const uint16_t*>(block + (4ull << (d.logBlockSize - d.logSampleRate)));
-            const uint64_t sr = startRank + b[sub];
-            const uint16_t sp = sbs[sub];
-            const uint8_t* sb = block + (sp & ~(uint16_t)kRdTypeMask);
-            const uint64_t r = i & (d.sampleRate - 1);
-            if (!sp) return rd_bits_select(bits, invert, sr, r, out);
-            switch (sp & kRdTypeMask)
-            {
-                case kRdFull32: *out = sr + reinterpret_cast<const uint32_t*>(sb)[r]; return true;
-                case kRdFull16: *out = sr + reinterpret_cast<const uint16_t*>(sb)[r]; return true;
-                case kRdFull8:  *out = sr + sb[r]; return true;
-                default: return false;
-            }
-        }
+        case kRdFull64: *out = reinterpret_cast<const uint64_t*>(t.at)[j]; return true;
+        case kRdFull32: *out = base + reinterpret_cast<const uint32_t*>(t.at)[j]; return true;
+        case kRdFull16: *out = base + reinterpret_cast<const uint16_t*>(t.at)[j]; return true;
+        case kRdFull8:  *out = base + t.at[j]; return true;
         default: return false;
     }
+}
+__device__ inline bool rd_dense_select(const RdDenseSelect& d, const RdBits& bits, uint64_t i, uint64_t* out)
+{
+    const uint64_t blk = i >> d.logBlockSize;
+    if (blk >= d.numBlocks) return false;
+    const uint64_t in_blk = i & (d.blockSize - 1);                 // which of the block's positions
+    const uint64_t sample = in_blk >> d.logSampleRate;             // which sample interval
+    const uint64_t behind = in_blk & (d.sampleRate - 1);           // how far behind the sample
+    const bool zeros = d.flags & 1;                                // the index is over the zero bits
+    const uint64_t base = reinterpret_cast<const uint64_t*>(d.data + d.rankArrayOffset)[blk];
+    const RdRef top = rd_ref(d.data, reinterpret_cast<const uint64_t*>(d.data + d.indexArrayOffset)[blk]);
+    if (top.kind == kRdSmall)                                      // scan from a 16-bit sample offset
+        return rd_bits_select(bits, zeros, base + reinterpret_cast<const uint16_t*>(top.at)[sample], behind, out);
+    if (top.kind != kRdIntermediate) return rd_explicit(top, base, in_blk, out);
+    // two-level: 32-bit sample offsets, then 16-bit references relative to the block
+    const uint64_t nsamples = 1ULL << (d.logBlockSize - d.logSampleRate);
+    const uint64_t from = base + reinterpret_cast<const uint32_t*>(top.at)[sample];
+    const uint16_t word = reinterpret_cast<const uint16_t*>(top.at + 4 * nsamples)[sample];
+    if (word == 0) return rd_bits_select(bits, zeros, from, behind, out);
+    const RdRef sub = rd_ref(top.at, word);
+    return sub.kind == kRdFull64 ? false : rd_explicit(sub, from, behind, out);
 }
 
 // low D bits of element i, from the IntegerArray column files (IntegerArray.cc:259-357)

@@ -107,58 +107,6 @@ void openSparse(const std::string& base, SparseFiles& s)
     }
 }
 
-// Positions of a small SparseArray of 64-bit positions, decoded on the host
-// (SparseArray::LazyIterator): the ord1p / ord2p presence maps of a VariableByteArray.
-std::vector<uint64_t> decodeSmallSparse(const std::string& base)
-{
-    SparseFiles s;
-    openSparse(base, s);
-    std::vector<uint64_t> out;
-    out.reserve(s.count);
-    const uint64_t* w = (const uint64_t*)s.high.p;
-    const uint64_t nw = s.high.n / 8;
-    uint64_t i = 0;
-    for (uint64_t k = 0; k < nw && i < s.count; ++k)
-    {
-        uint64_t x = w[k];
-        while (x && i < s.count)
-        {
-            uint64_t b = (uint64_t)__builtin_ctzll(x);
-            x &= x - 1;
-            uint64_t low = 0;
-            for (size_t c = 0; c < s.cols.size(); ++c)
-            {
-                uint64_t v = 0;
-                memcpy(&v, s.colFiles[c].p + i * s.cols[c].bytes, s.cols[c].bytes);
-                if (s.cols[c].shift < 64) low |= v << s.cols[c].shift;
-            }
-            uint64_t hi = k * 64 + b - i;
-            out.push_back((s.D >= 64 ? 0 : (hi << s.D)) + low);
-            ++i;
-        }
-    }
-    return out;
-}
-
-// VariableByteArray::GeneralIterator over the whole array (VariableByteArray.hh:120-195).
-std::vector<uint32_t> decodeCounts(const std::string& base, uint64_t n)
-{
-    Mapped o0, o1, o2;
-    o0.open(base + ".ord0"); o1.open(base + ".ord1"); o2.open(base + ".ord2");
-    if (o0.n < n) throw Error::General("\tfile '" + base + ".ord0' is shorter than the edge count\n");
-    std::vector<uint64_t> p1 = decodeSmallSparse(base + ".ord1p"), p2 = decodeSmallSparse(base + ".ord2p");
-    std::vector<uint32_t> c(n);
-    for (uint64_t i = 0; i < n; ++i) c[i] = o0.p[i];
-    for (size_t j = 0; j < p1.size() && j < o1.n; ++j)
-        if (p1[j] < n) c[p1[j]] |= (uint32_t)o1.p[j] << 8;
-    for (size_t j = 0; j < p2.size() && 2 * j + 2 <= o2.n; ++j)
-    {
-        uint16_t w; memcpy(&w, o2.p + 2 * j, 2);
-        if (p2[j] < p1.size() && p1[p2[j]] < n) c[p1[p2[j]]] |= (uint32_t)w << 16;
-    }
-    return c;
-}
-
 struct GpuCtx {
     goss_gpu_ctx* h = nullptr;
     ~GpuCtx() { if (h) goss_gpu_destroy(h); }
@@ -201,21 +149,43 @@ ObjectInfo objectInfo(const std::string& name, bool graph)
 // Decode one object into the context as a run.
 void pushObject(GpuCtx& g, const std::string& name, bool graph, uint32_t weight = 1)
 {
+    auto describe = [](const SparseFiles& s) {
+        goss_gpu_sparse_run r{};
+        r.D = s.D; r.count = s.count;
+        r.high_bits = (const uint64_t*)s.high.p; r.high_words = s.high.n / 8;
+        r.ncols = (uint32_t)s.cols.size();
+        for (size_t i = 0; i < s.cols.size(); ++i)
+        {
+            r.col[i] = s.colFiles[i].p; r.col_bytes[i] = s.cols[i].bytes; r.col_shift[i] = s.cols[i].shift;
+        }
+        return r;
+    };
     SparseFiles s;
     openSparse(graph ? name + "-edges" : name + ".kmers", s);
-    std::vector<uint32_t> counts;
-    if (graph) counts = decodeCounts(name + "-counts", s.count);
-    goss_gpu_sparse_run r{};
-    r.D = s.D; r.count = s.count;
-    r.high_bits = (const uint64_t*)s.high.p; r.high_words = s.high.n / 8;
-    r.ncols = (uint32_t)s.cols.size();
-    for (size_t i = 0; i < s.cols.size(); ++i)
-    {
-        r.col[i] = s.colFiles[i].p; r.col_bytes[i] = s.cols[i].bytes; r.col_shift[i] = s.cols[i].shift;
-    }
-    r.counts = graph ? counts.data() : nullptr;
+    goss_gpu_sparse_run r = describe(s);
     r.weight = weight;
-    g.check(goss_gpu_push_run_sparse(g.h, &r), "reading an input object");
+    if (!graph)
+    {
+        g.check(goss_gpu_push_run_sparse(g.h, &r), "reading an input object");
+        return;
+    }
+    // the multiplicities stay in their VariableByteArray files: the library reads them on the device
+    // (VariableByteArray::GeneralIterator, VariableByteArray.hh:120-195)
+    const std::string cb = name + "-counts";
+    Mapped o0, o1, o2;
+    o0.open(cb + ".ord0"); o1.open(cb + ".ord1"); o2.open(cb + ".ord2");
+    if (o0.n < s.count) throw Error::General("\tfile '" + cb + ".ord0' is shorter than the edge count\n");
+    SparseFiles p1, p2;
+    openSparse(cb + ".ord1p", p1);
+    openSparse(cb + ".ord2p", p2);
+    goss_gpu_vba v{};
+    v.ord0 = (const uint8_t*)o0.p; v.ord0_bytes = o0.n;
+    v.ord1p = describe(p1); v.ord1 = (const uint8_t*)o1.p; v.ord1_bytes = o1.n;
+    v.ord2p = describe(p2); v.ord2 = (const uint16_t*)o2.p; v.ord2_bytes = o2.n;
+    // a damaged object may list more items than its byte files hold: read what is there
+    v.ord1p.count = std::min<uint64_t>(v.ord1p.count, o1.n);
+    v.ord2p.count = std::min<uint64_t>(v.ord2p.count, o2.n / 2);
+    g.check(goss_gpu_push_run_graph(g.h, &r, &v), "reading an input object");
 }
 
 struct HostRun { std::vector<uint64_t> keys; std::vector<uint32_t> counts; uint64_t m = 0; };

@@ -214,6 +214,22 @@ typedef struct {
 } goss_gpu_sparse_run;
 int goss_gpu_push_run_sparse(goss_gpu_ctx* ctx, const goss_gpu_sparse_run* run);
 
+/*
+ * Feed an existing GRAPH as a run: its edge SparseArray as above and its multiplicities as the
+ * VariableByteArray files they are stored in -- read on the device the way VariableByteArray::operator[] /
+ * GeneralIterator read them (VariableByteArray.hh:120-247): ord0 holds byte 0 of every value, the items that
+ * the ord1p SparseArray lists take bits 8..15 from ord1, the entries of that list which ord2p names take bits
+ * 16..31 from ord2.  How merge-graphs reads its inputs (GossCmdMerge.tcc:52-69, Graph::LazyIterator).
+ */
+typedef struct {
+    const uint8_t* ord0;  uint64_t ord0_bytes;
+    goss_gpu_sparse_run ord1p;                 /* positions (universe = item count) of the items with a second byte */
+    const uint8_t* ord1;  uint64_t ord1_bytes;
+    goss_gpu_sparse_run ord2p;                 /* indices into the ord1 list of the items with an upper half */
+    const uint16_t* ord2; uint64_t ord2_bytes;
+} goss_gpu_vba;
+int goss_gpu_push_run_graph(goss_gpu_ctx* ctx, const goss_gpu_sparse_run* edges, const goss_gpu_vba* counts);
+
 /* A run in host memory (key_words u64 per key, strictly increasing) with u32 counts. */
 int goss_gpu_push_run_host(goss_gpu_ctx* ctx, const uint64_t* keys, const uint32_t* counts, uint64_t m);
 
