@@ -174,6 +174,58 @@ class Context:
         self._L.goss_gpu_prepare.argtypes = [C.c_void_p]
         self._check(self._L.goss_gpu_prepare(self._h))
 
+    def push_run_graph(self, files, key_bits):
+        """A graph given as {suffix: bytes} of its files ("-edges.*", "-counts.*") as one run, edges and
+        multiplicities decoded on the device (goss_gpu_push_run_graph)."""
+        import struct
+
+        class SparseRun(C.Structure):
+            _fields_ = [("D", C.c_uint64), ("count", C.c_uint64), ("high_bits", C.c_char_p), ("high_words", C.c_uint64),
+                        ("ncols", C.c_uint32), ("weight", C.c_uint32), ("col", C.c_char_p * 4), ("col_bytes", C.c_uint32 * 4),
+                        ("col_shift", C.c_uint32 * 4), ("counts", C.c_void_p)]
+
+        class Vba(C.Structure):
+            _fields_ = [("ord0", C.c_char_p), ("ord0_bytes", C.c_uint64), ("ord1p", SparseRun), ("ord1", C.c_char_p),
+                        ("ord1_bytes", C.c_uint64), ("ord2p", SparseRun), ("ord2", C.c_char_p), ("ord2_bytes", C.c_uint64)]
+
+        def layout(bits, prefix, shift, out):
+            split = {24: (8, 16), 40: (8, 32), 48: (16, 32), 56: (8, 48), 72: (8, 64), 80: (16, 64), 88: (8, 80),
+                     96: (32, 64), 104: (8, 96), 112: (16, 96), 120: (24, 96), 128: (64, 64)}
+            if bits in (8, 16, 32, 64):
+                out.append((prefix, bits // 8, shift))
+                return
+            ub, lb = split[bits]
+            layout(ub, prefix + ".upr", shift + lb, out)
+            layout(lb, prefix + ".lwr", shift, out)
+
+        keep = []
+
+        def run(base):
+            h = struct.unpack("<8Q", files[base + ".header"][:64])
+            r = SparseRun()
+            r.D, r.count = h[1], h[7]
+            hb = files[base + ".high-bits"]
+            keep.append(hb)
+            r.high_bits, r.high_words = hb, len(hb) // 8
+            cols = []
+            layout(h[2], "", 0, cols)
+            r.ncols = len(cols)
+            for i, (suffix, nbytes, shift) in enumerate(cols):
+                data = files[base + ".low-bits" + suffix] or b"\0"
+                keep.append(data)
+                r.col[i], r.col_bytes[i], r.col_shift[i] = data, nbytes, shift
+            return r
+
+        edges = run("-edges")
+        v = Vba()
+        v.ord0, v.ord0_bytes = files["-counts.ord0"] or b"\0", len(files["-counts.ord0"])
+        v.ord1p = run("-counts.ord1p")
+        v.ord1, v.ord1_bytes = files["-counts.ord1"] or b"\0", len(files["-counts.ord1"])
+        v.ord2p = run("-counts.ord2p")
+        v.ord2, v.ord2_bytes = files["-counts.ord2"] or b"\0", len(files["-counts.ord2"])
+        self._L.goss_gpu_push_run_graph.argtypes = [C.c_void_p, C.POINTER(SparseRun), C.POINTER(Vba)]
+        self._check(self._L.goss_gpu_push_run_graph(self._h, C.byref(edges), C.byref(v)))
+
     def set_path(self, path):
         """0: segment hash path with LSD fallback (default); 1: LSD radix sort only."""
         self._check(self._L.goss_gpu_set_path(self._h, path))

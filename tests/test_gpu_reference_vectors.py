@@ -133,6 +133,23 @@ def test_variable_byte_array(oracle, name):
     assert mine["-counts-hist.txt"] == theirs["-counts-hist.txt"]
 
 
+@pytest.mark.parametrize("name", ["vba_test1", "vba_test4"])
+def test_variable_byte_array_read_on_the_device(oracle, name):
+    """the read side (VariableByteArray::operator[] / GeneralIterator, VariableByteArray.hh:120-247) on the device:
+    the graph files of the previous test -- written by the ORACLE -- pushed back as a run
+    (goss_gpu_push_run_graph, what merge-graphs does with its inputs) give every edge and every value"""
+    values = refvec.cases()[name]["values"]
+    K = 15
+    keys = [7 * i + 3 for i in range(len(values))]
+    theirs = {n[1:]: b for n, b in oracle.write_graph(keys, values, K, out="x").items()}
+    with g.Context(K, g.MODE_GRAPH, hbm_budget=768 << 20) as ctx:
+        ctx.push_run_graph(theirs, 2 * (K + 1))
+        ctx.finish()
+        got_keys, got_counts = ctx.result()
+    assert got_keys == keys
+    assert [int(x) for x in got_counts] == values
+
+
 def test_graph_five_edges_and_out_degrees(oracle):
     t = KAT["graph_test1"]
     K = t["K"]
