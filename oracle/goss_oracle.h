@@ -12,12 +12,17 @@
  *
  * PINNING STATUS: the reference itself cannot be built in this image (it needs Boost,
  * which is absent, and writing stand-in headers is not allowed), so this restatement is
- * pinned against (i) the known answers held by the reference's own tests for this path
- * (testGossCmdBuildGraph.cc, testReverseComplementAdapter.cc, testUtils.cc,
- * testSparseArray.cc / testDenseArray.cc style writer->reader round trips restated from
- * the reference's reader code) and (ii) the known-answer vectors recorded in SURVEY.md
- * App. C.  No reference test pins output *bytes*: byte parity is "unpinned by the
- * reference's tests" (see DESIGN.md).
+ * pinned against (i) the reference's seeded unit tests for the structures on this path,
+ * replayed on regenerated inputs (std::mt19937 + libstdc++ distributions with the tests'
+ * seeds: tests/golden/gen_reference_inputs.cpp, digests and file:line in
+ * tests/golden/reference_kat.json) -- testSparseArray.cc, testDenseArray.cc,
+ * testWordyBitVector.cc, testVariableByteArray.cc, testGraph.cc, testBigInteger.cc
+ * (tests/test_reference_vectors.py); (ii) the known answers held by the reference's other
+ * tests for this path (testGossCmdBuildGraph.cc, testReverseComplementAdapter.cc,
+ * testUtils.cc, testVByteCodec.cc, testFastqParser.cc); (iii) the known-answer vectors
+ * recorded in SURVEY.md App. C.  No reference test compares output *bytes*: byte parity is
+ * pinned through the reference's reader semantics, not through files the reference wrote
+ * (see DESIGN.md section 5).
  */
 #ifndef GOSS_ORACLE_H
 #define GOSS_ORACLE_H
