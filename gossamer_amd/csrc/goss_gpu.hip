@@ -71,7 +71,9 @@ struct OutFile {
 };
 
 typedef std::map<std::pair<uint64_t, uint64_t>, uint64_t> BigMap;     // key (hi, lo) -> count that does not fit 32 bits
-struct Run { void* keys; uint32_t* counts; uint64_t m; int big = -1; };      // big: index into ctx.big_maps, or -1
+struct Run { void* keys; uint32_t* counts; uint64_t m; int big = -1; bool rep = false; };
+// big: index into ctx.big_maps, or -1.  rep: the keys are strand representatives (extract1_part_kernel), not yet
+// gossamer's canonical forms -- runs of ONE space are merged as they are, and the result is canonicalised once
 
 struct PhaseEvents { hipEvent_t a, b; int phase; uint64_t units; };
 
@@ -84,6 +86,7 @@ struct goss_gpu_ctx {
     int words = 1;
     int path = 0;                       // 0 auto, 1 LSD sort only
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
+    uint32_t order_bits = 0;            // group bits of the canonical re-ordering (GOSS_GPU_ORDER_BITS=16|20; 0 = by size)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
     uint64_t emit_estimate = 0;         // SparseArray estimate M for the next emit (merges)
@@ -897,12 +900,17 @@ template <class K>
 void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slots)
 {
     const uint64_t m = r.m;
+    r.rep = false;
     if (m == 0) return;
     PhaseTimer t(c, GOSS_T_ORDER, m);
     const uint64_t need = 2 * m * sizeof(K) + 2 * m * 4 + 64;
     uint64_t mark = c->arena.mark();
     uint8_t* p = (uint8_t*)scratch;
-    if (scratch_slots * sizeof(K) < need) p = (uint8_t*)c->arena.temp(need);
+    if (scratch_slots * sizeof(K) < need)
+    {
+        if (c->arena.avail() < need + (256ULL << 20)) grow_arena(c, need + (256ULL << 20));
+        p = (uint8_t*)c->arena.temp(need);
+    }
     K* ka = (K*)p;
     K* kb = ka + m;
     uint32_t* va = (uint32_t*)(kb + m);
@@ -916,22 +924,25 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
     const uint32_t keybits = 2 * c->len;
     if constexpr (std::is_same<K, Key1>::value)
     {
-        // canonical forms are uniform on their leading bits: two radix passes group the pairs by their top
-        // 16 bits, then every group (m / 65536 pairs) is ordered in LDS -- three passes over the pairs instead
-        // of one per key byte
-        if (keybits >= 26 && m >= (1u << 20) && m <= 65536ULL * 2400)
+        // canonical forms are uniform on their leading bits: two (three) radix passes group the pairs by their
+        // top 16 (20) bits, then every group (~m / 2^bits pairs, at most 4 096) is ordered in LDS -- three or four
+        // passes over the pairs instead of one per key byte.  20 bits for runs above 157 M keys (the ranks of a
+        // multi-GPU build hold up to the whole k-mer set before the exchange)
+        const uint32_t sb = c->order_bits ? c->order_bits : (m <= 65536ULL * 2400 ? 16u : 20u);
+        if (keybits >= sb + 10 && m >= (1u << 20) && m <= (1ULL << sb) * 2400)
         {
-            in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, 2, keybits - 16);
+            const uint32_t nseg = 1u << sb;
+            in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, (sb + 7) / 8, keybits - sb);
             K* sk = in_b ? kb : ka;
             uint32_t* sv = in_b ? vb : va;
             uint64_t m2 = c->arena.mark();
-            uint64_t* soff = (uint64_t*)c->arena.temp(65537 * 8);
+            uint64_t* soff = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
             uint32_t* flag = (uint32_t*)c->arena.temp(16);
             HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(65536 / 256 + 1), dim3(256), 0, c->stream,
-                               (const K*)sk, m, keybits - 16, 65536u, soff);
-            hipLaunchKernelGGL(seg_sort_pairs_kernel, unit_grid(65536), dim3(kTB), 0, c->stream, sk, sv, (const uint64_t*)soff,
-                               keybits - 16, flag);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_bounds_kernel<K>), dim3(nseg / 256 + 1), dim3(256), 0, c->stream,
+                               (const K*)sk, m, keybits - sb, nseg, soff);
+            hipLaunchKernelGGL(seg_sort_pairs_kernel, unit_grid(nseg), dim3(kTB), 0, c->stream, sk, sv, (const uint64_t*)soff,
+                               keybits - sb, flag);
             uint32_t* hf = (uint32_t*)c->h_pinned;
             HIP_TRY(hipMemcpyAsync(hf, flag, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -939,7 +950,7 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
             c->arena.release(m2);
             if (!ordered)
             {
-                // skewed bits: order everything by the remaining digits as well (the top 16 bits are in place,
+                // skewed bits: order everything by the remaining digits as well (the top bits are in place,
                 // a full stable sort from the current buffer is simply the general answer)
                 if (in_b) { std::swap(ka, kb); std::swap(va, vb); }
                 in_b = false;
@@ -1401,9 +1412,10 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     lap("segments counted");
     if (kOne && !graph_mode)
     {
-        canonicalize_run<K>(c, r, ka, ka_slots);
+        // the run stays in representative space: it is mapped to gossamer's canonical forms when it meets a run
+        // that is not, or at finish -- a build of several chunks pays for the re-ordering once, on the merged run
+        r.rep = true;
         c->rep_chunks++;
-        lap("canonical order");
     }
     c->runs.push_back(r);
     c->windows += hp->windows;
@@ -1491,6 +1503,16 @@ template <class K>
 void merge_runs(goss_gpu_ctx* c)
 {
     if (c->runs.size() <= 1) return;
+    bool all_rep = true, any_rep = false;
+    for (auto& r : c->runs) { all_rep = all_rep && r.rep; any_rep = any_rep || r.rep; }
+    if (any_rep && !all_rep)
+        for (auto& r : c->runs)
+            if (r.rep)
+            {
+                if constexpr (std::is_same<K, Key1>::value) canonicalize_run<K>(c, r, (K*)nullptr, 0);
+                else throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
+            }
+    const bool rep_out = all_rep;
     uint64_t total = 0;
     for (auto& r : c->runs) total += r.m;
     {
@@ -1568,6 +1590,7 @@ void merge_runs(goss_gpu_ctx* c)
                                    (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (K*)r.keys, r.counts);
                 t.stop();
                 HIP_TRY(hipStreamSynchronize(c->stream));
+                r.rep = rep_out;
                 c->runs.push_back(r);
                 c->seg_merges++;
                 c->hash_merges++;
@@ -1632,6 +1655,7 @@ void merge_runs(goss_gpu_ctx* c)
             t.stop();
             HIP_TRY(hipStreamSynchronize(c->stream));
             resolve_big_counts<K>(c, r, ka, va, run_off, in_bigs);
+            r.rep = rep_out;
             c->runs.push_back(r);
             c->seg_merges++;
             c->arena.release(mark);
@@ -1642,6 +1666,7 @@ void merge_runs(goss_gpu_ctx* c)
     PhaseTimer t(c, GOSS_T_REDUCE, total);
     Run r = reduce_runs<K>(c, in_b ? kb : ka, in_b ? vb : va, total, in_b ? ka : kb, &in_bigs);
     t.stop();
+    r.rep = rep_out;
     c->runs.push_back(r);
     c->arena.release(mark);
 }
@@ -2363,6 +2388,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     c->budget = hbm_budget;
     { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
+    { const char* e = std::getenv("GOSS_GPU_ORDER_BITS"); if (e && (std::atoi(e) == 16 || std::atoi(e) == 20)) c->order_bits = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
@@ -2498,6 +2524,11 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
         flush_staging(c);
         if (c->stage) { c->stage = nullptr; c->arena.hi = c->arena.size; }    // staging no longer needed
         if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
+        if (!c->runs.empty() && c->runs[0].rep)
+        {
+            if (c->words != 1) throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
+            canonicalize_run<Key1>(c, c->runs[0], (Key1*)nullptr, 0);
+        }
         if (!c->runs.empty()) { c->res_keys = c->runs[0].keys; c->res_counts = c->runs[0].counts; c->M = c->runs[0].m; }
         else { c->res_keys = c->arena.perm(16); c->res_counts = (uint32_t*)c->arena.perm(16); c->M = 0; }
         uint32_t* hf = (uint32_t*)c->h_pinned;

@@ -2337,6 +2337,141 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
 #define GOSS_SEG_UNROLL 16
 #endif
     constexpr int kSegUnroll = GOSS_SEG_UNROLL;
+    if constexpr (FILTER)
+    {
+        // Shared segments: three of four (one of two) keys this workgroup streams belong to another workgroup.
+        // Probing them as empty keys costs as many issue slots as counting them, so every wave first COMPACTS its
+        // own keys: a ballot per batch row, the owners write their key to the wave's ring in LDS (no barrier: a
+        // wave's LDS accesses execute in order), and whenever the ring holds kG keys per lane the wave takes them
+        // out, dense, and counts them with the same two-step insert as below.
+        constexpr int kG = 2, kQ = 256;
+        static_assert(kQ >= 64 * kG + 128, "ring: a drain's leftover + two batch rows");
+        __shared__ unsigned long long wq_all[NT / 64][kQ];
+        typedef volatile __attribute__((address_space(3))) unsigned long long* lds_vu64;
+        const lds_vu64 wq = (lds_vu64)wq_all[tid >> 6];
+        const uint32_t lane = tid & 63u;
+        const uint32_t rmask = (1u << round_bits) - 1u;
+        uint32_t head = 0, tail = 0;                    // wave-uniform ring positions (free-running)
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+        typedef const volatile __attribute__((address_space(3))) ull2* lds_bucket_ptr;
+        typedef const __attribute__((address_space(3))) ull2* lds_bucket_plain;
+        const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
+        const lds_bucket_plain pt2 = (lds_bucket_plain)tab;
+        auto insert_g = [&](const unsigned long long (&kq)[kG]) {
+            uint32_t bkt[kG];
+            ull2 q[kG];
+            uint32_t pend = 0;
+#pragma unroll
+            for (int j = 0; j < kG; ++j)
+            {
+                const uint32_t klo = (uint32_t)kq[j], khi = (uint32_t)(kq[j] >> 32);
+                bkt[j] = ((klo ^ __builtin_rotateleft32(khi, 15)) * 0x9E3779B1u) >> (32 - kBucketBits);
+                q[j] = pt2[bkt[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < kG; ++j)
+            {
+                const unsigned long long s0 = q[j].x, s1 = q[j].y;
+                const uint32_t live = kq[j] != kEmpty ? 1u : 0u;
+                const uint32_t h0 = s0 == kq[j] ? 1u : 0u, h1 = s1 == kq[j] ? 1u : 0u;
+                const uint32_t hit = (h0 | h1) & live;
+                atomicAdd(&cnt[2 * bkt[j] + h1], hit);
+                const uint32_t miss = live & (hit ^ 1u);
+                pend |= miss << j;
+                const uint32_t full = (s0 != kEmpty ? 1u : 0u) & (s1 != kEmpty ? 1u : 0u) & miss;
+                bkt[j] = (bkt[j] + full) & (SLOTS / 2 - 1);
+            }
+            unsigned long long key = kEmpty;
+            uint32_t bk = 0;
+            for (;;)
+            {
+                if (key == kEmpty && pend)
+                {
+                    const uint32_t u = __ffs(pend) - 1;
+                    pend &= pend - 1;
+#pragma unroll
+                    for (int uu = 0; uu < kG; ++uu)
+                        if (u == (uint32_t)uu) { key = kq[uu]; bk = bkt[uu]; }
+                }
+                if (!__ballot(key != kEmpty)) break;
+                if (key != kEmpty)
+                {
+                    const ull2 q01 = vt2[bk];
+                    const unsigned long long s0 = q01.x, s1 = q01.y;
+                    uint32_t hit = ~0u;
+                    if (s0 == key) hit = 2 * bk;
+                    else if (s1 == key) hit = 2 * bk + 1;
+                    else if (s0 == kEmpty || s1 == kEmpty)
+                    {
+                        const uint32_t slot = 2 * bk + (s0 == kEmpty ? 0u : 1u);
+                        const unsigned long long old = atomicCAS(&tab[slot], kEmpty, key);
+                        if (old == kEmpty)
+                        {
+                            uint32_t nd = atomicAdd(&ndist, 1u);
+                            if (nd + 1 > kLimit) *vovf = 1;
+                            hit = slot;
+                        }
+                        else if (old == key) hit = slot;
+                    }
+                    else bk = (bk + 1) & (SLOTS / 2 - 1);
+                    if (hit != ~0u) { atomicAdd(&cnt[hit], 1u); key = kEmpty; }
+                }
+                if (*vovf) break;
+            }
+        };
+        auto drain = [&](bool all) {
+            while (tail - head >= (all ? 1u : 64u * kG))
+            {
+                const uint32_t fill = tail - head;
+                unsigned long long kq[kG];
+#pragma unroll
+                for (int g = 0; g < kG; ++g)
+                {
+                    const uint32_t o = (uint32_t)g * 64u + lane;
+                    const unsigned long long v = wq[(head + o) & (kQ - 1)];
+                    kq[g] = o < fill ? v : kEmpty;
+                }
+                head += fill < 64u * kG ? fill : 64u * kG;
+                insert_g(kq);
+                if (*vovf) { head = tail; break; }
+            }
+        };
+        unsigned long long nxt[kSegUnroll];
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; ++u)
+        {
+            const uint64_t i = b + (uint64_t)u * NT + tid;
+            const unsigned long long v = __builtin_nontemporal_load(&keys[i < e ? i : e - 1].lo);
+            nxt[u] = i < e ? v : kEmpty;
+        }
+        for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)NT * kSegUnroll)
+        {
+            unsigned long long kv[kSegUnroll];
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; ++u) kv[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; ++u)
+            {
+                const uint64_t i = i0 + (uint64_t)(kSegUnroll + u) * NT + tid;
+                const unsigned long long v = __builtin_nontemporal_load(&keys[i < e ? i : e - 1].lo);
+                nxt[u] = i < e ? v : kEmpty;
+            }
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; ++u)
+            {
+                const uint32_t own = (kv[u] != kEmpty ? 1u : 0u) & ((((uint32_t)(kv[u] >> rem_bits)) & rmask) == rnd ? 1u : 0u);
+                const uint64_t m = __ballot(own != 0);
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (own) wq[(tail + before) & (kQ - 1)] = kv[u];
+                tail += (uint32_t)__popcll(m);
+                if (u & 1) drain(false);
+            }
+            if (*vovf) break;
+        }
+        drain(true);
+    }
+    else
+    {
     unsigned long long nxt[kSegUnroll];
 #pragma unroll
     for (int u = 0; u < kSegUnroll; ++u)
@@ -2453,6 +2588,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
             if (*vovf) break;
         }
         if (*vovf) break;
+    }
     }
     __syncthreads();
     if (ovf)

@@ -60,6 +60,49 @@ def test_fused_path_runs_and_matches_oracle(oracle):
     _same(got, exp)
 
 
+def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
+    """Several fused chunks: their runs hold strand representatives and are merged as such; gossamer's
+    canonical form and order are applied once, on the merged run, at finish (by 16-bit or 20-bit groups).  A run
+    handed in from outside (canonical keys) forces the mapping before the merge.  Files / (key, count) lists
+    against the oracle."""
+    import torch
+    reads = g.synth_reads_host(300000, 150, 1500000, seed=23)          # 45 M window starts, 1.5 M distinct 25-mers
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
+    exp = _suffix_map(exp, "ks")
+    for bits in ("16", "20"):
+        old = {n: os.environ.get(n) for n in ("GOSS_GPU_FUSED_MIN", "GOSS_GPU_ORDER_BITS")}
+        os.environ["GOSS_GPU_FUSED_MIN"] = "0"
+        os.environ["GOSS_GPU_ORDER_BITS"] = bits
+        try:
+            with g.Context(25, g.MODE_KMER_SET, hbm_budget=400 << 20) as ctx:
+                ctx.push_host(reads)
+                c = ctx.finish()
+                assert ctx.stat("rep_chunks") >= 3 and ctx.stat("fused_chunks") == ctx.stat("rep_chunks"), ctx.stat("rep_chunks")
+                assert c.windows == nwin
+                _same(ctx.emit(), exp)
+                keys, counts = ctx.result()
+            # the same build with a canonical run pushed between the chunks' runs and the merge
+            extra = {keys[0]: 5, keys[len(keys) // 2]: 7, keys[-1] + 1: 9}
+            ek = torch.tensor(sorted(extra), dtype=torch.int64, device="cuda")
+            ec = torch.tensor([extra[x] for x in sorted(extra)], dtype=torch.int32, device="cuda")
+            with g.Context(25, g.MODE_KMER_SET, hbm_budget=400 << 20) as ctx:
+                ctx.push_host(reads)
+                ctx.push_run(ek.data_ptr(), ec.data_ptr(), len(extra))
+                ctx.finish()
+                keys2, counts2 = ctx.result()
+            want = dict(zip(keys, (int(x) for x in counts)))
+            for x, n in extra.items():
+                want[x] = want.get(x, 0) + n
+            assert keys2 == sorted(want)
+            assert [int(x) for x in counts2] == [want[x] for x in keys2]
+        finally:
+            for n, v in old.items():
+                if v is None:
+                    os.environ.pop(n, None)
+                else:
+                    os.environ[n] = v
+
+
 @pytest.mark.parametrize("k", [16, 31])
 def test_fused_path_other_k(oracle, k):
     """Shortest key width with a fused path worth taking (32 bits) and the longest one-word key (62 bits)."""
