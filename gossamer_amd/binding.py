@@ -24,6 +24,7 @@ SYMBOLS = [
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
+    "goss_gpu_group_exchange", "goss_gpu_group_emit",
 ]
 
 
@@ -117,6 +118,28 @@ def _torch_ready():
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
         torch.cuda.synchronize()
+
+
+def group_exchange(contexts, sample_per_context=0):
+    """goss_gpu_group_exchange on several finished Contexts of one process: context j ends up holding range j
+    of the union.  Returns the range sizes."""
+    L = load()
+    n = len(contexts)
+    arr = (C.c_void_p * n)(*[c._h for c in contexts])
+    sizes = (C.c_uint64 * n)()
+    L.goss_gpu_group_exchange.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    _torch_ready()
+    contexts[0]._check(L.goss_gpu_group_exchange(arr, n, sample_per_context, sizes))
+    return [int(x) for x in sizes]
+
+
+def group_emit(contexts, estimate=0):
+    """goss_gpu_group_emit: every context's slices, the index files on contexts[0]"""
+    L = load()
+    n = len(contexts)
+    arr = (C.c_void_p * n)(*[c._h for c in contexts])
+    L.goss_gpu_group_emit.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64]
+    contexts[0]._check(L.goss_gpu_group_emit(arr, n, estimate))
 
 
 class Context:

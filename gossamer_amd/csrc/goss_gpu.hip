@@ -2680,6 +2680,233 @@ int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_by
     });
 }
 
+// ---- several contexts in one process (one per GPU): the exchange and the emission of gossamer_amd/dist.py
+// ---- without a process group -- device-to-device copies instead of collectives ---------------------------
+
+extern "C++" {
+namespace {
+
+template <class K>
+void group_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, uint32_t sample)
+{
+    const uint64_t ksz = sizeof(K);
+    // 1. splitters: quantiles of a pooled sample of every context's sorted distinct keys
+    std::vector<K> pool;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        goss_gpu_ctx* c = ctxs[i];
+        const uint64_t m = c->M;
+        if (m == 0) continue;
+        HIP_TRY(hipSetDevice(c->device));
+        const uint64_t take = std::min<uint64_t>(m, sample);
+        const uint64_t stride = m / take;
+        std::vector<K> h(take);
+        HIP_TRY(hipMemcpy2DAsync(h.data(), ksz, (const uint8_t*)c->res_keys + (stride / 2) * ksz, stride * ksz, ksz, take,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        pool.insert(pool.end(), h.begin(), h.end());
+    }
+    std::sort(pool.begin(), pool.end(), [](const K& a, const K& b) { return a < b; });
+    std::vector<K> split(n > 1 ? n - 1 : 0);
+    for (uint32_t p = 1; p < n; ++p)
+        split[p - 1] = pool.empty() ? K{} : pool[std::min<uint64_t>(pool.size() - 1, (uint64_t)p * pool.size() / n)];
+    // 2. where every context's run is cut
+    std::vector<std::vector<uint64_t>> cut(n, std::vector<uint64_t>(n + 1, 0));
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        goss_gpu_ctx* c = ctxs[i];
+        cut[i][n] = c->M;
+        if (n == 1 || c->M == 0) { for (uint32_t p = 1; p < n; ++p) cut[i][p] = 0; if (c->M == 0) continue; }
+        if (n == 1) continue;
+        HIP_TRY(hipSetDevice(c->device));
+        uint64_t mark = c->arena.mark();
+        K* dq = (K*)c->arena.temp((n - 1) * ksz);
+        uint64_t* dout = (uint64_t*)c->arena.temp((n - 1) * 8);
+        HIP_TRY(hipMemcpyAsync(dq, split.data(), (n - 1) * ksz, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lower_bound_keys_kernel<K>), dim3((n - 1 + 63) / 64), dim3(64), 0, c->stream,
+                           (const K*)c->res_keys, c->M, (const K*)dq, n - 1, dout);
+        HIP_TRY(hipMemcpyAsync(&cut[i][1], dout, (n - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->arena.release(mark);
+    }
+    // 3. range j of every run -> buffers on context j's device (outside the arenas: the arenas are reset below)
+    struct Inbox { uint8_t* keys = nullptr; uint32_t* counts = nullptr; std::vector<uint64_t> off; };
+    std::vector<Inbox> inbox(n);
+    auto free_all = [&]() {
+        for (uint32_t j = 0; j < n; ++j)
+        {
+            (void)hipSetDevice(ctxs[j]->device);
+            if (inbox[j].keys) (void)hipFree(inbox[j].keys);
+            if (inbox[j].counts) (void)hipFree(inbox[j].counts);
+        }
+    };
+    try
+    {
+        for (uint32_t j = 0; j < n; ++j)
+        {
+            goss_gpu_ctx* d = ctxs[j];
+            Inbox& in = inbox[j];
+            in.off.assign(n + 1, 0);
+            for (uint32_t i = 0; i < n; ++i) in.off[i + 1] = in.off[i] + (cut[i][j + 1] - cut[i][j]);
+            const uint64_t tot = in.off[n];
+            if (tot == 0) continue;
+            HIP_TRY(hipSetDevice(d->device));
+            HIP_TRY(hipMalloc((void**)&in.keys, tot * ksz));
+            HIP_TRY(hipMalloc((void**)&in.counts, tot * 4));
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const uint64_t cnt = cut[i][j + 1] - cut[i][j];
+                if (!cnt) continue;
+                goss_gpu_ctx* s = ctxs[i];
+                HIP_TRY(hipMemcpyPeerAsync(in.keys + in.off[i] * ksz, d->device, (const uint8_t*)s->res_keys + cut[i][j] * ksz, s->device,
+                                           cnt * ksz, d->stream));
+                HIP_TRY(hipMemcpyPeerAsync(in.counts + in.off[i], d->device, s->res_counts + cut[i][j], s->device, cnt * 4, d->stream));
+            }
+        }
+        for (uint32_t j = 0; j < n; ++j)
+        {
+            HIP_TRY(hipSetDevice(ctxs[j]->device));
+            HIP_TRY(hipStreamSynchronize(ctxs[j]->stream));
+        }
+        // 4. every context merges what it received (one host thread per device: the merges run side by side)
+        std::vector<int> status(n, GOSS_OK);
+        std::vector<std::thread> pool_t;
+        for (uint32_t j = 0; j < n; ++j)
+            pool_t.emplace_back([&, j]() {
+                goss_gpu_ctx* d = ctxs[j];
+                const uint64_t windows = d->windows, keys_total = d->keys_total;
+                int rc = goss_gpu_reset(d);
+                for (uint32_t i = 0; i < n && rc == GOSS_OK; ++i)
+                {
+                    const uint64_t cnt = inbox[j].off[i + 1] - inbox[j].off[i];
+                    if (cnt) rc = goss_gpu_push_run_device(d, inbox[j].keys + inbox[j].off[i] * ksz, inbox[j].counts + inbox[j].off[i], cnt);
+                }
+                d->windows = windows; d->keys_total = keys_total;
+                goss_gpu_counts cts;
+                if (rc == GOSS_OK) rc = goss_gpu_finish(d, &cts);
+                status[j] = rc;
+            });
+        for (auto& t : pool_t) t.join();
+        for (uint32_t j = 0; j < n; ++j)
+            if (status[j] != GOSS_OK) throw StatusError{status[j], "merging the received ranges: " + ctxs[j]->last_error};
+    }
+    catch (...)
+    {
+        free_all();
+        throw;
+    }
+    free_all();
+}
+
+}  // namespace
+}  // extern "C++"
+
+int goss_gpu_group_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, uint32_t sample_per_context, uint64_t* range_sizes)
+{
+    if (!ctxs || n == 0 || n > 64) return GOSS_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i) if (!ctxs[i]) return GOSS_ERR_INVALID_ARG;
+    goss_gpu_ctx* c0 = ctxs[0];
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        goss_gpu_ctx* c = ctxs[i];
+        if (c->k != c0->k || c->mode != c0->mode) { c0->last_error = "group: contexts of different k or mode"; return GOSS_ERR_INVALID_ARG; }
+        if (!c->finished || c->emitted) { c0->last_error = "group exchange needs every context finished and not emitted"; return GOSS_ERR_STATE; }
+        for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == c) { c0->last_error = "group: the same context twice"; return GOSS_ERR_INVALID_ARG; }
+        if (!c->res_big.empty())
+        {
+            c0->last_error = "group exchange: a multiplicity of 2^32 - 1 or more (exact counts do not travel between contexts)";
+            return GOSS_ERR_COUNT_OVERFLOW;
+        }
+    }
+    int rc = guarded(c0, [&]() {
+        const uint32_t sample = sample_per_context ? sample_per_context : 1024u;
+        if (c0->words == 1) group_exchange<Key1>(ctxs, n, sample); else group_exchange<Key2>(ctxs, n, sample);
+    });
+    if (rc == GOSS_OK && range_sizes) for (uint32_t i = 0; i < n; ++i) range_sizes[i] = ctxs[i]->M;
+    return rc;
+}
+
+int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate)
+{
+    if (!ctxs || n == 0 || n > 64) return GOSS_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i) if (!ctxs[i]) return GOSS_ERR_INVALID_ARG;
+    goss_gpu_ctx* c0 = ctxs[0];
+    for (uint32_t i = 0; i < n; ++i)
+        if (ctxs[i]->k != c0->k || ctxs[i]->mode != c0->mode) { c0->last_error = "group: contexts of different k or mode"; return GOSS_ERR_INVALID_ARG; }
+    uint64_t total = 0;
+    std::vector<uint64_t> first(n);
+    for (uint32_t i = 0; i < n; ++i) { first[i] = total; total += ctxs[i]->M; }
+    // every context's own span, side by side
+    {
+        std::vector<int> status(n, GOSS_OK);
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < n; ++i)
+            pool.emplace_back([&, i]() { status[i] = goss_gpu_emit_part(ctxs[i], first[i], total, estimate); });
+        for (auto& t : pool) t.join();
+        for (uint32_t i = 0; i < n; ++i)
+            if (status[i] != GOSS_OK) { if (i) c0->last_error = ctxs[i]->last_error; return status[i]; }
+    }
+    // the compact parts -> context 0
+    uint8_t* d_high = nullptr;
+    int rc = guarded(c0, [&]() {
+        std::vector<uint8_t> big;
+        std::vector<uint64_t> hist;
+        uint32_t high_bytes = 0;
+        std::vector<std::pair<const OutFile*, goss_gpu_ctx*>> highs;
+        uint64_t high_total = 0;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            goss_gpu_ctx* c = ctxs[i];
+            HIP_TRY(hipSetDevice(c->device));
+            for (const OutFile& f : c->files)
+            {
+                if (f.suffix == ".part.high32" || f.suffix == ".part.high64")
+                {
+                    const uint32_t hb = f.suffix == ".part.high32" ? 4u : 8u;
+                    if (high_bytes && hb != high_bytes) throw StatusError{GOSS_ERR_STATE, "group emit: parts of different width"};
+                    high_bytes = hb;
+                    highs.push_back({&f, c});
+                    high_total += f.size;
+                }
+                else if (f.suffix == ".part.big" || f.suffix == ".part.hist")
+                {
+                    std::vector<uint8_t> h(f.size);
+                    if (f.size)
+                    {
+                        if (f.dev)
+                        {
+                            HIP_TRY(hipMemcpyAsync(h.data(), f.dev, f.size, hipMemcpyDeviceToHost, c->stream));
+                            HIP_TRY(hipStreamSynchronize(c->stream));
+                        }
+                        else std::memcpy(h.data(), f.host.data(), f.size);
+                    }
+                    if (f.suffix == ".part.big") big.insert(big.end(), h.begin(), h.end());
+                    else { const size_t o = hist.size(); hist.resize(o + f.size / 8); if (f.size) std::memcpy(hist.data() + o, h.data(), f.size); }
+                }
+            }
+        }
+        if (highs.size() != n) throw StatusError{GOSS_ERR_STATE, "group emit: a context without its high part"};
+        HIP_TRY(hipSetDevice(c0->device));
+        if (high_total)
+        {
+            HIP_TRY(hipMalloc((void**)&d_high, high_total));
+            uint64_t at = 0;
+            for (auto& hp : highs)
+            {
+                if (hp.first->size)
+                    HIP_TRY(hipMemcpyPeerAsync(d_high + at, c0->device, hp.first->dev, hp.second->device, hp.first->size, c0->stream));
+                at += hp.first->size;
+            }
+            HIP_TRY(hipStreamSynchronize(c0->stream));
+        }
+        const int arc = goss_gpu_emit_assemble(c0, d_high, high_bytes ? high_bytes : 4u, total, estimate, big.empty() ? nullptr : big.data(),
+                                               big.size() / 16, hist.empty() ? nullptr : hist.data(), hist.size() / 2);
+        if (arc != GOSS_OK) throw StatusError{arc, c0->last_error};
+    });
+    if (d_high) { (void)hipSetDevice(c0->device); (void)hipFree(d_high); }
+    return rc;
+}
+
 int goss_gpu_file_device(goss_gpu_ctx* c, uint32_t i, const void** d_ptr)
 {
     if (!c || !d_ptr || i >= c->files.size()) return GOSS_ERR_INVALID_ARG;

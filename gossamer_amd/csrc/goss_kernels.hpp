@@ -1875,6 +1875,23 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     }
 }
 
+// out[q] = first index of the sorted array whose key is >= query[q] (one thread per query).
+template <class K>
+__global__ void lower_bound_keys_kernel(const K* __restrict__ keys, uint64_t n, const K* __restrict__ query, uint32_t nq,
+                                        uint64_t* __restrict__ out)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const K x = query[q];
+    uint64_t a = 0, b = n;
+    while (a < b)
+    {
+        const uint64_t mid = a + ((b - a) >> 1);
+        if (keys[mid] < x) a = mid + 1; else b = mid;
+    }
+    out[q] = a;
+}
+
 // Segment bounds of the sub-region layout: segment s holds cursors[s] keys from start[s].
 __global__ void sub_bounds_kernel(const SubTable* __restrict__ sub, const unsigned long long* __restrict__ cursors,
                                   uint64_t* __restrict__ seg_beg, uint64_t* __restrict__ seg_end)

@@ -313,6 +313,27 @@ int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, 
 int goss_gpu_emit_part(goss_gpu_ctx* ctx, uint64_t first_index, uint64_t total, uint64_t estimate);
 int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_high, uint32_t high_bytes, uint64_t total,
                            uint64_t estimate, const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist);
+
+/*
+ * Several contexts in ONE process, one per GPU (what `goss build-kmer-set --devices 0,1,..` drives; the
+ * process-per-GPU form of the same steps is gossamer_amd/dist.py over RCCL).  No reference counterpart.
+ *
+ * goss_gpu_group_exchange: every context has counted its share of the input and is finished (not emitted).
+ * Splitters are quantiles of a pooled sample (sample_per_context keys of every result, 0 = 1024); range j
+ * of every context's result is copied device to device into context j, which merges what it received:
+ * afterwards context j holds range j of the union (sorted, distinct, counts added), finished, and
+ * range_sizes[j] (may be NULL) its number of keys.  windows / keys of a context keep describing the input it
+ * counted.  A multiplicity of 2^32 - 1 or more in any context: GOSS_ERR_COUNT_OVERFLOW (exact counts do
+ * not travel).  The received ranges pass through device memory outside the arenas (12 or 20 bytes per key).
+ *
+ * goss_gpu_group_emit: goss_gpu_emit_part on every context (range order = array order), the compact parts
+ * copied to contexts[0], goss_gpu_emit_assemble there.  Afterwards contexts[0] lists every file of the
+ * object -- its own slices of the low-bits columns / "-counts.ord0" plus the assembled files -- and every
+ * other context its slices (same suffixes), which belong behind those of the contexts before it; the
+ * ".part.*" files are transport only.  estimate as in goss_gpu_emit_part.
+ */
+int goss_gpu_group_exchange(goss_gpu_ctx* const* contexts, uint32_t n, uint32_t sample_per_context, uint64_t* range_sizes);
+int goss_gpu_group_emit(goss_gpu_ctx* const* contexts, uint32_t n, uint64_t estimate);
 /* Device address of file i's image (NULL when the file was built on the host): for moving slices
  * between GPUs without a host copy.  Valid until the next emit, reset, push or destroy. */
 int goss_gpu_file_device(goss_gpu_ctx* ctx, uint32_t i, const void** d_ptr);
