@@ -363,6 +363,15 @@ struct GpuCtx {
 // them, so the copies into the page cache run on several cores while the next pieces arrive.
 void writeObjectFiles(goss_gpu_ctx* h, const std::string& out)
 {
+    writeObjectFiles(std::vector<goss_gpu_ctx*>{h}, out);
+}
+
+// The same for a group of contexts after goss_gpu_group_emit: context 0 lists every file of the object; the
+// low-bits column files and "-counts.ord0" are slices -- context j's bytes follow those of the contexts
+// before it; ".part.*" files are transport between the contexts and are not written.
+void writeObjectFiles(const std::vector<goss_gpu_ctx*>& hs, const std::string& out)
+{
+    goss_gpu_ctx* h = hs.at(0);
     auto check = [&](int rc, const char* what) {
         if (rc == GOSS_OK) return;
         std::string msg = std::string(what) + ": " + goss_gpu_strerror(rc);
@@ -420,27 +429,56 @@ void writeObjectFiles(goss_gpu_ctx* h, const std::string& out)
     };
     try
     {
-        uint32_t nfiles = 0;
-        check(goss_gpu_file_count(h, &nfiles), "listing output files");
-        for (uint32_t i = 0; i < nfiles; ++i)
+        auto isSlice = [](const std::string& n) {
+            return (n.find(".low-bits") != std::string::npos && n.find(".ord") == std::string::npos) || n == "-counts.ord0";
+        };
+        auto listFiles = [&](goss_gpu_ctx* c) {
+            std::vector<std::pair<std::string, uint64_t>> v;
+            uint32_t n = 0;
+            check(goss_gpu_file_count(c, &n), "listing output files");
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                char suffix[256]; uint64_t size = 0;
+                check(goss_gpu_file_info(c, i, suffix, sizeof suffix, &size), "listing output files");
+                v.emplace_back(suffix, size);
+            }
+            return v;
+        };
+        std::vector<std::vector<std::pair<std::string, uint64_t>>> lists;
+        for (goss_gpu_ctx* c : hs) lists.push_back(listFiles(c));
+        for (uint32_t i = 0; i < lists[0].size(); ++i)
         {
-            char suffix[256]; uint64_t size = 0;
-            check(goss_gpu_file_info(h, i, suffix, sizeof suffix, &size), "listing output files");
+            const std::string& suffix = lists[0][i].first;
+            if (suffix.compare(0, 6, ".part.") == 0) continue;
             int fd = ::open((out + suffix).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
             if (fd < 0) throw Error::Write(out);
             fds.push_back(fd);
-            for (uint64_t off = 0; off < size; off += kPiece)
+            uint64_t base = 0;
+            for (size_t j = 0; j < hs.size(); ++j)
             {
-                const size_t n = (size_t)std::min<uint64_t>(kPiece, size - off);
-                int b;
+                uint32_t idx = i;
+                if (j > 0)
                 {
-                    std::unique_lock<std::mutex> lk(m);
-                    cvFree.wait(lk, [&] { return !freeBufs.empty(); });
-                    b = freeBufs.back(); freeBufs.pop_back();
+                    if (!isSlice(suffix)) break;
+                    idx = ~0u;
+                    for (uint32_t q = 0; q < lists[j].size(); ++q) if (lists[j][q].first == suffix) idx = q;
+                    if (idx == ~0u) throw Error::General("a context of the group lacks its slice of " + suffix + "\n");
                 }
-                check(goss_gpu_file_read(h, i, off, bufs[b], n), "reading device file");
-                { std::lock_guard<std::mutex> lk(m); jobs.push_back(Job{fd, off, n, b}); }
-                cvJob.notify_one();
+                const uint64_t size = lists[j][idx].second;
+                for (uint64_t off = 0; off < size; off += kPiece)
+                {
+                    const size_t n = (size_t)std::min<uint64_t>(kPiece, size - off);
+                    int b;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cvFree.wait(lk, [&] { return !freeBufs.empty(); });
+                        b = freeBufs.back(); freeBufs.pop_back();
+                    }
+                    check(goss_gpu_file_read(hs[j], idx, off, bufs[b], n), "reading device file");
+                    { std::lock_guard<std::mutex> lk(m); jobs.push_back(Job{fd, base + off, n, b}); }
+                    cvJob.notify_one();
+                }
+                base += size;
             }
         }
     }
@@ -471,8 +509,13 @@ struct HostAlloc {                       // how the chunk buffers are obtained (
     std::function<void(void*)> release;
 };
 
+// pushOwned (optional): the consumer keeps the buffer until it calls `release` -- several devices then copy
+// from several buffers at once; without it `push` returns when the bytes are on their way.
+typedef std::function<void(const char*, size_t, std::function<void()>)> OwnedPush;
+
 uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t chunkBytes,
-                            const std::function<void(const char*, size_t)>& push, const HostAlloc& ha)
+                            const std::function<void(const char*, size_t)>& push, const HostAlloc& ha,
+                            const OwnedPush* pushOwned = nullptr)
 {
     if (threads < 2 || name == "-" || endsWith(name, ".gz")) return ~0ULL;
     int fd = ::open(name.c_str(), O_RDONLY);
@@ -515,6 +558,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         }
     });
     struct JoinAlloc { std::thread& t; ~JoinAlloc() { if (t.joinable()) t.join(); } } joinAlloc{allocator};
+    // buffers handed to pushOwned and not yet released: nothing here may be torn down before they are back
+    size_t lent = 0;
+    struct WaitLent { std::mutex& m; std::condition_variable& cv; size_t& lent;
+                      ~WaitLent() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return lent == 0; }); } } waitLent{m, cv, lent};
 
     auto worker = [&]() {
         for (;;)
@@ -586,7 +633,17 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         };
         if (r.start != expected || r.len > bufCap) { giveBack(); serialRest = true; break; }
         if (!r.ok) throw Error::Parse(name, r.fail.what + num(baseLine + r.fail.line - 1));
-        if (r.len) push(r.buf, r.len);
+        if (r.len && pushOwned)
+        {
+            char* b = r.buf;
+            r.buf = nullptr;
+            { std::lock_guard<std::mutex> lk(m); ++lent; }
+            (*pushOwned)(b, r.len, [&m, &cv, &freeBufs, &lent, b]() {
+                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); --lent; }
+                cv.notify_all();
+            });
+        }
+        else if (r.len) push(r.buf, r.len);
         giveBack();
         reads += r.reads;
         baseLine += r.lines;
@@ -644,7 +701,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         {
             const uint64_t keyBytes = (2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) <= 62) ? 8 : 16;
             const uint64_t perBase = (mode == GOSS_MODE_GRAPH ? 2 : 1) * (2 * keyBytes + 2) + 1;
-            budget = bases * perBase + (6ULL << 30);      // the library clamps to the free memory
+            // (with --devices every context sees its share of the input)
+            budget = bases / std::max<size_t>(1, cxt.devices.size()) * perBase + (6ULL << 30);      // the library clamps to the free memory
         }
         // Mapping HBM costs up to 30 ms/GB when the driver has to clear pages a previous process
         // left behind (measured: 264 GB in 7.7 s, or 0.2 s when clean), while counting in
@@ -654,13 +712,94 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         const uint64_t kDefaultCap = (wide ? 96ULL : 48ULL) << 30;
         if (budget == 0 || budget > kDefaultCap) budget = kDefaultCap;
     }
-    GpuCtx g;
-    g.check(goss_gpu_create(&g.h, cxt.device, (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
-    // a budget the user did not ask for is a starting size: inputs with little duplication (a
-    // genome in FASTA: every k-mer once) need room for runs that do not shrink
-    if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
-    // the arena is mapped while the first buffers are read and parsed
-    g.check(goss_gpu_prepare(g.h), "mapping HBM");
+    // One context per device.  With several (--devices) every context has a feeder thread with a short queue:
+    // batches go round the devices, each device copies and counts its own while the others do the same.
+    std::vector<int> devs = cxt.devices.empty() ? std::vector<int>{cxt.device} : cxt.devices;
+    const size_t P = devs.size();
+    std::vector<std::unique_ptr<GpuCtx>> gs;
+    for (size_t d = 0; d < P; ++d)
+    {
+        gs.emplace_back(new GpuCtx);
+        GpuCtx& g = *gs.back();
+        g.check(goss_gpu_create(&g.h, devs[d], (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
+        // a budget the user did not ask for is a starting size: inputs with little duplication (a
+        // genome in FASTA: every k-mer once) need room for runs that do not shrink
+        if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
+        // the arena is mapped while the first buffers are read and parsed
+        g.check(goss_gpu_prepare(g.h), "mapping HBM");
+    }
+    GpuCtx& g = *gs[0];
+    struct Feeder {
+        struct Job { const char* p; size_t n; std::function<void()> done; };
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<Job> q;
+        bool stop = false, busy = false;
+        std::string error;
+        std::thread t;
+    };
+    std::vector<std::unique_ptr<Feeder>> feeders;
+    std::atomic<bool> feedFailed{false};
+    if (P > 1)
+        for (size_t d = 0; d < P; ++d)
+        {
+            feeders.emplace_back(new Feeder);
+            Feeder* f = feeders.back().get();
+            goss_gpu_ctx* h = gs[d]->h;
+            f->t = std::thread([f, h, &feedFailed]() {
+                for (;;)
+                {
+                    Feeder::Job j;
+                    {
+                        std::unique_lock<std::mutex> lk(f->m);
+                        f->cv.wait(lk, [&] { return f->stop || !f->q.empty(); });
+                        if (f->q.empty()) return;
+                        j = std::move(f->q.front()); f->q.pop_front();
+                        f->busy = true;
+                    }
+                    if (f->error.empty())
+                    {
+                        const int rc = goss_gpu_push_bases_host(h, j.p, j.n);
+                        if (rc != GOSS_OK)
+                        {
+                            std::lock_guard<std::mutex> lk(f->m);
+                            f->error = std::string("counting k-mers: ") + goss_gpu_strerror(rc) + " (" + goss_gpu_last_error(h) + ")";
+                            feedFailed.store(true);
+                        }
+                    }
+                    if (j.done) j.done();
+                    { std::lock_guard<std::mutex> lk(f->m); f->busy = false; }
+                    f->cv.notify_all();
+                }
+            });
+        }
+    struct StopFeeders { std::vector<std::unique_ptr<Feeder>>& fs;
+                         ~StopFeeders() { for (auto& f : fs) { { std::lock_guard<std::mutex> lk(f->m); f->stop = true; } f->cv.notify_all(); if (f->t.joinable()) f->t.join(); } } } stopFeeders{feeders};
+    size_t nextDev = 0;
+    auto feedError = [&]() {
+        for (auto& f : feeders) { std::lock_guard<std::mutex> lk(f->m); if (!f->error.empty()) throw Error::General(f->error + "\n"); }
+    };
+    // hand a batch to the next device; `done` runs when the device has taken the bytes (wait = until then)
+    auto feed = [&](const char* p, size_t n, std::function<void()> done, bool wait) {
+        if (feedFailed.load()) { if (done) done(); feedError(); }
+        Feeder* f = feeders[nextDev].get();
+        nextDev = (nextDev + 1) % P;
+        {
+            std::unique_lock<std::mutex> lk(f->m);
+            f->cv.wait(lk, [&] { return f->q.size() < 2; });
+            f->q.push_back(Feeder::Job{p, n, std::move(done)});
+        }
+        f->cv.notify_all();
+        if (wait)
+        {
+            std::unique_lock<std::mutex> lk(f->m);
+            f->cv.wait(lk, [&] { return f->q.empty() && !f->busy; });
+        }
+    };
+    auto drainFeeders = [&]() {
+        for (auto& f : feeders) { std::unique_lock<std::mutex> lk(f->m); f->cv.wait(lk, [&] { return f->q.empty() && !f->busy; }); }
+        feedError();
+    };
 
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));
@@ -670,9 +809,11 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     double pushSeconds = 0;
     auto timedPush = [&](const char* p, size_t n) {
         auto a = std::chrono::steady_clock::now();
-        g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
+        if (P > 1) feed(p, n, nullptr, true);
+        else g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
         pushSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
     };
+    const OwnedPush ownedPush = [&](const char* p, size_t n, std::function<void()> release) { feed(p, n, std::move(release), false); };
     auto flush = [&]() {
         if (batch.empty()) return;
         timedPush(batch.data(), batch.size());
@@ -744,30 +885,64 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         if (gzFiles.size() > 1 && threads > 1 && endsWith(f, ".gz")) continue;      // done above
         log(info, "parsing sequences from " + f);
         flush();
-        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned);
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned,
+                                        P > 1 ? &ownedPush : nullptr);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
     if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
     flush();
+    if (P > 1) drainFeeders();
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "
         << pushSeconds << "s)"; log(info, o.str()); }
+    for (size_t d = 0; d < P; ++d)
     {
         uint64_t ms = 0, bytes = 0;
-        goss_gpu_stat(g.h, "arena_ms", &ms); goss_gpu_stat(g.h, "arena_bytes", &bytes);
-        std::ostringstream o; o << "HBM arena: " << (bytes >> 30) << " GB mapped in " << ms / 1000.0 << "s";
+        goss_gpu_stat(gs[d]->h, "arena_ms", &ms); goss_gpu_stat(gs[d]->h, "arena_bytes", &bytes);
+        std::ostringstream o; o << "HBM arena";
+        if (P > 1) o << " of device " << devs[d];
+        o << ": " << (bytes >> 30) << " GB mapped in " << ms / 1000.0 << "s";
         log(info, o.str());
     }
 
     log(info, "sorting the hashtable...");
     goss_gpu_counts counts;
-    g.check(goss_gpu_finish(g.h, &counts), "sorting");
+    if (P == 1) g.check(goss_gpu_finish(g.h, &counts), "sorting");
+    else
+    {
+        // every device finishes its own count (side by side), then the ranges are exchanged and merged
+        std::vector<goss_gpu_counts> each(P);
+        std::vector<int> rcs(P, GOSS_OK);
+        std::vector<std::thread> pool;
+        for (size_t d = 0; d < P; ++d) pool.emplace_back([&, d]() { rcs[d] = goss_gpu_finish(gs[d]->h, &each[d]); });
+        for (auto& t : pool) t.join();
+        for (size_t d = 0; d < P; ++d) gs[d]->check(rcs[d], "sorting");
+        counts = each[0];
+        for (size_t d = 1; d < P; ++d) { counts.windows += each[d].windows; counts.keys += each[d].keys; }
+        { std::ostringstream o; o << "counted on " << P << " devices at " << secs() << "s"; log(info, o.str()); }
+        std::vector<goss_gpu_ctx*> hs;
+        for (auto& x : gs) hs.push_back(x->h);
+        std::vector<uint64_t> sizes(P);
+        g.check(goss_gpu_group_exchange(hs.data(), (uint32_t)P, 0, sizes.data()), "exchanging the key ranges");
+        counts.distinct = 0;
+        for (uint64_t v : sizes) counts.distinct += v;
+    }
     log(info, "sorting done.");
     { std::ostringstream o; o << "merged at " << secs() << "s"; log(info, o.str()); }
     log(info, "writing out graph.");
-    g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
-    writeObjectFiles(g.h, out);
+    if (P == 1)
+    {
+        g.check(goss_gpu_emit(g.h), "building the on-disk arrays");
+        writeObjectFiles(g.h, out);
+    }
+    else
+    {
+        std::vector<goss_gpu_ctx*> hs;
+        for (auto& x : gs) hs.push_back(x->h);
+        g.check(goss_gpu_group_emit(hs.data(), (uint32_t)P, 0), "building the on-disk arrays");
+        writeObjectFiles(hs, out);
+    }
     { std::ostringstream o; o << "written at " << secs() << "s"; log(info, o.str()); }
     stats.reads = reads; stats.windows = counts.windows; stats.keys = counts.keys; stats.distinct = counts.distinct;
     stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -825,6 +1000,7 @@ const OptDef kKmerSetSpecific[] = {
 // not in the reference: where and how much HBM to use
 const OptDef kGpuSpecific[] = {
     {"device", "", kU64, "HIP device ordinal (default 0)"},
+    {"devices", "", kString, "build commands: comma-separated HIP device ordinals to count on side by side (one context each)"},
     {"hbm-budget", "", kU64, "HBM budget in GB for keys and sort workspace (default: 80% of free HBM)"},
 };
 
@@ -1307,6 +1483,22 @@ int gossMain(int argc, char* argv[])
         uint64_t dev = 0, budgetGb = 0;
         if (chk.optionalU64("device", dev)) cxt.device = (int)dev;
         if (chk.optionalU64("hbm-budget", budgetGb)) cxt.hbmBudget = budgetGb << 30;
+        if (opts.count("devices"))
+        {
+            // "0,1,2,3": one context per listed device (an ordinal may appear twice: two contexts share that GPU)
+            const std::string& v = opts.str("devices");
+            size_t at = 0;
+            while (at <= v.size())
+            {
+                const size_t comma = std::min(v.find(',', at), v.size());
+                const std::string item = v.substr(at, comma - at);
+                if (item.empty() || item.find_first_not_of("0123456789") != std::string::npos || item.size() > 3)
+                    throw Error::Usage("--devices takes a comma-separated list of device ordinals, e.g. 0,1,2,3\n");
+                cxt.devices.push_back(atoi(item.c_str()));
+                at = comma + 1;
+            }
+            if (cxt.devices.size() > 64) throw Error::Usage("--devices: at most 64 devices\n");
+        }
         try
         {
             if (isKmerSet) { GossCmdBuildKmerSet cmd(K, S, N, T, outName, fastas, fastqs, lines); cmd(cxt); }

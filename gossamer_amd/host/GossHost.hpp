@@ -110,6 +110,7 @@ struct GossCmdContext {
     Logger& log;
     std::string cmdName;
     int device = 0;                 // HIP device ordinal
+    std::vector<int> devices = {};  // --devices a,b,..: the build commands count on all of them (one context each)
     uint64_t hbmBudget = 0;         // bytes; 0 = library default (80% of free HBM)
     size_t batchBytes = 256u << 20; // bases handed to the device per push
 };
@@ -251,6 +252,7 @@ namespace gosshost {
 // Writes every file image of the emitted object to "<out><suffix>" (the write half of the
 // reference's FileFactory for KmerSet::Builder / Graph::Builder::end()).
 void writeObjectFiles(goss_gpu_ctx* h, const std::string& out);
+void writeObjectFiles(const std::vector<goss_gpu_ctx*>& hs, const std::string& out);      // a group after goss_gpu_group_emit
 
 // App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);

@@ -80,3 +80,49 @@ def test_group_refuses_mixed_contexts():
             g.group_exchange([a, b])
         with pytest.raises(g.GossGpuError):
             g.group_exchange([a, a])
+
+
+def test_goss_devices_option(oracle, tmp_path):
+    """`goss build-kmer-set / build-graph --devices 0,0[,0]`: one context per listed device (here the same GPU
+    several times), batches dealt round the contexts by feeder threads, ranges exchanged, every context's slices
+    written behind one another -- files byte for byte the oracle's; FASTQ parsed in parallel chunks whose buffers
+    are handed over to the feeders (GOSS_PARSE_CHUNK makes the chunks small), plus FASTA and line input."""
+    import os
+    import random
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    goss = os.path.join(root, "gossamer_amd", "goss")
+    rng = random.Random(5)
+    genome = "".join(rng.choice("ACGT") for _ in range(40000))
+    reads = []
+    for _ in range(9000):
+        L = rng.randint(40, 150)
+        p = rng.randint(0, len(genome) - L)
+        reads.append(genome[p:p + L])
+    fq = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads[:8000]))
+    fa = "".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(reads[8000:8500]))
+    ln = "\n".join(reads[8500:]) + "\n"
+    (tmp_path / "a.fq").write_text(fq)
+    (tmp_path / "b.fa").write_text(fa)
+    (tmp_path / "c.txt").write_text(ln)
+    inputs = [(oracle.LINE, "c.txt", ln), (oracle.FASTA, "b.fa", fa), (oracle.FASTQ, "a.fq", fq)]
+    env = dict(os.environ, GOSS_PARSE_CHUNK="65536")
+    for cmd, k, obuild, base, devices in (("build-kmer-set", 25, oracle.build_kmer_set, "ks", "0,0"),
+                                          ("build-graph", 27, oracle.build_graph, "gr", "0,0,0"),
+                                          ("build-graph", 55, oracle.build_graph, "g55", "0,0")):
+        exp, nwin = obuild(inputs, k, out=base)
+        out = tmp_path / base
+        p = subprocess.run([goss, cmd, "-k", str(k), "-i", str(tmp_path / "a.fq"), "-I", str(tmp_path / "b.fa"),
+                            "--line-in", str(tmp_path / "c.txt"), "-O", str(out), "--hbm-budget", "1", "-T", "4", "-v",
+                            "--devices", devices],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        assert ("counted on %d devices" % len(devices.split(","))).encode() in p.stderr
+        assert ("k-mer windows: %d," % nwin).encode() in p.stderr
+        got = {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
+        assert sorted(got) == sorted(exp)
+        for name in exp:
+            assert got[name] == exp[name], name
+    p = subprocess.run([goss, "build-kmer-set", "-k", "25", "-i", str(tmp_path / "a.fq"), "-O", str(tmp_path / "x"), "--devices", "0,x"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode != 0 and b"--devices" in p.stderr
