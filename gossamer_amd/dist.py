@@ -32,6 +32,8 @@ orders its streams itself (include/goss_gpu.h, goss_gpu_push_run_device).
 import torch
 import torch.distributed as dist
 
+from .binding import MODE_GRAPH
+
 
 _SIGN = -(1 << 63)
 _MASK = (1 << 64) - 1
@@ -275,6 +277,11 @@ def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters=
     c = ctx.finish()
     words = c.key_words
     windows = c.windows
+    if ctx.mode == MODE_GRAPH and ctx.big_counts():
+        # the u32 count of such an edge is its value modulo 2^32 and the exact value lives beside the
+        # result in this context only: summing the ranges would be silently wrong
+        raise OverflowError("an edge occurred 2^32 - 1 times or more on this rank: exact 64-bit counts do not travel "
+                            "through the exchange (build on one GPU, or split the input differently)")
     if (key_bits > 62) != (words == 2):
         raise ValueError("key_bits = %d does not match the context's %d-word keys (2*len: len = k, or k+1 for graphs)" % (key_bits, words))
     keys, counts = result_views(ctx, words, device)
