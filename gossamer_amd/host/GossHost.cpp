@@ -608,13 +608,21 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     uint64_t reads = 0, baseLine = 1;
     size_t expected = 0;
     bool serialRest = false;
+    double waitSeconds = 0, pushSeconds = 0;         // GOSS_PARSE_STATS=1: where the in-order consumer spends its time
+    const bool stats = std::getenv("GOSS_PARSE_STATS") != nullptr;
+    struct Report { bool on; double& w; double& p; const std::string& n;
+                    ~Report() { if (on) std::fprintf(stderr, "goss: %s: consumer waited %.3f s for parsed chunks, %.3f s in pushes\n", n.c_str(), w, p); } }
+        report{stats, waitSeconds, pushSeconds, name};
+    auto now = [] { return std::chrono::steady_clock::now(); };
     for (size_t i = 0; i < nchunks && !serialRest; ++i)
     {
         ChunkResult r;
         {
+            const auto a = now();
             std::unique_lock<std::mutex> lk(m);
             cv.wait(lk, [&] { return res[i].done; });
             r = res[i];
+            waitSeconds += std::chrono::duration<double>(now() - a).count();
         }
         const size_t limit = std::min(size, (i + 1) * chunkBytes);
         if (r.start == (size_t)-1)
@@ -643,7 +651,12 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 cv.notify_all();
             });
         }
-        else if (r.len) push(r.buf, r.len);
+        else if (r.len)
+        {
+            const auto a = now();
+            push(r.buf, r.len);
+            pushSeconds += std::chrono::duration<double>(now() - a).count();
+        }
         giveBack();
         reads += r.reads;
         baseLine += r.lines;
