@@ -2,7 +2,7 @@
 # End-to-end wall-clock of the goss CLI (FASTQ on disk -> KmerSet files on disk), PCIe included.
 N=${1:-20000000}
 shift
-D=/tmp/goss_e2e; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 ls -la $D/reads.fq
 cat $D/reads.fq > /dev/null      # page cache warm: measure parsing + PCIe + GPU, not the disk

@@ -3,7 +3,7 @@
 # usage: tools/e2e_budgets.sh <reads> <budgetGB>...
 N=${1:-100000000}
 shift
-D=/tmp/goss_e2e; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 ls -la $D/reads.fq
 cat $D/reads.fq > /dev/null

@@ -1,7 +1,7 @@
 #!/bin/bash
 # C2 end to end: 100 M x 150 bp reads as a FASTQ file in /dev/shm -> KmerSet files, with the consumer's time split.
 N=${1:-100000000}
-D=/dev/shm/goss_e2e; mkdir -p $D
+D=$(mktemp -d /dev/shm/goss_e2e.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 ls -la $D/reads.fq
 TIMEFORMAT="wall %R s  user %U s  sys %S s"

@@ -3,7 +3,7 @@
 # box can show): same files, wall-clock of both.  usage: tools/e2e_devices.sh [reads] [devices]
 N=${1:-20000000}
 DEV=${2:-0,0}
-D=/tmp/goss_e2e; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 cat $D/reads.fq > /dev/null
 TIMEFORMAT="wall %R s  user %U s  sys %S s"

@@ -2,7 +2,7 @@
 # End-to-end wall-clock of `goss build-kmer-set -I genome.fa` (multi-line FASTA, a few long records).
 # usage: tools/e2e_fasta.sh <megabases>
 MB=${1:-1000}
-D=/tmp/goss_e2e_fa; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e_fa.XXXXXX)
 python3 - <<PY
 import numpy as np
 rng = np.random.default_rng(1)

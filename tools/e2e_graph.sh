@@ -1,7 +1,7 @@
 #!/bin/bash
 # End to end: goss build-graph on a synthetic FASTQ, then lint-graph.  usage: tools/e2e_graph.sh <reads> <genome> <k>
 N=${1:-50000000}; G=${2:-100000000}; K=${3:-55}
-D=/tmp/goss_e2e_gr; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e_gr.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $G 1 $D/reads.fq
 ls -la $D/reads.fq
 TIMEFORMAT="wall %R s  user %U s  sys %S s"

@@ -2,7 +2,7 @@
 # Low-coverage regime: <reads> 150 bp reads of a <genome> bp genome through the goss CLI with the
 # default (growing) arena.  usage: tools/e2e_lowcov.sh <reads> <genome>
 N=${1:-60000000}; G=${2:-3000000000}
-D=/tmp/goss_e2e_lc; mkdir -p $D
+D=$(mktemp -d /tmp/goss_e2e_lc.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $G 1 $D/reads.fq
 ls -la $D/reads.fq
 TIMEFORMAT="wall %R s  user %U s  sys %S s"
