@@ -740,14 +740,83 @@ inline uint64_t birthday_estimate(uint64_t s, uint64_t d)
     return std::max<uint64_t>(d, (uint64_t)hi);
 }
 
+// Number of distinct keys of a population of `population` keys of which keys[0, avail) are a random part
+// (any prefix of a chunk: reads arrive in no particular order).  The birthday estimate above assumes
+// that every key is equally frequent; sequencing reads are not like that -- the k-mers of the genome occur
+// `coverage` times each, the k-mers that contain a base-calling error once -- and it then reports little more
+// than the genome (1e8 for C2 with 0.1 % errors, where 3.3e8 is right): the counting tables overflow and the
+// chunk is redone with more partition bits, several times.  So: the multiplicity SPECTRUM of a slice of
+// the key space.  The keys whose mixed bits are zero (all copies of a key or none) are sorted and the keys
+// seen exactly once / twice / three times counted (f1, f2, f3).  A key that occurs c times in the population
+// shows Poisson(c p) copies in the part (p = avail / population): the frequent component is fitted from
+// f2 and f3 (lambda = 3 f3 / f2, G = 2 f2 e^lambda / lambda^2), the singletons it does not explain are
+// population keys of multiplicity ~1 seen with probability p each.  Never less than the plain estimate.
+template <class K>
+uint64_t spectrum_estimate(goss_gpu_ctx* c, const K* keys, uint64_t avail, double population)
+{
+    if (avail < 2) return avail;
+    const uint64_t scan = std::min<uint64_t>(avail, 1ULL << 30);
+    uint32_t q = 1;
+    while ((scan / q) > (3u << 20) && q < (1u << 16)) q <<= 1;          // 1.5 to 3 M keys survive
+    const uint64_t cap = scan / q + scan / q / 4 + (1u << 16);
+    uint64_t mark = c->arena.mark();
+    K* a = (K*)c->arena.temp(cap * sizeof(K));
+    K* b = (K*)c->arena.temp(cap * sizeof(K));
+    unsigned long long* ctr = (unsigned long long*)c->arena.temp(64);
+    HIP_TRY(hipMemsetAsync(ctr, 0, 64, c->stream));
+    const bool lb = c->lookback, mute = c->mute_timing;
+    c->mute_timing = true;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(slice_filter_kernel<K>), dim3((uint32_t)std::min<uint64_t>(2048, (scan + kTB - 1) / kTB)), dim3(kTB), 0, c->stream,
+                       keys, scan, q - 1, a, ctr, cap);
+    unsigned long long* h = (unsigned long long*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t sf = std::min<uint64_t>(h[0], cap);
+    uint64_t est = 0;
+    if (sf >= 2)
+    {
+        c->lookback = false;
+        const bool in_b = radix_sort<K, false>(c, a, b, nullptr, nullptr, sf, key_digits(c));
+        c->lookback = lb;
+        HIP_TRY(hipMemsetAsync(ctr, 0, 64, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spectrum_kernel<K>), dim3((uint32_t)std::min<uint64_t>(1024, (sf + kTB - 1) / kTB)), dim3(kTB), 0, c->stream,
+                           (const K*)(in_b ? b : a), sf, ctr);
+        HIP_TRY(hipMemcpyAsync(h, ctr, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const double d = (double)h[0], f1 = (double)h[1], f2 = (double)h[2], f3 = (double)h[3];
+        const double p = std::min(1.0, (double)scan / std::max(population, (double)scan));
+        const double scale_q = (double)q;
+        // plain estimate on the slice (equally frequent keys), scaled to the key space
+        const uint64_t plain = scan >= (uint64_t)population ? (uint64_t)(d * scale_q) : (uint64_t)((double)birthday_estimate(sf, (uint64_t)d) * scale_q);
+        double model = 0;
+        if (p >= 1.0) model = d;                                  // the whole population was looked at
+        else if (f2 >= 256.0 && f3 >= 64.0)
+        {
+            const double lambda = 3.0 * f3 / f2;
+            const double G = 2.0 * f2 * std::exp(lambda) / (lambda * lambda);
+            const double rare = std::max(0.0, f1 - G * lambda * std::exp(-lambda)) / p;
+            // (seen but fitted by neither: the keys seen four times and more are part of G already)
+            model = G + rare;
+        }
+        est = std::max<uint64_t>(plain, (uint64_t)(model * scale_q));
+        est = std::max<uint64_t>(est, (uint64_t)(d * scale_q));
+        if (plain == 0 && model == 0) est = 0;                    // no repeated key at all: unknown
+        if (c->debug)
+            std::fprintf(stderr, "libgossgpu: spectrum of 1/%u of the key space over %llu keys (p = %.4f): d %.0f f1 %.0f f2 %.0f f3 %.0f -> plain %llu, fitted %.0f, estimate %llu\n",
+                         q, (unsigned long long)scan, p, d, f1, f2, f3, (unsigned long long)plain, model * scale_q, (unsigned long long)est);
+    }
+    c->mute_timing = mute;
+    c->arena.release(mark);
+    return est;
+}
+
 template <class K>
 uint64_t estimate_distinct(goss_gpu_ctx* c, const K* keys, uint64_t n)
 {
-    const uint64_t s = std::min<uint64_t>(n, 4u << 20);
-    if (s < 2) return s;
-    const uint64_t d = count_distinct_sample<K>(c, keys, s);
-    if (s == n) return d;
-    return birthday_estimate(s, d);
+    if (n < 2) return n;
+    if (n <= (4u << 20)) return count_distinct_sample<K>(c, keys, n);
+    // a prefix of the chunk stands for the chunk: reads arrive in no particular order
+    return spectrum_estimate<K>(c, keys, std::min<uint64_t>(n, 256u << 20), (double)n);
 }
 
 // Partition ka on its top `segbits` bits (result back in ka or kb), count every segment in LDS.
@@ -1071,12 +1140,10 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (ns < (1u << 20)) return decline("mostly non-bases");
     lap("sample extracted");
     const bool exact = nslices == 1;                                   // the sample is the chunk
-    const uint64_t s4 = std::min<uint64_t>(ns, 4u << 20);
-    const uint64_t d_s = count_distinct_sample<K>(c, ka, s4);
-    const uint64_t m_est = birthday_estimate(s4, d_s);
-    lap("distinct keys estimated");
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
+    const uint64_t m_est = spectrum_estimate<K>(c, ka, ns, (double)n_exp);
+    lap("distinct keys estimated");
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
     // buffers sized from the estimated share of valid windows must hold what the sample promises
     {

@@ -103,6 +103,34 @@ def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
                     os.environ[n] = v
 
 
+def test_reads_with_sequencing_errors_need_no_retry(oracle):
+    """Reads with 1 % substituted bases: the k-mers of the genome occur ~30 times, the ~25 k-mers around every
+    error once -- 5 times more distinct keys than the genome has.  An estimate that takes all keys for equally
+    frequent (the birthday estimate on a sample) sees the genome only and sends the chunk through counting
+    tables that overflow; the spectrum estimate (singletons beyond what the frequent keys explain) must pick a
+    form that holds them at the first attempt.  Files against the oracle."""
+    import random
+    base = g.synth_reads_host(300000, 150, 1500000, seed=41).decode()
+    rng = random.Random(41)
+    out = []
+    for line in base.split("\n")[:-1]:
+        b = list(line)
+        for i in range(len(b)):
+            if rng.random() < 0.01:
+                b[i] = rng.choice("ACGT")
+        out.append("".join(b))
+    reads = ("\n".join(out) + "\n").encode()
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
+    exp = _suffix_map(exp, "ks")
+    import struct
+    M = struct.unpack("<8Q", exp[".kmers.header"])[7]
+    assert M > 4 * 1500000
+    c, got, st = _build(reads, 25)
+    assert c.windows == nwin and c.distinct == M
+    assert st["segment_retries"] == 0 and st["fused_overflows"] == 0, st
+    _same(got, exp)
+
+
 @pytest.mark.parametrize("k", [16, 31])
 def test_fused_path_other_k(oracle, k):
     """Shortest key width with a fused path worth taking (32 bits) and the longest one-word key (62 bits)."""
