@@ -1017,6 +1017,7 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
             HIP_TRY(hipStreamSynchronize(c->stream));
             ordered = hf[0] == 0;
             c->arena.release(m2);
+            if (c->debug) std::fprintf(stderr, "libgossgpu: canonical order of %llu keys by %u-bit groups: %s\n", (unsigned long long)m, sb, ordered ? "done" : "skewed, full sort");
             if (!ordered)
             {
                 // skewed bits: order everything by the remaining digits as well (the top bits are in place,

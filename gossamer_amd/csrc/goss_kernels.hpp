@@ -3690,8 +3690,8 @@ __global__ __launch_bounds__(kTB) void seg_merge_kernel(const K* __restrict__ ke
 // bits (segment s = [seg_off[s], seg_off[s+1])), at most kSortCap per segment.  One workgroup per
 // segment: pairs into registers, bucket sort through LDS on the 10 bits below the segment prefix (rank
 // by LDS atomic, scan, scatter, insertion sort of the ~1.5-pair buckets), coalesced write-back.  A
-// segment above kSortCap or a bucket above 24 pairs (skewed bits) raises *fallback: the host orders the
-// array by a full radix sort instead.  Used by canonicalize_run after two radix passes on the top 16 bits.
+// segment above kSortCap raises *fallback: the host orders the array by a full radix sort instead; a bucket
+// above 24 pairs (clustered keys) sends that segment through a bitonic network.  Used by canonicalize_run after two radix passes on the top 16 bits.
 constexpr int kSortCap = 4096;
 __global__ __launch_bounds__(kTB) void seg_sort_pairs_kernel(Key1* __restrict__ keys, uint32_t* __restrict__ vals,
                                                              const uint64_t* __restrict__ seg_off, uint32_t rem_bits,
@@ -3736,7 +3736,39 @@ __global__ __launch_bounds__(kTB) void seg_sort_pairs_kernel(Key1* __restrict__ 
         bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
         big |= bn[q] > 24;
     }
-    if (__syncthreads_or(big)) { if (tid == 0) atomicOr(fallback, 1u); return; }
+    if (__syncthreads_or(big))
+    {
+        // clustered keys (the variants of a k-mer that differ in their last bases share a bin): this segment is
+        // ordered by a bitonic network over its pairs instead -- a local matter, the other segments keep the fast way
+        uint32_t nsort = 64;
+        while (nsort < n) nsort <<= 1;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j)
+        {
+            const uint32_t i = tid + j * kTB;
+            if (i < nsort) { tab[i] = ck[j]; cnt[i] = cc[j]; }        // beyond n: all ones, sorts last
+        }
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += kTB)
+                {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t p = i + j;
+                    const bool up = (i & k2) == 0;
+                    const unsigned long long a = tab[i], c2 = tab[p];
+                    if ((a > c2) == up)
+                    {
+                        tab[i] = c2; tab[p] = a;
+                        const uint32_t ca = cnt[i]; cnt[i] = cnt[p]; cnt[p] = ca;
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = tid; i < n; i += kTB) { keys[b + i].lo = tab[i]; vals[b + i] = cnt[i]; }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
         if (tid + j * kTB < n)
