@@ -963,30 +963,24 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
 // A run counted in strand-representative space (extract1_part_kernel, MODE 0) -> the run the rest of
 // the library expects: every key replaced by gossamer's canonical form (the strand with the smaller
 // FNV-1a hash), then (key,count) pairs put back in key order.  The map is a bijection between the
-// two choices of representative, so counts carry over and no two entries collide.  `scratch` (the
-// chunk's first key buffer, dead by now) holds the sort's ping-pong.
+// two choices of representative, so counts carry over and no two entries collide.
 template <class K>
-void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slots)
+void canonicalize_run(goss_gpu_ctx* c, Run& r)
 {
     const uint64_t m = r.m;
     r.rep = false;
     if (m == 0) return;
     PhaseTimer t(c, GOSS_T_ORDER, m);
-    const uint64_t need = 2 * m * sizeof(K) + 2 * m * 4 + 64;
+    // the run's own storage is one side of the sort's ping-pong, a temporary copy the other
+    const uint64_t need = m * sizeof(K) + m * 4 + 512;
+    if (c->arena.avail() < need + (256ULL << 20)) grow_arena(c, need + (256ULL << 20));      // (rebases r: it lives in c->runs)
     uint64_t mark = c->arena.mark();
-    uint8_t* p = (uint8_t*)scratch;
-    if (scratch_slots * sizeof(K) < need)
-    {
-        if (c->arena.avail() < need + (256ULL << 20)) grow_arena(c, need + (256ULL << 20));
-        p = (uint8_t*)c->arena.temp(need);
-    }
-    K* ka = (K*)p;
-    K* kb = ka + m;
-    uint32_t* va = (uint32_t*)(kb + m);
-    uint32_t* vb = va + m;
+    K* ka = (K*)r.keys;
+    uint32_t* va = r.counts;
+    K* kb = (K*)c->arena.temp(m * sizeof(K));
+    uint32_t* vb = (uint32_t*)c->arena.temp(m * 4);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(canonical_map_kernel<K>), dim3(grid_for(m, kTB)), dim3(kTB), 0, c->stream,
-                       (const K*)r.keys, ka, m, c->len);
-    HIP_TRY(hipMemcpyAsync(va, r.counts, m * 4, hipMemcpyDeviceToDevice, c->stream));
+                       (const K*)ka, ka, m, c->len);
     const bool mute = c->mute_timing;
     c->mute_timing = true;                  // the sort's passes belong to this phase, not to the partition classes
     bool in_b = false, ordered = false;
@@ -1029,8 +1023,11 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r, K* scratch, uint64_t scratch_slot
     }
     if (!ordered) in_b = radix_sort<K, true>(c, ka, kb, va, vb, m, key_digits(c));
     c->mute_timing = mute;
-    HIP_TRY(hipMemcpyAsync(r.keys, in_b ? kb : ka, m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(r.counts, in_b ? vb : va, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    if ((in_b ? kb : ka) != (K*)r.keys)
+    {
+        HIP_TRY(hipMemcpyAsync(r.keys, in_b ? kb : ka, m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(r.counts, in_b ? vb : va, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     t.stop();
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena.release(mark);
@@ -1577,7 +1574,7 @@ void merge_runs(goss_gpu_ctx* c)
         for (auto& r : c->runs)
             if (r.rep)
             {
-                if constexpr (std::is_same<K, Key1>::value) canonicalize_run<K>(c, r, (K*)nullptr, 0);
+                if constexpr (std::is_same<K, Key1>::value) canonicalize_run<K>(c, r);
                 else throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
             }
     const bool rep_out = all_rep;
@@ -2595,7 +2592,7 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
         if (!c->runs.empty() && c->runs[0].rep)
         {
             if (c->words != 1) throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
-            canonicalize_run<Key1>(c, c->runs[0], (Key1*)nullptr, 0);
+            canonicalize_run<Key1>(c, c->runs[0]);
         }
         if (!c->runs.empty()) { c->res_keys = c->runs[0].keys; c->res_counts = c->runs[0].counts; c->M = c->runs[0].m; }
         else { c->res_keys = c->arena.perm(16); c->res_counts = (uint32_t*)c->arena.perm(16); c->M = 0; }

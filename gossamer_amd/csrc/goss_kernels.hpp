@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
 // Strand representatives -> gossamer's canonical form (position_type::normalize, RankSelect.hh:126-140),
 // for the distinct keys only; the result is no longer sorted.
 template <class K>
-__global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* __restrict__ in, K* __restrict__ outk, uint64_t m, uint32_t len)
+__global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* in, K* outk, uint64_t m, uint32_t len)       // in == outk is fine
 {
     const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
     if (i >= m) return;
