@@ -1399,7 +1399,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         HIP_TRY(hipMemsetAsync(cur2, 0, 65536ULL * kSubCursorStride * 8, c->stream));
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)tiles), dim3(kTB), 0,
+            // (a multiple of 8 workgroups: the kernel deals the tiles out by XCD)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)((tiles + 7) / 8 * 8)), dim3(kTB), 0,
                                c->stream, (const K*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, ctl, cur2,
                                (const GapTable*)dgt, (const SubTable*)dsub, big_table == -2 ? 1u : 0u);

@@ -1639,15 +1639,29 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     // a give-up makes the host redo the pass with the histogram-table kernels.
     if (ORDERED) { if (tid == 0) sh_tile = atomicAdd(&ctl->ticket, 1u); }
     if (tid == 0) sh_skip = 0;
+    // Sub-region mode (no chain, any tile order): workgroups go round the eight XCDs in blockIdx order, and each
+    // XCD has its own L2.  Tile = (blockIdx % 8) * tiles/8 + blockIdx / 8 gives every XCD a contiguous range of
+    // tiles, i.e. its own bucket regions: the runs that consecutive tiles append to a sub-region then pass through
+    // ONE L2, where the partial 64-byte granules at their seams can meet.  (The grid is rounded up to a multiple of 8.)
+    uint32_t my_tile = blockIdx.x;
+    if (GAPPED && !ORDERED && sub)
+    {
+        const uint32_t total = (uint32_t)gt->tile_first[256];
+#ifndef GOSS_K2_NO_XCD
+        const uint32_t per = (total + 7u) / 8u;
+        my_tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#endif
+        if (my_tile >= total) return;
+    }
     if (GAPPED && !ORDERED)
     {
-        const unsigned long long t = blockIdx.x;
+        const unsigned long long t = my_tile;
         if (gt->tile_first[tid] <= t && t < gt->tile_first[tid + 1]) sh_bucket = tid;
     }
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
     __syncthreads();
-    const uint32_t tile = ORDERED ? sh_tile : blockIdx.x;
+    const uint32_t tile = ORDERED ? sh_tile : my_tile;
     uint64_t tile_base = (uint64_t)tile * kSortTile;
     uint32_t tile_n = 0;
     if (GAPPED)
