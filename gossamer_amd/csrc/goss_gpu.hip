@@ -1371,12 +1371,13 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (n == 0) return kFusedDeclined;
     if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");
     uint64_t tiles = 0, sum = 0;
+    const uint64_t tile_keys = msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
     for (int d = 0; d < 256; ++d)
     {
         // one-word keys: slots handed out in whole blocks, padding included (the next pass skips it)
         gt.cnt[d] = hp->cursors[d * kCursorStride];
         gt.tile_first[d] = tiles;
-        tiles += (gt.cnt[d] + kTile - 1) / kTile;
+        tiles += (gt.cnt[d] + tile_keys - 1) / tile_keys;
         sum += gt.cnt[d];
     }
     gt.tile_first[256] = tiles;
@@ -1400,7 +1401,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
             // (a multiple of 8 workgroups: the kernel deals the tiles out by XCD)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true>), dim3((uint32_t)((tiles + 7) / 8 * 8)), dim3(kTB), 0,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<K, false, false, true, SubCfg<K>::kItems>), dim3((uint32_t)((tiles + 7) / 8 * 8)), dim3(kTB), 0,
                                c->stream, (const K*)ka, (const uint32_t*)nullptr, kb, (uint32_t*)nullptr, n, shift, shift,
                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, ctl, cur2,
                                (const GapTable*)dgt, (const SubTable*)dsub, big_table == -2 ? 1u : 0u);

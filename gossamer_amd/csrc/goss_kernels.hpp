@@ -1410,6 +1410,14 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
 #ifndef GOSS_LB_BATCH
 #define GOSS_LB_BATCH 1
 #endif
+// Tile of the second level in sub-region mode: 5632 (u64) / 2816 (u128) keys -- 52 KB of LDS, three workgroups
+// per CU.  With the tiles dealt out by XCD the shorter runs cost nothing and the third workgroup hides the LDS
+// phases of the other two (C2: 41.0 -> 37.5 ms; the chained passes keep the large tile, their bound is the chain).
+template <class K> struct SubCfg {
+    static constexpr int kItems = sizeof(K) == 8 ? 22 : 11;
+    static constexpr int kTile = 256 * kItems;
+};
+
 template <class K, bool HAS_VAL = false> struct SortCfg {
     static constexpr int kItems = sizeof(K) == 8 ? (HAS_VAL ? 16 : GOSS_SORT_ITEMS1) : (HAS_VAL ? 8 : GOSS_SORT_ITEMS2);   // keys per thread
     static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
@@ -1603,7 +1611,7 @@ constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
 // GAPPED: the input is the output of extract1_part_kernel -- 256 bucket regions with unused
 // slots between them (GapTable); tile t is the (t - tile_first[b])-th tile of bucket b.  Every
 // tile then lies inside one bucket of the previous digit, so no tile needs a stable rank.
-template <class K, bool HAS_VAL, bool ORDERED, bool GAPPED = false>
+template <class K, bool HAS_VAL, bool ORDERED, bool GAPPED = false, int ITEMS = SortCfg<K, HAS_VAL>::kItems>
 __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              uint64_t n, uint32_t digit, uint32_t sorted_lo,
@@ -1618,8 +1626,8 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
     // rem_out (two-word keys, sub-region mode): slot o of keys_out is a 12-byte record holding the key's low
     // `digit` bits -- what is left below the 16-bit segment prefix, which the slot's sub-region implies; the
     // counting kernel of 96-bit remainders reads those (a quarter less to write here and to read there)
-    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
-    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
+    constexpr int kSortItems = ITEMS;
+    constexpr int kSortTile = kTB * ITEMS;
     __shared__ uint32_t wave_hist[kWaves][256];
     __shared__ uint32_t digit_start[256];
     __shared__ uint64_t global_base[256];
