@@ -887,12 +887,23 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
             uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
             uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
             const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
-            uint32_t m = 0;
-#pragma unroll
-            for (int i = 0; i < P; ++i)
+            // window i is valid iff bits [i, i + len) of `inv` are zero.  All P windows at once: runs of good bases
+            // of length 1, 2, 4, .. by doubling, and the AND of the runs that make up len (its binary digits) at
+            // their offsets -- six steps of a few 64-bit operations instead of a shift, mask and compare per window
+            uint32_t m;
             {
-                bool ok = ((inv >> i) & lmask) == 0 && (p0 + i < nstarts);
-                m |= ok ? (1u << i) : 0u;
+                uint64_t run = ~inv, acc = ~0ULL;
+                uint32_t covered = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)               // len <= 31
+                {
+                    if ((len >> j) & 1u) { acc &= run >> covered; covered += 1u << j; }
+                    run &= run >> (1u << j);
+                }
+                // (bits of `inv` above the 64 that were read count as good: they belong to windows beyond P anyway)
+                const uint64_t left = nstarts > p0 ? nstarts - p0 : 0;
+                const uint32_t lim = left >= (uint64_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << (uint32_t)left) - 1u);
+                m = (uint32_t)acc & lim;
             }
             vm = m;
             nvalid += __popc(m);
