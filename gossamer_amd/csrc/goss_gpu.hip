@@ -86,6 +86,7 @@ struct goss_gpu_ctx {
     int words = 1;
     int path = 0;                       // 0 auto, 1 LSD sort only
     bool lookback = true;               // single-pass radix scatter (GOSS_GPU_NO_LOOKBACK=1 disables)
+    double est_scale = 1.0;             // GOSS_GPU_EST_SCALE: factor on the distinct-key estimate of the fused path (tests)
     uint32_t order_bits = 0;            // group bits of the canonical re-ordering (GOSS_GPU_ORDER_BITS=16|20; 0 = by size)
     bool ordered_tiles = false;         // take tile numbers from a ticket instead of blockIdx
     uint32_t lookback_failures = 0;
@@ -1140,7 +1141,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const bool exact = nslices == 1;                                   // the sample is the chunk
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
-    const uint64_t m_est = spectrum_estimate<K>(c, ka, ns, (double)n_exp);
+    uint64_t m_est = spectrum_estimate<K>(c, ka, ns, (double)n_exp);
+    if (c->est_scale != 1.0) m_est = (uint64_t)((double)m_est * c->est_scale);      // tests: a wrong estimate on purpose
     lap("distinct keys estimated");
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
     // buffers sized from the estimated share of valid windows must hold what the sample promises
@@ -1161,7 +1163,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     int big_table = 0;
     if (kOne && c->fused_msd && c->big_table && segbits > (uint32_t)kSegBits && keybits >= (uint32_t)kSegBits + 8 + 2)
         for (int r = std::max(0, c->big_rounds_min); r <= c->big_rounds_max; ++r)
-            if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 3 / 4) { segbits = kSegBits; big_table = 1 + r; break; }
+            if ((m_est >> (kSegBits + r)) <= (uint64_t)kSegBigLimit * 17 / 20) { segbits = kSegBits; big_table = 1 + r; break; }   // (an overflow costs one more counting pass, no more)
     // two-word keys: the 4096-slot table, up to two workgroups per segment (a pass over 16-byte
     // keys costs more than one over 8-byte keys)
     // two-word keys whose bits below a 16-bit prefix fit 96: 16-byte slots, 8192 of them
@@ -1414,7 +1416,18 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if (hctl->error) { c->fused_overflows++; return decline("a sub-region overflowed"); }
         lap("second level");
         // (-3: the second level wrote 12-byte remainders for the 96-bit table)
-        const int rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end, big_table == -2 ? -3 : big_table);
+        int rc;
+        for (;;)
+        {
+            rc = segment_reduce<K>(c, kb, ka, n, segbits, &r, seg_beg, seg_end, big_table == -2 ? -3 : big_table);
+            // a table that overflowed (one-word keys): the keys are still in their sub-regions, so only the counting
+            // is redone, with the next larger form -- 8192 slots, then 2 and 4 workgroups per segment -- instead of
+            // the whole chunk with the unfused kernels
+            if (rc != 1 || !kOne || !c->big_table || big_table < 0 || big_table >= 1 + c->big_rounds_max) break;
+            c->segment_retries++;
+            ++big_table;
+            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: a counting table overflowed, next form %d\n", big_table);
+        }
         if (rc != 0)
         {
             c->segment_retries++;
@@ -2455,6 +2468,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     c->budget = hbm_budget;
     { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
+    { const char* e = std::getenv("GOSS_GPU_EST_SCALE"); if (e && std::atof(e) > 0) c->est_scale = std::atof(e); }
     { const char* e = std::getenv("GOSS_GPU_ORDER_BITS"); if (e && (std::atoi(e) == 16 || std::atoi(e) == 20)) c->order_bits = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }

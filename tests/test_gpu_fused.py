@@ -337,6 +337,41 @@ def test_big_counting_table_two_level_form():
     assert int(res[0][1].to(torch.int64).sum().item()) == res[0][2]
 
 
+def test_counting_table_too_small_is_replaced_without_redoing_the_chunk():
+    """The distinct-key estimate halved on purpose (GOSS_GPU_EST_SCALE): the fused path picks the 4096-slot
+    tables for 2.2e8 distinct k-mers (3 350 per segment, the table takes 3 072), they overflow, and only the
+    counting is redone with the 8192-slot table (the keys are still in their sub-regions) -- one retry, still
+    one fused chunk, same keys and counts."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 6_000_000, 150, 230_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for env in ({}, {"GOSS_GPU_EST_SCALE": "0.5"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=55)
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert ctx.stat("fused_chunks") == 1 and ctx.stat("fused_msd_chunks") == 1 and ctx.stat("big_table_chunks") == 1
+        assert ctx.stat("segment_retries") == (1 if env else 0)
+        kp, cp, m = ctx.result_ptrs()
+        res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_big_counting_table_two_word_keys():
     """k = 45, 1.1e8 distinct two-word k-mers in one chunk: more than 65 536 segments of the
     2048-slot table take with margin (1152 each), fewer than seg_hash_reduce2_big_kernel's 4096
