@@ -989,10 +989,12 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r)
     if constexpr (std::is_same<K, Key1>::value)
     {
         // canonical forms are uniform on their leading bits: two (three) radix passes group the pairs by their
-        // top 16 (20) bits, then every group (~m / 2^bits pairs, at most 4 096) is ordered in LDS -- three or four
-        // passes over the pairs instead of one per key byte.  20 bits for runs above 157 M keys (the ranks of a
-        // multi-GPU build hold up to the whole k-mer set before the exchange)
-        const uint32_t sb = c->order_bits ? c->order_bits : (m <= 65536ULL * 2400 ? 16u : 20u);
+        // top 16 (17 .. 24) bits, then every group (~m / 2^bits pairs, at most 4 096) is ordered in LDS -- three or
+        // four passes over the pairs instead of one per key byte.  More than 16 bits for runs above 157 M keys
+        // (reads with errors; the ranks of a multi-GPU build hold up to the whole k-mer set before the exchange)
+        uint32_t sb = 16;
+        while (sb < 24 && m > (1ULL << sb) * 2400) ++sb;                // the fewest groups of at most ~2 400 pairs
+        if (c->order_bits) sb = c->order_bits;
         if (keybits >= sb + 10 && m >= (1u << 20) && m <= (1ULL << sb) * 2400)
         {
             const uint32_t nseg = 1u << sb;
@@ -2469,7 +2471,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_LOOKBACK"); if (e && *e == '1') c->lookback = false; }
     { const char* e = std::getenv("GOSS_GPU_ORDERED_TILES"); if (e && *e == '1') c->ordered_tiles = true; }
     { const char* e = std::getenv("GOSS_GPU_EST_SCALE"); if (e && std::atof(e) > 0) c->est_scale = std::atof(e); }
-    { const char* e = std::getenv("GOSS_GPU_ORDER_BITS"); if (e && (std::atoi(e) == 16 || std::atoi(e) == 20)) c->order_bits = (uint32_t)std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_ORDER_BITS"); if (e && std::atoi(e) >= 16 && std::atoi(e) <= 24) c->order_bits = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_EXTRACT_V1"); if (e && *e == '1') c->extract_v1 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_CURSOR_PASS0"); if (e && *e == '1') c->cursor_pass0 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_FUSED"); if (e && *e == '1') c->fused = false; }
