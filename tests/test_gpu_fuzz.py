@@ -1,0 +1,19 @@
+"""A short run of tools/fuzz_parity.py inside the suite: random (k, mode, read shape, error rate, arena size,
+path switches) combinations, product against oracle, files byte for byte."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_configurations_against_the_oracle():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "30", "11"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-4000:]
+    assert "30 cases, 0 failed" in out

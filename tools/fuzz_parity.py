@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU box: many (k, mode, read shape, error rate, budget) combinations, every one
+through the product (fused path forced on where the input is small) and through the oracle; the object files
+must be byte-identical.  Complements the fixed cases of tests/: a place to catch what a particular tile count,
+key width or table form breaks.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gossamer_amd as g  # noqa: E402
+import oracle_lib as oracle  # noqa: E402
+
+
+def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
+    genome = "".join(rng.choice("ACGT") for _ in range(genome_len))
+    out = []
+    for _ in range(nreads):
+        L = rng.randint(lmin, lmax)
+        p = rng.randint(0, genome_len - L)
+        r = genome[p:p + L]
+        if err or nrate or lower:
+            b = list(r)
+            for i in range(L):
+                x = rng.random()
+                if x < err:
+                    b[i] = rng.choice("ACGT")
+                elif x < err + nrate:
+                    b[i] = rng.choice("NnRY.-")
+                elif lower and rng.random() < 0.2:
+                    b[i] = b[i].lower()
+            r = "".join(b)
+        out.append(r)
+    return ("\n".join(out) + "\n").encode()
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    oracle.lib()
+    bad = 0
+    t00 = time.time()
+    for case in range(cases):
+        graph = rng.random() < 0.4
+        k = rng.choice([11, 13, 15, 16, 21, 24, 25, 27, 30, 31, 32, 33, 40, 45, 55, 62 if graph else 63])
+        if graph:
+            k = min(k, 62)
+        nreads = rng.choice([20000, 60000, 150000])
+        lmin, lmax = rng.choice([(150, 150), (30, 200), (k, k + 5), (100, 101)])
+        lmin = max(lmin, 1)
+        genome_len = rng.choice([5000, 60000, 400000, 2000000])
+        genome_len = max(genome_len, lmax + 1)
+        err = rng.choice([0.0, 0.0, 0.002, 0.02])
+        nrate = rng.choice([0.0, 0.001, 0.01])
+        reads = make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, rng.random() < 0.3)
+        env = {"GOSS_GPU_FUSED_MIN": "0"}
+        if rng.random() < 0.3:
+            env["GOSS_GPU_NO_MSD"] = "1"
+        if rng.random() < 0.15:
+            env["GOSS_GPU_NO_FUSED"] = "1"
+        if rng.random() < 0.2:
+            env["GOSS_GPU_EST_SCALE"] = rng.choice(["0.3", "3.0"])
+        if rng.random() < 0.2:
+            env["GOSS_GPU_ORDER_BITS"] = rng.choice(["16", "17", "20"])
+        budget = rng.choice([96 << 20, 256 << 20, 1 << 30, 4 << 30])
+        t0 = time.time()
+        build = oracle.build_graph if graph else oracle.build_kmer_set
+        exp, nwin = build([(oracle.LINE, "r", reads)], k, out="o")
+        exp = {n[1:]: b for n, b in exp.items()}
+        old = {n: os.environ.get(n) for n in env}
+        os.environ.update(env)
+        try:
+            try:
+                with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+                    ctx.push_host(reads)
+                    c = ctx.finish()
+                    got = ctx.emit()
+                    stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "runs")}
+                ok = c.windows == nwin and sorted(got) == sorted(exp) and all(got[n] == exp[n] for n in exp)
+                why = "" if ok else "windows %d/%d, files differ: %s" % (c.windows, nwin, [n for n in exp if got.get(n) != exp[n]][:4])
+            except g.GossGpuError as e:
+                # a budget too small for the input is a legitimate refusal, anything else is not
+                ok = e.status == -3
+                why = "refused: %s" % e
+                stats = {}
+        finally:
+            for n, v in old.items():
+                if v is None:
+                    os.environ.pop(n, None)
+                else:
+                    os.environ[n] = v
+        bad += 0 if ok else 1
+        print("%s case %d: %s k=%d reads=%d len=%d..%d genome=%d err=%g n=%g budget=%dM env=%s windows=%d %s %.1fs %s"
+              % ("ok  " if ok else "FAIL", case, "graph" if graph else "kmer", k, nreads, lmin, lmax, genome_len, err, nrate, budget >> 20,
+                 {a: b for a, b in env.items() if a != "GOSS_GPU_FUSED_MIN"}, nwin, stats, time.time() - t0, why), flush=True)
+    print("fuzz: %d cases, %d failed, %.0f s" % (cases, bad, time.time() - t00))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
