@@ -2452,6 +2452,19 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
+    // A key has TWO buckets of two slots, both given by one 32-bit mix of its words (the top kBucketBits bits and the
+    // kBucketBits below them; equal -> the neighbour).  It lives in the first that had room when it came, else in the
+    // second, else in the buckets behind the second: insertion and search walk the same sequence, and a bucket that is
+    // full stays full, so a key is never behind an empty slot of its sequence.  With the neighbour as second bucket
+    // 1.2 % of C2's keys sat further out and took the wave-wide slow path at each of their ~126 occurrences; an
+    // independent second bucket leaves a third of that.
+    auto key_mix = [](unsigned long long k) -> uint32_t {
+        return ((uint32_t)k ^ __builtin_rotateleft32((uint32_t)(k >> 32), 15)) * 0x9E3779B1u;
+    };
+    auto second_bucket = [](uint32_t f, uint32_t b1) -> uint32_t {
+        const uint32_t b = (f >> (32 - 2 * kBucketBits)) & (uint32_t)(SLOTS / 2 - 1);
+        return b == b1 ? ((b1 + 1u) & (uint32_t)(SLOTS / 2 - 1)) : b;
+    };
     lds_vu32 vovf = (lds_vu32)&ovf;
     // kSegUnroll independent coalesced loads are issued before the first insert so that
     // enough bytes are in flight per CU to cover the HBM latency
@@ -2480,16 +2493,17 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
         const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
         const lds_bucket_plain pt2 = (lds_bucket_plain)tab;
         auto insert_g = [&](const unsigned long long (&kq)[kG]) {
-            uint32_t bkt[kG];
+            uint32_t bkt[kG], b2[kG];
             ull2 q[kG], q2[kG];
-            uint32_t pend = 0;
+            uint32_t pend = 0, stm = 0;
 #pragma unroll
             for (int j = 0; j < kG; ++j)
             {
-                const uint32_t klo = (uint32_t)kq[j], khi = (uint32_t)(kq[j] >> 32);
-                bkt[j] = ((klo ^ __builtin_rotateleft32(khi, 15)) * 0x9E3779B1u) >> (32 - kBucketBits);
+                const uint32_t f = key_mix(kq[j]);
+                bkt[j] = f >> (32 - kBucketBits);
+                b2[j] = second_bucket(f, bkt[j]);
                 q[j] = pt2[bkt[j]];
-                q2[j] = pt2[(bkt[j] + 1) & (SLOTS / 2 - 1)];
+                q2[j] = pt2[b2[j]];
             }
 #pragma unroll
             for (int j = 0; j < kG; ++j)
@@ -2500,20 +2514,22 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
                 const uint32_t h2 = s2 == kq[j] ? 1u : 0u, h3 = s3 == kq[j] ? 1u : 0u;
                 const uint32_t hit = (h0 | h1 | h2 | h3) & live;
                 const uint32_t second = h2 | h3;
-                atomicAdd(&cnt[2 * ((bkt[j] + second) & (SLOTS / 2 - 1)) + (h1 | h3)], hit);
+                atomicAdd(&cnt[2 * (second ? b2[j] : bkt[j]) + (h1 | h3)], hit);
                 const uint32_t miss = live & (hit ^ 1u);
                 pend |= miss << j;
                 const uint32_t full = (s0 != kEmpty ? 1u : 0u) & (s1 != kEmpty ? 1u : 0u) & miss;
-                bkt[j] = (bkt[j] + full) & (SLOTS / 2 - 1);
+                bkt[j] = full ? b2[j] : bkt[j];
+                stm |= full << j;
             }
             unsigned long long key = kEmpty;
-            uint32_t bk = 0;
+            uint32_t bk = 0, st = 0;
             for (;;)
             {
                 if (key == kEmpty && pend)
                 {
                     const uint32_t u = __ffs(pend) - 1;
                     pend &= pend - 1;
+                    st = (stm >> u) & 1u;
 #pragma unroll
                     for (int uu = 0; uu < kG; ++uu)
                         if (u == (uint32_t)uu) { key = kq[uu]; bk = bkt[uu]; }
@@ -2538,6 +2554,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
                         }
                         else if (old == key) hit = slot;
                     }
+                    else if (st == 0) { bk = second_bucket(key_mix(key), bk); st = 1; }
                     else bk = (bk + 1) & (SLOTS / 2 - 1);
                     if (hit != ~0u) { atomicAdd(&cnt[hit], 1u); key = kEmpty; }
                 }
@@ -2629,7 +2646,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
         typedef const volatile __attribute__((address_space(3))) ull2* lds_bucket_ptr;
         const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
         uint32_t bkt[kSegUnroll];
-        uint32_t pend = 0;
+        uint32_t pend = 0, stm = 0;
         // The probes of half a batch are issued together (plain LDS loads: a stale miss only sends
         // the key to the slow path, which reads the bucket again through the volatile view; keys are
         // never removed, so there is no stale hit) and then consumed -- as volatile loads the
@@ -2644,16 +2661,18 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
             // a full home bucket, and such a key would take the slow path -- a wave-wide loop -- every one of
             // the ~100 times it occurs; two buckets leave about 0.5 %)
             ull2 q[kHalf], q2[kHalf];
+            uint32_t b2[kHalf];
 #pragma unroll
             for (int j = 0; j < kHalf; ++j)
             {
                 const int u = h * kHalf + j;
                 // one 32-bit multiply (a 64-bit one is three quarter-rate instructions): the high
                 // word, rotated, folded into the low one, times the golden ratio
-                const uint32_t klo = (uint32_t)kv[u], khi = (uint32_t)(kv[u] >> 32);
-                bkt[u] = ((klo ^ __builtin_rotateleft32(khi, 15)) * 0x9E3779B1u) >> (32 - kBucketBits);
+                const uint32_t f = key_mix(kv[u]);
+                bkt[u] = f >> (32 - kBucketBits);
+                b2[j] = second_bucket(f, bkt[u]);
                 q[j] = pt2[bkt[u]];
-                q2[j] = pt2[(bkt[u] + 1) & (SLOTS / 2 - 1)];
+                q2[j] = pt2[b2[j]];
             }
 #pragma unroll
             for (int j = 0; j < kHalf; ++j)
@@ -2669,26 +2688,28 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
                 const uint32_t h2 = s2 == kv[u] ? 1u : 0u, h3 = s3 == kv[u] ? 1u : 0u;
                 const uint32_t hit = (h0 | h1 | h2 | h3) & live;
                 const uint32_t second = h2 | h3;
-                const uint32_t slot = 2 * ((bkt[u] + second) & (SLOTS / 2 - 1)) + (h1 | h3);
+                const uint32_t slot = 2 * (second ? b2[j] : bkt[u]) + (h1 | h3);
                 atomicAdd(&cnt[slot], hit);
                 const uint32_t miss = live & (hit ^ 1u);
                 pend |= miss << u;
-                // a full home bucket cannot take the key: the slow path starts at the next one
+                // a full first bucket cannot take the key: the slow path starts at the second one
                 const uint32_t full = (s0 != kEmpty ? 1u : 0u) & (s1 != kEmpty ? 1u : 0u) & miss;
-                bkt[u] = (bkt[u] + full) & (SLOTS / 2 - 1);
+                bkt[u] = full ? b2[j] : bkt[u];
+                stm |= full << u;
             }
         }
         // slow path (key absent from its home bucket): every lane walks its OWN queue of
         // leftover keys, one probe per wave iteration, so the wave iterates max-over-lanes of the
         // lane totals instead of the sum over the eight keys of per-key maxima
         unsigned long long key = kEmpty;
-        uint32_t bk = 0;
+        uint32_t bk = 0, st = 0;                          // st: 0 = at the first bucket, 1 = at the second or beyond
         for (;;)
         {
             if (key == kEmpty && pend)
             {
                 const uint32_t u = __ffs(pend) - 1;
                 pend &= pend - 1;
+                st = (stm >> u) & 1u;
 #pragma unroll
                 for (int uu = 0; uu < kSegUnroll; ++uu)
                     if (u == (uint32_t)uu) { key = kv[uu]; bk = bkt[uu]; }
@@ -2714,7 +2735,8 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
                     else if (old == key) hit = slot;
                     // else: somebody else took the slot; look at this bucket again
                 }
-                else bk = (bk + 1) & (SLOTS / 2 - 1);
+                else if (st == 0) { bk = second_bucket(key_mix(key), bk); st = 1; }      // full: on to the second bucket,
+                else bk = (bk + 1) & (SLOTS / 2 - 1);                                     // then to the ones behind it
                 if (hit != ~0u) { atomicAdd(&cnt[hit], 1u); key = kEmpty; }
             }
             if (*vovf) break;
