@@ -518,6 +518,11 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                             const OwnedPush* pushOwned = nullptr)
 {
     if (threads < 2 || name == "-" || endsWith(name, ".gz")) return ~0ULL;
+    const auto tEnter = std::chrono::steady_clock::now();
+    struct Whole { std::chrono::steady_clock::time_point t0; bool on;
+                   ~Whole() { if (on) std::fprintf(stderr, "goss: parallel parser: %.3f s from entry to return\n",
+                                                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } }
+        whole{tEnter, std::getenv("GOSS_PARSE_STATS") != nullptr};
     int fd = ::open(name.c_str(), O_RDONLY);
     if (fd < 0) throw Error::Errno(name, errno);
     struct stat st;
@@ -610,9 +615,11 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     bool serialRest = false;
     double waitSeconds = 0, pushSeconds = 0;         // GOSS_PARSE_STATS=1: where the in-order consumer spends its time
     const bool stats = std::getenv("GOSS_PARSE_STATS") != nullptr;
-    struct Report { bool on; double& w; double& p; const std::string& n;
-                    ~Report() { if (on) std::fprintf(stderr, "goss: %s: consumer waited %.3f s for parsed chunks, %.3f s in pushes\n", n.c_str(), w, p); } }
-        report{stats, waitSeconds, pushSeconds, name};
+    struct Report { bool on; double& w; double& p; const std::string& n; std::chrono::steady_clock::time_point t0;
+                    ~Report() { if (on) std::fprintf(stderr, "goss: %s: consumer waited %.3f s for parsed chunks, %.3f s in pushes; loop started %.3f s after entry, ended at %.3f s\n",
+                                                     n.c_str(), w, p, start, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+                    double start; }
+        report{stats, waitSeconds, pushSeconds, name, tEnter, std::chrono::duration<double>(std::chrono::steady_clock::now() - tEnter).count()};
     auto now = [] { return std::chrono::steady_clock::now(); };
     for (size_t i = 0; i < nchunks && !serialRest; ++i)
     {
@@ -756,7 +763,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     };
     std::vector<std::unique_ptr<Feeder>> feeders;
     std::atomic<bool> feedFailed{false};
-    if (P > 1)
+    const bool fed = P > 1;           // (one device: the consumer pushes itself -- a feeder thread was measured and gave nothing, the pushes are the bound)
+    if (fed)
         for (size_t d = 0; d < P; ++d)
         {
             feeders.emplace_back(new Feeder);
@@ -825,7 +833,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     double pushSeconds = 0;
     auto timedPush = [&](const char* p, size_t n) {
         auto a = std::chrono::steady_clock::now();
-        if (P > 1) feed(p, n, nullptr, true);
+        if (fed) feed(p, n, nullptr, true);
         else g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
         pushSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
     };
@@ -899,16 +907,17 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     for (auto& f : fastqs)
     {
         if (gzFiles.size() > 1 && threads > 1 && endsWith(f, ".gz")) continue;      // done above
-        log(info, "parsing sequences from " + f);
+        { std::ostringstream o; o << "parsing sequences from " << f << " (contexts ready at "
+            << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s)"; log(info, o.str()); }
         flush();
         uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned,
-                                        P > 1 ? &ownedPush : nullptr);
+                                        fed ? &ownedPush : nullptr);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
     if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
     flush();
-    if (P > 1) drainFeeders();
+    if (fed) drainFeeders();
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "
         << pushSeconds << "s)"; log(info, o.str()); }
