@@ -1,0 +1,134 @@
+// kernels_common.hpp -- wave / block primitives, scans, small helpers shared by all kernels.
+// Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp, in this order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "goss_key.hpp"
+
+namespace goss {
+
+constexpr int kTB = 256;           // threads per workgroup
+constexpr int kWaves = kTB / 64;
+
+// Volatile views of __shared__ arrays keep their address space: through a generic volatile
+// pointer the compiler emits FLAT loads and stores instead of ds_read / ds_write.
+typedef volatile __attribute__((address_space(3))) uint32_t* lds_vu32;
+typedef volatile __attribute__((address_space(3))) unsigned long long* lds_vu64;
+
+// --------------------------------------------------------------------------------------
+// wave / block primitives
+// --------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+// Kernels with one workgroup per segment are launched on a (x, y) grid (unit_grid in goss_gpu.hip):
+// HIP refuses a launch whose gridDim.x * blockDim.x reaches 2^32, which 2^24 segments of 256
+// threads do.  The workgroup's unit number:
+__device__ __forceinline__ uint32_t unit_block() { return blockIdx.y * gridDim.x + blockIdx.x; }
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        T o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across the 256-thread block; `sh` holds kWaves+1
+// elements of scratch.  Returns the exclusive prefix; *total = block sum.
+template <class T>
+__device__ __forceinline__ T block_excl_scan(T v, T* sh, T* total)
+{
+    T inc = wave_incl_scan(v);
+    if (lane_id() == 63) sh[wave_id()] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+    {
+        T s = sh[w];
+        if ((int)wave_id() > w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// The same for a workgroup of NW waves.
+template <class T, int NW>
+__device__ __forceinline__ T block_excl_scan_n(T v, T* sh, T* total)
+{
+    T inc = wave_incl_scan(v);
+    if (lane_id() == 63) sh[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+    {
+        T s = sh[w];
+        if ((int)(threadIdx.x >> 6) > w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// --------------------------------------------------------------------------------------
+// device-wide exclusive scan of a u64 array (in place): reduce / scan partials / apply
+// --------------------------------------------------------------------------------------
+
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kTB * kScanItems;
+
+__global__ __launch_bounds__(kTB) void scan_reduce_kernel(const uint64_t* __restrict__ a, uint64_t n,
+                                                          uint64_t* __restrict__ partial)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) s += a[i];
+    }
+    uint64_t tot;
+    block_excl_scan<uint64_t>(s, sh, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// Exclusive scan of one chunk, adding partial[blockIdx] (already exclusive-scanned) as offset.
+__global__ __launch_bounds__(kTB) void scan_apply_kernel(uint64_t* __restrict__ a, uint64_t n,
+                                                         const uint64_t* __restrict__ partial)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + j;
+        v[j] = i < n ? a[i] : 0;
+        s += v[j];
+    }
+    uint64_t tot;
+    uint64_t off = block_excl_scan<uint64_t>(s, sh, &tot) + (partial ? partial[blockIdx.x] : 0);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+    {
+        uint64_t i = base + j;
+        if (i < n) a[i] = off;
+        off += v[j];
+    }
+}
+
+}  // namespace goss

@@ -1,0 +1,1287 @@
+// kernels_extract.hpp -- k-mer extraction: plain kernels and the extraction fused with the first partition level.
+// Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp, in this order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "goss_key.hpp"
+#include "kernels_common.hpp"
+
+namespace goss {
+
+// --------------------------------------------------------------------------------------
+// K2: rolling / canonical k-mer extraction straight from ASCII bases
+// --------------------------------------------------------------------------------------
+//
+// One workgroup handles a tile of T = 256*P window starts.  Phase A loads T+80 bytes with
+// 16-byte vector loads and writes one code byte (0..3, 4 = not a base) per position to LDS.
+// Phase B1: every thread derives the validity mask of its P windows; block scan gives the
+// compacted slot of each thread.  Phase B2: threads roll the forward and reverse-complement
+// key together, hash both (FNV-1a, in registers) for valid windows only and store the
+// canonical key (or both strands) into an LDS staging buffer at the compacted slot.
+// Phase C: one atomicAdd per tile reserves dense output space; staged keys are written with
+// fully coalesced stores.
+//
+// MODE 0: canonical key per window.  MODE 1: forward key and its reverse complement.
+
+struct ExtractCounters {
+    unsigned long long keys_out;   // dense output cursor (keys)
+    unsigned long long windows;    // valid windows
+    unsigned long long hist[512];  // partition digit histograms (extract1_kernel)
+};
+
+// Bytes that are not one of ACGTacgt in `nslices` slices of `slice` bytes (a multiple of 16),
+// `stride` bytes apart, of a 16-byte aligned string: out[0] += such bytes, out[1] += bytes looked
+// at.  The host sizes the key buffers of a chunk from it (a non-base removes at most `len` windows).
+__global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __restrict__ aligned, uint64_t nslices,
+                                                             uint64_t stride, uint32_t slice,
+                                                             unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0, seen = 0;
+    auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+    for (uint64_t s = blockIdx.x; s < nslices; s += gridDim.x)
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(aligned + s * stride);
+        for (uint32_t v = threadIdx.x; v < slice / 16; v += kTB)
+        {
+            const uint4 q = p[v];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const uint32_t l = w[i] | 0x20202020u;
+                bad += __popc(nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u));
+            }
+            seen += 16;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_down(bad, o, 64); seen += __shfl_down(seen, o, 64); }
+    if ((threadIdx.x & 63u) == 0 && seen) { atomicAdd(&out[0], bad); atomicAdd(&out[1], seen); }
+}
+
+// Strand representative of a k-mer for COUNTING: of {x, rc(x)} the one whose bits, rotated left
+// by len (the central bases first), are smaller.  It is a function of the unordered pair, so both
+// strands of a k-mer count as one key; the rotation makes the choice depend on the central bases,
+// which leaves the leading bases -- the partition digits -- uniform; and it costs a handful of
+// integer operations where gossamer's canonical form (the smaller FNV-1a hash, RankSelect.hh:126-140)
+// costs two chains of 64-bit multiplies per window.  The distinct representatives are mapped to
+// that canonical form once, after counting (canonical_map_kernel): 126 x fewer hashes on 150 x
+// coverage.  x == rc(x) is the only tie.
+__device__ __forceinline__ uint64_t rot_half(uint64_t v, uint32_t len, uint64_t lmask)
+{
+    return ((v & lmask) << len) | (v >> len);
+}
+__device__ __forceinline__ Key1 strand_rep(const Key1& f, const Key1& rc, uint32_t len, uint64_t lmask)
+{
+    return rot_half(rc.lo, len, lmask) < rot_half(f.lo, len, lmask) ? rc : f;
+}
+
+struct Rem96 { uint32_t r0, r1, r2; };           // the low 96 bits of a two-word key, packed (12-byte records)
+__device__ __forceinline__ bool is_pad_key(const Key1& k) { return k.lo == ~0ULL; }
+__device__ __forceinline__ bool is_pad_key(const Key2& k) { return (k.lo & k.hi) == ~0ULL; }
+
+template <class K> struct KeyOps;
+template <> struct KeyOps<Key1> {
+    static __device__ __forceinline__ Key1 zero() { return Key1{0}; }
+    static __device__ __forceinline__ void push(Key1& f, Key1& r, uint32_t c, uint64_t mask_lo, uint64_t, uint32_t topshift)
+    {
+        f.lo = ((f.lo << 2) | c) & mask_lo;
+        r.lo = (r.lo >> 2) | ((uint64_t)(3u - c) << topshift);
+    }
+};
+template <> struct KeyOps<Key2> {
+    static __device__ __forceinline__ Key2 zero() { return Key2{0, 0}; }
+    static __device__ __forceinline__ void push(Key2& f, Key2& r, uint32_t c, uint64_t mask_lo, uint64_t mask_hi, uint32_t topshift)
+    {
+        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+        f.lo = ((f.lo << 2) | c) & mask_lo;
+        r.lo = (r.lo >> 2) | (r.hi << 62);
+        r.hi >>= 2;
+        uint64_t cc = (uint64_t)(3u - c);
+        if (topshift >= 64) r.hi |= cc << (topshift - 64);
+        else r.lo |= cc << topshift;
+    }
+};
+
+template <class K, int MODE, int P>
+__global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                      uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                      K* __restrict__ out, ExtractCounters* __restrict__ ctr)
+{
+    constexpr int T = kTB * P;
+    constexpr int NVEC = T / 16 + 5;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t code[NVEC * 16];
+    __shared__ K stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+
+    const uint64_t tile_base = (uint64_t)blockIdx.x * T;   // first window start of the tile
+    const uint32_t tid = threadIdx.x;
+
+    // ---- phase A: ASCII -> code bytes -------------------------------------------------
+    // LDS index a corresponds to byte (tile_base + a) of the aligned stream, i.e. window
+    // position (tile_base + a - mis).  Bytes whose position is >= navail are invalid.
+    for (uint32_t v = tid; v < NVEC; v += kTB)
+    {
+        uint64_t byte0 = tile_base + (uint64_t)v * 16;            // aligned-stream offset
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        // positions byte0-mis .. byte0-mis+15 ; fully in range?
+        if (byte0 + 16 <= navail + mis)
+        {
+            uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        else if (byte0 < navail + mis)
+        {
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            // SWAR over 4 bytes: lower-case, 2-bit code, validity.
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            // nz(v): 0x80 in every byte of v that is non-zero
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            // bad byte -> code 4
+            uint32_t badm = (bad >> 7) * 0xFFu;      // 0xFF in bad bytes
+            o[i] = (x & ~badm) | ((bad >> 5) & 0x04040404u);
+        }
+        *reinterpret_cast<uint4*>(&code[v * 16]) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+
+    // ---- phase B1: validity of this thread's P windows --------------------------------
+    const uint32_t q0 = tid * P + mis;               // LDS index of the first base of window 0
+    const uint64_t p0 = tile_base + (uint64_t)tid * P;   // global window start
+    uint32_t vmask = 0;
+    {
+        uint32_t run = 0;
+        const uint32_t steps = P + len - 1;
+        for (uint32_t j = 0; j < steps; ++j)
+        {
+            uint32_t c = code[q0 + j];
+            run = c < 4 ? run + 1 : 0;
+            if (j + 1 >= len && run >= len) vmask |= 1u << (j + 1 - len);
+        }
+        // windows starting at or beyond nstarts do not belong to this launch
+        if (p0 + P > nstarts)
+        {
+            uint32_t keep = p0 >= nstarts ? 0u : (uint32_t)(nstarts - p0);
+            vmask &= keep >= 32 ? 0xFFFFFFFFu : ((1u << keep) - 1u);
+        }
+    }
+    uint32_t cnt = __popc(vmask);
+    uint32_t tile_cnt;
+    uint32_t slot = block_excl_scan<uint32_t>(cnt, sh_scan, &tile_cnt);
+
+    // ---- phase B2: roll keys, canonicalise valid windows ------------------------------
+    if (cnt)
+    {
+        const uint32_t bits = 2 * len;
+        uint64_t mask_lo, mask_hi;
+        if (bits >= 128) { mask_lo = ~0ULL; mask_hi = ~0ULL; }
+        else if (bits >= 64) { mask_lo = ~0ULL; mask_hi = bits == 64 ? 0 : ((1ULL << (bits - 64)) - 1); }
+        else { mask_lo = (1ULL << bits) - 1; mask_hi = 0; }
+        const uint32_t topshift = bits - 2;
+        K f = KeyOps<K>::zero(), r = KeyOps<K>::zero();
+        const uint32_t steps = P + len - 1;
+        uint32_t s = slot * S;
+        for (uint32_t j = 0; j < steps; ++j)
+        {
+            uint32_t c = code[q0 + j] & 3u;
+            KeyOps<K>::push(f, r, c, mask_lo, mask_hi, topshift);
+            if (j + 1 >= len && ((vmask >> (j + 1 - len)) & 1u))
+            {
+                if (MODE == 0) stage[s++] = canonical(f, r);
+                else { stage[s++] = f; stage[s++] = r; }
+            }
+        }
+    }
+    if (tid == 0)
+    {
+        unsigned long long b = 0;
+        if (tile_cnt)
+        {
+            b = atomicAdd(&ctr->keys_out, (unsigned long long)tile_cnt * S);
+            atomicAdd(&ctr->windows, (unsigned long long)tile_cnt);
+        }
+        sh_base = b;
+    }
+    __syncthreads();
+
+    // ---- phase C: coalesced dense store -----------------------------------------------
+    const uint64_t ob = sh_base;
+    const uint32_t total = tile_cnt * S;
+    for (uint32_t i = tid; i < total; i += kTB) out[ob + i] = stage[i];
+}
+
+// --------------------------------------------------------------------------------------
+// K2, one-word keys: windows cut out of packed registers
+// --------------------------------------------------------------------------------------
+//
+// Same contract as extract_kernel<Key1,...>.  Phase A packs every 16 loaded bytes into a
+// 32-bit word of 2-bit codes (base j at bits 2j) and a 16-bit mask of non-bases.  A thread then
+// holds the 128 code bits + 64 mask bits that cover its P windows in registers: the window
+// starting at base i is the field E_i = bits [2i, 2i+2len), its reverse complement is simply
+// ~E_i (complement of every 2-bit code; little-endian packing already reverses the order), its
+// forward value is rolled, and it is valid iff the mask bits [i, i+len) are all zero.  No LDS
+// access and no per-base loop remains in the window loop.
+
+// NB = number of significant key bytes, ceil(2*len / 8): the FNV rounds of the zero bytes above
+// them fold into one multiplication (goss_key.hpp, key_hash_short).
+// REP: MODE 0 stores the strand representative (strand_rep) instead of the canonical form -- the
+// key space extract1_part_kernel counts in; its sample must be drawn from the same space.
+template <int MODE, int P, int G, int NB, bool REP = false>
+__global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                       uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                       Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
+                                                       uint32_t hist_shift, uint64_t nsuper,
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
+{
+    // Persistent grid: a workgroup loops over super-tiles (blockIdx.x, +gridDim.x, ...).
+    // A super-tile is G consecutive sub-tiles of T = 256*P window starts and reserves the
+    // output space of all of them with ONE atomicAdd: a single cursor word serves only ~88 M
+    // returning atomics per second chip-wide, which bounded the one-reservation-per-tile form.
+    constexpr int T = kTB * P;
+    constexpr int NVEC = G * T / 16 + 4;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    static_assert(P <= 16, "window mask is 16 bits");
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key1 stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+    // histograms of the two partition digits (bits hist_shift.. and hist_shift+8..) of every key
+    // this workgroup emits: saves the sort's separate histogram read of all keys
+    __shared__ uint32_t lh[512];
+
+    const uint32_t tid = threadIdx.x;
+    const bool do_hist = hist_shift != 0xFFFFFFFFu;
+    lh[tid] = 0; lh[tid + 256] = 0;
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+    // sampling mode (slice_tiles != 0): super-tile st is the (st % slice_tiles)-th of slice
+    // st / slice_tiles, slices lie slice_stride window starts apart (a multiple of 16)
+    const uint64_t tile_base = slice_tiles ? (st / slice_tiles) * slice_stride + (st % slice_tiles) * (uint64_t)(G * T)
+                                           : st * (uint64_t)(G * T);
+
+    // ---- phase A: ASCII -> packed 2-bit codes + non-base mask, all G sub-tiles -------------
+    for (uint32_t v = tid; v < NVEC; v += kTB)
+    {
+        uint64_t byte0 = tile_base + (uint64_t)v * 16;
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        if (byte0 + 16 <= navail + mis)
+        {
+            uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        else if (byte0 < navail + mis)
+        {
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+        }
+        uint32_t codes = 0, bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            // four code bytes -> 8 bits, four bad flags -> 4 bits
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+        pk[v] = codes;
+        iv[v] = bads;
+    }
+    __syncthreads();
+
+    const uint32_t bits = 2 * len;
+    const uint64_t kmask = (1ULL << bits) - 1;               // len <= 31
+    const uint64_t lmask = (1ULL << len) - 1;
+
+    // ---- phase B: validity masks and compacted slots of every sub-tile ---------------------
+    uint32_t vmask[G], slot[G], sub_cnt[G];
+    uint32_t total = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+        const uint32_t q0 = (g * kTB + tid) * P + mis;
+        const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+        const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+        uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+        const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+        {
+            bool ok = ((inv >> i) & lmask) == 0 && (p0 + i < nstarts);
+            m |= ok ? (1u << i) : 0u;
+        }
+        vmask[g] = m;
+        uint32_t tc;
+        slot[g] = block_excl_scan<uint32_t>(__popc(m), sh_scan, &tc);
+        sub_cnt[g] = tc;
+        total += tc;
+    }
+    if (tid == 0)
+    {
+        unsigned long long b = 0;
+        if (total) b = atomicAdd(&ctr->keys_out, (unsigned long long)total * S);
+        sh_base = b;
+    }
+    __syncthreads();
+    uint64_t ob = sh_base;
+
+    // ---- phase C: per sub-tile, cut the windows out of registers, stage, store --------------
+#pragma unroll 1
+    for (int g = 0; g < G; ++g)
+    {
+        const uint32_t vm = vmask[g];
+        if (vm)
+        {
+            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
+            uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+            const uint32_t s2 = 2 * sh;
+            const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            const uint64_t bhi = hi >> s2;
+            uint32_t s = slot[g] * S;
+            // forward value of window 0: base-4 reversal of its field
+            uint64_t f = rev64(blo & kmask) >> (64 - bits);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                // field of window i: bits [2i, 2i + 2len) of the 128-bit buffer
+                uint64_t e = i ? ((blo >> (2 * i)) | (bhi << (64 - 2 * i))) : blo;
+                e &= kmask;
+                if (i)
+                {
+                    uint32_t pos = 2 * (i + len - 1);      // new last base of the window
+                    uint64_t nb = (pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                    f = ((f << 2) | nb) & kmask;
+                }
+                if ((vm >> i) & 1u)
+                {
+                    Key1 fk{f}, rk{(~e) & kmask};
+                    if (MODE == 0) stage[s++] = REP ? strand_rep(fk, rk, len, lmask) : canonical_short<NB>(fk, rk);
+                    else { stage[s++] = fk; stage[s++] = rk; }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nk = sub_cnt[g] * S;
+        for (uint32_t i = tid; i < nk; i += kTB)
+        {
+            const Key1 k = stage[i];
+            out[ob + i] = k;
+            if (do_hist)
+            {
+                atomicAdd(&lh[(uint32_t)(k.lo >> hist_shift) & 0xFFu], 1u);
+                atomicAdd(&lh[256u + ((uint32_t)(k.lo >> (hist_shift + 8)) & 0xFFu)], 1u);
+            }
+        }
+        ob += nk;
+        __syncthreads();
+    }
+    }   // super-tile loop
+    if (do_hist)
+    {
+        if (lh[tid]) atomicAdd(&ctr->hist[tid], (unsigned long long)lh[tid]);
+        if (lh[tid + 256]) atomicAdd(&ctr->hist[tid + 256], (unsigned long long)lh[tid + 256]);
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K2, two-word keys (32 <= len <= 63): the same windows-out-of-registers scheme with a 192-bit
+// buffer of 2-bit codes per thread (96 bases >= 15 + P - 1 + 63)
+// --------------------------------------------------------------------------------------
+template <int MODE, int P, int G, int NBH = 8>
+__global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                       uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                       Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper,
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
+{
+    constexpr int T = kTB * P;
+    constexpr int NVEC = G * T / 16 + 6;
+    constexpr int S = MODE == 1 ? 2 : 1;
+    static_assert(P <= 16, "96 bases per thread");
+    __shared__ uint32_t pk[NVEC];
+    __shared__ uint32_t iv[NVEC];
+    __shared__ Key2 stage[T * S];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bits = 2 * len;                                       // 64..126
+    const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
+    const uint64_t lmask = (1ULL << len) - 1;                            // len <= 63
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        // sampling mode (slice_tiles != 0): as in extract1_kernel
+        const uint64_t tile_base = slice_tiles ? (st / slice_tiles) * slice_stride + (st % slice_tiles) * (uint64_t)(G * T)
+                                               : st * (uint64_t)(G * T);
+        // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
+        for (uint32_t v = tid; v < NVEC; v += kTB)
+        {
+            uint64_t byte0 = tile_base + (uint64_t)v * 16;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            if (byte0 + 16 <= navail + mis)
+            {
+                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            }
+            else if (byte0 < navail + mis)
+            {
+                for (int j = 0; j < 16; ++j)
+                {
+                    uint64_t b = byte0 + j;
+                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+            }
+            uint32_t codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                uint32_t l = w[i] | 0x20202020u;
+                uint32_t x = (l >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                uint32_t b1 = bad >> 7;
+                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                codes |= c8 << (8 * i);
+                bads |= b4 << (4 * i);
+            }
+            pk[v] = codes;
+            iv[v] = bads;
+        }
+        __syncthreads();
+
+        // ---- phase B: validity masks and compacted slots of every sub-tile ---------------------
+        uint32_t vmask[G], slot[G], sub_cnt[G];
+        uint32_t total = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+            const uint32_t q0 = (g * kTB + tid) * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)(g * kTB + tid) * P;
+            const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
+            const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t t = sh + i;                               // 0..30
+                const uint64_t win = t ? ((inv_lo >> t) | (inv_hi << (64 - t))) : inv_lo;
+                bool ok = (win & lmask) == 0 && (p0 + i < nstarts);
+                m |= ok ? (1u << i) : 0u;
+            }
+            vmask[g] = m;
+            uint32_t tc;
+            slot[g] = block_excl_scan<uint32_t>(__popc(m), sh_scan, &tc);
+            sub_cnt[g] = tc;
+            total += tc;
+        }
+        if (tid == 0)
+        {
+            unsigned long long b = 0;
+            if (total) b = atomicAdd(&ctr->keys_out, (unsigned long long)total * S);
+            sh_base = b;
+        }
+        __syncthreads();
+        uint64_t ob = sh_base;
+
+        // ---- phase C: per sub-tile, cut the windows out of registers, stage, store --------------
+#pragma unroll 1
+        for (int g = 0; g < G; ++g)
+        {
+            const uint32_t vm = vmask[g];
+            if (vm)
+            {
+                const uint32_t q0 = (g * kTB + tid) * P + mis;
+                const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+                const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
+                const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
+                const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
+                uint32_t s = slot[g] * S;
+                Key2 f{0, 0};
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                {
+                    // field of window i: bits [2(sh+i), 2(sh+i) + 2len) of the 192-bit buffer
+                    const uint32_t t2 = 2 * (sh + i);                    // 0..60
+                    Key2 e;
+                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
+                    if (i == 0)
+                    {
+                        // forward value of window 0: base-4 reversal of its field
+                        const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);   // reversed 128 bits = {rhi:rlo}
+                        const uint32_t sft = 128 - bits;                        // 2..64
+                        if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                        else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                    }
+                    else
+                    {
+                        const uint32_t pos = 2 * (sh + i + len - 1);     // new last base, bit position in the buffer
+                        const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
+                        f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+                        f.lo = (f.lo << 2) | nb;
+                    }
+                    if ((vm >> i) & 1u)
+                    {
+                        const Key2 rk{~e.lo, (~e.hi) & mask_hi};
+                        if (MODE == 0) stage[s++] = canonical_tail<NBH>(f, rk);
+                        else { stage[s++] = f; stage[s++] = rk; }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nk = sub_cnt[g] * S;
+            for (uint32_t i = tid; i < nk; i += kTB) out[ob + i] = stage[i];
+            ob += nk;
+            __syncthreads();
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K2+K4 fused, one-word canonical keys: extraction that writes its keys already partitioned on
+// the first partition digit
+// --------------------------------------------------------------------------------------
+//
+// The first partition pass of the segment path may place tiles inside a bucket in any order, so
+// it needs no scan over tiles -- only room in every bucket.  This kernel therefore partitions
+// the keys of a super-tile (G*256*P window starts, at most 8192 keys) while they are still in
+// registers: rank by LDS atomics on the digit at bit `shift`, reserve the tile's share of every
+// bucket region with one atomic per digit, sort through LDS, store coalesced bucket runs.  That
+// removes one write and one read of every key (16 of the 48 bytes per k-mer the unfused pipeline
+// moves).  Bucket regions are sized by the host from a sample of the input (GapTable); a region
+// that turns out too small raises `overflow` and the host redoes the chunk with the unfused
+// kernels.  The histograms of the next two digits are accumulated for the passes that follow.
+
+constexpr int kCursorStride = 32;                // u64 words between bucket cursors (256 B)
+
+struct GapTable {
+    unsigned long long reg_start[256];   // first key slot of bucket d
+    unsigned long long reg_cap[256];     // slots reserved for bucket d
+    unsigned long long cnt[256];         // keys actually in bucket d (filled by the host after extraction)
+    unsigned long long tile_first[257];  // first tile of bucket d when its keys are cut into sort tiles
+};
+
+struct PartCounters {
+    unsigned long long keys_out, windows, overflow, pad;
+    unsigned long long hist[512];                        // digits at shift+8 and shift+16
+    unsigned long long cursors[256 * kCursorStride];     // keys placed in bucket d so far
+};
+
+// Second level of the same idea (used when exactly two partition digits are needed): the fused
+// kernel partitions on the HIGH digit, and the next pass places the keys of region b by their
+// LOW digit into sub-regions (b, d) of the second key buffer, again by atomic cursors -- no
+// look-back chain, no digit histograms.  Sub-region (b, d) IS segment b*256+d of the counting
+// kernel.  Capacities come from the joint histogram of a larger sample; an overflow anywhere
+// makes the host redo the chunk with the exact (look-back) sequence.
+constexpr int kSubCursorStride = 4;              // u64 words between sub-region cursors (32 B)
+struct SubTable {
+    unsigned long long start[65536];     // first slot of sub-region (b, d), index b*256+d
+    unsigned long long cap[65536];
+};
+
+constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at most 62 bits
+
+// Extraction fused with the first partition level, third form.  What bounded the second form
+// (one returning atomic per tile and bucket on 256 cursor words, bucket runs of ~128 bytes landing
+// on partial 64-byte granules of HBM, two FNV chains per window) is designed out:
+//   * a workgroup owns a private BLOCK of B key slots in every bucket region and appends to it;
+//     a bucket cursor is touched only when a block is used up (B = 256: 16 x fewer atomics);
+//   * stores reach HBM as they are issued (nothing merges two partial writes of a 64-byte granule
+//     on the way: 1.4-1.5 x the bytes when runs start anywhere), so a tile stores only whole
+//     granules: per bucket the keys beyond a multiple of 8 wait in the registers of the thread that
+//     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket; in LDS the
+//     stored parts of all buckets lie back to back, each a multiple of 8 keys, so that 8 aligned
+//     lanes of ONE store instruction cover one aligned granule;
+//   * MODE 0 stores the strand representative (strand_rep) instead of the canonical form.
+// The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
+// skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
+// The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
+template <int MODE, int NH, bool ODD>
+__global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                            uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                            Key1* __restrict__ out, PartCounters* __restrict__ pc,
+                                                            const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
+                                                            uint32_t blk_log2)
+{
+    // MODE 0: one key per window, 16 windows per thread.  MODE 1 (graph): forward key and
+    // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
+    constexpr int S = MODE == 1 ? 2 : 1;
+    constexpr int P = 16 / S;
+    constexpr int T = kTB * P;                   // window starts per tile
+    constexpr int NVEC = T / 16 + 4;
+    constexpr int NK = P * S;                    // keys per thread
+    constexpr int kCarry = 7;
+    // the tile's keys and the keys carried in: first the parts stored now, bucket after bucket
+    // (each a multiple of 8), then the parts carried out
+    // (+ 64 slots nobody reads: LDS writes that do not apply go there instead of under a branch, whose
+    // exec-mask bookkeeping costs scalar issue slots; reads past the live part land there too)
+    constexpr uint32_t kSpare = T * S + 256 * kCarry;
+    __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry + 64];
+    __shared__ uint32_t dh[256 + 32];            // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
+    // per bucket: x = first slot in `sorted` of the stored part | its length << 16,
+    //             y = first slot of the part carried out | keys carried in << 13 | stored keys that fit the current block << 16
+    __shared__ uint2 t_lay[256];
+    // per bucket: slot / 8 of the current block's write position (x) and of the new block(s) (y)
+    __shared__ uint2 t_base[256];
+    __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t lh[NH ? 256 * NH : 1];   // histograms of the next NH digits
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    uint32_t* pk = reinterpret_cast<uint32_t*>(sorted);
+    uint32_t* iv = pk + NVEC;
+
+    const uint32_t tid = threadIdx.x;
+    if (NH > 0) lh[tid] = 0;
+    if (NH > 1) lh[tid + 256] = 0;
+    dh[tid] = 0;
+    if (tid == 0) sh_ovf = 0;
+    const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t B = 1u << blk_log2;
+    const uint32_t bits = 2 * len;
+    const uint64_t kmask = (1ULL << bits) - 1;               // len <= 31
+    const uint64_t lmask = (1ULL << len) - 1;
+    unsigned long long nvalid = 0;
+    uint64_t wpos = 0;                           // next slot of bucket tid's open block (a block boundary = none open)
+    uint32_t ccnt = 0;                           // keys of bucket tid carried over from the previous tile
+    Key1 kc[kCarry];                             // ... and the keys themselves
+#pragma unroll
+    for (int j = 0; j < kCarry; ++j) kc[j].lo = 0;
+
+    // 16 bytes of the input at `byte0` -> 32 bits of 2-bit codes + 16 non-base flags
+    auto fetch = [&](uint64_t byte0, uint4& q) -> bool {
+        if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return true; }
+        q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        if (byte0 < navail + mis)
+        {
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return true;
+    };
+    auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        codes = 0; bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+    };
+    // The bytes of a tile are fetched one tile ahead and wait, encoded, in registers: the load's
+    // latency passes behind the previous tile's ranking and sorting, and the stores of a tile have
+    // half a tile's time to drain before anything waits on this wave's memory counter again.
+    constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..3 also vector NV0 + tid
+    static_assert(NVEC == NV0 + 4 && NV0 <= kTB, "one vector per thread and four more");
+    uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
+    if (blockIdx.x < nsuper)
+    {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const uint64_t tb = (uint64_t)blockIdx.x * T;
+        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+        if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        encode(q0, c0, b0);
+        if (tid < 4) encode(q1, c1, b1);
+    }
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        const uint64_t tile_base = st * (uint64_t)T;
+
+        // ---- phase A: this tile's codes from registers to LDS, the next tile's bytes on their way ----
+        if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
+        if (tid < 4) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
+        __syncthreads();
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const bool more = st + gridDim.x < nsuper;
+        if (more)
+        {
+            const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
+            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+            if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        }
+
+        // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
+        // Written without branches around the LDS operations: a window that is not valid still gets a
+        // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
+        // of a thread are issued back to back and waited for once, not one round trip after the other.
+        Key1 kreg[NK];
+        uint32_t rk[NK];
+        uint32_t vm;
+        {
+            const uint32_t q0 = tid * P + mis;
+            const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)tid * P;
+            uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+            uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
+            const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
+            // window i is valid iff bits [i, i + len) of `inv` are zero.  All P windows at once: runs of good bases
+            // of length 1, 2, 4, .. by doubling, and the AND of the runs that make up len (its binary digits) at
+            // their offsets -- six steps of a few 64-bit operations instead of a shift, mask and compare per window
+            uint32_t m;
+            {
+                uint64_t run = ~inv, acc = ~0ULL;
+                uint32_t covered = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)               // len <= 31
+                {
+                    if ((len >> j) & 1u) { acc &= run >> covered; covered += 1u << j; }
+                    run &= run >> (1u << j);
+                }
+                // (bits of `inv` above the 64 that were read count as good: they belong to windows beyond P anyway)
+                const uint64_t left = nstarts > p0 ? nstarts - p0 : 0;
+                const uint32_t lim = left >= (uint64_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << (uint32_t)left) - 1u);
+                m = (uint32_t)acc & lim;
+            }
+            vm = m;
+            nvalid += __popc(m);
+            const uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+            const uint32_t s2 = 2 * sh;
+            const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            const uint64_t bhi = hi >> s2;
+            // forward key f and reverse complement r of window 0, then one base rolled in per window
+            uint64_t f = rev64(blo & kmask) >> (64 - bits);
+            uint64_t r = (~blo) & kmask;
+            const uint32_t top = bits - 2;
+            const uint32_t spare = 256u + (tid & 31u);          // counters nobody reads
+            uint32_t bin[NK];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                if (i)
+                {
+                    const uint32_t pos = 2 * (i + len - 1);
+                    const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                    f = ((f << 2) | nb) & kmask;
+                    r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
+                }
+                const bool ok = (m >> i) & 1u;
+                const Key1 fk{f}, rck{r};
+                if (MODE == 0)
+                {
+                    // odd length: the central base decides (its low bit differs between the strands)
+                    const Key1 k = ODD ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
+                    kreg[i] = k;
+                    bin[i] = ok ? ((uint32_t)(k.lo >> shift) & 0xFFu) : spare;
+                }
+                else
+                {
+                    kreg[i * 2] = fk;
+                    bin[i * 2] = ok ? ((uint32_t)(fk.lo >> shift) & 0xFFu) : spare;
+                    kreg[i * 2 + 1] = rck;
+                    bin[i * 2 + 1] = ok ? ((uint32_t)(rck.lo >> shift) & 0xFFu) : spare;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
+        }
+        __syncthreads();
+
+        // ---- phase C: bookkeeping of bucket tid: what is stored now, where, what is carried out ----
+        uint32_t total_store;
+        {
+            const uint32_t cnt = dh[tid];
+            const uint32_t tot = ccnt + cnt;           // the bucket's stream: carried keys, then the new ones by rank
+            const uint32_t fl = tot & ~7u, rem = tot & 7u;
+            uint32_t sums;
+            const uint32_t pre = block_excl_scan<uint32_t>(fl | (rem << 16), sh_scan, &sums);
+            total_store = sums & 0xFFFFu;
+            const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
+            dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            uint32_t thr = fl;
+            uint2 tb = make_uint2((uint32_t)(wpos >> 3), 0u);
+            if (fl > room)
+            {
+                thr = room;
+                const uint32_t need = fl - room;
+                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                // a region that is too small: nothing of this tile is stored, the host redoes the chunk
+                if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+                tb.y = (uint32_t)((my_start + at) >> 3);
+                wpos = my_start + at + need;
+            }
+            else wpos += fl;
+            t_base[tid] = tb;
+            t_lay[tid] = make_uint2(f_at | (fl << 16), l_at | (ccnt << 13) | (thr << 16));
+            // the keys carried in go first (phase A's arrays in `sorted` are dead: every thread is past phase B)
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                sorted[(uint32_t)j < ccnt ? ((uint32_t)j < fl ? f_at + j : l_at + j) : kSpare + (tid & 63u)] = kc[j];
+            ccnt = rem;
+        }
+        __syncthreads();
+        // new keys to their place: position ccnt_in + rank of the bucket's stream (the table reads of
+        // all sixteen keys first, then the writes: no round trip per key)
+        {
+            uint2 tl[NK];
+#pragma unroll
+            for (int i = 0; i < NK; ++i) tl[i] = t_lay[(uint32_t)(kreg[i].lo >> shift) & 0xFFu];
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
+            {
+                const bool ok = (vm >> (i / S)) & 1u;
+                const Key1 k = kreg[i];
+                const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
+                const uint32_t fl = tl[i].x >> 16;
+                const uint32_t at = p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl);
+                sorted[ok ? at : kSpare + (tid & 63u)] = k;
+                if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], ok ? 1u : 0u);
+                if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], ok ? 1u : 0u);
+            }
+        }
+        if (more)
+        {
+            encode(q0, c0, b0);
+            if (tid < 4) encode(q1, c1, b1);
+        }
+        __syncthreads();
+
+        // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------
+        if (sh_ovf == 0)
+            for (uint32_t i0 = tid; i0 < total_store; i0 += 4 * kTB)
+            {
+                // four keys at a time: their LDS reads, then their table reads, then their stores
+                Key1 kk[4];
+                uint2 tl[4], tb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kk[u] = sorted[min(i0 + u * kTB, kSpare)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t d = (uint32_t)(kk[u].lo >> shift) & 0xFFu;
+                    tl[u] = t_lay[d]; tb[u] = t_base[d];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t i = i0 + u * kTB;
+                    if (i < total_store)
+                    {
+                        const uint32_t p = i - (tl[u].x & 0xFFFFu);
+                        const uint32_t thr = tl[u].y >> 16;
+                        const uint64_t o = p < thr ? ((uint64_t)tb[u].x << 3) + p : ((uint64_t)tb[u].y << 3) + (p - thr);
+                        out[o] = kk[u];
+                    }
+                }
+            }
+        // what bucket tid carries out, back into registers
+        {
+            const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];       // (those beyond ccnt are never used)
+        }
+        __syncthreads();
+    }
+
+    // ---- the end: carried keys and the unused tail of every open block ---------------------------
+    if (sh_ovf == 0)
+    {
+        if (ccnt)
+        {
+            // one more granule: the carried keys, padding behind them
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            if (room == 0)
+            {
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
+                else wpos = my_start + at;
+            }
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) out[wpos + j] = kc[j];
+            wpos += ccnt;
+        }
+        const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+        // pad [wpos, end of block) of every bucket: all threads share the work through LDS
+        __syncthreads();
+        t_base[tid].x = tail;
+        reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        __syncthreads();
+        for (uint32_t d = 0; d < 256; ++d)
+        {
+            const uint32_t n = t_base[d].x;
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{kPadKey};
+        }
+    }
+    if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
+    if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
+    // valid windows of this workgroup
+    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
+    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
+}
+
+// Strand representatives -> gossamer's canonical form (position_type::normalize, RankSelect.hh:126-140),
+// for the distinct keys only; the result is no longer sorted.
+template <class K>
+__global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* in, K* outk, uint64_t m, uint32_t len)       // in == outk is fine
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= m) return;
+    const K x = in[i];
+    outk[i] = canonical(x, revcomp(x, len));
+}
+
+// The same fusion for two-word keys (32 <= len <= 63): windows out of a 192-bit register buffer
+// (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`,
+// in the form of extract1_part_kernel: private blocks of B slots per workgroup and bucket (a cursor is
+// touched once per block), whole 64-byte granules (4 keys) stored from 4 aligned lanes, the remainder of a
+// bucket (<= 3 keys) carried in the registers of the thread that owns it, kPadKey pairs behind the last
+// keys of every last block, the next tile's bytes fetched one tile ahead.  MODE 0 still computes gossamer's
+// canonical form in the kernel (two FNV chains over 16 bytes).
+template <int MODE, int NH, int NKEYS, int NBH = 8>
+__global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                               uint64_t nstarts, uint64_t navail, uint32_t len,
+                                                               Key2* __restrict__ out, PartCounters* __restrict__ pc,
+                                                               const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
+                                                               uint32_t blk_log2)
+{
+    constexpr int S = MODE == 1 ? 2 : 1;
+    constexpr int P = NKEYS / S;                 // windows per thread; NKEYS keys per thread
+    constexpr int T = kTB * P;
+    constexpr int NVEC = T / 16 + 6;
+    constexpr int NK = P * S;
+    constexpr int kCarry = 3;                    // keys of a bucket below a granule of 4
+    constexpr uint32_t kSpare = T * S + 256 * kCarry;
+    __shared__ __attribute__((aligned(64))) Key2 sorted[T * S + 256 * kCarry + 64];
+    __shared__ uint32_t dh[256 + 32];
+    __shared__ uint2 t_lay[256];                 // x = first slot of the stored part | its length << 16; y = first slot of the carried part | keys carried in << 13 | stored keys that fit the current block << 16
+    __shared__ uint2 t_base[256];                // slot / 4 of the current block's write position (x) and of the new block(s) (y)
+    __shared__ uint32_t lh[NH ? 256 * NH : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ uint32_t sh_ovf;
+    uint32_t* pk = reinterpret_cast<uint32_t*>(sorted);
+    uint32_t* iv = pk + NVEC;
+
+    const uint32_t tid = threadIdx.x;
+    if (NH > 0) lh[tid] = 0;
+    if (NH > 1) lh[tid + 256] = 0;
+    dh[tid] = 0;
+    if (tid < 32) dh[256 + tid] = 0;
+    if (tid == 0) sh_ovf = 0;
+    const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
+    const uint32_t B = 1u << blk_log2;
+    const uint32_t bits = 2 * len;                                       // 64..126
+    const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
+    const uint64_t lmask = (1ULL << len) - 1;
+    unsigned long long nvalid = 0;
+    uint64_t wpos = 0;
+    uint32_t ccnt = 0;
+    Key2 kc[kCarry];
+#pragma unroll
+    for (int j = 0; j < kCarry; ++j) kc[j] = Key2{0, 0};
+
+    auto fetch = [&](uint64_t byte0, uint4& q) {
+        if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return; }
+        q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        if (byte0 < navail + mis)
+        {
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (int j = 0; j < 16; ++j)
+            {
+                uint64_t b = byte0 + j;
+                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        codes = 0; bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t l = w[i] | 0x20202020u;
+            uint32_t x = (l >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+            uint32_t b1 = bad >> 7;
+            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            codes |= c8 << (8 * i);
+            bads |= b4 << (4 * i);
+        }
+    };
+    constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..5 also vector NV0 + tid
+    static_assert(NVEC == NV0 + 6 && NV0 <= kTB, "one vector per thread and six more");
+    uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
+    if (blockIdx.x < nsuper)
+    {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const uint64_t tb = (uint64_t)blockIdx.x * T;
+        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+        if (tid < 6) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        encode(q0, c0, b0);
+        if (tid < 6) encode(q1, c1, b1);
+    }
+
+    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    {
+        const uint64_t tile_base = st * (uint64_t)T;
+        if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
+        if (tid < 6) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
+        __syncthreads();
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const bool more = st + gridDim.x < nsuper;
+        if (more)
+        {
+            const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
+            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+            if (tid < 6) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        }
+
+        // ---- windows out of registers, keys, rank inside their digit (no branch around the LDS atomics) ----
+        Key2 kreg[NK];
+        uint32_t rk[NK];
+        uint32_t vm = 0;
+        {
+            const uint32_t q0i = tid * P + mis;
+            const uint32_t v0 = q0i >> 4, sh = q0i & 15u;
+            const uint64_t p0 = tile_base + (uint64_t)tid * P;
+            const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
+            const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+            const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
+            const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
+            const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t t = sh + i;
+                const uint64_t win = t ? ((inv_lo >> t) | (inv_hi << (64 - t))) : inv_lo;
+                bool ok = (win & lmask) == 0 && (p0 + i < nstarts);
+                vm |= ok ? (1u << i) : 0u;
+            }
+            nvalid += __popc(vm);
+            const uint32_t spare = 256u + (tid & 31u);
+            uint32_t bin[NK];
+            // forward key f and reverse complement r of window 0 from the register buffer, then one base
+            // rolled into both per window
+            Key2 f{0, 0}, r{0, 0};
+            const uint32_t top = bits - 2;                  // position of a key's first base (>= 62)
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                if (i == 0)
+                {
+                    const uint32_t t2 = 2 * sh;
+                    Key2 e;
+                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
+                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
+                    const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
+                    const uint32_t sft = 128 - bits;
+                    if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                    else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                    r.lo = ~e.lo; r.hi = (~e.hi) & mask_hi;
+                }
+                else
+                {
+                    const uint32_t pos = 2 * (sh + i + len - 1);
+                    const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
+                    f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
+                    f.lo = (f.lo << 2) | nb;
+                    const uint64_t cb = nb ^ 3u;
+                    r.lo = (r.lo >> 2) | (r.hi << 62);
+                    r.hi = (r.hi >> 2) | (top >= 64 ? cb << (top - 64) : 0ULL);
+                    if (top < 64) r.lo |= cb << top;
+                }
+                const bool ok = (vm >> i) & 1u;
+                const Key2 rck = r;
+                if (MODE == 0)
+                {
+                    const Key2 k = canonical_tail<NBH>(f, rck);
+                    kreg[i] = k;
+                    bin[i] = ok ? key_digit(k, shift) : spare;
+                }
+                else
+                {
+                    kreg[2 * i] = f;
+                    bin[2 * i] = ok ? key_digit(f, shift) : spare;
+                    kreg[2 * i + 1] = rck;
+                    bin[2 * i + 1] = ok ? key_digit(rck, shift) : spare;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
+        }
+        __syncthreads();
+
+        // ---- bookkeeping of bucket tid: what is stored now, where, what is carried out ----
+        uint32_t total_store;
+        {
+            const uint32_t cnt = dh[tid];
+            const uint32_t tot = ccnt + cnt;
+            const uint32_t fl = tot & ~3u, rem = tot & 3u;
+            uint32_t sums;
+            const uint32_t pre = block_excl_scan<uint32_t>(fl | (rem << 16), sh_scan, &sums);
+            total_store = sums & 0xFFFFu;
+            const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
+            dh[tid] = 0;
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            uint32_t thr = fl;
+            uint2 tb = make_uint2((uint32_t)(wpos >> 2), 0u);
+            if (fl > room)
+            {
+                thr = room;
+                const uint32_t need = fl - room;
+                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+                tb.y = (uint32_t)((my_start + at) >> 2);
+                wpos = my_start + at + need;
+            }
+            else wpos += fl;
+            t_base[tid] = tb;
+            t_lay[tid] = make_uint2(f_at | (fl << 16), l_at | (ccnt << 13) | (thr << 16));
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                sorted[(uint32_t)j < ccnt ? ((uint32_t)j < fl ? f_at + j : l_at + j) : kSpare + (tid & 63u)] = kc[j];
+            ccnt = rem;
+        }
+        __syncthreads();
+        {
+            uint2 tl[NK];
+#pragma unroll
+            for (int i = 0; i < NK; ++i) tl[i] = t_lay[key_digit(kreg[i], shift)];
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
+            {
+                const bool ok = (vm >> (i / S)) & 1u;
+                const Key2 k = kreg[i];
+                const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
+                const uint32_t fl = tl[i].x >> 16;
+                const uint32_t at = p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl);
+                sorted[ok ? at : kSpare + (tid & 63u)] = k;
+                if (NH > 0) atomicAdd(&lh[key_digit(k, shift + 8)], ok ? 1u : 0u);
+                if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], ok ? 1u : 0u);
+            }
+        }
+        if (more)
+        {
+            encode(q0, c0, b0);
+            if (tid < 6) encode(q1, c1, b1);
+        }
+        __syncthreads();
+
+        // ---- whole granules to the bucket blocks; every 4 aligned lanes store one ----
+        if (sh_ovf == 0)
+            for (uint32_t i0 = tid; i0 < total_store; i0 += 2 * kTB)
+            {
+                Key2 kk[2];
+                uint2 tl[2], tb[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) kk[u] = sorted[min(i0 + u * kTB, kSpare)];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t d = key_digit(kk[u], shift);
+                    tl[u] = t_lay[d]; tb[u] = t_base[d];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const uint32_t i = i0 + u * kTB;
+                    if (i < total_store)
+                    {
+                        const uint32_t p = i - (tl[u].x & 0xFFFFu);
+                        const uint32_t thr = tl[u].y >> 16;
+                        const uint64_t o = p < thr ? ((uint64_t)tb[u].x << 2) + p : ((uint64_t)tb[u].y << 2) + (p - thr);
+                        out[o] = kk[u];
+                    }
+                }
+            }
+        {
+            const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];
+        }
+        __syncthreads();
+    }
+
+    // ---- the end: carried keys and the unused tail of every open block ----
+    if (sh_ovf == 0)
+    {
+        if (ccnt)
+        {
+            const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+            if (room == 0)
+            {
+                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
+                else wpos = my_start + at;
+            }
+#pragma unroll
+            for (int j = 0; j < kCarry; ++j)
+                if ((uint32_t)j < ccnt) out[wpos + j] = kc[j];
+            wpos += ccnt;
+        }
+        const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+        __syncthreads();
+        t_base[tid].x = tail;
+        reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        __syncthreads();
+        for (uint32_t d = 0; d < 256; ++d)
+        {
+            const uint32_t n = t_base[d].x;
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key2{~0ULL, ~0ULL};
+        }
+    }
+    if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
+    if (NH > 1) { if (lh[tid + 256]) atomicAdd(&pc->hist[tid + 256], (unsigned long long)lh[tid + 256]); }
+    for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o, 64);
+    if (lane_id() == 0 && nvalid) { atomicAdd(&pc->keys_out, nvalid * S); atomicAdd(&pc->windows, nvalid); }
+}
+
+}  // namespace goss

@@ -1,0 +1,540 @@
+// kernels_partition.hpp -- radix partition passes (histogram-table form, look-back form, sub-region second level).
+// Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp, in this order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "goss_key.hpp"
+#include "kernels_common.hpp"
+
+namespace goss {
+
+// --------------------------------------------------------------------------------------
+// K4: LSD radix sort, 8-bit digits: per-tile histogram, scan (above), stable scatter
+// --------------------------------------------------------------------------------------
+
+#ifndef GOSS_SORT_ITEMS1
+#define GOSS_SORT_ITEMS1 32
+#endif
+#ifndef GOSS_SORT_ITEMS2
+#define GOSS_SORT_ITEMS2 16
+#endif
+#ifndef GOSS_LB_BATCH
+#define GOSS_LB_BATCH 1
+#endif
+// Tile of the second level in sub-region mode: 5632 (u64) / 2816 (u128) keys -- 52 KB of LDS, three workgroups
+// per CU.  With the tiles dealt out by XCD the shorter runs cost nothing and the third workgroup hides the LDS
+// phases of the other two (C2: 41.0 -> 37.5 ms; the chained passes keep the large tile, their bound is the chain).
+template <class K> struct SubCfg {
+    static constexpr int kItems = sizeof(K) == 8 ? 22 : 11;
+    static constexpr int kTile = 256 * kItems;
+};
+
+template <class K, bool HAS_VAL = false> struct SortCfg {
+    static constexpr int kItems = sizeof(K) == 8 ? (HAS_VAL ? 16 : GOSS_SORT_ITEMS1) : (HAS_VAL ? 8 : GOSS_SORT_ITEMS2);   // keys per thread
+    static constexpr int kTile = kTB * kItems;                 // 4096 (u64) / 2048 (u128) keys
+};
+
+// table layout: table[digit * ntiles + tile]
+template <class K, bool HAS_VAL>
+__global__ __launch_bounds__(kTB) void radix_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t digit,
+                                                         uint64_t ntiles, uint64_t* __restrict__ table)
+{
+    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
+    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+#pragma unroll 4
+    for (int j = 0; j < kSortItems; ++j)
+    {
+        uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
+        if (i < n) atomicAdd(&hist[key_digit(keys[i], digit)], 1u);
+    }
+    __syncthreads();
+    table[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Peers of this lane = lanes of the wave whose (valid) item has the same 8-bit digit.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+    {
+        bool bit = (d >> b) & 1u;
+        uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+template <class K, bool HAS_VAL>
+__global__ __launch_bounds__(kTB) void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint64_t n, uint32_t digit, uint64_t ntiles,
+                                                            const uint64_t* __restrict__ table)
+{
+    constexpr int kSortItems = SortCfg<K, HAS_VAL>::kItems;
+    constexpr int kSortTile = SortCfg<K, HAS_VAL>::kTile;
+    __shared__ uint32_t wave_hist[kWaves][256];
+    __shared__ uint32_t digit_start[256];
+    __shared__ uint64_t global_base[256];
+    __shared__ K stage[kSortTile];
+    __shared__ uint32_t vstage[HAS_VAL ? kSortTile : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t tile_base = (uint64_t)blockIdx.x * kSortTile;
+    const uint32_t tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
+
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
+    __syncthreads();
+
+    K key[kSortItems];
+    uint32_t val[HAS_VAL ? kSortItems : 1];
+    uint16_t rank[kSortItems];
+    const uint32_t wbase = w * 64 * kSortItems;
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        bool valid = li < tile_n;
+        if (valid)
+        {
+            key[r] = keys_in[tile_base + li];
+            if (HAS_VAL) val[r] = vals_in[tile_base + li];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        bool valid = li < tile_n;
+        uint32_t d = valid ? key_digit(key[r], digit) : 0u;
+        uint64_t peers = match_digit(d, valid);
+        uint32_t before = __popcll(peers & lt_mask);
+        uint32_t base = 0;
+        lds_vu32 wh = (lds_vu32)wave_hist[w];
+        if (valid) base = wh[d];
+        // all reads of this round happen before the leader's update (same wave, in order)
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) wh[d] = base + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = (uint16_t)(base + before);
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over waves, tile totals, exclusive scan over digits
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i)
+        {
+            uint32_t c = wave_hist[i][tid];
+            wave_hist[i][tid] = tot;
+            tot += c;
+        }
+        uint32_t tile_total;
+        uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
+        digit_start[tid] = start;
+        global_base[tid] = table[(uint64_t)tid * ntiles + blockIdx.x] - start;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n)
+        {
+            uint32_t d = key_digit(key[r], digit);
+            uint32_t pos = digit_start[d] + wave_hist[w][d] + rank[r];
+            stage[pos] = key[r];
+            if (HAS_VAL) vstage[pos] = val[r];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = tid; i < tile_n; i += kTB)
+    {
+        K k = stage[i];
+        uint64_t o = global_base[key_digit(k, digit)] + i;
+        keys_out[o] = k;
+        if (HAS_VAL) vals_out[o] = vstage[i];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K4 single-pass form: global digit histograms once, then a scatter whose tile offsets come
+// from a chained scan with decoupled look-back (no per-tile histogram table, no second read
+// of the keys).
+// --------------------------------------------------------------------------------------
+
+// hist[p * 256 + d] += number of keys whose digit at bit (first_shift + 8p) is d, for
+// p < npass (npass <= 16).  Persistent grid: every workgroup accumulates in LDS over many
+// tiles and flushes once.
+template <class K>
+__global__ __launch_bounds__(kTB) void global_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t first_shift,
+                                                          uint32_t npass, unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t lh[16 * 256];
+    for (uint32_t i = threadIdx.x; i < npass * 256; i += kTB) lh[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kTB;
+    uint32_t since_flush = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x; i < n; i += stride)
+    {
+        K k = keys[i];
+        for (uint32_t p = 0; p < npass; ++p) atomicAdd(&lh[p * 256 + key_digit(k, first_shift + 8 * p)], 1u);
+        // a 32-bit LDS bin cannot overflow before 2^32 keys have gone through this workgroup
+        (void)since_flush;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < npass * 256; i += kTB)
+        if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+// In-place exclusive scan of each 256-entry row (one workgroup per row).
+__global__ __launch_bounds__(kTB) void scan_rows256_kernel(unsigned long long* __restrict__ hist)
+{
+    __shared__ uint64_t sh[kWaves + 1];
+    uint64_t v = hist[blockIdx.x * 256 + threadIdx.x];
+    uint64_t tot;
+    uint64_t ex = block_excl_scan<uint64_t>(v, sh, &tot);
+    hist[blockIdx.x * 256 + threadIdx.x] = ex;
+}
+
+struct LookbackCtl {
+    uint32_t ticket;       // next tile number
+    uint32_t error;        // a look-back spin gave up (never expected)
+    // diagnostics (GOSS_LB_STATS builds only): per-tile sums recorded by digit 0's thread
+    unsigned long long walk_steps, spin_polls, max_depth, tiles;
+};
+
+constexpr uint64_t kLbFlagAgg = 1ULL << 62;      // tile's own count is published
+constexpr uint64_t kLbFlagPrefix = 2ULL << 62;   // inclusive prefix up to this tile is published
+constexpr uint64_t kLbValueMask = (1ULL << 62) - 1;
+
+// GAPPED: the input is the output of extract1_part_kernel -- 256 bucket regions with unused
+// slots between them (GapTable); tile t is the (t - tile_first[b])-th tile of bucket b.  Every
+// tile then lies inside one bucket of the previous digit, so no tile needs a stable rank.
+template <class K, bool HAS_VAL, bool ORDERED, bool GAPPED = false, int ITEMS = SortCfg<K, HAS_VAL>::kItems>
+__global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                             uint64_t n, uint32_t digit, uint32_t sorted_lo,
+                                                             const unsigned long long* __restrict__ bucket_base,
+                                                             unsigned long long* __restrict__ status,
+                                                             LookbackCtl* __restrict__ ctl,
+                                                             unsigned long long* __restrict__ cursors,
+                                                             const GapTable* __restrict__ gt = nullptr,
+                                                             const SubTable* __restrict__ sub = nullptr,
+                                                             uint32_t rem_out = 0)
+{
+    // rem_out (two-word keys, sub-region mode): slot o of keys_out is a 12-byte record holding the key's low
+    // `digit` bits -- what is left below the 16-bit segment prefix, which the slot's sub-region implies; the
+    // counting kernel of 96-bit remainders reads those (a quarter less to write here and to read there)
+    constexpr int kSortItems = ITEMS;
+    constexpr int kSortTile = kTB * ITEMS;
+    __shared__ uint32_t wave_hist[kWaves][256];
+    __shared__ uint32_t digit_start[256];
+    __shared__ uint64_t global_base[256];
+    __shared__ K stage[kSortTile];
+    __shared__ uint32_t vstage[HAS_VAL ? kSortTile : 1];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ uint32_t sh_tile;
+    __shared__ uint32_t sh_bucket;
+    __shared__ uint32_t sh_skip;
+    __shared__ uint32_t sh_total;
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    // Tile number.  ORDERED: a ticket (one returning atomic per tile: every lower-numbered tile
+    // has then started, so the chain cannot stall, but a single word serves only ~88 M
+    // tickets/s chip-wide).  Otherwise blockIdx.x: the dispatcher starts workgroups in
+    // blockIdx order in practice; HIP does not promise it, so the look-back spin is bounded and
+    // a give-up makes the host redo the pass with the histogram-table kernels.
+    if (ORDERED) { if (tid == 0) sh_tile = atomicAdd(&ctl->ticket, 1u); }
+    if (tid == 0) sh_skip = 0;
+    // Sub-region mode (no chain, any tile order): workgroups go round the eight XCDs in blockIdx order, and each
+    // XCD has its own L2.  Tile = (blockIdx % 8) * tiles/8 + blockIdx / 8 gives every XCD a contiguous range of
+    // tiles, i.e. its own bucket regions: the runs that consecutive tiles append to a sub-region then pass through
+    // ONE L2, where the partial 64-byte granules at their seams can meet.  (The grid is rounded up to a multiple of 8.)
+    uint32_t my_tile = blockIdx.x;
+    if (GAPPED && !ORDERED && sub)
+    {
+        const uint32_t total = (uint32_t)gt->tile_first[256];
+#ifndef GOSS_K2_NO_XCD
+        const uint32_t per = (total + 7u) / 8u;
+        my_tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#endif
+        if (my_tile >= total) return;
+    }
+    if (GAPPED && !ORDERED)
+    {
+        const unsigned long long t = my_tile;
+        if (gt->tile_first[tid] <= t && t < gt->tile_first[tid + 1]) sh_bucket = tid;
+    }
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) wave_hist[i][tid] = 0;
+    __syncthreads();
+    const uint32_t tile = ORDERED ? sh_tile : my_tile;
+    uint64_t tile_base = (uint64_t)tile * kSortTile;
+    uint32_t tile_n = 0;
+    if (GAPPED)
+    {
+        const uint32_t b = sh_bucket;
+        const uint64_t j = (uint64_t)tile - gt->tile_first[b];
+        const uint64_t left = gt->cnt[b] - j * kSortTile;
+        tile_base = gt->reg_start[b] + j * kSortTile;
+        tile_n = (uint32_t)(left < (uint64_t)kSortTile ? left : (uint64_t)kSortTile);
+    }
+    else tile_n = (uint32_t)(n - tile_base < (uint64_t)kSortTile ? n - tile_base : (uint64_t)kSortTile);
+
+    K key[kSortItems];
+    uint32_t val[HAS_VAL ? kSortItems : 1];
+    uint16_t rank[kSortItems];
+    const uint32_t wbase = w * 64 * kSortItems;
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+    // GAPPED: slots of a bucket region that hold no key (the padding of extract1_part_kernel's
+    // last blocks) are skipped: bit r of `have` = item r of this thread is a key
+    uint32_t have = 0;
+    static_assert(kSortItems <= 32, "one validity bit per item");
+
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+    {
+        uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n)
+        {
+            key[r] = keys_in[tile_base + li];
+            if (HAS_VAL) val[r] = vals_in[tile_base + li];
+            have |= 1u << r;
+        }
+    }
+    // (a second loop: looking at a key inside the load loop would wait for every load in turn)
+    if (GAPPED)
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+            if (((have >> r) & 1u) && is_pad_key(key[r])) have &= ~(1u << r);
+    }
+    // Does this tile need a STABLE rank?  Stability only matters when the tile holds keys
+    // that differ in the bits the previous passes sorted (bits [sorted_lo, digit)): a tile whose
+    // keys all share them -- almost every tile of the second partition pass -- may be ranked in
+    // any order, which costs one LDS atomic per key instead of eight ballots.
+    bool stable = false;
+    if (!GAPPED && digit > sorted_lo)
+    {
+        const uint32_t nb = digit - sorted_lo;
+        if (nb > 56) stable = true;
+        else
+        {
+            const uint64_t fmask = (1ULL << nb) - 1;
+            const uint64_t first = key_shr64(keys_in[tile_base], sorted_lo) & fmask;
+            uint64_t diff = 0;
+#pragma unroll
+            for (int r = 0; r < kSortItems; ++r)
+            {
+                uint32_t li = wbase + r * 64 + lane;
+                if (li < tile_n) diff |= (key_shr64(key[r], sorted_lo) & fmask) ^ first;
+            }
+            stable = __syncthreads_or(diff != 0);
+        }
+    }
+    if (stable)
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+        {
+            bool valid = (have >> r) & 1u;
+            uint32_t d = valid ? key_digit(key[r], digit) : 0u;
+            uint64_t peers = match_digit(d, valid);
+            uint32_t before = __popcll(peers & lt_mask);
+            uint32_t base = 0;
+            lds_vu32 wh = (lds_vu32)wave_hist[w];
+            if (valid) base = wh[d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && before == 0) wh[d] = base + __popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = (uint16_t)(base + before);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+            if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&wave_hist[0][key_digit(key[r], digit)], 1u);
+    }
+    __syncthreads();
+
+    {
+        // thread tid owns digit tid
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i)
+        {
+            uint32_t c = wave_hist[i][tid];
+            wave_hist[i][tid] = stable ? tot : 0u;     // unstable ranks are tile-wide already
+            tot += c;
+        }
+        unsigned long long* mine = status + (uint64_t)tile * 256 + tid;
+        uint64_t excl = 0;
+        const bool chain = !cursors && tile != 0;
+        uint64_t sub_start = 0;
+        if (GAPPED && sub)
+        {
+            // sub-region mode: the tile's keys of low digit tid go to sub-region (bucket, tid)
+            const uint32_t sidx = sh_bucket * 256u + tid;
+            excl = tot ? atomicAdd(&cursors[(uint64_t)sidx * kSubCursorStride], (unsigned long long)tot) : 0ULL;
+            sub_start = sub->start[sidx];
+            // too small a sub-region: nothing of this tile is stored, the host redoes the chunk
+            if (tot && excl + tot > sub->cap[sidx]) { atomicOr(&ctl->error, 2u); sh_skip = 1; }
+        }
+        else if (cursors)
+        {
+            // first pass of a sort: the order of tiles inside a bucket is irrelevant, so the
+            // tile just reserves its share of every bucket with one atomic per digit (cursor
+            // words 256 B apart: separate lines and channels) -- no chain, no waiting
+            excl = tot ? atomicAdd(&cursors[tid * kCursorStride], (unsigned long long)tot) : 0ULL;
+        }
+        else if (tile == 0)
+            __hip_atomic_store(mine, kLbFlagPrefix | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            __hip_atomic_store(mine, kLbFlagAgg | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t tile_total;
+        const uint32_t start = block_excl_scan<uint32_t>(tot, sh_scan, &tile_total);
+        digit_start[tid] = start;
+        if (tid == 0) sh_total = tile_total;
+        __syncthreads();
+
+        // the keys go to their sorted place in LDS before the look-back: that work needs only the
+        // tile's own counts, and the predecessors get time to publish theirs
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+        {
+            if ((have >> r) & 1u)
+            {
+                uint32_t d = key_digit(key[r], digit);
+                // unstable ranks are tile-wide already: no per-wave offset to read
+                uint32_t pos = digit_start[d] + rank[r] + (stable ? wave_hist[w][d] : 0u);
+                stage[pos] = key[r];
+                if (HAS_VAL) vstage[pos] = val[r];
+            }
+        }
+
+        if (chain)
+        {
+            // Walk back over the predecessors kLbBatch tiles at a time: the loads of one batch
+            // are independent, so a deep walk costs one memory latency per batch instead of
+            // one per tile.
+            constexpr int kLbBatch = GOSS_LB_BATCH;
+            int64_t t = (int64_t)tile - 1;
+            uint32_t spins = 0;
+            bool found = false;
+            while (!found)
+            {
+                unsigned long long v[kLbBatch];
+#pragma unroll
+                for (int j = 0; j < kLbBatch; ++j)
+                {
+                    int64_t tj = t - j;
+                    v[j] = tj >= 0 ? __hip_atomic_load(status + (uint64_t)tj * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : kLbFlagPrefix;       // before tile 0: an empty prefix
+                }
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < kLbBatch; ++j)
+                {
+                    if (found || used != j) continue;     // stopped at an unpublished tile
+                    uint64_t f = v[j] & ~kLbValueMask;
+                    if (f == 0) continue;
+                    excl += v[j] & kLbValueMask;
+                    used = j + 1;
+                    if (f == kLbFlagPrefix) found = true;
+                }
+                t -= used;
+#if defined(GOSS_LB_STATS)
+                if (tid == 0) { atomicAdd(&ctl->walk_steps, (unsigned long long)used); }
+#endif
+                if (!found && used < kLbBatch)
+                {
+                    if (++spins > (1u << 20)) { atomicOr(&ctl->error, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+#if defined(GOSS_LB_STATS)
+            if (tid == 0)
+            {
+                atomicAdd(&ctl->spin_polls, (unsigned long long)spins);
+                atomicMax(&ctl->max_depth, (unsigned long long)((int64_t)tile - 1 - t));
+                atomicAdd(&ctl->tiles, 1ULL);
+            }
+#endif
+            __hip_atomic_store(mine, kLbFlagPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        global_base[tid] = ((GAPPED && sub) ? sub_start : bucket_base[tid]) + excl - start;
+    }
+    __syncthreads();
+
+    if (GAPPED && sh_skip) return;
+    const uint32_t tile_keys = GAPPED ? sh_total : tile_n;      // padding slots hold no key
+    if constexpr (sizeof(K) == 16)
+    {
+        if (rem_out)
+        {
+            const uint32_t hb = digit > 64 ? digit - 64 : 0;
+            const uint32_t hmask = hb >= 32 ? 0xFFFFFFFFu : ((1u << hb) - 1u);
+            const uint64_t lmask64 = digit >= 64 ? ~0ULL : ((1ULL << digit) - 1ULL);
+            Rem96* out96 = reinterpret_cast<Rem96*>(keys_out);
+            for (uint32_t i = tid; i < tile_keys; i += kTB)
+            {
+                const K k = stage[i];
+                const uint64_t o = global_base[key_digit(k, digit)] + i;
+                const uint64_t lo = key_lo_word(k) & lmask64;
+                out96[o] = Rem96{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)key_hi_word(k) & hmask};
+            }
+            return;
+        }
+    }
+    for (uint32_t i = tid; i < tile_keys; i += kTB)
+    {
+        K k = stage[i];
+        uint64_t o = global_base[key_digit(k, digit)] + i;
+        keys_out[o] = k;
+        if (HAS_VAL) vals_out[o] = vstage[i];
+    }
+}
+
+// out[q] = first index of the sorted array whose key is >= query[q] (one thread per query).
+template <class K>
+__global__ void lower_bound_keys_kernel(const K* __restrict__ keys, uint64_t n, const K* __restrict__ query, uint32_t nq,
+                                        uint64_t* __restrict__ out)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const K x = query[q];
+    uint64_t a = 0, b = n;
+    while (a < b)
+    {
+        const uint64_t mid = a + ((b - a) >> 1);
+        if (keys[mid] < x) a = mid + 1; else b = mid;
+    }
+    out[q] = a;
+}
+
+// Segment bounds of the sub-region layout: segment s holds cursors[s] keys from start[s].
+__global__ void sub_bounds_kernel(const SubTable* __restrict__ sub, const unsigned long long* __restrict__ cursors,
+                                  uint64_t* __restrict__ seg_beg, uint64_t* __restrict__ seg_end)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 65536u) return;
+    seg_beg[s] = sub->start[s];
+    seg_end[s] = sub->start[s] + cursors[(uint64_t)s * kSubCursorStride];
+}
+
+}  // namespace goss
