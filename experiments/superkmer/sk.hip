@@ -200,9 +200,7 @@ __global__ __launch_bounds__(kTB) void sk_extract_kernel(const uint8_t* __restri
         const uint64_t flo = (uint64_t)field, fhi = (uint64_t)(field >> 64);
         unsigned __int128 rv = (((unsigned __int128)rev2(flo)) << 64) | rev2(fhi);
         rv >>= (128 - 2 * nbases);
-        // bin: a second hash of the minimizer (the canonical m-mer at the position in mn[s])
-        const uint32_t mpos = mn[0] & 63u;           // placeholder, replaced below by a select over s
-        (void)mpos;
+        // bin: a second hash of the run's minimizer (its first-hash value, the upper bits of mn[s])
         uint32_t mv = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) if ((uint32_t)i == s) mv = mn[i];
@@ -293,6 +291,5 @@ int main(int argc, char** argv)
     std::printf("expansion: %llu windows, multiset hash %016llx (%.1f ms, one thread per record)\n", got[1], got[0], ms);
     const bool ok = got[0] == ref[0] && got[1] == ref[1] && st[0] == ref[1];
     std::printf("%s\n", ok ? "OK: the records hold exactly the k-mers of the reads" : "MISMATCH");
-    // bin balance: records per 16-bit bin (max / mean)
     return ok ? 0 : 1;
 }
