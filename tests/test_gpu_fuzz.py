@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_random_configurations_against_the_oracle():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "30", "11"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "30", "11", "groups"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-4000:]

@@ -2,7 +2,8 @@
 """Randomised parity run on the GPU box: many (k, mode, read shape, error rate, budget) combinations, every one
 through the product (fused path forced on where the input is small) and through the oracle; the object files
 must be byte-identical.  Complements the fixed cases of tests/: a place to catch what a particular tile count,
-key width or table form breaks.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+key width or table form breaks.  usage: python tools/fuzz_parity.py [cases] [seed] [groups]
+("groups": half of the cases count on 2 or 3 contexts of the process and go through the group exchange / emission)"""
 import os
 import random
 import sys
@@ -37,9 +38,14 @@ def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
     return ("\n".join(out) + "\n").encode()
 
 
+GROUPS = False       # third argument "groups": some cases count on 2 or 3 contexts and exchange
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    global GROUPS
+    GROUPS = len(sys.argv) > 3 and sys.argv[3] == "groups"
     rng = random.Random(seed)
     oracle.lib()
     bad = 0
@@ -73,15 +79,38 @@ def main():
         exp = {n[1:]: b for n, b in exp.items()}
         old = {n: os.environ.get(n) for n in env}
         os.environ.update(env)
+        parts = rng.choice([1, 1, 2, 3]) if GROUPS else 1
         try:
             try:
-                with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
-                    ctx.push_host(reads)
-                    c = ctx.finish()
-                    got = ctx.emit()
-                    stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "runs")}
-                ok = c.windows == nwin and sorted(got) == sorted(exp) and all(got[n] == exp[n] for n in exp)
-                why = "" if ok else "windows %d/%d, files differ: %s" % (c.windows, nwin, [n for n in exp if got.get(n) != exp[n]][:4])
+                if parts == 1:
+                    with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+                        ctx.push_host(reads)
+                        c = ctx.finish()
+                        got = ctx.emit()
+                        windows = c.windows
+                        stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "runs")}
+                else:
+                    # several contexts of this process, each counting a share of the reads (goss_gpu_group_exchange / _emit)
+                    from gossamer_amd import dist as gd
+                    lines = reads.split(b"\n")[:-1]
+                    per = (len(lines) + parts - 1) // parts
+                    shards = [b"".join(x + b"\n" for x in lines[i * per:(i + 1) * per]) for i in range(parts)]
+                    ctxs = [g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=max(budget, 256 << 20)) for _ in shards]
+                    try:
+                        windows = 0
+                        for cx, sh in zip(ctxs, shards):
+                            if sh:
+                                cx.push_host(sh)
+                            windows += cx.finish().windows
+                        g.group_exchange(ctxs, sample_per_context=rng.choice([0, 64, 1000]))
+                        g.group_emit(ctxs)
+                        got = gd.assemble_files([cx.files() for cx in ctxs])
+                        stats = {"contexts": parts}
+                    finally:
+                        for cx in ctxs:
+                            cx.close()
+                ok = windows == nwin and sorted(got) == sorted(exp) and all(got[n] == exp[n] for n in exp)
+                why = "" if ok else "windows %d/%d, files differ: %s" % (windows, nwin, [n for n in exp if got.get(n) != exp[n]][:4])
             except g.GossGpuError as e:
                 # a budget too small for the input is a legitimate refusal, anything else is not
                 ok = e.status == -3
