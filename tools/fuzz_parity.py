@@ -38,14 +38,17 @@ def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
     return ("\n".join(out) + "\n").encode()
 
 
-GROUPS = False       # third argument "groups": some cases count on 2 or 3 contexts and exchange
+GROUPS = False       # argument "groups": some cases count on 2 or 3 contexts and exchange
+LARGE = False        # argument "large": 0.4 to 1 M reads per case (several chunks, fused path without forcing)
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     global GROUPS
-    GROUPS = len(sys.argv) > 3 and sys.argv[3] == "groups"
+    GROUPS = len(sys.argv) > 3 and "groups" in sys.argv[3:]
+    global LARGE
+    LARGE = "large" in sys.argv[3:]
     rng = random.Random(seed)
     oracle.lib()
     bad = 0
@@ -55,7 +58,7 @@ def main():
         k = rng.choice([11, 13, 15, 16, 21, 24, 25, 27, 30, 31, 32, 33, 40, 45, 55, 62 if graph else 63])
         if graph:
             k = min(k, 62)
-        nreads = rng.choice([20000, 60000, 150000])
+        nreads = rng.choice([400000, 1000000]) if LARGE else rng.choice([20000, 60000, 150000])
         lmin, lmax = rng.choice([(150, 150), (30, 200), (k, k + 5), (100, 101)])
         lmin = max(lmin, 1)
         genome_len = rng.choice([5000, 60000, 400000, 2000000])
@@ -63,7 +66,7 @@ def main():
         err = rng.choice([0.0, 0.0, 0.002, 0.02])
         nrate = rng.choice([0.0, 0.001, 0.01])
         reads = make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, rng.random() < 0.3)
-        env = {"GOSS_GPU_FUSED_MIN": "0"}
+        env = {} if LARGE and rng.random() < 0.5 else {"GOSS_GPU_FUSED_MIN": "0"}
         if rng.random() < 0.3:
             env["GOSS_GPU_NO_MSD"] = "1"
         if rng.random() < 0.15:
@@ -72,7 +75,7 @@ def main():
             env["GOSS_GPU_EST_SCALE"] = rng.choice(["0.3", "3.0"])
         if rng.random() < 0.2:
             env["GOSS_GPU_ORDER_BITS"] = rng.choice(["16", "17", "20"])
-        budget = rng.choice([96 << 20, 256 << 20, 1 << 30, 4 << 30])
+        budget = rng.choice([512 << 20, 2 << 30, 8 << 30]) if LARGE else rng.choice([96 << 20, 256 << 20, 1 << 30, 4 << 30])
         t0 = time.time()
         build = oracle.build_graph if graph else oracle.build_kmer_set
         exp, nwin = build([(oracle.LINE, "r", reads)], k, out="o")
