@@ -2,14 +2,14 @@
 """Randomised parity run on the GPU box: many (k, mode, read shape, error rate, budget) combinations, every one
 through the product (fused path forced on where the input is small) and through the oracle; the object files
 must be byte-identical.  Complements the fixed cases of tests/: a place to catch what a particular tile count,
-key width or table form breaks.  usage: python tools/fuzz_parity.py [cases] [seed] [groups]
+key width or table form breaks.  usage: python tests/fuzz_parity.py [cases] [seed] [groups]
 ("groups": half of the cases count on 2 or 3 contexts of the process and go through the group exchange / emission)"""
 import os
 import random
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # (this file lives in tests/: it uses the oracle)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gossamer_amd as g  # noqa: E402

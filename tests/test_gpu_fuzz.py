@@ -1,4 +1,4 @@
-"""A short run of tools/fuzz_parity.py inside the suite: random (k, mode, read shape, error rate, arena size,
+"""A short run of tests/fuzz_parity.py inside the suite: random (k, mode, read shape, error rate, arena size,
 path switches) combinations, product against oracle, files byte for byte."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_random_configurations_against_the_oracle():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "30", "11", "groups"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "30", "11", "groups"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-4000:]
