@@ -2,6 +2,7 @@
 // libgossgpu.so; there is no CPU counting path in this program.
 #include "GossHost.hpp"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -37,11 +38,50 @@ static bool endsWith(const std::string& s, const char* suf)
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// bzip2 input (PhysicalFileFactory.cc:262-298 puts a bzip2 filter in front of "*.bz2").  The image has the
+// system's libbz2.so.1.0 but no bzlib.h, so the library is loaded at run time and its four documented reading
+// functions are declared here; a system without it gets the error the build used to give for every .bz2 file.
+namespace {
+struct Bz2Api {
+    void* (*readOpen)(int*, FILE*, int, int, void*, int) = nullptr;
+    int (*read)(int*, void*, void*, int) = nullptr;
+    void (*readClose)(int*, void*) = nullptr;
+    void (*getUnused)(int*, void*, void**, int*) = nullptr;
+    bool ok = false;
+};
+const Bz2Api& bz2Api()
+{
+    static Bz2Api api = [] {
+        Bz2Api a;
+        void* h = dlopen("libbz2.so.1.0", RTLD_NOW);
+        if (!h) h = dlopen("libbz2.so.1", RTLD_NOW);
+        if (!h) return a;
+        a.readOpen = (void* (*)(int*, FILE*, int, int, void*, int))dlsym(h, "BZ2_bzReadOpen");
+        a.read = (int (*)(int*, void*, void*, int))dlsym(h, "BZ2_bzRead");
+        a.readClose = (void (*)(int*, void*))dlsym(h, "BZ2_bzReadClose");
+        a.getUnused = (void (*)(int*, void*, void**, int*))dlsym(h, "BZ2_bzReadGetUnused");
+        a.ok = a.readOpen && a.read && a.readClose && a.getUnused;
+        return a;
+    }();
+    return api;
+}
+constexpr int kBzOk = 0, kBzStreamEnd = 4;
+}  // namespace
+
 InFile::InFile(const std::string& name) : mName(name)
 {
     if (name == "-") { mStdin = true; mFd = 0; return; }
     if (endsWith(name, ".bz2"))
-        throw Error::General("bzip2 input is not supported by this build: '" + name + "'\n");
+    {
+        if (!bz2Api().ok) throw Error::General("bzip2 input needs libbz2.so.1.0, which this system lacks: '" + name + "'\n");
+        FILE* f = fopen(name.c_str(), "rb");
+        if (!f) throw Error::Errno(name, errno ? errno : ENOENT);
+        int err = 0;
+        mBzFile = f;
+        mBz = bz2Api().readOpen(&err, f, 0, 0, nullptr, 0);
+        if (!mBz || err != kBzOk) { fclose(f); mBzFile = nullptr; throw Error::General("cannot read bzip2 stream '" + name + "'\n"); }
+        return;
+    }
     if (endsWith(name, ".gz"))
     {
         mGz = gzopen(name.c_str(), "rb");
@@ -55,12 +95,43 @@ InFile::InFile(const std::string& name) : mName(name)
 
 InFile::~InFile()
 {
+    if (mBz) { int err = 0; bz2Api().readClose(&err, mBz); }
+    if (mBzFile) fclose((FILE*)mBzFile);
     if (mGz) gzclose((gzFile)mGz);
     else if (mFd > 0) ::close(mFd);
 }
 
 size_t InFile::read(char* dst, size_t cap)
 {
+    if (mBzFile)
+    {
+        // a .bz2 file may hold several streams one after the other (pbzip2, cat a.bz2 b.bz2): at the end of one,
+        // the bytes the decoder read ahead start the next
+        const Bz2Api& bz = bz2Api();
+        size_t got = 0;
+        while (got < cap && !mBzEnd)
+        {
+            int err = 0;
+            const int n = bz.read(&err, mBz, dst + got, (int)std::min<size_t>(cap - got, 1u << 30));
+            if (err != kBzOk && err != kBzStreamEnd) throw Error::General("corrupt bzip2 stream '" + mName + "'\n");
+            got += (size_t)std::max(n, 0);
+            if (err == kBzStreamEnd)
+            {
+                void* unused = nullptr; int nUnused = 0;
+                bz.getUnused(&err, mBz, &unused, &nUnused);
+                std::vector<char> rest((char*)unused, (char*)unused + std::max(nUnused, 0));
+                bz.readClose(&err, mBz);
+                mBz = nullptr;
+                FILE* f = (FILE*)mBzFile;
+                int c = EOF;
+                if (rest.empty() && (c = fgetc(f)) == EOF) { mBzEnd = true; break; }
+                if (rest.empty()) ungetc(c, f);
+                mBz = bz.readOpen(&err, f, 0, 0, rest.empty() ? nullptr : rest.data(), (int)rest.size());
+                if (!mBz || err != kBzOk) throw Error::General("corrupt bzip2 stream '" + mName + "'\n");
+            }
+        }
+        return got;
+    }
     if (mGz)
     {
         int n = gzread((gzFile)mGz, dst, (unsigned)std::min<size_t>(cap, 1u << 30));

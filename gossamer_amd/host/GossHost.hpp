@@ -69,6 +69,9 @@ public:
 private:
     std::string mName;
     void* mGz = nullptr;
+    void* mBz = nullptr;            // BZFILE* of the stream being read (libbz2, loaded at run time)
+    void* mBzFile = nullptr;        // FILE* under it
+    bool mBzEnd = false;
     int mFd = -1;
     bool mStdin = false;
 };

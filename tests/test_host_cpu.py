@@ -233,3 +233,32 @@ def test_parallel_fastq_parser_matches_serial(tmp_path):
     assert serial.returncode == 1 and par.returncode == 1
     assert b"expected '+' at beginning of line 16005" in serial.stderr
     assert par.stderr == serial.stderr
+
+
+def test_bzip2_input_single_and_concatenated_streams(tmp_path):
+    """PhysicalFileFactory.cc:262-298: "*.bz2" is read through a bzip2 filter.  The host loads the system's libbz2 at
+    run time; the bytes handed to the device must be those of the plain file -- for one stream and for several
+    streams one after the other (pbzip2 / cat a.bz2 b.bz2), FASTQ, FASTA and line input."""
+    import bz2
+    rng = random.Random(9)
+    reads = ["".join(rng.choice("ACGTN") for _ in range(rng.randint(30, 160))) for _ in range(4000)]
+    fq = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
+    fa = "".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(reads[:500]))
+    (tmp_path / "a.fq").write_text(fq)
+    (tmp_path / "a.fq.bz2").write_bytes(bz2.compress(fq.encode()))
+    half = fq.index("@r2000\n")
+    (tmp_path / "two.fq.bz2").write_bytes(bz2.compress(fq[:half].encode()) + bz2.compress(fq[half:].encode(), 1))
+    (tmp_path / "b.fa").write_text(fa)
+    (tmp_path / "b.fa.bz2").write_bytes(bz2.compress(fa.encode()))
+    rc, plain, err = run_goss("dump-bases", "-i", str(tmp_path / "a.fq"))
+    assert rc == 0, err
+    for name in ("a.fq.bz2", "two.fq.bz2"):
+        rc, out, err = run_goss("dump-bases", "-i", str(tmp_path / name))
+        assert rc == 0, err
+        assert out == plain, name
+    rc, plain_fa, err = run_goss("dump-bases", "-I", str(tmp_path / "b.fa"))
+    rc2, out_fa, err2 = run_goss("dump-bases", "-I", str(tmp_path / "b.fa.bz2"))
+    assert rc == 0 and rc2 == 0 and out_fa == plain_fa, err + err2
+    (tmp_path / "bad.fq.bz2").write_bytes(bz2.compress(fq.encode())[:-40])
+    rc, _, err = run_goss("dump-bases", "-i", str(tmp_path / "bad.fq.bz2"))
+    assert rc != 0 and "bzip2" in err
