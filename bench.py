@@ -26,16 +26,32 @@ def algorithmic_bytes_per_window(k, read_len, key_bytes=8, keys_per_window=1):
     return read_len / (read_len - k + 1) * 3.0 / 8.0 + 2.0 * key_bytes * keys_per_window
 
 
+def kernels_hash():
+    """sha256 over the device sources the built library comes from (what profiles/traffic.json is keyed by)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gossamer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "kernels_*.hpp")) + [os.path.join(d, "goss_key.hpp")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel_class):
     """HBM bytes per unit of the dominant kernel from the PMC passes committed under profiles/
-    ((2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md HBM section), or None."""
+    ((2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md HBM section).  The table is keyed by a hash of
+    the kernel sources it was measured on: returns (entry or None, warning or None)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(p) as f:
             t = json.load(f)
-        return t.get(kernel_class)
     except (OSError, ValueError):
-        return None
+        return None, "profiles/traffic.json missing"
+    if t.get("kernels_sha") != kernels_hash():
+        return None, ("profiles/traffic.json was measured on kernel sources %s, the tree has %s: re-run tools/profile_round.sh"
+                      % (t.get("kernels_sha"), kernels_hash()))
+    return t.get(kernel_class), None
 
 
 def cpu_model():
@@ -80,7 +96,17 @@ def cpu_baseline(k, read_len, genome_len, seed, sample_reads):
     t0 = time.perf_counter()
     files, nwinT = o.build_kmer_set_mt(readsT, k, T)
     dtT = time.perf_counter() - t0
+    eight = None
+    if T > 8:          # the thread count of BASELINE.md section 2's figure for the reference's own code (7.45 M k-mers/s)
+        n8 = min(nT, sample_reads * 2)
+        t0 = time.perf_counter()
+        _, nwin8 = o.build_kmer_set_mt(readsT[:n8 * (read_len + 1)] if n8 < nT else readsT, k, 8)
+        dt8 = time.perf_counter() - t0
+        eight = {"value": nwin8 / dt8 / 1e6, "unit": "M k-mers/s", "cores": 8,
+                 "sample": "first %d reads, go_build_kmer_set_mt with 8 threads, %.1f s; BASELINE.md section 2 has the "
+                           "reference's own code at 7.45 M k-mers/s with -T 8 (other hardware)" % (n8, dt8)}
     return {"value": nwinT / dtT / 1e6, "unit": "M k-mers/s", "cores": T, "kind": "port", "cpu_model": cpu_model(),
+            "eight_threads": eight,
             "host_cores": cores,
             "sample": "first %d reads of the same synthetic set (%d k-mers) through oracle go_build_kmer_set_mt with %d "
                       "threads (per shard: parse + canonicalise + sort-count; parallel merge by key range; serial "
@@ -202,8 +228,57 @@ def c4_record(g, torch, device, local_rank):
         return {"failed": repr(e)[:300]}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without an outer launcher: this process starts the N rank processes (one
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and does nothing else -- it never
+    imports torch, never loads libgossgpu.so and never touches a GPU, so nothing is exec'ed or forked from a
+    process that has initialised HIP.  Rank 0's standard output (the JSON line) is relayed last; the exit
+    code is non-zero if any rank's is."""
+    import subprocess
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):          # a rank failed: its peers would wait in a collective for ever
+                if codes[r] is None:
+                    p.terminate()
+        time.sleep(0.05)
+    reader.join(10)
+    out0 = b"".join(chunks)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    rc = next((c for c in codes if c != 0), 0)
+    if rc:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+    raise SystemExit(1 if rc else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process group of the N > 1 path: nccl (= RCCL over xGMI, one GPU per rank) or gloo (the exchange "
+                         "staged through host memory; ranks share GPUs round robin when there are fewer GPUs than ranks)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -224,24 +299,37 @@ def main():
                     "two keys per window); not the headline metric")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])          # does not return
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE = %d but --gpus %d" % (world, args.gpus))
+
     import torch
     import torch.distributed as dist
     import gossamer_amd as g
     from gossamer_amd import dist as gdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py: no GPU visible (the product has no CPU path)")
+    if args.backend == "nccl" and ndev < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, %d visible (use --backend gloo to share GPUs)" % (world, world, ndev))
+    dev_index = local_rank % ndev
+    sharing = (world + ndev - 1) // ndev          # ranks per GPU (1 except under gloo on a small box)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    xdev = device if args.backend == "nccl" else torch.device("cpu")          # where small collectives' tensors live
 
     k, L = args.k, args.read_len
     # BASELINE.json configs: C2 on one GPU; with N GPUs the per-GPU share of C3 (10^9 reads of a
@@ -264,9 +352,11 @@ def main():
     budget = int(free_b * 0.94)
     if use_dist:
         budget = min(budget, free_b - (32 << 30))
+    if sharing > 1:          # ranks that share a GPU split it (their mem_get_info calls race with each other's allocations)
+        budget = int(total_b * 0.8) // sharing - nbytes
     if args.hbm_budget_gb > 0:
         budget = int(args.hbm_budget_gb * (1 << 30))
-    ctx = g.Context(k, g.MODE_GRAPH if args.graph else g.MODE_KMER_SET, device=local_rank, hbm_budget=budget)
+    ctx = g.Context(k, g.MODE_GRAPH if args.graph else g.MODE_KMER_SET, device=dev_index, hbm_budget=budget)
     ctx.synth_reads(bases.data_ptr(), nreads, L, genome_len, seed=args.seed, first_read=rank * nreads)
     torch.cuda.synchronize(device)
 
@@ -302,10 +392,10 @@ def main():
     fused = ctx.stat("fused_chunks") > 0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        wt = torch.tensor([windows], dtype=torch.int64, device=device)
+        wt = torch.tensor([windows], dtype=torch.int64, device=xdev)
         dist.all_reduce(wt, op=dist.ReduceOp.SUM)
         windows = int(wt.item())
 
@@ -342,7 +432,7 @@ def main():
         r = against_roofline(dom)
         d, avg_ms, per_unit, per_launch_units, achieved = r["d"], r["avg_ms"], r["per_unit"], r["units"], r["achieved"]
         dev_ms = sum(v["ms"] for n, v in tim.items())
-        tr = measured_traffic(dom)
+        tr, traffic_warning = measured_traffic(dom)
         traffic = tr["bytes_per_unit"] * per_launch_units if tr else None
         out = {
             "metric": ("M rho-mer windows/s (both strands counted) at k=%d, %d bp reads" if args.graph
@@ -362,7 +452,8 @@ def main():
                                    "sort-count, %s emitted" % (config_name, k, nreads, L, genome_len, args.seed,
                                                                "Graph (edge SparseArray + counts)" if args.graph else "KmerSet SparseArray"),
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
-                       "parallelism": "1 GPU" if world == 1 else "range-partition over %d GPUs, RCCL all-to-all(v)" % world},
+                       "parallelism": "1 GPU" if world == 1 else "range-partition over %d ranks on %d GPU(s), %s all-to-all(v)"
+                                      % (world, min(world, ndev), "RCCL" if args.backend == "nccl" else "gloo (host-staged)")},
             "roofline": {"bound": "hbm", "kernel": {"extract": "extract1_part_kernel" if fused else "extract1_kernel",
                                                     "order": "canonical_map_kernel + radix passes over (key,count) pairs",
                                                     "hist": "radix_hist_kernel",
@@ -371,6 +462,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": tr["source"] if tr else None,
+                         "traffic_warning": traffic_warning,
                          "launch_avg_ms": avg_ms, "launches": d["launches"], "units_per_launch": per_launch_units,
                          "algorithmic_bytes_per_unit": per_unit,
                          "pipeline": {"algorithmic_bytes_per_kmer": b_per_window,
@@ -391,6 +483,10 @@ def main():
         out["roofline"]["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
+            # BASELINE.md holds no published figure for this metric: the ratio is against the CPU port timed on
+            # this box's host cores just above (same synthetic workload, bounded sample)
+            out["vs_baseline"] = value / out["cpu_baseline"]["value"]
+            out["vs_baseline_of"] = "cpu_baseline.value (oracle port, %d threads, this box)" % out["cpu_baseline"]["cores"]
         # beside the headline, never part of `value`: the end-to-end CLI on a bounded FASTQ sample, and
         # BASELINE config C4 (build-graph k = 55, 200 M x 150 bp reads) through the same library
         if world == 1 and not use_dist and not args.graph:
@@ -401,7 +497,7 @@ def main():
             if not args.no_extra and not (args.reads or args.genome):
                 del bases
                 torch.cuda.empty_cache()
-                out["extra"] = c4_record(g, torch, device, local_rank)
+                out["extra"] = c4_record(g, torch, device, dev_index)
         # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
         import ctypes
         ctypes.CDLL(None).fflush(None)

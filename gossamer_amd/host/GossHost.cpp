@@ -65,7 +65,7 @@ const Bz2Api& bz2Api()
     }();
     return api;
 }
-constexpr int kBzOk = 0, kBzStreamEnd = 4;
+constexpr int kBzOk = 0, kBzStreamEnd = 4, kBzBadMagic = -5;
 }  // namespace
 
 InFile::InFile(const std::string& name) : mName(name)
@@ -113,8 +113,20 @@ size_t InFile::read(char* dst, size_t cap)
         {
             int err = 0;
             const int n = bz.read(&err, mBz, dst + got, (int)std::min<size_t>(cap - got, 1u << 30));
-            if (err != kBzOk && err != kBzStreamEnd) throw Error::General("corrupt bzip2 stream '" + mName + "'\n");
+            if (err != kBzOk && err != kBzStreamEnd)
+            {
+                // bytes behind the last stream that are not a stream (padding, a tape block's fill): the bzip2 tool
+                // warns "trailing garbage after EOF ignored" and so does this reader
+                if (err == kBzBadMagic && mBzStreams > 0 && mBzFresh)
+                {
+                    std::fprintf(stderr, "goss: %s: trailing garbage after the last bzip2 stream ignored\n", mName.c_str());
+                    mBzEnd = true;
+                    break;
+                }
+                throw Error::General("corrupt bzip2 stream '" + mName + "'\n");
+            }
             got += (size_t)std::max(n, 0);
+            if (n > 0) mBzFresh = false;
             if (err == kBzStreamEnd)
             {
                 void* unused = nullptr; int nUnused = 0;
@@ -122,6 +134,8 @@ size_t InFile::read(char* dst, size_t cap)
                 std::vector<char> rest((char*)unused, (char*)unused + std::max(nUnused, 0));
                 bz.readClose(&err, mBz);
                 mBz = nullptr;
+                ++mBzStreams;
+                mBzFresh = true;
                 FILE* f = (FILE*)mBzFile;
                 int c = EOF;
                 if (rest.empty() && (c = fgetc(f)) == EOF) { mBzEnd = true; break; }
@@ -588,7 +602,8 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                             const std::function<void(const char*, size_t)>& push, const HostAlloc& ha,
                             const OwnedPush* pushOwned = nullptr)
 {
-    if (threads < 2 || name == "-" || endsWith(name, ".gz")) return ~0ULL;
+    // (compressed inputs are framed by the serial parser behind InFile's decompressor)
+    if (threads < 2 || name == "-" || endsWith(name, ".gz") || endsWith(name, ".bz2")) return ~0ULL;
     const auto tEnter = std::chrono::steady_clock::now();
     struct Whole { std::chrono::steady_clock::time_point t0; bool on;
                    ~Whole() { if (on) std::fprintf(stderr, "goss: parallel parser: %.3f s from entry to return\n",
@@ -627,8 +642,15 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     std::thread allocator([&]() {
         for (size_t i = 0; i < nbuf && !abortAll.load() && nextChunk.load() < nchunks; ++i)
         {
-            void* b = ha.alloc(bufCap);
-            if (!b) { allocFailed.store(true); abortAll.store(true); cv.notify_all(); return; }
+            // (GOSS_TEST_FAIL_PARSER_ALLOC: fault injection for the test of this path -- the second buffer cannot be had)
+            void* b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufCap);
+            if (!b)
+            {
+                // (under the lock: a worker or the consumer between its predicate and its wait must not miss this)
+                { std::lock_guard<std::mutex> lk(m); allocFailed.store(true); abortAll.store(true); }
+                cv.notify_all();
+                return;
+            }
             { std::lock_guard<std::mutex> lk(m); allBufs.push_back(b); freeBufs.push_back((char*)b); }
             cv.notify_all();
         }
@@ -698,7 +720,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         {
             const auto a = now();
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return res[i].done; });
+            cv.wait(lk, [&] { return res[i].done || allocFailed.load(); });
+            // no buffer could be had: the workers have left and nobody will parse this chunk
+            if (!res[i].done) throw Error::General("cannot allocate parser buffers\n");
             r = res[i];
             waitSeconds += std::chrono::duration<double>(now() - a).count();
         }
@@ -783,6 +807,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
             if (f == "-" || ::stat(f.c_str(), &st) != 0) { unknown = true; return; }
             double b = (double)st.st_size * basesPerByte;
             if (endsWith(f, ".gz")) b *= 4.5;
+            if (endsWith(f, ".bz2")) b *= 5.0;
             bases += (uint64_t)b;
         };
         for (auto& f : lines) add(f, 1.0);

@@ -72,6 +72,8 @@ private:
     void* mBz = nullptr;            // BZFILE* of the stream being read (libbz2, loaded at run time)
     void* mBzFile = nullptr;        // FILE* under it
     bool mBzEnd = false;
+    unsigned mBzStreams = 0;        // complete streams decoded so far
+    bool mBzFresh = true;           // nothing decoded from the current stream yet
     int mFd = -1;
     bool mStdin = false;
 };

@@ -1,0 +1,42 @@
+"""`python bench.py --gpus N` starts its own rank processes (no outer launcher): two ranks share the one GPU of
+the test box over gloo, and the distinct-key count of the distributed build equals that of one context over all
+the reads (the ranks generate disjoint slices of the same synthetic read set)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "1", "--warmup", "0", "--no-extra",
+                        "--e2e-reads", "0", "--no-cpu-baseline", "--hbm-budget-gb", "6"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    return json.loads(p.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    two = _bench("--gpus", "2", "--backend", "gloo", "--reads", "2000000", "--genome", "3000000")
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    one = _bench("--gpus", "1", "--reads", "4000000", "--genome", "6000000")
+    assert one["n_gpus"] == 1
+    assert two["config"]["distinct_kmers"] == one["config"]["distinct_kmers"] > 0
+    # value = the windows of BOTH ranks over the slowest rank's time
+    windows = 2 * 2000000 * (150 - 25 + 1)
+    assert abs(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 / windows - 1) < 0.02
+
+
+def test_launcher_fails_loudly_when_a_rank_fails():
+    """No GPU here: every rank exits with an error, the launcher must not hang and must exit non-zero."""
+    import torch
+    if torch.cuda.device_count():
+        pytest.skip("a GPU is visible")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "1000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b"no GPU visible" in p.stderr

@@ -262,3 +262,34 @@ def test_bzip2_input_single_and_concatenated_streams(tmp_path):
     (tmp_path / "bad.fq.bz2").write_bytes(bz2.compress(fq.encode())[:-40])
     rc, _, err = run_goss("dump-bases", "-i", str(tmp_path / "bad.fq.bz2"))
     assert rc != 0 and "bzip2" in err
+    # several parser threads and a compressed file larger than two parser chunks: the compressed bytes must not be
+    # framed as FASTQ by the parallel parser (it maps plain files only)
+    env = dict(os.environ, GOSS_PARSE_CHUNK="4096")
+    for name in ("a.fq.bz2", "two.fq.bz2"):
+        assert os.path.getsize(tmp_path / name) > 3 * 4096
+        p = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(tmp_path / name)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=env, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == plain, name
+    # bytes behind the last stream that are no stream: ignored with a warning, as the bzip2 tool does
+    (tmp_path / "tail.fq.bz2").write_bytes(bz2.compress(fq.encode()) + b"\0" * 512)
+    rc, out, err = run_goss("dump-bases", "-i", str(tmp_path / "tail.fq.bz2"))
+    assert rc == 0 and out == plain and "trailing garbage" in err
+
+
+def test_parallel_parser_reports_a_failed_buffer_allocation(tmp_path):
+    """The buffer pool is filled lazily by a thread of its own: when it cannot get a buffer the command must end
+    with the error, not wait for chunks nobody will parse."""
+    rng = random.Random(3)
+    fq = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r))
+                 for i, r in enumerate("".join(rng.choice("ACGT") for _ in range(100)) for _ in range(40000)))
+    (tmp_path / "big.fq").write_text(fq)
+    env = dict(os.environ, GOSS_PARSE_CHUNK=str(1 << 20))
+    ok = subprocess.run([GOSS, "dump-bases", "-T", "2", "-i", str(tmp_path / "big.fq")], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, env=env, timeout=120)
+    assert ok.returncode == 0
+    env["GOSS_TEST_FAIL_PARSER_ALLOC"] = "1"          # the allocator thread gets one buffer and then none
+    p = subprocess.run([GOSS, "dump-bases", "-T", "2", "-i", str(tmp_path / "big.fq")], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=60)
+    assert p.returncode == 1
+    assert b"cannot allocate parser buffers" in p.stderr

@@ -5,8 +5,9 @@ TAG=${1:-kstats}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/trace.err
-cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --e2e-reads 0 --no-extra "$@" > $OUT/bench.json 2> $OUT/trace.err
+# (no child process is profiled: --e2e-reads 0 --no-extra; take the largest statistics file should there be several)
+cp "$(ls -S $OUT/trace/*/*kernel_stats.csv | head -1)" $OUT/kernel_stats.csv
 rm -rf $OUT/trace
 python3 - "$OUT/kernel_stats.csv" <<'PY'
 import csv, sys
