@@ -25,6 +25,7 @@ SYMBOLS = [
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
+    "goss_gpu_push_keys_host", "goss_gpu_push_keys_device",
 ]
 
 
@@ -154,6 +155,7 @@ class Context:
             raise GossGpuError(rc, self._L.goss_gpu_strerror(rc).decode())
         self.k = k
         self.mode = mode
+        self.key_words = 1 if 2 * (k + (1 if mode == MODE_GRAPH else 0)) <= 62 else 2
 
     def close(self):
         if getattr(self, "_h", None):
@@ -191,6 +193,21 @@ class Context:
         """A counted run in host memory (goss_gpu_push_run_host): m keys of key_words u64, m u32 counts."""
         self._L.goss_gpu_push_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         self._check(self._L.goss_gpu_push_run_host(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), m))
+
+    def push_keys_host(self, keys):
+        """Raw k-mers (unsorted, un-normalised) in host memory: a numpy uint64 array of n * key_words values
+        (goss_gpu_push_keys_host)."""
+        import numpy as np
+        a = np.ascontiguousarray(keys, dtype=np.uint64)
+        n = a.size // self.key_words
+        self._L.goss_gpu_push_keys_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_push_keys_host(self._h, C.c_void_p(a.ctypes.data), n))
+
+    def push_keys_device(self, ptr, n):
+        """Raw k-mers resident in HBM (goss_gpu_push_keys_device)."""
+        _torch_ready()
+        self._L.goss_gpu_push_keys_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_push_keys_device(self._h, C.c_void_p(ptr), n))
 
     def prepare(self):
         """Start mapping the HBM arena in the background (goss_gpu_prepare)."""

@@ -3150,6 +3150,73 @@ int goss_gpu_push_run_host(goss_gpu_ctx* c, const uint64_t* keys, const uint32_t
 }
 
 extern "C++" {
+// Raw keys (unsorted, un-normalised) -> normalise (mode 0) -> count -> one run per piece.
+template <class K>
+static void push_keys(goss_gpu_ctx* c, const void* keys, uint64_t n, bool on_host)
+{
+    ensure_arena(c);
+    flush_staging(c);
+    const uint64_t ksz = sizeof(K);
+    uint64_t done = 0;
+    while (done < n)
+    {
+        // two key buffers, the sort's tables and the worst-case run of the piece (chunk_capacity's pessimistic sizing)
+        auto capacity = [&]() { return (uint64_t)((double)c->arena.avail() * 0.95 / (2.0 * ksz + 1.2 + (ksz + 12.0))) & ~4095ULL; };
+        uint64_t cap = capacity();
+        if (cap < 4096 && c->runs.size() > 1) { merge_runs<K>(c); cap = capacity(); }
+        if (cap < 4096 && grow_arena(c, 0)) cap = capacity();
+        if (cap < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one piece of keys"};
+        const uint64_t m = std::min(cap, n - done);
+        const uint64_t mark = c->arena.mark();
+        K* ka = (K*)c->arena.temp(m * ksz);
+        K* kb = (K*)c->arena.temp(m * ksz);
+        const K* src = (const K*)keys + done;
+        if (on_host)
+        {
+            HIP_TRY(hipMemcpyAsync(kb, src, m * ksz, hipMemcpyHostToDevice, c->stream));
+            src = kb;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_flags + 2, 0, 4, c->stream));
+        {
+            PhaseTimer t(c, GOSS_T_EXTRACT, m);
+            if (c->mode == GOSS_MODE_GRAPH)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(normalize_keys_kernel<K, 1>), dim3(grid_for(m, kTB)), dim3(kTB), 0, c->stream, src, ka, m, c->len, c->d_flags);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(normalize_keys_kernel<K, 0>), dim3(grid_for(m, kTB)), dim3(kTB), 0, c->stream, src, ka, m, c->len, c->d_flags);
+            t.stop();
+        }
+        uint32_t* hf = (uint32_t*)c->h_pinned;
+        HIP_TRY(hipMemcpyAsync(hf, c->d_flags + 2, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hf[0]) { c->arena.release(mark); throw StatusError{GOSS_ERR_INVALID_ARG, "a pushed key has bits beyond 2*len"}; }
+        Run r = count_keys<K>(c, ka, kb, m);
+        c->runs.push_back(r);
+        c->arena.release(mark);
+        // a k-mer is one window and one key; a graph key is one of the two a rho-mer window contributes
+        c->keys_total += m;
+        c->windows += c->mode == GOSS_MODE_GRAPH ? m / 2 : m;
+        done += m;
+        uint64_t run_bytes = 0;
+        for (auto& q : c->runs) run_bytes += q.m * (ksz + 4);
+        if (c->runs.size() > 1 && run_bytes > c->arena.size / 4 &&
+            (c->arena.avail() >= 2 * run_bytes + (512ULL << 20) || grow_arena(c, 2 * run_bytes + (512ULL << 20)))) merge_runs<K>(c);
+    }
+}
+}
+
+static int push_keys_entry(goss_gpu_ctx* c, const void* keys, uint64_t n, bool on_host)
+{
+    if (!c || (n && !keys)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (n == 0) return GOSS_OK;
+    return guarded(c, [&]() {
+        if (c->words == 1) push_keys<Key1>(c, keys, n, on_host); else push_keys<Key2>(c, keys, n, on_host);
+    });
+}
+int goss_gpu_push_keys_device(goss_gpu_ctx* c, const void* d_keys, uint64_t n) { return push_keys_entry(c, d_keys, n, false); }
+int goss_gpu_push_keys_host(goss_gpu_ctx* c, const uint64_t* keys, uint64_t n) { return push_keys_entry(c, keys, n, true); }
+
+extern "C++" {
 // SparseArray in its on-disk form (host pointers) -> m decoded positions on the device
 // (SparseArray::LazyIterator, SparseArray.hh:185-224).  Temporaries above `out` in the arena are the caller's to release.
 template <class K>

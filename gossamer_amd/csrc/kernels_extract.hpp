@@ -972,6 +972,25 @@ __global__ __launch_bounds__(kTB) void canonical_map_kernel(const K* in, K* outk
     outk[i] = canonical(x, revcomp(x, len));
 }
 
+// Raw keys handed over by a caller that kmerises itself (goss_gpu_push_keys_*: the templated
+// GossCmdBuildKmerSet::operator()(cxt, KmerSrc&), GossCmdBuildKmerSet.tcc:246-249): mode 0 normalises every key
+// (position_type::normalize, RankSelect.hh:126-140), mode 1 takes the keys as they are (the graph builder inserts
+// what its adapter yields).  A key with bits at or above 2*len is not a len-mer: flagged, the push is refused.
+template <class K, int MODE>
+__global__ __launch_bounds__(kTB) void normalize_keys_kernel(const K* __restrict__ in, K* __restrict__ out, uint64_t n, uint32_t len,
+                                                              uint32_t* __restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const K x = in[i];
+    bool wide;
+    if constexpr (sizeof(K) == 8) wide = (x.lo >> (2 * len)) != 0;
+    else wide = 2 * len < 128 && (x.hi >> (2 * len - 64)) != 0;
+    if (wide) atomicOr(flags + 2, 1u);
+    if constexpr (MODE == 0) out[i] = canonical(x, revcomp(x, len));
+    else out[i] = x;
+}
+
 // The same fusion for two-word keys (32 <= len <= 63): windows out of a 192-bit register buffer
 // (extract2_kernel), NKEYS keys per thread, a tile of 256*NKEYS keys partitioned on the digit at `shift`,
 // in the form of extract1_part_kernel: private blocks of B slots per workgroup and bucket (a cursor is

@@ -407,6 +407,23 @@ int goss_gpu_push_run_device(goss_gpu_ctx* ctx, const void* d_keys, const uint32
                              uint64_t m);
 
 /*
+ * Feed k-mers the caller has already cut out of its input: n keys of key_words u64 each ({lo,hi} for two
+ * words), first base in the most significant used bits, in any order, with repeats, NOT normalised.
+ * Takes over the loop of the templated GossCmdBuildKmerSet::operator()(cxt, KmerSrc&)
+ * (GossCmdBuildKmerSet.hh:23-30, GossCmdBuildKmerSet.tcc:246-256: `kmer = *pKmerSrc; kmer.normalize(mK);
+ * blk->push_back(kmer)` + BackyardHash::insert), which electus drives with a GossRead::Iterator or a
+ * KmerizingAdapter of its own (ElectApp.cc:183-215).  kmer-set mode: every key is replaced by its canonical
+ * form (position_type::normalize, RankSelect.hh:126-140) and counted; graph mode: the keys are counted as they
+ * are (GossCmdBuildGraph.cc:276,307 inserts what ReverseComplementAdapter yields -- the caller pushes both
+ * strands).  A key with bits at or above 2*len (len = k, or k+1 in graph mode): GOSS_ERR_INVALID_ARG and
+ * nothing of this call is counted.  Keys and bases may be mixed in one build; counts add up at finish.
+ * `windows` grows by n (n/2 in graph mode).  _device: resident in HBM, complete before the call (see
+ * goss_gpu_push_bases_device), not modified.
+ */
+int goss_gpu_push_keys_host(goss_gpu_ctx* ctx, const uint64_t* keys, uint64_t n);
+int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n);
+
+/*
  * Deterministic synthetic read generator: fills d_out (device) with
  * nreads reads of read_len bases sampled from an i.i.d. uniform genome of genome_len bases,
  * each followed by '\n'; strand flipped with p = 1/2; one 'N' in every 97th read.

@@ -1,0 +1,52 @@
+"""BASELINE.json config C1 at its stated size: `goss build-kmer-set -k 25` and `goss build-graph -k 25` on 1 M synthetic
+150 bp reads (genome 5 Mbp, seed 1) given as a 4-line FASTQ file.  The files on disk are compared byte for byte with the
+oracle's build of the same FASTQ text run here, and with the md5 digests committed by tests/golden/make_golden.py
+(tests/golden/c1_md5.json: the oracle's output when the fixture was made) -- the second comparison has no oracle in
+the loop."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import c1_input
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOSS = os.path.join(ROOT, "gossamer_amd", "goss")
+
+
+@pytest.fixture(scope="module")
+def c1(tmp_path_factory):
+    d = tmp_path_factory.mktemp("c1")
+    fq = c1_input.fastq_bytes()
+    (d / "c1.fq").write_bytes(fq)
+    with open(os.path.join(ROOT, "tests", "golden", "c1_md5.json")) as f:
+        golden = json.load(f)
+    assert hashlib.md5(fq).hexdigest() == golden["fastq_md5"]          # the generator has not drifted
+    return d, fq, golden
+
+
+@pytest.mark.parametrize("cmd", ["build-kmer-set", "build-graph"])
+def test_c1_files_equal_oracle_and_committed_digests(oracle, c1, cmd):
+    d, fq, golden = c1
+    base = "ks" if cmd == "build-kmer-set" else "gr"
+    p = subprocess.run([GOSS, cmd, "-k", str(c1_input.K), "-T", "8", "-i", str(d / "c1.fq"), "-O", str(d / base), "-v"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = {n[len(base):]: (d / n).read_bytes() for n in os.listdir(d) if n.startswith(base + ".") or n.startswith(base + "-")}
+    # (1) the committed digests
+    want = golden[cmd]["files"]
+    assert sorted(got) == sorted(want)
+    for name, rec in want.items():
+        assert len(got[name]) == rec["bytes"], name
+        assert hashlib.md5(got[name]).hexdigest() == rec["md5"], name
+    # (2) the oracle, run here on the same text
+    build = oracle.build_kmer_set if cmd == "build-kmer-set" else oracle.build_graph
+    exp, nwin = build([(oracle.FASTQ, "c1.fq", fq)], c1_input.K, out=base)
+    assert nwin == golden[cmd]["windows"]
+    assert ("k-mer windows: %d" % nwin).encode() in p.stderr or str(nwin).encode() in p.stderr
+    for name, data in exp.items():
+        assert got[name[len(base):]] == data, name
