@@ -26,7 +26,10 @@ SYMBOLS = [
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
     "goss_gpu_push_keys_host", "goss_gpu_push_keys_device",
+    "goss_gpu_route_records_device", "goss_gpu_push_records_device",
 ]
+
+RECORD_BYTES = 12
 
 
 class GossGpuError(RuntimeError):
@@ -208,6 +211,28 @@ class Context:
         _torch_ready()
         self._L.goss_gpu_push_keys_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         self._check(self._L.goss_gpu_push_keys_device(self._h, C.c_void_p(ptr), n))
+
+    def route_records(self, bases_ptr, nbytes, nparts, records_ptr, part_first, part_cap):
+        """goss_gpu_route_records_device: the windows of a device-resident base string as super-k-mer records in
+        nparts buffers.  Returns (records per part, windows per part, ok); ok False = some part_cap was too small
+        and `records` holds what every part needs."""
+        _torch_ready()
+        U = C.c_uint64 * nparts
+        first, cap, recs, wins = U(*part_first), U(*part_cap), U(), U()
+        self._L.goss_gpu_route_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                          C.POINTER(C.c_uint64)]
+        rc = self._L.goss_gpu_route_records_device(self._h, C.c_void_p(bases_ptr), nbytes, nparts, C.c_void_p(records_ptr),
+                                                   first, cap, recs, wins)
+        if rc not in (0, -9):
+            self._check(rc)
+        return [int(x) for x in recs], [int(x) for x in wins], rc == 0
+
+    def push_records(self, records_ptr, nrecords, nwindows=0):
+        """goss_gpu_push_records_device: count the windows of super-k-mer records resident in HBM."""
+        _torch_ready()
+        self._L.goss_gpu_push_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        self._check(self._L.goss_gpu_push_records_device(self._h, C.c_void_p(records_ptr), nrecords, nwindows))
 
     def prepare(self):
         """Start mapping the HBM arena in the background (goss_gpu_prepare)."""

@@ -133,6 +133,9 @@ struct goss_gpu_ctx {
     int big_rounds_min = 0;             // GOSS_GPU_BIG_ROUNDS_MIN=<r>: at least 2^r (tests)
     uint32_t big_table_chunks = 0;      // chunks counted that way
     uint32_t wide_table_chunks = 0;     // ... of them, two-word keys in the 6144-slot table
+    bool rec_mode = false;              // the current push is a string of super-k-mer records (goss_gpu_push_records_device): "bases" point at
+                                        // SkRec records, a "window start" is one of a record's P window slots (16, graph mode 8)
+    uint32_t rec_chunks = 0;            // chunks counted from records by the fused path
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
     uint64_t budget = 0;
@@ -573,10 +576,35 @@ void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     }
 #undef GOSS_LAUNCH_E1
 }
+// window slots of a record: the keys a thread of the fused extraction takes (16, or 8 windows of two keys each)
+inline uint32_t rec_slots(const goss_gpu_ctx* c) { return c->mode == GOSS_MODE_GRAPH ? 8u : 16u; }
+
+// records -> keys with the plain kernel: all records (slice_groups = 0) or slices of them (the fused path's sample)
+void launch_extract_records(goss_gpu_ctx* c, const SkRec* recs, uint64_t nrecs, Key1* out, uint64_t ngroups, uint64_t slice_groups,
+                            uint64_t slice_stride, bool rep)
+{
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ngroups, 1), 256 * 16);
+    if (c->mode == GOSS_MODE_GRAPH)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records_kernel<1, false>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out,
+                           c->d_ctr, ngroups, slice_groups, slice_stride);
+    else if (rep)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records_kernel<0, true>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out,
+                           c->d_ctr, ngroups, slice_groups, slice_stride);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records_kernel<0, false>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out,
+                           c->d_ctr, ngroups, slice_groups, slice_stride);
+}
+
 template <>
 void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
     c->extract_hist_shift = 0xFFFFFFFFu;
+    if (c->rec_mode)
+    {
+        const uint64_t nrecs = nstarts / rec_slots(c);
+        launch_extract_records(c, (const SkRec*)aligned, nrecs, out, (nrecs + kRecGroup - 1) / kRecGroup, 0, 0, c->extract_rep);
+        return;
+    }
     if (c->extract_v1)
     {
         if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key1, 0, 16>(c, aligned, mis, nstarts, navail, out);
@@ -1103,7 +1131,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     {
         const uintptr_t addr0 = (uintptr_t)d_bases;
-        const uint32_t mis0 = (uint32_t)(addr0 & 15u);
+        const uint32_t mis0 = c->rec_mode ? 0u : (uint32_t)(addr0 & 15u);          // (records are taken where they lie)
         if (nslices == 1)
         {
             c->extract_rep = kOne && !graph_mode;
@@ -1117,6 +1145,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             (void)grid;
             if (graph_mode) launch_extract2<1, 4, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
             else launch_extract2<0, 8, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
+        }
+        else if (c->rec_mode)
+        {
+            // slices of kPlainSuper window slots = 2048 records each, in strand-representative space for k-mer sets
+            const uint64_t P = rec_slots(c);
+            const uint64_t slice_groups = slice_starts / P / kRecGroup;
+            launch_extract_records(c, (const SkRec*)d_bases, nstarts / P, (Key1*)ka, slice_groups * nslices, slice_groups, slice_stride / P,
+                                   !graph_mode);
         }
         else
         {
@@ -1320,8 +1356,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if constexpr (kOne)
         {
 #define GOSS_LAUNCH_EP3(MODE, NH, ODD)                                                                                \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD>), dim3(grid), dim3(kTB), 0, c->stream,         \
-                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2)
+    do {                                                                                                              \
+        if (c->rec_mode)                                                                                              \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               d_bases, 0u, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+        else                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+    } while (0)
             if (graph)
             {
                 if (nh == 0) GOSS_LAUNCH_EP3(1, 0, false);
@@ -1503,6 +1545,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     c->windows += hp->windows;
     c->keys_total += n;
     c->fused_chunks++;
+    if (c->rec_mode) c->rec_chunks++;
     return kFusedDone;
 }
 
@@ -1558,7 +1601,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     uintptr_t addr = (uintptr_t)d_bases;
-    uint32_t mis = (uint32_t)(addr & 15u);
+    uint32_t mis = c->rec_mode ? 0u : (uint32_t)(addr & 15u);
     const uint8_t* aligned = (const uint8_t*)(addr - mis);
     {
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
@@ -1881,6 +1924,66 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
             if (c->arena.avail() >= 2 * run_bytes + (512ULL << 20) || grow_arena(c, 2 * run_bytes + (512ULL << 20))) merge_runs<K>(c);
             follow_stage();
         }
+    }
+}
+
+// A string of super-k-mer records (kernels_route.hpp) counted like a string of bases: the same chunk loop, a
+// "window start" being one of a record's P window slots.  nwindows (0 = unknown) sizes the key buffers.
+template <class K>
+void push_records(goss_gpu_ctx* c, const uint8_t* d, uint64_t nrecs, uint64_t nwindows)
+{
+    if (nrecs == 0) return;
+    ensure_arena(c);
+    const uint64_t P = rec_slots(c);
+    struct Mode { goss_gpu_ctx* c; ~Mode() { c->rec_mode = false; c->valid_frac = 1.0; } } mode{c};
+    c->rec_mode = true;
+    const uint64_t nstarts_total = nrecs * P;
+    c->valid_frac = 1.0;
+    if (nwindows && c->size_by_valid && c->fused && c->path == 0 && nstarts_total > kValidSizingMin)
+        c->valid_frac = std::min(1.0, std::max(0.05, (double)nwindows / (double)nstarts_total + 0.01));
+    uint64_t done = 0, limit = 0;
+    while (done < nstarts_total)
+    {
+        const bool optimistic = use_segment_path<K>(c);
+        uint64_t capn = chunk_capacity(c, optimistic);
+        if (capn < 4096) capn = chunk_capacity(c, false);
+        if (capn < 4096)
+        {
+            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c, false); }
+            if (capn < 4096 && grow_arena(c, 0)) capn = chunk_capacity(c, false);
+            if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
+        }
+        if (limit && capn > limit) capn = limit;
+        {
+            const uint64_t left = nstarts_total - done;
+            if (left > capn)
+            {
+                const uint64_t parts = (left + capn - 1) / capn;
+                capn = std::min<uint64_t>(capn, ((left + parts - 1) / parts + 4095) & ~4095ULL);
+            }
+        }
+        const uint64_t ns = std::min(capn, nstarts_total - done);          // (a multiple of 4096 slots = whole records, but for the last)
+        const uint64_t lo0 = c->arena.lo, hi0 = c->arena.hi;
+        const size_t runs0 = c->runs.size();
+        try
+        {
+            process_chunk<K>(c, d + (done / P) * sizeof(SkRec), ns, 0);
+        }
+        catch (const StatusError& e)
+        {
+            if (e.status != GOSS_ERR_OOM || ns <= 8192) throw;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->arena.lo = lo0; c->arena.hi = hi0;
+            c->runs.resize(runs0);
+            if (grow_arena(c, 0)) continue;
+            limit = (ns / 2) & ~4095ULL;
+            continue;
+        }
+        done += ns;
+        uint64_t run_bytes = 0;
+        for (auto& r : c->runs) run_bytes += r.m * (c->words * 8 + 4);
+        if (c->runs.size() > 1 && run_bytes > c->arena.size / 4 &&
+            (c->arena.avail() >= 2 * run_bytes + (512ULL << 20) || grow_arena(c, 2 * run_bytes + (512ULL << 20)))) merge_runs<K>(c);
     }
 }
 
@@ -2441,6 +2544,7 @@ const char* goss_gpu_strerror(int status)
         case GOSS_ERR_K_RANGE: return "unable to build a graph with that k";
         case GOSS_ERR_COUNT_OVERFLOW: return "a key count does not fit 32 bits";
         case GOSS_ERR_TOO_LARGE: return "SparseArray high bits do not fit 64 bits";
+        case GOSS_ERR_BUFFER: return "a buffer of the caller is too small";
         default: return "unknown status";
     }
 }
@@ -3189,6 +3293,7 @@ static void push_keys(goss_gpu_ctx* c, const void* keys, uint64_t n, bool on_hos
         HIP_TRY(hipMemcpyAsync(hf, c->d_flags + 2, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hf[0]) { c->arena.release(mark); throw StatusError{GOSS_ERR_INVALID_ARG, "a pushed key has bits beyond 2*len"}; }
+        c->extract_hist_shift = 0xFFFFFFFFu;          // no extraction kernel histogrammed THESE keys
         Run r = count_keys<K>(c, ka, kb, m);
         c->runs.push_back(r);
         c->arena.release(mark);
@@ -3213,6 +3318,68 @@ static int push_keys_entry(goss_gpu_ctx* c, const void* keys, uint64_t n, bool o
         if (c->words == 1) push_keys<Key1>(c, keys, n, on_host); else push_keys<Key2>(c, keys, n, on_host);
     });
 }
+int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes, uint32_t nparts, void* d_records,
+                                  const uint64_t* part_first, const uint64_t* part_cap, uint64_t* part_records, uint64_t* part_windows)
+{
+    if (!c || (!d_bases && nbytes) || nparts == 0 || nparts > (uint32_t)kRouteMaxParts || !part_first || !part_cap || !part_records)
+        return GOSS_ERR_INVALID_ARG;
+    if (c->words != 1) { c->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+    return guarded(c, [&]() {
+        for (uint32_t p = 0; p < nparts; ++p) { part_records[p] = 0; if (part_windows) part_windows[p] = 0; }
+        if (nbytes < c->len) return;
+        // counters and the parts' places: a small device block of its own (the arena may not be mapped yet, and need not be)
+        struct Dev { void* p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } dev;
+        const size_t tab = (size_t)kRouteMaxParts * 8;
+        HIP_TRY(hipMalloc(&dev.p, sizeof(RouteCounters) + 2 * tab));
+        RouteCounters* rc = (RouteCounters*)dev.p;
+        unsigned long long* dfirst = (unsigned long long*)((uint8_t*)dev.p + sizeof(RouteCounters));
+        unsigned long long* dcap = dfirst + kRouteMaxParts;
+        HIP_TRY(hipMemsetAsync(rc, 0, sizeof(RouteCounters), c->stream));
+        HIP_TRY(hipMemcpyAsync(dfirst, part_first, nparts * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dcap, part_cap, nparts * 8, hipMemcpyHostToDevice, c->stream));
+        const uint64_t nstarts = nbytes - c->len + 1;
+        const uint64_t ntiles = (nstarts + kTB * 16 - 1) / (kTB * 16);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 6);
+        const uintptr_t addr = (uintptr_t)d_bases;
+        const uint32_t mis = (uint32_t)(addr & 15u);
+        const uint8_t* aligned = (const uint8_t*)(addr - mis);
+        const uint32_t maxwin = rec_slots(c);
+        {
+            PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
+#define GOSS_LAUNCH_ROUTE(W)                                                                                                \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, nbytes, \
+                       c->len, maxwin, nparts, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles)
+            switch (route_positions(c->len))
+            {
+                case 17: GOSS_LAUNCH_ROUTE(17); break;
+                case 13: GOSS_LAUNCH_ROUTE(13); break;
+                case 9: GOSS_LAUNCH_ROUTE(9); break;
+                case 5: GOSS_LAUNCH_ROUTE(5); break;
+                default: GOSS_LAUNCH_ROUTE(1); break;
+            }
+#undef GOSS_LAUNCH_ROUTE
+            t.stop();
+        }
+        std::vector<unsigned long long> h(sizeof(RouteCounters) / 8);
+        HIP_TRY(hipMemcpyAsync(h.data(), rc, sizeof(RouteCounters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const RouteCounters* hr = (const RouteCounters*)h.data();
+        for (uint32_t p = 0; p < nparts; ++p) { part_records[p] = hr->records[p]; if (part_windows) part_windows[p] = hr->windows[p]; }
+        if (hr->overflow) throw StatusError{GOSS_ERR_BUFFER, "a part's record buffer is too small (part_records holds what every part needs)"};
+    });
+}
+
+int goss_gpu_push_records_device(goss_gpu_ctx* c, const void* d_records, uint64_t nrecords, uint64_t nwindows)
+{
+    if (!c || (nrecords && !d_records)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->words != 1) { c->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+    return guarded(c, [&]() {
+        flush_staging(c);
+        push_records<Key1>(c, (const uint8_t*)d_records, nrecords, nwindows);
+    });
+}
+
 int goss_gpu_push_keys_device(goss_gpu_ctx* c, const void* d_keys, uint64_t n) { return push_keys_entry(c, d_keys, n, false); }
 int goss_gpu_push_keys_host(goss_gpu_ctx* c, const uint64_t* keys, uint64_t n) { return push_keys_entry(c, keys, n, true); }
 
@@ -3465,6 +3632,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     const std::string n = name;
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "rep_chunks") *value = c->rep_chunks;
+    else if (n == "rec_chunks") *value = c->rec_chunks;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;

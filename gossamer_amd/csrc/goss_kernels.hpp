@@ -12,6 +12,7 @@
 
 #include "kernels_common.hpp"
 #include "kernels_extract.hpp"
+#include "kernels_route.hpp"
 #include "kernels_partition.hpp"
 #include "kernels_runs.hpp"
 #include "kernels_text.hpp"

@@ -631,7 +631,10 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
 // skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
 // The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
-template <int MODE, int NH, bool ODD>
+// REC: the input is not bases but super-k-mer records (kernels_route.hpp: 12 bytes = up to 16 windows and their
+// bases, 8 windows in graph mode): thread t of a tile takes record tile * 256 + t, whose windows stand where a
+// thread's window registers stand after phase A; nstarts = records * P, bases_aligned = the records.
+template <int MODE, int NH, bool ODD, bool REC = false>
 __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
@@ -722,14 +725,27 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
     constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..3 also vector NV0 + tid
     static_assert(NVEC == NV0 + 4 && NV0 <= kTB, "one vector per thread and four more");
     uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
+    // REC: one record per thread and tile (three words; nrec = records in all)
+    const uint32_t* recw = reinterpret_cast<const uint32_t*>(bases_aligned);
+    const uint64_t nrec = nstarts / P;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, rn = 0;                 // this tile's record and its number of windows (0: none)
+    auto fetch_rec = [&](uint64_t st, uint32_t& a, uint32_t& b, uint32_t& cc, uint32_t& nw) {
+        const uint64_t ri = st * (uint64_t)kTB + tid;
+        a = b = cc = nw = 0;
+        if (ri < nrec) { a = recw[3 * ri]; b = recw[3 * ri + 1]; cc = recw[3 * ri + 2]; nw = (cc >> 28) + 1; }
+    };
     if (blockIdx.x < nsuper)
     {
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
-        const uint64_t tb = (uint64_t)blockIdx.x * T;
-        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
-        if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
-        encode(q0, c0, b0);
-        if (tid < 4) encode(q1, c1, b1);
+        if constexpr (REC) fetch_rec(blockIdx.x, r0, r1, r2, rn);
+        else
+        {
+            uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+            const uint64_t tb = (uint64_t)blockIdx.x * T;
+            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+            if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+            encode(q0, c0, b0);
+            if (tid < 4) encode(q1, c1, b1);
+        }
     }
 
     for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
@@ -737,16 +753,24 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
         const uint64_t tile_base = st * (uint64_t)T;
 
         // ---- phase A: this tile's codes from registers to LDS, the next tile's bytes on their way ----
-        if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
-        if (tid < 4) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
+        if constexpr (!REC)
+        {
+            if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
+            if (tid < 4) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
+        }
         __syncthreads();
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
         const bool more = st + gridDim.x < nsuper;
+        const uint32_t cr0 = r0, cr1 = r1, cr2 = r2, crn = rn;          // (REC) this tile's record; the next one on its way
         if (more)
         {
-            const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
-            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
-            if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+            if constexpr (REC) fetch_rec(st + gridDim.x, r0, r1, r2, rn);
+            else
+            {
+                const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
+                if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+                if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+            }
         }
 
         // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
@@ -757,6 +781,17 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
         uint32_t rk[NK];
         uint32_t vm;
         {
+            uint32_t m;
+            uint64_t blo, bhi;
+            if constexpr (REC)
+            {
+                // the record's windows 0 .. nw-1 are valid, its bases stand as a thread's do (base j at bits 2j)
+                m = crn >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << crn) - 1u);
+                blo = (uint64_t)cr0 | ((uint64_t)cr1 << 32);
+                bhi = cr2 & 0x0FFFFFFFu;
+            }
+            else
+            {
             const uint32_t q0 = tid * P + mis;
             const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
             const uint64_t p0 = tile_base + (uint64_t)tid * P;
@@ -766,7 +801,6 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
             // window i is valid iff bits [i, i + len) of `inv` are zero.  All P windows at once: runs of good bases
             // of length 1, 2, 4, .. by doubling, and the AND of the runs that make up len (its binary digits) at
             // their offsets -- six steps of a few 64-bit operations instead of a shift, mask and compare per window
-            uint32_t m;
             {
                 uint64_t run = ~inv, acc = ~0ULL;
                 uint32_t covered = 0;
@@ -781,12 +815,13 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
                 const uint32_t lim = left >= (uint64_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << (uint32_t)left) - 1u);
                 m = (uint32_t)acc & lim;
             }
-            vm = m;
-            nvalid += __popc(m);
             const uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
             const uint32_t s2 = 2 * sh;
-            const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-            const uint64_t bhi = hi >> s2;
+            blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            bhi = hi >> s2;
+            }
+            vm = m;
+            nvalid += __popc(m);
             // forward key f and reverse complement r of window 0, then one base rolled in per window
             uint64_t f = rev64(blo & kmask) >> (64 - bits);
             uint64_t r = (~blo) & kmask;
@@ -879,11 +914,14 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
                 if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], ok ? 1u : 0u);
             }
         }
-        if (more)
+        if (more && !REC)
         {
             encode(q0, c0, b0);
             if (tid < 4) encode(q1, c1, b1);
         }
+        // (REC: the next record must have arrived before this tile's stores are issued -- loads and stores share one
+        // in-order counter, and a wait at its first use in the next tile would wait for those stores as well)
+        if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------

@@ -1,0 +1,337 @@
+// kernels_route.hpp -- reads -> super-k-mer records, routed by minimizer (the exchange BEFORE counting of a
+// multi-GPU build), and records -> keys.
+//
+// The reference has no distributed path; what these kernels must preserve is the key
+// stream of its adapters: every valid window of every read exactly once (KmerizingAdapter.hh:20-86; for graphs
+// every (k+1)-mer, which the counting side turns into both strands, ReverseComplementAdapter.hh:20-93), and
+// that all copies of a key -- whatever strand they were read from -- are counted by ONE rank, so that the
+// per-rank counts are final (position_type::normalize, RankSelect.hh:126-140, picks one strand per k-mer).
+//
+// Routing function: the MINIMIZER of a window = the smallest (under a multiplicative hash) canonical m-mer
+// among its W = len - m + 1 m-mers, canonical = min(m-mer, reverse complement).  The set of canonical m-mers of
+// a window and of its reverse complement are the same set, so both strands of a k-mer have the same minimizer:
+// destination = second hash of the minimizer, scaled to [0, nparts).  Consecutive windows of a read mostly share
+// their minimizer (~(W + 1) / 2 windows in a row), so a run of windows with one destination travels as ONE
+// record holding its bases once: 12 bytes for up to 16 windows instead of 8 bytes per window.
+//
+// Record (SkRec, 12 bytes): bits 0..91 = the run's (nwin + len - 1 <= 46) bases as 2-bit codes, base j of the
+// run at bits [2j, 2j + 2) (the bit order of the extraction kernels' window registers); bits 92..95 = nwin - 1.
+// A record never spans a non-base, a read boundary, or the 16 windows a routing thread owns; in graph mode
+// (two keys per window) records hold at most 8 windows, the keys a counting thread takes.
+// Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp.
+#pragma once
+
+#include "kernels_common.hpp"
+#include "kernels_extract.hpp"
+
+namespace goss {
+
+struct SkRec { uint32_t w0, w1, w2; };
+static_assert(sizeof(SkRec) == 12, "records are 12 bytes");
+
+constexpr int kRouteMaxParts = 256;
+struct RouteCounters {
+    unsigned long long records[kRouteMaxParts];   // records asked for by part (also past the capacity: the caller learns the need)
+    unsigned long long windows[kRouteMaxParts];   // windows routed to part p
+    unsigned long long overflow;                  // a part's buffer was too small: nothing of that tile was stored for it
+};
+
+// minimizer length m and positions per window W = len - m + 1 for a window of `len` bases: W from a small set
+// (the kernel is instantiated per W), m at least 7 where the window allows it and at most 15 (30 bits)
+__host__ __device__ inline uint32_t route_positions(uint32_t len)
+{
+    const uint32_t ws[5] = {17, 13, 9, 5, 1};
+    for (int i = 0; i < 5; ++i)
+        if (len >= ws[i] && len - ws[i] + 1 >= (len < 7 ? len : 7) && len - ws[i] + 1 <= 15) return ws[i];
+    return 1;      // (len <= 15: the window is its own minimizer)
+}
+
+__device__ __forceinline__ uint32_t route_mix(uint32_t x)
+{
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x;
+}
+
+// reads (ASCII, any non-ACGT byte ends a run of windows) -> records appended to `nparts` buffers.
+// out + part_first[p] = first record slot of part p, part_cap[p] its capacity.  Tile = 4096 window starts,
+// 16 per thread; phase A (bytes -> 2-bit codes + non-base flags in LDS) is the extraction kernels'.
+template <int W>
+__global__ __launch_bounds__(kTB, 2) void route_records_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+                                                               uint64_t nstarts, uint64_t navail, uint32_t len, uint32_t maxwin,
+                                                               uint32_t nparts, SkRec* __restrict__ out,
+                                                               const unsigned long long* __restrict__ part_first,
+                                                               const unsigned long long* __restrict__ part_cap,
+                                                               RouteCounters* __restrict__ rc, uint64_t ntiles)
+{
+    constexpr int P = 16;
+    constexpr int T = kTB * P;
+    constexpr int NVEC = T / 16 + 4;
+    constexpr int NPOS = P + W - 1;                 // m-mer positions a thread looks at
+    __shared__ uint32_t pk[NVEC], iv[NVEC];
+    __shared__ uint16_t rkbuf[T];                   // rank of every record inside its part's share of the tile (a record per window at worst)
+    __shared__ uint32_t cnt[kRouteMaxParts], win[kRouteMaxParts];
+    __shared__ unsigned long long gbase[kRouteMaxParts];
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t m = len - W + 1;
+    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    {
+        const uint64_t tb = tile * (uint64_t)T;
+        // ---- phase A: bytes of the tile -> codes + non-base flags ------------------------------------------
+        for (uint32_t v = tid; v < (uint32_t)NVEC; v += kTB)
+        {
+            const uint64_t byte0 = tb + (uint64_t)v * 16;
+            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            if (byte0 + 16 <= navail + mis) q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
+            else if (byte0 < navail + mis)
+            {
+                uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                for (int j = 0; j < 16; ++j)
+                {
+                    const uint64_t b = byte0 + j;
+                    const uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
+                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+                q = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // (bytes in front of the string, when it does not start on a 16-byte boundary, are not bases)
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const uint32_t l = w[i] | 0x20202020u;
+                uint32_t x = (l >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                auto nz = [](uint32_t u) { return (((u & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | u) & 0x80808080u; };
+                const uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+                const uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                const uint32_t b1 = bad >> 7;
+                const uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                codes |= c8 << (8 * i);
+                bads |= b4 << (4 * i);
+            }
+            if (byte0 < mis) bads |= (1u << (uint32_t)(mis - byte0 > 16 ? 16 : mis - byte0)) - 1u;
+            pk[v] = codes; iv[v] = bads;
+        }
+        if (tid < nparts) { cnt[tid] = 0; win[tid] = 0; }
+        __syncthreads();
+
+        // ---- phase B: this thread's 16 windows: validity, minimizers, destinations, runs --------------------
+        const uint32_t q0 = tid * P + mis;
+        const uint32_t v0 = q0 >> 4, sh = q0 & 15u;
+        const uint64_t p0 = tb + (uint64_t)tid * P;
+        const uint64_t i0 = iv[v0], i1 = iv[v0 + 1], i2 = iv[v0 + 2], i3 = iv[v0 + 3];
+        const uint64_t w0 = pk[v0], w1 = pk[v0 + 1], w2 = pk[v0 + 2], w3 = pk[v0 + 3];
+        const uint64_t inv = (i0 | (i1 << 16) | (i2 << 32) | (i3 << 48)) >> sh;
+        uint32_t valid;
+        {
+            uint64_t run = ~inv, acc = ~0ULL;
+            uint32_t covered = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)               // len <= 31
+            {
+                if ((len >> j) & 1u) { acc &= run >> covered; covered += 1u << j; }
+                run &= run >> (1u << j);
+            }
+            const uint64_t left = nstarts > p0 ? nstarts - p0 : 0;
+            valid = (uint32_t)acc & (left >= (uint64_t)P ? 0xFFFFu : ((1u << (uint32_t)left) - 1u));
+        }
+        const uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
+        const uint32_t s2 = 2 * sh;
+        const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;      // base j of this thread at bits [2j, 2j + 2)
+        const uint64_t bhi = hi >> s2;
+
+        uint32_t nrec = 0, starts = 0;
+        uint32_t dest[P];
+        if (valid)
+        {
+            // hashed canonical m-mers at positions 0 .. NPOS-1: forward and reverse complement rolled; the first
+            // m - 1 bases prime the roll, then position `pos` takes base pos + m - 1
+            uint32_t val[NPOS];
+            uint32_t fm = 0, rm = 0;
+            for (uint32_t j = 0; j + 1 < m; ++j)
+            {
+                const uint32_t nb = (uint32_t)(blo >> (2 * j)) & 3u;          // (m - 1 <= 14 bases: all in blo)
+                fm = ((fm << 2) | nb) & mmask;
+                rm = (rm >> 2) | ((nb ^ 3u) << (2 * (m - 1)));
+            }
+            const uint32_t ms = 2 * (m - 1);
+            const uint64_t clo = ms ? ((blo >> ms) | (bhi << (64 - ms))) : blo;
+            const uint64_t chi = bhi >> ms;
+#pragma unroll
+            for (int pos = 0; pos < NPOS; ++pos)
+            {
+                const uint32_t nb = (uint32_t)(pos < 32 ? (clo >> (2 * pos)) : (chi >> (2 * (pos - 32)))) & 3u;
+                fm = ((fm << 2) | nb) & mmask;
+                rm = (rm >> 2) | ((nb ^ 3u) << (2 * (m - 1)));
+                val[pos] = (fm < rm ? fm : rm) * 0x9E3779B1u;
+            }
+            // minimum over W positions for every window
+            uint32_t mn[P];
+            if constexpr (W >= P)
+            {
+                uint32_t suf[W];
+                suf[W - 1] = val[W - 1];
+#pragma unroll
+                for (int j = W - 2; j >= 0; --j) suf[j] = min(val[j], suf[j + 1]);
+                mn[0] = suf[0];
+                uint32_t pre = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 1; i < P; ++i) { pre = min(pre, val[W - 1 + i]); mn[i] = min(suf[i], pre); }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                {
+                    uint32_t x = val[i];
+#pragma unroll
+                    for (int j = 1; j < W; ++j) x = min(x, val[i + j]);
+                    mn[i] = x;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) dest[i] = __umulhi(route_mix(mn[i]), nparts);
+            // a record starts at a valid window whose predecessor is not valid, goes elsewhere, or filled a record
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t ok = (valid >> i) & 1u;
+                const uint32_t prev_ok = i ? (valid >> (i - 1)) & 1u : 0u;
+                const uint32_t same = i ? (dest[i] == dest[i - 1] ? 1u : 0u) : 0u;
+                const uint32_t forced = (maxwin < (uint32_t)P && i == (int)maxwin) ? 1u : 0u;      // (maxwin is 8 or 16)
+                starts |= (ok & (((prev_ok & same) ^ 1u) | forced)) << i;
+            }
+            nrec = __popc(starts);
+        }
+        uint32_t tot;
+        const uint32_t at = block_excl_scan<uint32_t>(nrec, sh_scan, &tot);
+        (void)tot;
+
+        // ---- phase C: every record of this thread takes a rank inside its part's share of the tile ----------------
+        {
+            uint32_t todo = starts, r = 0;
+            while (todo)
+            {
+                const uint32_t s = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const uint32_t stop = (todo | ~valid | (1u << P)) >> s;            // bit j set: window s + j ends the run
+                const uint32_t n = __ffs(stop & ~1u) - 1;                          // (bit 0 is the start itself)
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) if ((uint32_t)i == s) d = dest[i];
+                rkbuf[at + r] = (uint16_t)atomicAdd(&cnt[d], 1u);
+                atomicAdd(&win[d], n);
+                ++r;
+            }
+        }
+        __syncthreads();
+        // ---- phase D: room in every part's buffer (one atomic per part and tile), then the records leave --------
+        if (tid < nparts)
+        {
+            const uint32_t c = cnt[tid];
+            unsigned long long g = ~0ULL;
+            if (c)
+            {
+                g = atomicAdd(&rc->records[tid], (unsigned long long)c);
+                if (g + c > part_cap[tid]) { g = ~0ULL; atomicOr(&rc->overflow, 1ULL); }
+                else g += part_first[tid];
+                if (win[tid]) atomicAdd(&rc->windows[tid], (unsigned long long)win[tid]);
+            }
+            gbase[tid] = g;
+        }
+        __syncthreads();
+        {
+            uint32_t todo = starts, r = 0;
+            while (todo)
+            {
+                const uint32_t s = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const uint32_t stop = (todo | ~valid | (1u << P)) >> s;
+                const uint32_t n = __ffs(stop & ~1u) - 1;
+                const uint32_t nbases = n + len - 1;                               // <= 46
+                // bases s .. s + nbases - 1 of this thread
+                const uint32_t ss = 2 * s;
+                const uint64_t flo = ss ? ((blo >> ss) | (bhi << (64 - ss))) : blo;
+                const uint64_t fhi = bhi >> ss;
+                const uint32_t nb2 = 2 * nbases;
+                const uint64_t klo = nb2 >= 64 ? flo : (flo & ((1ULL << nb2) - 1ULL));
+                const uint32_t khi = nb2 > 64 ? (uint32_t)(fhi & ((1ULL << (nb2 - 64)) - 1ULL)) : 0u;
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) if ((uint32_t)i == s) d = dest[i];
+                const unsigned long long g = gbase[d];
+                if (g != ~0ULL)
+                {
+                    SkRec rec{(uint32_t)klo, (uint32_t)(klo >> 32), khi | ((n - 1) << 28)};
+                    out[g + rkbuf[at + r]] = rec;
+                }
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// records -> keys, densely (the role of extract1_kernel for a record source): one thread per record, its
+// keys written at the cursor position of its workgroup.  MODE 0: one key per window -- gossamer's canonical form
+// (position_type::normalize), or the strand representative of the fused pipeline's key space when REP; MODE 1:
+// every window's key and its reverse complement.  Sampling mode as extract1_kernel's: `nsuper` groups of
+// kRecGroup records, group g of slice s = g / slice_groups starts at record s * slice_stride + (g % slice_groups) *
+// kRecGroup.
+constexpr int kRecGroup = kTB;
+template <int MODE, bool REP>
+__global__ __launch_bounds__(kTB) void extract_records_kernel(const SkRec* __restrict__ recs, uint64_t nrecs, uint32_t len,
+                                                              Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
+                                                              uint64_t ngroups, uint64_t slice_groups, uint64_t slice_stride)
+{
+    constexpr int S = MODE == 1 ? 2 : 1;
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ unsigned long long sh_base;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bits = 2 * len;
+    const uint64_t kmask = (1ULL << bits) - 1;
+    const uint64_t lmask = (1ULL << len) - 1;
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        uint64_t r0 = g * (uint64_t)kRecGroup;
+        if (slice_groups) r0 = (g / slice_groups) * slice_stride + (g % slice_groups) * (uint64_t)kRecGroup;
+        const uint64_t ri = r0 + tid;
+        uint32_t nw = 0;
+        SkRec rec{0, 0, 0};
+        if (ri < nrecs) { rec = recs[ri]; nw = (rec.w2 >> 28) + 1; }
+        uint32_t tot;
+        const uint32_t at = block_excl_scan<uint32_t>(nw * S, sh_scan, &tot);
+        if (tid == 0) sh_base = tot ? atomicAdd(&ctr->keys_out, (unsigned long long)tot) : 0ULL;
+        __syncthreads();
+        const uint64_t ob = sh_base + at;
+        const uint64_t blo = (uint64_t)rec.w0 | ((uint64_t)rec.w1 << 32), bhi = rec.w2 & 0x0FFFFFFFu;
+        uint64_t f = rev64(blo & kmask) >> (64 - bits);
+        uint64_t r = (~blo) & kmask;
+        const uint32_t top = bits - 2;
+        for (uint32_t i = 0; i < nw; ++i)
+        {
+            if (i)
+            {
+                const uint32_t pos = 2 * (i + len - 1);
+                const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                f = ((f << 2) | nb) & kmask;
+                r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
+            }
+            const Key1 fk{f}, rck{r};
+            if (MODE == 0)
+            {
+                if (REP) out[ob + i] = (len & 1u) ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
+                else out[ob + i] = canonical(fk, rck);
+            }
+            else { out[ob + 2 * i] = fk; out[ob + 2 * i + 1] = rck; }
+        }
+        if (tid == 0 && tot) atomicAdd(&ctr->windows, (unsigned long long)(tot / S));
+        __syncthreads();
+    }
+}
+
+}  // namespace goss

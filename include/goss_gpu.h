@@ -33,7 +33,8 @@ typedef enum {
     GOSS_ERR_K_RANGE      = -6,   /* "unable to build a graph with k=<K>" (KmerSet.hh:89-95, Graph.cc:152-158) */
     GOSS_ERR_COUNT_OVERFLOW = -7, /* graph mode: more than 256 keys occurred >= 2^32 - 1 times each (up to that many are
                                      kept exactly, goss_gpu_big_counts) */
-    GOSS_ERR_TOO_LARGE    = -8    /* high-bits value does not fit 64 bits (SparseArray.hh:91-95) */
+    GOSS_ERR_TOO_LARGE    = -8,   /* high-bits value does not fit 64 bits (SparseArray.hh:91-95) */
+    GOSS_ERR_BUFFER       = -9    /* a buffer supplied by the caller is too small; the sizes needed were returned */
 } goss_status;
 
 /* mode: which reference command's key stream is produced. */
@@ -422,6 +423,40 @@ int goss_gpu_push_run_device(goss_gpu_ctx* ctx, const void* d_keys, const uint32
  */
 int goss_gpu_push_keys_host(goss_gpu_ctx* ctx, const uint64_t* keys, uint64_t n);
 int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n);
+
+/*
+ * The exchange BEFORE counting of a multi-GPU build (no reference counterpart: the reference is single-node; what
+ * must be preserved is the adapters' key stream -- every valid window of every read once, KmerizingAdapter.hh:20-86 /
+ * ReverseComplementAdapter.hh:20-93 -- and that all copies of a key, from either strand, are counted in ONE place,
+ * which is what position_type::normalize, RankSelect.hh:126-140, exists for).
+ *
+ * goss_gpu_route_records_device cuts the windows of a base string (as goss_gpu_push_bases_device takes it) into
+ * SUPER-K-MER RECORDS and appends each to one of nparts buffers: a record is a run of up to 16 consecutive windows
+ * (8 in graph mode) that have the same destination, with the run's bases stored once -- 12 bytes (GOSS_RECORD_BYTES)
+ * instead of 8 bytes per window.  The destination of a window is a hash of its MINIMIZER (the smallest canonical
+ * m-mer inside it, m = 7..15 depending on the window length), scaled to [0, nparts): a window and its reverse
+ * complement have the same minimizer, so every occurrence of a k-mer -- and of a graph edge and its reverse
+ * complement -- reaches the same part, and the counts of a part are final.  Only contexts with one-word keys
+ * (2*len <= 62, len = k or k + 1) route; others get GOSS_ERR_INVALID_ARG.
+ *   d_records           device memory for the records of all parts
+ *   part_first[p]       first record slot of part p inside d_records, part_cap[p] the slots it may use
+ *   part_records[p]     (out) records of part p -- what it NEEDS when the call returns GOSS_ERR_BUFFER because some
+ *                       part_cap was too small (nothing usable was written for that part: call again with room)
+ *   part_windows[p]     (out, may be NULL) windows routed to part p
+ * The context only lends its device, stream and (k, mode): nothing is counted and no state changes.
+ *
+ * goss_gpu_push_records_device counts the windows of records (its own or received from other ranks) exactly as
+ * goss_gpu_push_bases_* counts the windows of bases; nwindows (0 = unknown) = the sum of the parts' part_windows,
+ * which sizes the key buffers.  Records and bases may be mixed in one build.
+ *
+ * Record layout (little endian, three u32): bits 0..91 the run's nwin + len - 1 <= 46 bases as 2-bit codes
+ * (A=0 C=1 G=2 T=3), base j at bits [2j, 2j+2); bits 92..95 nwin - 1.
+ */
+#define GOSS_RECORD_BYTES 12
+int goss_gpu_route_records_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t nparts, void* d_records,
+                                  const uint64_t* part_first, const uint64_t* part_cap, uint64_t* part_records,
+                                  uint64_t* part_windows);
+int goss_gpu_push_records_device(goss_gpu_ctx* ctx, const void* d_records, uint64_t nrecords, uint64_t nwindows);
 
 /*
  * Deterministic synthetic read generator: fills d_out (device) with
