@@ -295,6 +295,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed-by-the-headline C4 record (build-graph k=55, 200 M reads)")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--exchange", default="records", choices=("records", "counted"),
+                    help="N > 1: what travels in the first all-to-all -- super-k-mer records routed by minimizer BEFORE counting "
+                         "(each rank counts 1/N of the key space), or the (key,count) pairs of every rank's local count")
+    ap.add_argument("--route-parts", type=int, default=0, help="with --force-dist on one rank: cut the records as a build over "
+                    "this many ranks would (the rank then receives all its own parts: one rank's load of an N-rank build)")
     ap.add_argument("--graph", action="store_true", help="build-graph instead of build-kmer-set (windows are (k+1)-mers, "
                     "two keys per window); not the headline metric")
     args = ap.parse_args()
@@ -322,6 +327,8 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
+    if args.route_parts:
+        os.environ["GOSS_DIST_ROUTE_PARTS"] = str(args.route_parts)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -367,7 +374,7 @@ def main():
             c = ctx.finish()
             ctx.emit_device()
             return c.windows, c.distinct
-        r = gdist.count_distributed(ctx, bases.data_ptr(), nbytes, 2 * (k + 1 if args.graph else k), device)
+        r = gdist.count_distributed(ctx, bases.data_ptr(), nbytes, 2 * (k + 1 if args.graph else k), device, exchange=args.exchange)
         return r["windows"], r["M"]
 
     def barrier():
@@ -453,7 +460,8 @@ def main():
                                                                "Graph (edge SparseArray + counts)" if args.graph else "KmerSet SparseArray"),
                        "reads_per_gpu": nreads, "read_len": L, "k": k, "distinct_kmers": distinct,
                        "parallelism": "1 GPU" if world == 1 else "range-partition over %d ranks on %d GPU(s), %s all-to-all(v)"
-                                      % (world, min(world, ndev), "RCCL" if args.backend == "nccl" else "gloo (host-staged)")},
+                                      % (world, min(world, ndev), "RCCL" if args.backend == "nccl" else "gloo (host-staged)"),
+                       "exchange": (args.exchange if use_dist else None), "route_parts": (args.route_parts or None)},
             "roofline": {"bound": "hbm", "kernel": {"extract": "extract1_part_kernel" if fused else "extract1_kernel",
                                                     "order": "canonical_map_kernel + radix passes over (key,count) pairs",
                                                     "hist": "radix_hist_kernel",

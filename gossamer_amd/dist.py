@@ -9,9 +9,19 @@ fixes the Elias-Fano split D) and each range's rank offset.  There is no ring al
 bulk data anywhere.  The reference has no distributed path; this module
 is new design, constrained only by having to produce the reference's single-pass result.
 
-Per exchange there are two collectives and one host synchronisation: an all-gather of the
-P x P matrix of run lengths (every rank then knows what it receives), and one all-to-all(v) of
-bytes in which the segment for destination p holds that range's keys followed by its counts.
+Two forms of the first step (count_range, `exchange=`):
+  "counted"  every rank counts ITS reads, then the distinct (key,count) pairs are range-partitioned (what is described
+             above).  Cheap on the wire, but with P ranks a rank's local distinct set approaches the whole k-mer set.
+  "records"  the exchange comes BEFORE counting: every rank cuts its reads into super-k-mer records routed by
+             minimizer (goss_gpu_route_records_device: ~2 bytes per window instead of 8), ONE all-to-all(v) moves
+             them, and each rank counts only the keys of its minimizer class -- 1/P of the key space at the
+             single-GPU cost, whatever P is.  The classes are not key ranges, so the (now final, disjoint) counted
+             sets are range-partitioned afterwards by the same splitter exchange, which then moves 1/P as much.
+             One-word keys only (2*len <= 62); wider keys take "counted".
+
+Per exchange of counted runs there are three collectives and one host synchronisation: an all-gather of the
+P x P matrix of run lengths (every rank then knows what it receives), and an all-to-all(v) each for the keys and
+the counts, sent straight from the library's result arrays (sorted, so range p is a contiguous slice: nothing is packed).
 Splitters are quantiles of a sample of every rank's distinct keys (all-gathered, a few KB), so
 skewed key distributions still give ranges of equal size; uniform splitters remain available.
 
@@ -132,64 +142,25 @@ def _exchange_device(device, group=None):
     return torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
-def _segment_bytes(n, words):
-    """bytes of one all-to-all segment: n keys (8*words each), then n u32 counts padded to 8"""
-    return n * 8 * words + 8 * ((n + 1) // 2)
-
-
-def exchange_packed(keys, counts, splitters, group=None):
-    """all-to-all(v): send range p of (keys, counts) to rank p.  Returns (rbuf, recv, segs): a byte
-    buffer on the exchange device (the keys' device under RCCL, host memory under gloo) holding one
-    segment per source rank -- that rank's keys of this range, then their u32 counts -- the run
-    lengths, and the byte offset of every segment."""
+def exchange_runs(keys, counts, splitters, group=None):
+    """all-to-all(v): range p of (keys, counts) goes to rank p.  Returns (recv_keys, recv_counts, recv_sizes) -- the
+    concatenation of one sorted run per source rank, and the run lengths.  The keys are sorted, so every range is a
+    contiguous slice of both arrays: they are sent as they lie (no packing pass, no staging copy on the GPU)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    words = 1 if keys.dim() == 1 else 2
-    xdev = _exchange_device(keys.device, group)
     send = split_sizes(keys, splitters)
     assert len(send) == world
     # every rank learns the whole matrix of run lengths: one collective, one host synchronisation
-    mine = torch.tensor(send, dtype=torch.int64, device=xdev)
-    rows = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(rows, mine, group=group)
-    matrix = torch.stack(rows).cpu().tolist()
+    mine = torch.tensor(send, dtype=torch.int64, device=keys.device)
+    rows = torch.empty((world, world), dtype=torch.int64, device=keys.device)
+    dist.all_gather(list(rows.unbind(0)), mine, group=group)
+    matrix = rows.cpu().tolist()
     recv = [int(matrix[q][rank]) for q in range(world)]
-    # one buffer of bytes: for destination p the keys of range p, then their counts
-    sbytes = [_segment_bytes(n, words) for n in send]
-    rbytes = [_segment_bytes(n, words) for n in recv]
-    sbuf = torch.zeros(max(1, sum(sbytes)), dtype=torch.uint8, device=xdev)
-    kflat = keys.reshape(-1)
-    off = at = 0
-    for n, nb in zip(send, sbytes):
-        if n:
-            sbuf[at:at + 8 * words * n].view(torch.int64).copy_(kflat[off * words:(off + n) * words])
-            sbuf[at + 8 * words * n:at + 8 * words * n + 4 * n].view(torch.int32).copy_(counts[off:off + n])
-        off += n
-        at += nb
-    rbuf = torch.empty(max(1, sum(rbytes)), dtype=torch.uint8, device=xdev)
-    dist.all_to_all_single(rbuf[:sum(rbytes)], sbuf[:sum(sbytes)], rbytes, sbytes, group=group)
-    segs, at = [], 0
-    for nb in rbytes:
-        segs.append(at)
-        at += nb
-    return rbuf, recv, segs
-
-
-def exchange_runs(keys, counts, splitters, group=None):
-    """exchange_packed, unpacked: (recv_keys, recv_counts, recv_sizes) -- the concatenation of one
-    sorted run per source rank, and the run lengths."""
-    words = 1 if keys.dim() == 1 else 2
-    rbuf, recv, segs = exchange_packed(keys, counts, splitters, group)
     total = sum(recv)
-    rk = torch.empty((total,) + tuple(keys.shape[1:]), dtype=torch.int64, device=rbuf.device)
-    rc = torch.empty(total, dtype=torch.int32, device=rbuf.device)
-    rkf = rk.reshape(-1)
-    off = 0
-    for n, at in zip(recv, segs):
-        if n:
-            rkf[off * words:(off + n) * words].copy_(rbuf[at:at + 8 * words * n].view(torch.int64))
-            rc[off:off + n].copy_(rbuf[at + 8 * words * n:at + 8 * words * n + 4 * n].view(torch.int32))
-        off += n
+    rk = torch.empty((total,) + tuple(keys.shape[1:]), dtype=torch.int64, device=keys.device)
+    rc = torch.empty(total, dtype=torch.int32, device=keys.device)
+    dist.all_to_all_single(rk, keys, recv, send, group=group)          # splits along dim 0: whole keys
+    dist.all_to_all_single(rc, counts, recv, send, group=group)
     return rk, rc, recv
 
 
@@ -253,11 +224,85 @@ def _push_run(ctx, on_gpu, keys_ptr, counts_ptr, n):
         ctx.push_run_host(keys_ptr, counts_ptr, n)
 
 
-def _push_packed(ctx, rbuf, recv, segs, words):
-    """the segments of an exchange buffer (on the GPU or in host memory) -> runs of the context"""
-    for n, at in zip(recv, segs):
+def _push_received(ctx, rk, rc, recv, words):
+    """the runs of an exchange (concatenated, on the GPU or in host memory) -> runs of the context"""
+    off = 0
+    for n in recv:
         if n:
-            _push_run(ctx, rbuf.device.type == "cuda", rbuf.data_ptr() + at, rbuf.data_ptr() + at + 8 * words * n, n)
+            _push_run(ctx, rk.device.type == "cuda", rk.data_ptr() + off * 8 * words, rc.data_ptr() + off * 4, n)
+        off += n
+
+
+_ROUTE_SIZES = {}          # (bases_ptr, nbytes, parts) -> records per part of the last routing of that input (the probe below)
+
+
+def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None):
+    """The exchange before counting: this rank's reads -> super-k-mer records routed by minimizer into one buffer
+    per rank (goss_gpu_route_records_device) -> ONE all-to-all(v) of record bytes -> the records this rank received
+    are counted (goss_gpu_push_records_device; not yet finished).  Returns the windows of this rank's own reads."""
+    import os
+    from .binding import RECORD_BYTES as RB
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device(device)
+    probe = int(os.environ.get("GOSS_DIST_ROUTE_PARTS", "0"))
+    if world == 1 and probe > 1:
+        # one rank's load of a `probe`-rank build, measured on one GPU (tools/scale_probe.sh): the records are cut as
+        # they would be for that many destinations and the rank takes all its own parts -- the number of windows one
+        # rank of the real build receives from everybody
+        need = _ROUTE_SIZES.get((bases_ptr, nbytes, probe), [1] * probe)          # (exact after the first call on this input)
+        for attempt in range(2):
+            first = [sum(need[:p]) for p in range(probe)]
+            sbuf = torch.empty(sum(need) * RB, dtype=torch.uint8, device=dev)
+            recs, wins, ok = ctx.route_records(bases_ptr, nbytes, probe, sbuf.data_ptr(), first, need)
+            if ok:
+                break
+            need = recs
+        _ROUTE_SIZES[(bases_ptr, nbytes, probe)] = recs
+        ctx.push_records(sbuf.data_ptr(), sum(recs), sum(wins))
+        return sum(wins)
+    # room per part: ~6 windows per record at 8 parts (fewer parts cut less often), a third of slack; a part that
+    # needs more is reported by the library and the routing is redone with exact sizes
+    guess = nbytes // 5 // world + nbytes // 15 // world + 4096
+    caps = [guess] * world
+    for attempt in range(2):
+        first = [sum(caps[:p]) for p in range(world)]
+        sbuf = torch.empty(max(1, sum(caps)) * RB, dtype=torch.uint8, device=dev)
+        recs, wins, ok = ctx.route_records(bases_ptr, nbytes, world, sbuf.data_ptr(), first, caps)
+        if ok:
+            break
+        del sbuf
+        caps = [n + 1 for n in recs]
+    else:
+        raise RuntimeError("routing did not fit the sizes it asked for")
+    xdev = _exchange_device(dev, group)
+    mine = torch.tensor(recs + wins, dtype=torch.int64, device=xdev)
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine, group=group)
+    matrix = torch.stack(rows).cpu().tolist()
+    recv = [int(matrix[q][rank]) for q in range(world)]
+    recv_windows = sum(int(matrix[q][world + rank]) for q in range(world))
+    total = sum(recv)
+    parts = [sbuf[first[p] * RB:(first[p] + recs[p]) * RB] for p in range(world)]
+    if xdev.type == "cuda":
+        rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev)
+        outs, at = [], 0
+        for n in recv:
+            outs.append(rbuf[at * RB:(at + n) * RB])
+            at += n
+        dist.all_to_all(outs, parts, group=group)          # views of both buffers: nothing is packed or copied
+        _sync(dev)
+    else:
+        send = torch.cat([p.cpu() for p in parts]) if total or sum(recs) else torch.empty(0, dtype=torch.uint8)
+        rhost = torch.empty(total * RB, dtype=torch.uint8)
+        dist.all_to_all_single(rhost, send, [n * RB for n in recv], [n * RB for n in recs], group=group)
+        rbuf = rhost.to(dev)
+        _sync(dev)
+    del sbuf, parts
+    if total:
+        ctx.push_records(rbuf.data_ptr(), total, recv_windows)
+    del rbuf               # (the push has consumed the records)
+    return sum(wins)
 
 
 def result_views(ctx, words, device):
@@ -266,38 +311,82 @@ def result_views(ctx, words, device):
     return key_view(kp, m, words, device), device_view(cp, m, torch.int32, device)
 
 
-def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled"):
-    """local count -> exchange -> merge of the received runs: this rank's range of the global
-    result stays in the Context.  Returns (this rank's windows, key words, the splitters used).
-    `splitters`: "sampled", "uniform", or a tensor from an earlier call (set algebra: every set
-    must be cut at the same places)."""
+def _carry_big_counts(ctx, keys, counts, words, group):
+    """Graph mode: a multiplicity of 2^32 - 1 or more is a marker in the u32 array and an exact u64 beside the result
+    (goss_gpu_big_counts).  The marker must not be summed: the sender zeroes it in a copy of its counts, every rank
+    learns all (key, exact count) pairs (a handful), and the owner of the key's range adds the exact value after the
+    merge (_add_big_counts).  Returns (counts to send, [(key, exact)] of all ranks)."""
     world = dist.get_world_size(group)
+    if ctx.mode != MODE_GRAPH:          # (a k-mer set stores no counts)
+        return counts, []
+    big = sorted(ctx.big_counts().items())
+    everyone = [None] * world
+    dist.all_gather_object(everyone, big, group=group)
+    allbig = [kv for lst in everyone for kv in lst]
+    if big:
+        counts = counts.clone()
+        probe = _key_tensor([k for k, _ in big], words == 2, keys.device)
+        if words == 1:
+            idx = torch.searchsorted(keys, probe)
+        else:
+            idx = torch.tensor([_lower_bound2(keys, int(lo), int(hi)) for lo, hi in probe.tolist()], dtype=torch.int64, device=keys.device)
+        counts[idx] = 0
+    return counts, allbig
+
+
+def _add_big_counts(ctx, allbig, splitters, words, rank):
+    """the exact counts of _carry_big_counts for the keys of THIS rank's range, as single-key runs of at most
+    2^32 - 2 each: the merge adds them up and keeps the exact sum beside the result again"""
+    import numpy as np
+    cuts = _key_ints(splitters)
+    for k, exact in allbig:
+        owner = sum(1 for c in cuts if k >= c)
+        if owner != rank:
+            continue
+        kw = np.array([k & _MASK] if words == 1 else [k & _MASK, k >> 64], dtype=np.uint64)
+        while exact > 0:
+            piece = min(exact, (1 << 32) - 2)
+            cw = np.array([piece], dtype=np.uint32)
+            ctx.push_run_host(kw.ctypes.data, cw.ctypes.data, 1)
+            exact -= piece
+
+
+def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled", exchange="counted"):
+    """count -> range-partition -> merge of the received runs: this rank's range of the global result stays in the
+    Context.  Returns (this rank's windows, key words, the splitters used).
+    `exchange`: "counted" (local count of this rank's reads, then the exchange of its distinct pairs) or "records"
+    (super-k-mer records routed by minimizer and exchanged BEFORE counting; module docstring).
+    `splitters`: "sampled", "uniform", or a tensor from an earlier call (set algebra: every set must be cut at the
+    same places)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     ctx.reset()
-    ctx.push_device(bases_ptr, nbytes)
-    c = ctx.finish()
+    if exchange == "records" and key_bits <= 62:
+        windows = route_and_exchange_records(ctx, bases_ptr, nbytes, device, group)
+        c = ctx.finish()
+    else:
+        ctx.push_device(bases_ptr, nbytes)
+        c = ctx.finish()
+        windows = c.windows
     words = c.key_words
-    windows = c.windows
-    if ctx.mode == MODE_GRAPH and ctx.big_counts():
-        # the u32 count of such an edge is its value modulo 2^32 and the exact value lives beside the
-        # result in this context only: summing the ranges would be silently wrong
-        raise OverflowError("an edge occurred 2^32 - 1 times or more on this rank: exact 64-bit counts do not travel "
-                            "through the exchange (build on one GPU, or split the input differently)")
     if (key_bits > 62) != (words == 2):
         raise ValueError("key_bits = %d does not match the context's %d-word keys (2*len: len = k, or k+1 for graphs)" % (key_bits, words))
     keys, counts = result_views(ctx, words, device)
     xdev = _exchange_device(device, group)
     if xdev.type == "cpu":
         keys, counts = keys.cpu(), counts.cpu()
+    counts, allbig = _carry_big_counts(ctx, keys, counts, words, group)
     if isinstance(splitters, str):
         splitters = sampled_splitters(keys, world, group) if splitters == "sampled" else uniform_splitters(key_bits, world, device=keys.device)
-    rbuf, recv, segs = exchange_packed(keys, counts, splitters, group)
+    rk, rc, recv = exchange_runs(keys, counts, splitters, group)
     _sync(device)          # the library runs on its own stream: finish the collectives first
     del keys, counts
     # merge the received runs: they replace the local result
     ctx.reset()
-    _push_packed(ctx, rbuf, recv, segs, words)
+    _push_received(ctx, rk, rc, recv, words)
+    _add_big_counts(ctx, allbig, splitters, words, rank)
     ctx.finish()
-    del rbuf               # the runs were copied into the library's arena
+    del rk, rc             # the runs were copied into the library's arena
     return windows, words, splitters
 
 
@@ -368,13 +457,13 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
 
 
 def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True, splitters="sampled",
-                      emission="distributed"):
+                      emission="distributed", exchange="counted"):
     """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
     local count -> exchange -> merge own range -> all-gather M -> emit.  emission = "distributed": every
     rank emits its span, rank 0 the index (emit_distributed); "root": the ranges are gathered on rank 0,
     which builds every file (the first form of this path, kept for comparison).
     Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>, ranges, first)."""
-    windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters)
+    windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters, exchange)
     m_range = ctx.counts.distinct
     ms, M, first = gather_counts(m_range, device, group)
     out = {"windows": windows, "M": M, "m_range": m_range, "ranges": ms, "first": first}
@@ -402,7 +491,7 @@ def assemble_files(per_rank_files):
     return out
 
 
-def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_on_root=True):
+def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_on_root=True, exchange="counted"):
     """BASELINE config C5 across ranks: every input (bases_ptr, nbytes) is this rank's share of the
     reads of one k-mer set.  The sets are counted and range-partitioned one after the other with
     the same splitters (those sampled from the first set), so the set operation needs no further
@@ -416,7 +505,7 @@ def set_algebra_distributed(ctx, inputs, key_bits, op, device, group=None, emit_
     ranges, sizes, words = [], [], 1
     splitters = "sampled"
     for ptr, nbytes in inputs:
-        _, words, splitters = count_range(ctx, ptr, nbytes, key_bits, device, group, splitters)
+        _, words, splitters = count_range(ctx, ptr, nbytes, key_bits, device, group, splitters, exchange)
         keys, _ = result_views(ctx, words, device)
         ranges.append(keys.clone())          # the context is reused for the next set
         sizes.append(gather_counts(ranges[-1].shape[0], device, group)[1])

@@ -46,7 +46,8 @@ def _worker(rank, world, port, cases, q):
             with gg.Context(k, gg.MODE_GRAPH if graph else gg.MODE_KMER_SET, device=0, hbm_budget=768 << 20) as ctx:
                 if kind in ("kmer", "graph"):
                     buf = torch.frombuffer(bytearray(case["shards"][rank]), dtype=torch.uint8).to(dev)
-                    r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), key_bits, dev, splitters=case.get("splitters", "sampled"))
+                    r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), key_bits, dev, splitters=case.get("splitters", "sampled"),
+                                             exchange=case.get("exchange", "counted"))
                     assert sum(r["ranges"]) == r["M"]
                     if case.get("balanced"):
                         # sampled splitters: no range far from M / world, whatever the key distribution
@@ -56,7 +57,8 @@ def _worker(rank, world, port, cases, q):
                     assert int(windows.item()) == case["windows"], (name, int(windows.item()), case["windows"])
                 else:
                     bufs = [torch.frombuffer(bytearray(s[rank]), dtype=torch.uint8).to(dev) for s in case["sets"]]
-                    r = gd.set_algebra_distributed(ctx, [(b.data_ptr(), b.numel()) for b in bufs], key_bits, kind, dev)
+                    r = gd.set_algebra_distributed(ctx, [(b.data_ptr(), b.numel()) for b in bufs], key_bits, kind, dev,
+                                                   exchange=case.get("exchange", "counted"))
                     assert r["sizes"] == case["sizes"], (name, r["sizes"], case["sizes"])
                 # every rank holds its span of the object: the test plays the per-rank writers
                 mine = ctx.files()
@@ -123,6 +125,10 @@ def _build_cases(oracle, world):
     exp = _suffix_map(exp, "ob")
     cases.append({"kind": "kmer", "k": 21, "name": "kmer k=21 skewed", "shards": _split_reads(skew, world), "expect": exp,
                   "windows": nwin, "M": struct.unpack("<8Q", exp[".kmers.header"])[7], "balanced": True})
+    # the exchange BEFORE counting (super-k-mer records routed by minimizer): one-word keys take it, the two-word
+    # cases fall back to the exchange of counted runs by themselves
+    for c in list(cases):
+        cases.append(dict(c, name=c["name"] + ", records", exchange="records"))
     return cases
 
 
@@ -155,4 +161,6 @@ def test_set_algebra_with_two_ranks(oracle):
             exp = _suffix_map(exp, "out")
             cases.append({"kind": op, "k": k, "name": "%s %s k=%d" % (op, sel, k), "sets": [shards[j] for j in sel],
                           "sizes": [sizes[j] for j in sel], "expect": exp, "M": struct.unpack("<QQQ", exp[".header"])[2]})
+            if k == 25:
+                cases.append(dict(cases[-1], name=cases[-1]["name"] + ", records", exchange="records"))
     _run(world, cases)
