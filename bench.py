@@ -358,7 +358,8 @@ def main():
     # (received runs, this rank's range, the gathered set on rank 0: ~21 GB at 8 ranks)
     budget = int(free_b * 0.94)
     if use_dist:
-        budget = min(budget, free_b - (32 << 30))
+        # (the record exchange holds this rank's records twice for a moment: as routed and as received, ~1.6 bytes per input byte each)
+        budget = min(budget, free_b - max(32 << 30, int(3.6 * nbytes) if args.exchange == "records" else 0))
     if sharing > 1:          # ranks that share a GPU split it (their mem_get_info calls race with each other's allocations)
         budget = int(total_b * 0.8) // sharing - nbytes
     if args.hbm_budget_gb > 0:

@@ -142,6 +142,33 @@ def _exchange_device(device, group=None):
     return torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+# RCCL 2.26 (ROCm 7.0, measured on MI355X with one rank sending to itself): an all-to-all segment above 1 GiB arrives
+# with its second half missing -- no error.  Every all-to-all below therefore moves at most _A2A_CHUNK bytes per
+# (source, destination) pair and round; all ranks derive the number of rounds from sizes they all know.
+_A2A_CHUNK = 512 << 20
+
+
+def all_to_all_views(outs, ins, max_bytes, group=None):
+    """all-to-all(v) over 1-D tensors: ins[p] goes to rank p, outs[p] comes from rank p (views of larger buffers are
+    fine: nothing is packed).  max_bytes = the largest segment between ANY pair of ranks (the same value on every rank).
+    RCCL: list form, in rounds of at most _A2A_CHUNK bytes per segment.  gloo (CPU tensors): one all_to_all_single of
+    the concatenation (ProcessGroupGloo has no list form)."""
+    if dist.get_backend(group) != "nccl":
+        send = torch.cat([t.reshape(-1) for t in ins]) if len(ins) > 1 else ins[0].reshape(-1).contiguous()
+        recv = torch.empty(sum(int(t.numel()) for t in outs), dtype=send.dtype)
+        dist.all_to_all_single(recv, send, [int(t.numel()) for t in outs], [int(t.numel()) for t in ins], group=group)
+        at = 0
+        for t in outs:
+            n = int(t.numel())
+            t.reshape(-1).copy_(recv[at:at + n])
+            at += n
+        return
+    step = _A2A_CHUNK // ins[0].element_size()
+    rounds = max(1, -(-int(max_bytes) // _A2A_CHUNK))
+    for r in range(rounds):
+        dist.all_to_all([t[r * step:(r + 1) * step] for t in outs], [t[r * step:(r + 1) * step] for t in ins], group=group)
+
+
 def exchange_runs(keys, counts, splitters, group=None):
     """all-to-all(v): range p of (keys, counts) goes to rank p.  Returns (recv_keys, recv_counts, recv_sizes) -- the
     concatenation of one sorted run per source rank, and the run lengths.  The keys are sorted, so every range is a
@@ -157,10 +184,19 @@ def exchange_runs(keys, counts, splitters, group=None):
     matrix = rows.cpu().tolist()
     recv = [int(matrix[q][rank]) for q in range(world)]
     total = sum(recv)
+    words = 1 if keys.dim() == 1 else 2
     rk = torch.empty((total,) + tuple(keys.shape[1:]), dtype=torch.int64, device=keys.device)
     rc = torch.empty(total, dtype=torch.int32, device=keys.device)
-    dist.all_to_all_single(rk, keys, recv, send, group=group)          # splits along dim 0: whole keys
-    dist.all_to_all_single(rc, counts, recv, send, group=group)
+    largest = max(max(row) for row in matrix)
+
+    def cut(t, sizes, per):          # 1-D views of the slices of t (per elements per item) that go to / come from each rank
+        flat, out, at = t.reshape(-1), [], 0
+        for n in sizes:
+            out.append(flat[at * per:(at + n) * per])
+            at += n
+        return out
+    all_to_all_views(cut(rk, recv, words), cut(keys, send, words), largest * 8 * words, group)
+    all_to_all_views(cut(rc, recv, 1), cut(counts, send, 1), largest * 4, group)
     return rk, rc, recv
 
 
@@ -187,8 +223,16 @@ def gather_ranges_to_root(keys, counts, ms, group=None):
     recv = ms if rank == 0 else [0] * world
     rk = torch.empty((sum(recv),) + tuple(keys.shape[1:]), dtype=keys.dtype, device=xdev)
     rc = torch.empty(sum(recv), dtype=counts.dtype, device=xdev)
-    dist.all_to_all_single(rk, keys, recv, send, group=group)        # splits along dim 0: whole keys
-    dist.all_to_all_single(rc, counts, recv, send, group=group)
+    words = 1 if keys.dim() == 1 else 2
+
+    def cut(t, sizes, per):
+        flat, out, at = t.reshape(-1), [], 0
+        for n in sizes:
+            out.append(flat[at * per:(at + n) * per])
+            at += n
+        return out
+    all_to_all_views(cut(rk, recv, words), cut(keys, send, words), max(ms) * 8 * words, group)
+    all_to_all_views(cut(rc, recv, 1), cut(counts, send, 1), max(ms) * 4, group)
     return rk, rc
 
 
@@ -246,7 +290,7 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None):
     rank = dist.get_rank(group)
     dev = torch.device(device)
     probe = int(os.environ.get("GOSS_DIST_ROUTE_PARTS", "0"))
-    if world == 1 and probe > 1:
+    if world == 1 and probe >= 1:
         # one rank's load of a `probe`-rank build, measured on one GPU (tools/scale_probe.sh): the records are cut as
         # they would be for that many destinations and the rank takes all its own parts -- the number of windows one
         # rank of the real build receives from everybody
@@ -284,20 +328,20 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None):
     recv_windows = sum(int(matrix[q][world + rank]) for q in range(world))
     total = sum(recv)
     parts = [sbuf[first[p] * RB:(first[p] + recs[p]) * RB] for p in range(world)]
+    largest = max(max(row[:world]) for row in matrix) * RB
     if xdev.type == "cuda":
         rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev)
-        outs, at = [], 0
-        for n in recv:
-            outs.append(rbuf[at * RB:(at + n) * RB])
-            at += n
-        dist.all_to_all(outs, parts, group=group)          # views of both buffers: nothing is packed or copied
-        _sync(dev)
     else:
-        send = torch.cat([p.cpu() for p in parts]) if total or sum(recs) else torch.empty(0, dtype=torch.uint8)
-        rhost = torch.empty(total * RB, dtype=torch.uint8)
-        dist.all_to_all_single(rhost, send, [n * RB for n in recv], [n * RB for n in recs], group=group)
-        rbuf = rhost.to(dev)
-        _sync(dev)
+        parts = [p.cpu() for p in parts]
+        rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8)
+    outs, at = [], 0
+    for n in recv:
+        outs.append(rbuf[at * RB:(at + n) * RB])
+        at += n
+    all_to_all_views(outs, parts, largest, group)          # views of both buffers: nothing is packed or copied on the GPU
+    if xdev.type != "cuda":
+        rbuf = rbuf.to(dev)
+    _sync(dev)
     del sbuf, parts
     if total:
         ctx.push_records(rbuf.data_ptr(), total, recv_windows)
@@ -434,13 +478,20 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
     recv = [int(r[0]) for r in metas] if rank == 0 else [0] * world
     send = [size] + [0] * (world - 1)
     allhigh = torch.empty(max(1, sum(recv)), dtype=torch.uint8, device=xdev)
-    dist.all_to_all_single(allhigh[:sum(recv)], mine, recv, send, group=group)
+
+    def cut(t, sizes):
+        out, at = [], 0
+        for n in sizes:
+            out.append(t[at:at + n])
+            at += n
+        return out
+    all_to_all_views(cut(allhigh, recv), cut(mine, send), max(int(r[0]) for r in metas), group)
     # the small records: padded to the longest, gathered through the same kind of collective
     rec = torch.frombuffer(bytearray(small + hist), dtype=torch.uint8).to(xdev) if small or hist else torch.empty(0, dtype=torch.uint8, device=xdev)
     recv2 = [int(r[1] + r[2]) for r in metas] if rank == 0 else [0] * world
     send2 = [int(rec.numel())] + [0] * (world - 1)
     allrec = torch.empty(max(1, sum(recv2)), dtype=torch.uint8, device=xdev)
-    dist.all_to_all_single(allrec[:sum(recv2)], rec, recv2, send2, group=group)
+    all_to_all_views(cut(allrec, recv2), cut(rec, send2), max(int(r[1] + r[2]) for r in metas), group)
     _sync(device)
     if rank == 0:
         big, hst = b"", b""

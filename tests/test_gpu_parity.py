@@ -372,6 +372,45 @@ def test_distributed_path_world1(oracle, nccl_world1, k, graph):
         assert got[name] == exp[name], name
 
 
+@pytest.mark.parametrize("k,graph", [(25, False), (27, True)])
+def test_record_exchange_world1(oracle, nccl_world1, k, graph):
+    """The exchange before counting (super-k-mer records routed by minimizer, all-to-all over RCCL, count of what was
+    received) with a single rank: exactly the single-GPU files."""
+    import torch
+    from gossamer_amd import dist as gd
+    reads = g.synth_reads_host(20000, 150, 100000, seed=9)
+    exp, nwin = (oracle.build_graph if graph else oracle.build_kmer_set)([(oracle.LINE, "reads", reads)], k, out="ob")
+    exp = _suffix_map(exp, "ob")
+    buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
+    with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
+        r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), exchange="records")
+        got = gd.assemble_files([ctx.files()])
+    assert r["windows"] == nwin
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
+def test_all_to_all_segments_above_one_gib(nccl_world1):
+    """RCCL 2.26 drops the second half of an all-to-all segment above 1 GiB without an error (found on this box: one rank
+    sending to itself).  gossamer_amd.dist moves every segment in rounds of 512 MiB: 1.5 GiB must arrive whole."""
+    import torch
+    from gossamer_amd import dist as gd
+    n = 3 << 29
+    src = torch.randint(0, 251, (n,), dtype=torch.uint8, device="cuda")
+    big = torch.empty(n + 4096, dtype=torch.uint8, device="cuda")
+    big[100:100 + n] = src
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    gd.all_to_all_views([out], [big[100:100 + n]], n)
+    torch.cuda.synchronize()
+    assert torch.equal(out, src)
+    # int64 views (keys) of the same size
+    out64 = torch.zeros(n // 8, dtype=torch.int64, device="cuda")
+    gd.all_to_all_views([out64], [src.view(torch.int64)], n)
+    torch.cuda.synchronize()
+    assert torch.equal(out64, src.view(torch.int64))
+
+
 @pytest.mark.parametrize("k", [25, 45])
 def test_distributed_set_algebra_world1(oracle, nccl_world1, k):
     """BASELINE config C5 through the multi-GPU code path with one rank: two (three) k-mer sets

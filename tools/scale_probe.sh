@@ -1,14 +1,16 @@
 #!/bin/bash
-# One rank's share of the N-GPU bench (C3 share: 125 M reads per GPU, genome N x 125 Mbp) run on ONE GPU
-# through the multi-GPU code path (exchange with itself): what a rank's step costs as N grows.
-# Usage (GPU box): tools/scale_probe.sh [out-dir]
+# One rank's share of the N-GPU bench (C3 share: 125 M reads per GPU) run on ONE GPU through the multi-GPU code
+# path (the exchange is with itself): what a rank's step costs as N grows.
+#   counted: the rank counts its reads of a genome of N x 125 Mbp (its local distinct set grows with N), then
+#            exchanges and merges the pairs;
+#   records: the rank routes its reads as for N destinations and counts all its own parts -- the windows a rank
+#            of the real build receives (its share of the key space: 125 M distinct keys whatever N is).
+# Usage (GPU box): tools/scale_probe.sh [out-dir] ["1 2 4 8"]
 out=${1:-gpurun_out/scale}
+ns=${2:-"1 2 4 8"}
 mkdir -p "$out"
-for n in 1 2 4 8; do
-  python bench.py --force-dist --reads 125000000 --genome $((125000000 * n)) --steps 2 --warmup 1 \
-      --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/n$n.json" 2> "$out/n$n.err"
-  echo "N=$n rc=$?"
-  python - "$out/n$n.json" <<'PY'
+show() {
+  python - "$1" <<'PY'
 import json, sys
 try:
     r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -16,4 +18,12 @@ try:
 except Exception as e:
     print("  no line:", e)
 PY
+}
+for n in $ns; do
+  python bench.py --force-dist --exchange counted --reads 125000000 --genome $((125000000 * n)) --steps 2 --warmup 1 \
+      --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/counted_n$n.json" 2> "$out/counted_n$n.err"
+  echo "counted N=$n rc=$?"; show "$out/counted_n$n.json"
+  python bench.py --force-dist --exchange records --route-parts $n --reads 125000000 --genome 125000000 --steps 2 --warmup 1 \
+      --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/records_n$n.json" 2> "$out/records_n$n.err"
+  echo "records N=$n rc=$?"; show "$out/records_n$n.json"
 done
