@@ -576,8 +576,8 @@ void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     }
 #undef GOSS_LAUNCH_E1
 }
-// window slots of a record: the keys a thread of the fused extraction takes (16, or 8 windows of two keys each)
-inline uint32_t rec_slots(const goss_gpu_ctx* c) { return c->mode == GOSS_MODE_GRAPH ? 8u : 16u; }
+// window slots of a record (the most windows one holds): a string of n records counts as 16 n window starts
+inline uint32_t rec_slots(const goss_gpu_ctx*) { return 16u; }
 
 // records -> keys with the plain kernel: all records (slice_groups = 0) or slices of them (the fused path's sample)
 void launch_extract_records(goss_gpu_ctx* c, const SkRec* recs, uint64_t nrecs, Key1* out, uint64_t ngroups, uint64_t slice_groups,
@@ -1359,7 +1359,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     do {                                                                                                              \
         if (c->rec_mode)                                                                                              \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true>), dim3(grid), dim3(kTB), 0, c->stream, \
-                               d_bases, 0u, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+                               d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
         else                                                                                                          \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD>), dim3(grid), dim3(kTB), 0, c->stream, \
                                aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
@@ -3339,11 +3339,11 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
         HIP_TRY(hipMemcpyAsync(dcap, part_cap, nparts * 8, hipMemcpyHostToDevice, c->stream));
         const uint64_t nstarts = nbytes - c->len + 1;
         const uint64_t ntiles = (nstarts + kTB * 16 - 1) / (kTB * 16);
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 6);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 4);
         const uintptr_t addr = (uintptr_t)d_bases;
         const uint32_t mis = (uint32_t)(addr & 15u);
         const uint8_t* aligned = (const uint8_t*)(addr - mis);
-        const uint32_t maxwin = rec_slots(c);
+        const uint32_t maxwin = 16;          // (the counting side takes records of any length in both modes)
         {
             PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
 #define GOSS_LAUNCH_ROUTE(W)                                                                                                \

@@ -631,9 +631,11 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
 // skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
 // The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
-// REC: the input is not bases but super-k-mer records (kernels_route.hpp: 12 bytes = up to 16 windows and their
-// bases, 8 windows in graph mode): thread t of a tile takes record tile * 256 + t, whose windows stand where a
-// thread's window registers stand after phase A; nstarts = records * P, bases_aligned = the records.
+// REC: the input is not bases but super-k-mer records (kernels_route.hpp: 12 bytes = 1..16 windows and their bases);
+// bases_aligned = the records, navail = their number.  A workgroup walks its own contiguous share of the records: per
+// tile it stages up to 512 of them in LDS, takes as many whole records as hold at most T windows (prefix sums of
+// their window counts), and thread t extracts windows 16 t .. 16 t + 15 of the tile's window sequence -- wherever the
+// record boundaries fall -- so every key register holds a valid window whatever the records' lengths are.
 template <int MODE, int NH, bool ODD, bool REC = false>
 __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
@@ -725,47 +727,80 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
     constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..3 also vector NV0 + tid
     static_assert(NVEC == NV0 + 4 && NV0 <= kTB, "one vector per thread and four more");
     uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
-    // REC: one record per thread and tile (three words; nrec = records in all)
+    // REC: this workgroup's records [rc_next, rc_end), two per thread and tile staged (three words each)
     const uint32_t* recw = reinterpret_cast<const uint32_t*>(bases_aligned);
-    const uint64_t nrec = nstarts / P;
-    uint32_t r0 = 0, r1 = 0, r2 = 0, rn = 0;                 // this tile's record and its number of windows (0: none)
-    auto fetch_rec = [&](uint64_t st, uint32_t& a, uint32_t& b, uint32_t& cc, uint32_t& nw) {
-        const uint64_t ri = st * (uint64_t)kTB + tid;
-        a = b = cc = nw = 0;
-        if (ri < nrec) { a = recw[3 * ri]; b = recw[3 * ri + 1]; cc = recw[3 * ri + 2]; nw = (cc >> 28) + 1; }
+    const uint64_t nrec = navail;                            // (REC: the number of records travels in `navail`)
+    uint64_t rc_next = 0, rc_end = 0;
+    uint32_t ra0 = 0, ra1 = 0, ra2 = 0, rb0 = 0, rb1 = 0, rb2 = 0, rna = 0, rnb = 0;      // the records the thread stages next
+    uint32_t* rbuf = pk;                                     // [512][3] record words, then [513] prefix sums: phase A's share of `sorted`
+    uint32_t* rpre = pk + 512 * 3;
+    uint32_t* rmark = rpre + 520;                            // [256] the record that holds thread g's first window; [256] = records that fit
+    auto fetch_recs = [&](uint64_t base) {
+        const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
+        ra0 = ra1 = ra2 = rb0 = rb1 = rb2 = rna = rnb = 0;
+        if (ia < rc_end) { ra0 = recw[3 * ia]; ra1 = recw[3 * ia + 1]; ra2 = recw[3 * ia + 2]; rna = (ra2 >> 28) + 1; }
+        if (ib < rc_end) { rb0 = recw[3 * ib]; rb1 = recw[3 * ib + 1]; rb2 = recw[3 * ib + 2]; rnb = (rb2 >> 28) + 1; }
     };
-    if (blockIdx.x < nsuper)
+    if constexpr (REC)
     {
-        if constexpr (REC) fetch_rec(blockIdx.x, r0, r1, r2, rn);
-        else
-        {
-            uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
-            const uint64_t tb = (uint64_t)blockIdx.x * T;
-            if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
-            if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
-            encode(q0, c0, b0);
-            if (tid < 4) encode(q1, c1, b1);
-        }
+        const uint64_t per = ((nrec + gridDim.x - 1) / gridDim.x + 1) & ~1ULL;
+        rc_next = (uint64_t)blockIdx.x * per;
+        rc_end = rc_next + per < nrec ? rc_next + per : nrec;
+        if (rc_next < rc_end) fetch_recs(rc_next);
+    }
+    else if (blockIdx.x < nsuper)
+    {
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        const uint64_t tb = (uint64_t)blockIdx.x * T;
+        if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
+        if (tid < 4) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
+        encode(q0, c0, b0);
+        if (tid < 4) encode(q1, c1, b1);
     }
 
-    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    for (uint64_t st = blockIdx.x;; st += gridDim.x)
     {
+        if constexpr (REC) { if (rc_next >= rc_end) break; }
+        else { if (st >= nsuper) break; }
         const uint64_t tile_base = st * (uint64_t)T;
 
         // ---- phase A: this tile's codes from registers to LDS, the next tile's bytes on their way ----
-        if constexpr (!REC)
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        bool more;
+        uint32_t wt = 0;                          // (REC) windows of this tile
+        if constexpr (REC)
+        {
+            // the staged records and the running sum of their windows; R = the records that fit the tile
+            rbuf[6 * tid] = ra0; rbuf[6 * tid + 1] = ra1; rbuf[6 * tid + 2] = ra2;
+            rbuf[6 * tid + 3] = rb0; rbuf[6 * tid + 4] = rb1; rbuf[6 * tid + 5] = rb2;
+            if (tid == 0) rmark[kTB] = 512;                       // (records that fit: all, unless a thread finds the one that does not)
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<uint32_t>(rna + rnb, sh_scan, &tot);
+            const uint32_t ea = ex + rna, eb = ea + rnb;          // ends of the thread's two records in the window sequence
+            rpre[2 * tid] = ex; rpre[2 * tid + 1] = ea;
+            if (tid == kTB - 1) rpre[512] = tot;
+            // the first record that does not fit ends the tile (records beyond the share's end hold no window and fit)
+            if (ex <= (uint32_t)T && eb > (uint32_t)T) rmark[kTB] = 2 * tid + (ea <= (uint32_t)T ? 1u : 0u);
+            // thread g starts at window P g: a record of at most 16 windows holds at most one such window and tells g
+            {
+                const uint32_t ga = (ex + P - 1) / P, gb = (ea + P - 1) / P;
+                if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = 2 * tid;
+                if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = 2 * tid + 1;
+            }
+            __syncthreads();
+            const uint32_t nfit = rmark[kTB];
+            wt = rpre[nfit];
+            rc_next += nfit;
+            more = rc_next < rc_end;
+            if (more) fetch_recs(rc_next);
+        }
+        else
         {
             if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
             if (tid < 4) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
-        }
-        __syncthreads();
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
-        const bool more = st + gridDim.x < nsuper;
-        const uint32_t cr0 = r0, cr1 = r1, cr2 = r2, crn = rn;          // (REC) this tile's record; the next one on its way
-        if (more)
-        {
-            if constexpr (REC) fetch_rec(st + gridDim.x, r0, r1, r2, rn);
-            else
+            __syncthreads();
+            more = st + gridDim.x < nsuper;
+            if (more)
             {
                 const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
                 if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
@@ -782,13 +817,23 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
         uint32_t vm;
         {
             uint32_t m;
-            uint64_t blo, bhi;
+            uint64_t blo = 0, bhi = 0;
+            [[maybe_unused]] uint32_t r_at = 0, r_off = 0, r_nw = 0;          // (REC) record, window inside it, its windows
+            auto load_rec = [&]() {
+                blo = (uint64_t)rbuf[3 * r_at] | ((uint64_t)rbuf[3 * r_at + 1] << 32);
+                const uint32_t w2 = rbuf[3 * r_at + 2];
+                bhi = w2 & 0x0FFFFFFFu;
+                r_nw = (w2 >> 28) + 1;
+            };
             if constexpr (REC)
             {
-                // the record's windows 0 .. nw-1 are valid, its bases stand as a thread's do (base j at bits 2j)
-                m = crn >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << crn) - 1u);
-                blo = (uint64_t)cr0 | ((uint64_t)cr1 << 32);
-                bhi = cr2 & 0x0FFFFFFFu;
+                // windows P tid .. P tid + P - 1 of the tile's sequence, starting in record rmark[tid]
+                const uint32_t j0 = tid * P;
+                const uint32_t left = wt > j0 ? wt - j0 : 0;
+                m = left >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << left) - 1u);
+                r_at = left ? rmark[tid] : 0u;                     // (marked by the record itself in phase A)
+                r_off = j0 - rpre[r_at];
+                load_rec();
             }
             else
             {
@@ -831,7 +876,21 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
 #pragma unroll
             for (int i = 0; i < P; ++i)
             {
-                if (i)
+                if constexpr (REC)
+                {
+                    // window r_off of record r_at, cut out of the record's bases; then on to the next window, which
+                    // may be the first of the next record
+                    const uint32_t s2 = 2 * r_off;
+                    const uint64_t x = (s2 ? ((blo >> s2) | (bhi << (64 - s2))) : blo) & kmask;
+                    f = rev64(x) >> (64 - bits);
+                    r = (~x) & kmask;
+                    if (i + 1 < P)
+                    {
+                        ++r_off;
+                        if (r_off >= r_nw && r_at < 511) { ++r_at; r_off = 0; load_rec(); }
+                    }
+                }
+                else if (i)
                 {
                     const uint32_t pos = 2 * (i + len - 1);
                     const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;

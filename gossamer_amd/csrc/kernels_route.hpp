@@ -16,8 +16,7 @@
 //
 // Record (SkRec, 12 bytes): bits 0..91 = the run's (nwin + len - 1 <= 46) bases as 2-bit codes, base j of the
 // run at bits [2j, 2j + 2) (the bit order of the extraction kernels' window registers); bits 92..95 = nwin - 1.
-// A record never spans a non-base, a read boundary, or the 16 windows a routing thread owns; in graph mode
-// (two keys per window) records hold at most 8 windows, the keys a counting thread takes.
+// A record never spans a non-base, a read boundary, or the 16 windows a routing thread owns.
 // Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp.
 #pragma once
 
@@ -56,7 +55,7 @@ __device__ __forceinline__ uint32_t route_mix(uint32_t x)
 // out + part_first[p] = first record slot of part p, part_cap[p] its capacity.  Tile = 4096 window starts,
 // 16 per thread; phase A (bytes -> 2-bit codes + non-base flags in LDS) is the extraction kernels'.
 template <int W>
-__global__ __launch_bounds__(kTB, 2) void route_records_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+__global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                uint64_t nstarts, uint64_t navail, uint32_t len, uint32_t maxwin,
                                                                uint32_t nparts, SkRec* __restrict__ out,
                                                                const unsigned long long* __restrict__ part_first,

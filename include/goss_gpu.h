@@ -432,7 +432,7 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  *
  * goss_gpu_route_records_device cuts the windows of a base string (as goss_gpu_push_bases_device takes it) into
  * SUPER-K-MER RECORDS and appends each to one of nparts buffers: a record is a run of up to 16 consecutive windows
- * (8 in graph mode) that have the same destination, with the run's bases stored once -- 12 bytes (GOSS_RECORD_BYTES)
+ * that have the same destination, with the run's bases stored once -- 12 bytes (GOSS_RECORD_BYTES)
  * instead of 8 bytes per window.  The destination of a window is a hash of its MINIMIZER (the smallest canonical
  * m-mer inside it, m = 7..15 depending on the window length), scaled to [0, nparts): a window and its reverse
  * complement have the same minimizer, so every occurrence of a k-mer -- and of a graph edge and its reverse
