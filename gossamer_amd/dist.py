@@ -148,11 +148,12 @@ def _exchange_device(device, group=None):
 _A2A_CHUNK = 512 << 20
 
 
-def all_to_all_views(outs, ins, max_bytes, group=None):
+def all_to_all_views(outs, ins, max_bytes, group=None, async_op=False):
     """all-to-all(v) over 1-D tensors: ins[p] goes to rank p, outs[p] comes from rank p (views of larger buffers are
     fine: nothing is packed).  max_bytes = the largest segment between ANY pair of ranks (the same value on every rank).
     RCCL: list form, in rounds of at most _A2A_CHUNK bytes per segment.  gloo (CPU tensors): one all_to_all_single of
-    the concatenation (ProcessGroupGloo has no list form)."""
+    the concatenation (ProcessGroupGloo has no list form).  async_op (RCCL): returns the rounds' work handles at once
+    -- the collective runs on RCCL's stream while the caller goes on; wait for every handle before touching `outs`."""
     if dist.get_backend(group) != "nccl":
         send = torch.cat([t.reshape(-1) for t in ins]) if len(ins) > 1 else ins[0].reshape(-1).contiguous()
         recv = torch.empty(sum(int(t.numel()) for t in outs), dtype=send.dtype)
@@ -162,11 +163,16 @@ def all_to_all_views(outs, ins, max_bytes, group=None):
             n = int(t.numel())
             t.reshape(-1).copy_(recv[at:at + n])
             at += n
-        return
+        return []
     step = _A2A_CHUNK // ins[0].element_size()
     rounds = max(1, -(-int(max_bytes) // _A2A_CHUNK))
+    works = []
     for r in range(rounds):
-        dist.all_to_all([t[r * step:(r + 1) * step] for t in outs], [t[r * step:(r + 1) * step] for t in ins], group=group)
+        w = dist.all_to_all([t[r * step:(r + 1) * step] for t in outs], [t[r * step:(r + 1) * step] for t in ins], group=group,
+                            async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
 
 
 def exchange_runs(keys, counts, splitters, group=None):
@@ -280,10 +286,12 @@ def _push_received(ctx, rk, rc, recv, words):
 _ROUTE_SIZES = {}          # (bases_ptr, nbytes, parts) -> records per part of the last routing of that input (the probe below)
 
 
-def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None):
+def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, pieces=0):
     """The exchange before counting: this rank's reads -> super-k-mer records routed by minimizer into one buffer
-    per rank (goss_gpu_route_records_device) -> ONE all-to-all(v) of record bytes -> the records this rank received
-    are counted (goss_gpu_push_records_device; not yet finished).  Returns the windows of this rank's own reads."""
+    per rank (goss_gpu_route_records_device) -> all-to-all(v) of record bytes -> the records this rank received are
+    counted (goss_gpu_push_records_device; not yet finished).  `pieces` (0 = by size): the reads go through these
+    steps in that many pieces, the all-to-all of one overlapping the routing of the next and the counting of the one
+    before.  Returns the windows of this rank's own reads."""
     import os
     from .binding import RECORD_BYTES as RB
     world = dist.get_world_size(group)
@@ -305,49 +313,81 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None):
         _ROUTE_SIZES[(bases_ptr, nbytes, probe)] = recs
         ctx.push_records(sbuf.data_ptr(), sum(recs), sum(wins))
         return sum(wins)
-    # room per part: ~6 windows per record at 8 parts (fewer parts cut less often), a third of slack; a part that
-    # needs more is reported by the library and the routing is redone with exact sizes
-    guess = nbytes // 5 // world + nbytes // 15 // world + 4096
-    caps = [guess] * world
-    for attempt in range(2):
-        first = [sum(caps[:p]) for p in range(world)]
-        sbuf = torch.empty(max(1, sum(caps)) * RB, dtype=torch.uint8, device=dev)
-        recs, wins, ok = ctx.route_records(bases_ptr, nbytes, world, sbuf.data_ptr(), first, caps)
-        if ok:
-            break
-        del sbuf
-        caps = [n + 1 for n in recs]
-    else:
-        raise RuntimeError("routing did not fit the sizes it asked for")
+    # The reads are cut into pieces (window starts [s_i, s_i+1): piece i = bytes [s_i, s_i+1 + len - 1), so no window is
+    # lost or taken twice) and the pieces go through route -> all-to-all -> count as a pipeline: while the records of
+    # piece i travel (RCCL's stream), piece i + 1 is routed and piece i - 1 counted (the library's stream).
+    klen = ctx.k + (1 if ctx.mode == MODE_GRAPH else 0)
+    nstarts = nbytes - klen + 1 if nbytes >= klen else 0
+    if pieces <= 0:
+        pieces = max(1, min(8, nstarts // (2 << 30)))          # ~2 G window starts each: ~4 GB of records per piece
+    pieces = max(1, min(pieces, max(1, nstarts // 65536)))
     xdev = _exchange_device(dev, group)
-    mine = torch.tensor(recs + wins, dtype=torch.int64, device=xdev)
-    rows = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(rows, mine, group=group)
-    matrix = torch.stack(rows).cpu().tolist()
-    recv = [int(matrix[q][rank]) for q in range(world)]
-    recv_windows = sum(int(matrix[q][world + rank]) for q in range(world))
-    total = sum(recv)
-    parts = [sbuf[first[p] * RB:(first[p] + recs[p]) * RB] for p in range(world)]
-    largest = max(max(row[:world]) for row in matrix) * RB
-    if xdev.type == "cuda":
-        rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev)
-    else:
-        parts = [p.cpu() for p in parts]
-        rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8)
-    outs, at = [], 0
-    for n in recv:
-        outs.append(rbuf[at * RB:(at + n) * RB])
-        at += n
-    all_to_all_views(outs, parts, largest, group)          # views of both buffers: nothing is packed or copied on the GPU
-    if xdev.type != "cuda":
-        rbuf = rbuf.to(dev)
-    _sync(dev)
-    del sbuf, parts
-    if total:
-        ctx.push_records(rbuf.data_ptr(), total, recv_windows)
-    del rbuf               # (the push has consumed the records)
-    return sum(wins)
+    on_gpu = xdev.type == "cuda"
+    if world > 1:          # every piece is a collective: all ranks take the same number (a short share has empty ones)
+        agreed = torch.tensor([pieces], dtype=torch.int64, device=xdev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
+        pieces = int(agreed.item())
+    cuts = [nstarts * i // pieces for i in range(pieces + 1)]
+    own_windows = 0
+    inflight = None          # (works, rbuf, total records, windows, buffers kept alive)
 
+    def land(job):
+        works, rbuf, total, nwin, keep = job
+        for w in works:
+            w.wait()
+        if not on_gpu:
+            rbuf = rbuf.to(dev)
+        _sync(dev)
+        del keep
+        if total:
+            ctx.push_records(rbuf.data_ptr(), total, nwin)
+
+    for i in range(pieces):
+        ptr = bases_ptr + cuts[i]
+        n = nbytes - cuts[i] if i == pieces - 1 else min(cuts[i + 1] - cuts[i] + klen - 1, nbytes - cuts[i])
+        # room per part: ~6 windows per record at 8 parts (fewer parts cut less often), a third of slack; a part that
+        # needs more is reported by the library and the routing is redone with exact sizes
+        guess = n // 5 // world + n // 15 // world + 4096
+        caps = [guess] * world
+        for attempt in range(2):
+            first = [sum(caps[:p]) for p in range(world)]
+            sbuf = torch.empty(max(1, sum(caps)) * RB, dtype=torch.uint8, device=dev)
+            recs, wins, ok = ctx.route_records(ptr, n, world, sbuf.data_ptr(), first, caps)
+            if ok:
+                break
+            del sbuf
+            caps = [x + 1 for x in recs]
+        else:
+            raise RuntimeError("routing did not fit the sizes it asked for")
+        own_windows += sum(wins)
+        mine = torch.tensor(recs + wins, dtype=torch.int64, device=xdev)
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine, group=group)
+        matrix = torch.stack(rows).cpu().tolist()
+        recv = [int(matrix[q][rank]) for q in range(world)]
+        recv_windows = sum(int(matrix[q][world + rank]) for q in range(world))
+        total = sum(recv)
+        parts = [sbuf[first[p] * RB:(first[p] + recs[p]) * RB] for p in range(world)]
+        largest = max(max(row[:world]) for row in matrix) * RB
+        if on_gpu:
+            rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev)
+        else:
+            parts = [p.cpu() for p in parts]
+            rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8)
+        outs, at = [], 0
+        for m in recv:
+            outs.append(rbuf[at * RB:(at + m) * RB])
+            at += m
+        # (views of both buffers: nothing is packed or copied on the GPU)
+        works = all_to_all_views(outs, parts, largest, group, async_op=on_gpu and pieces > 1)
+        job = (works, rbuf, total, recv_windows, (sbuf, parts, outs))
+        del sbuf, parts, outs, rbuf
+        if inflight is not None:
+            land(inflight)          # the previous piece has arrived meanwhile: count it while this one travels
+        inflight = job
+    if inflight is not None:
+        land(inflight)
+    return own_windows
 
 def result_views(ctx, words, device):
     """zero-copy views of the context's result: valid until its next emit, reset, push or close"""
@@ -395,7 +435,7 @@ def _add_big_counts(ctx, allbig, splitters, words, rank):
             exact -= piece
 
 
-def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled", exchange="counted"):
+def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled", exchange="counted", record_pieces=0):
     """count -> range-partition -> merge of the received runs: this rank's range of the global result stays in the
     Context.  Returns (this rank's windows, key words, the splitters used).
     `exchange`: "counted" (local count of this rank's reads, then the exchange of its distinct pairs) or "records"
@@ -406,7 +446,7 @@ def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters=
     rank = dist.get_rank(group)
     ctx.reset()
     if exchange == "records" and key_bits <= 62:
-        windows = route_and_exchange_records(ctx, bases_ptr, nbytes, device, group)
+        windows = route_and_exchange_records(ctx, bases_ptr, nbytes, device, group, record_pieces)
         c = ctx.finish()
     else:
         ctx.push_device(bases_ptr, nbytes)
@@ -508,13 +548,13 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
 
 
 def count_distributed(ctx, bases_ptr, nbytes, key_bits, device, group=None, emit_on_root=True, splitters="sampled",
-                      emission="distributed", exchange="counted"):
+                      emission="distributed", exchange="counted", record_pieces=0):
     """The whole multi-GPU job on an already created Context (either mode, one- or two-word keys):
     local count -> exchange -> merge own range -> all-gather M -> emit.  emission = "distributed": every
     rank emits its span, rank 0 the index (emit_distributed); "root": the ranges are gathered on rank 0,
     which builds every file (the first form of this path, kept for comparison).
     Returns dict(windows=<this rank's windows>, M=<global distinct>, m_range=<this range>, ranges, first)."""
-    windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters, exchange)
+    windows, words, _ = count_range(ctx, bases_ptr, nbytes, key_bits, device, group, splitters, exchange, record_pieces)
     m_range = ctx.counts.distinct
     ms, M, first = gather_counts(m_range, device, group)
     out = {"windows": windows, "M": M, "m_range": m_range, "ranges": ms, "first": first}

@@ -47,7 +47,7 @@ def _worker(rank, world, port, cases, q):
                 if kind in ("kmer", "graph"):
                     buf = torch.frombuffer(bytearray(case["shards"][rank]), dtype=torch.uint8).to(dev)
                     r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), key_bits, dev, splitters=case.get("splitters", "sampled"),
-                                             exchange=case.get("exchange", "counted"))
+                                             exchange=case.get("exchange", "counted"), record_pieces=case.get("pieces", 0))
                     assert sum(r["ranges"]) == r["M"]
                     if case.get("balanced"):
                         # sampled splitters: no range far from M / world, whatever the key distribution
@@ -129,6 +129,9 @@ def _build_cases(oracle, world):
     # cases fall back to the exchange of counted runs by themselves
     for c in list(cases):
         cases.append(dict(c, name=c["name"] + ", records", exchange="records"))
+    # ... in three pieces: the all-to-all of one piece overlaps the routing of the next and the counting of the one before
+    cases.append(dict(cases[0], name="kmer k=25, records in 3 pieces", exchange="records", pieces=3))
+    cases.append(dict(cases[2], name="graph k=27, records in 3 pieces", exchange="records", pieces=3))
     return cases
 
 

@@ -385,6 +385,10 @@ def test_record_exchange_world1(oracle, nccl_world1, k, graph):
     with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
         r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), exchange="records")
         got = gd.assemble_files([ctx.files()])
+        # in pieces: asynchronous all-to-alls on RCCL's stream beside the library's kernels
+        r4 = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), exchange="records",
+                                  record_pieces=4)
+        assert r4["windows"] == nwin and gd.assemble_files([ctx.files()]) == got
     assert r["windows"] == nwin
     assert sorted(got) == sorted(exp)
     for name in exp:
