@@ -27,9 +27,35 @@ SYMBOLS = [
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
     "goss_gpu_push_keys_host", "goss_gpu_push_keys_device",
     "goss_gpu_route_records_device", "goss_gpu_push_records_device",
+    "goss_gpu_push_bases_host_async", "goss_gpu_push_packed_host", "goss_gpu_push_packed_host_async", "goss_gpu_flush",
 ]
 
 RECORD_BYTES = 12
+
+
+RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def pack_bases(text):
+    """bytes of bases -> (codes u32 per 16 positions, nonbase u16 per 16 positions): the packed form of
+    goss_gpu_push_packed_host (numpy restatement of the host parser's packer, for the tests)."""
+    import numpy as np
+    a = np.frombuffer(text if isinstance(text, (bytes, bytearray)) else text.encode(), dtype=np.uint8)
+    n = a.size
+    g = (n + 15) // 16
+    pad = np.full(g * 16, 10, dtype=np.uint8)
+    pad[:n] = a
+    low = pad | 0x20
+    code = np.zeros(g * 16, dtype=np.uint32)
+    code[low == ord("c")] = 1
+    code[low == ord("g")] = 2
+    code[low == ord("t")] = 3
+    bad = ~((low == ord("a")) | (low == ord("c")) | (low == ord("g")) | (low == ord("t")))
+    shifts = (2 * np.arange(16, dtype=np.uint32))[None, :]
+    codes = np.bitwise_or.reduce(code.reshape(g, 16) << shifts, axis=1).astype(np.uint32)
+    bshift = np.arange(16, dtype=np.uint32)[None, :]
+    nonbase = np.bitwise_or.reduce(bad.reshape(g, 16).astype(np.uint32) << bshift, axis=1).astype(np.uint16)
+    return np.ascontiguousarray(codes), np.ascontiguousarray(nonbase)
 
 
 class GossGpuError(RuntimeError):
@@ -183,6 +209,48 @@ class Context:
         if isinstance(data, str):
             data = data.encode()
         self._check(self._L.goss_gpu_push_bases_host(self._h, data, len(data)))
+
+    def push_host_async(self, data, on_release=None):
+        """goss_gpu_push_bases_host_async: the bytes object stays referenced until the library hands it back."""
+        if isinstance(data, str):
+            data = data.encode()
+        if not hasattr(self, "_lent"):
+            self._lent, self._lent_id = {}, 0
+            self._release_cb = RELEASE_FN(self._released)
+        self._lent_id += 1
+        self._lent[self._lent_id] = (data, on_release)
+        self._L.goss_gpu_push_bases_host_async.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, RELEASE_FN, C.c_void_p]
+        self._check(self._L.goss_gpu_push_bases_host_async(self._h, data, len(data), self._release_cb, C.c_void_p(self._lent_id)))
+
+    def _released(self, user):
+        data, cb = self._lent.pop(int(user or 0))
+        if cb:
+            cb()
+
+    def push_packed_host(self, text, async_=False):
+        """Pack a byte string of bases on the host (2 bits per base + 1 flag bit) and push it
+        (goss_gpu_push_packed_host / _async).  Returns (codes, nonbase) numpy arrays."""
+        import numpy as np
+        codes, bad = pack_bases(text)
+        n = len(text)
+        if async_:
+            if not hasattr(self, "_lent"):
+                self._lent, self._lent_id = {}, 0
+                self._release_cb = RELEASE_FN(self._released)
+            self._lent_id += 1
+            self._lent[self._lent_id] = ((codes, bad), None)
+            self._L.goss_gpu_push_packed_host_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, RELEASE_FN, C.c_void_p]
+            self._check(self._L.goss_gpu_push_packed_host_async(self._h, C.c_void_p(codes.ctypes.data), C.c_void_p(bad.ctypes.data), n,
+                                                                self._release_cb, C.c_void_p(self._lent_id)))
+        else:
+            self._L.goss_gpu_push_packed_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+            self._check(self._L.goss_gpu_push_packed_host(self._h, C.c_void_p(codes.ctypes.data), C.c_void_p(bad.ctypes.data), n))
+        return codes, bad
+
+    def flush(self):
+        """goss_gpu_flush: wait for the queued copies; every lent buffer comes back."""
+        self._L.goss_gpu_flush.argtypes = [C.c_void_p]
+        self._check(self._L.goss_gpu_flush(self._h))
 
     def push_device(self, ptr, nbytes):
         _torch_ready()

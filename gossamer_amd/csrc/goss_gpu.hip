@@ -92,6 +92,8 @@ struct goss_gpu_ctx {
     uint32_t lookback_failures = 0;
     uint64_t emit_estimate = 0;         // SparseArray estimate M for the next emit (merges)
     bool has_emit_estimate = false;
+    struct Pending { hipEvent_t ev; void (*fn)(void*); void* user; };
+    std::vector<Pending> pending;       // asynchronous host pushes whose buffers the caller has not got back yet
     uint8_t* stage = nullptr;           // staging buffer for host pushes (top of the arena)
     uint64_t stage_cap = 0, stage_fill = 0;
     bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
@@ -2629,6 +2631,7 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
     if (c->arena_thread.joinable()) c->arena_thread.join();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& pd : c->pending) { if (pd.fn) pd.fn(pd.user); (void)hipEventDestroy(pd.ev); }
     for (auto& pe : c->events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -2661,45 +2664,175 @@ int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nb
     });
 }
 
+// Buffers of asynchronous pushes whose copies have completed go back to the caller (from the caller's own
+// thread, inside this call); wait = all of them.
+static void release_pending(goss_gpu_ctx* c, bool wait)
+{
+    size_t done = 0;
+    for (; done < c->pending.size(); ++done)
+    {
+        auto& pd = c->pending[done];
+        if (wait) HIP_TRY(hipEventSynchronize(pd.ev));
+        else
+        {
+            const hipError_t e = hipEventQuery(pd.ev);
+            if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }          // (the stream is in order: the rest is not ready either)
+            if (e != hipSuccess) throw HipError{e, "hipEventQuery(pending push)"};
+        }
+        if (pd.fn) pd.fn(pd.user);
+        c->event_pool.push_back(pd.ev);
+    }
+    c->pending.erase(c->pending.begin(), c->pending.begin() + done);
+}
+
+static void note_pending(goss_gpu_ctx* c, void (*fn)(void*), void* user)
+{
+    hipEvent_t e;
+    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(e, c->stream));
+    c->pending.push_back({e, fn, user});
+}
+
+// positions unpacked per landing of a packed push (24 MB of packed bytes at most; a small arena lands less at a time)
+static inline uint64_t land_positions(const goss_gpu_ctx* c) { return std::min<uint64_t>(64ULL << 20, (c->stage_cap + 15) & ~15ULL); }
+static void ensure_stage(goss_gpu_ctx* c)
+{
+    ensure_arena(c);
+    if (c->stage) return;
+    // 1/24 of the arena: with ~17 bytes of key workspace per base the staged bases then
+    // fill about three quarters of the rest when they are counted
+    c->stage_cap = std::max<uint64_t>(c->arena.avail() / 24, 1u << 20) & ~4095ULL;
+    // (one block: the staging buffer, and behind it the landing area of packed pushes -- the arena moves them together when it grows)
+    c->stage = (uint8_t*)c->arena.temp(c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64);
+    c->stage_fill = 0;
+}
+static inline uint8_t* landing(goss_gpu_ctx* c) { return c->stage + ((c->stage_cap + 16 + 255) & ~255ULL); }
+
+static inline bool is_base_byte(char ch) { const char l = (char)(ch | 0x20); return l == 'a' || l == 'c' || l == 'g' || l == 't'; }
+
+// bases -> staging buffer.  release == nullptr && !async: the copy has completed on return (the caller may
+// reuse its buffer); else the buffer comes back through release(user) once its copy has.
+static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes, bool async, void (*release)(void*), void* user)
+{
+    if (nbytes < c->len) { if (release) release(user); return; }
+    ensure_stage(c);
+    if (nbytes + 1 > c->stage_cap)
+    {
+        // larger than the staging buffer: count it on its own, in pieces that overlap by
+        // len-1 bytes so that no window is lost at a cut
+        flush_staging(c);
+        uint64_t done = 0;
+        const uint64_t nstarts_total = nbytes - c->len + 1;
+        while (done < nstarts_total)
+        {
+            uint64_t ns = std::min<uint64_t>(c->stage_cap - c->len, nstarts_total - done);
+            uint64_t nb = ns + c->len - 1;
+            HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->stream));
+            if (c->words == 1) push_device<Key1>(c, c->stage, nb); else push_device<Key2>(c, c->stage, nb);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            done += ns;
+        }
+        if (release) release(user);
+        return;
+    }
+    if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging(c);
+    HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    // reads of two pushes must not join: a separator unless the caller's bytes end with one already
+    const bool sep = is_base_byte(bases[nbytes - 1]);
+    if (sep) HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->stream));
+    c->stage_fill += nbytes + (sep ? 1 : 0);
+    if (async) { note_pending(c, release, user); release_pending(c, false); }
+    else { HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, false); if (release) release(user); }
+}
+
+// packed bases -> landing area -> unpacked into the staging buffer (unpack_bases_kernel), 16 positions per group
+static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases, bool async,
+                             void (*release)(void*), void* user)
+{
+    if (nbases < c->len) { if (release) release(user); return; }
+    ensure_stage(c);
+    const uint64_t kPiece = land_positions(c);
+    // The pieces of one push are staged back to back without separators (all but the last are whole groups), so no
+    // window is lost where one piece ends.  When the staging buffer must be counted in between, the last len - 1
+    // positions are staged again in front of the rest -- their groups from the start, the positions whose windows
+    // have been counted turned into separators.
+    uint64_t pos = 0, kill = 0;
+    bool cont = false;
+    while (pos < nbases)
+    {
+        uint64_t at = cont ? c->stage_fill : ((c->stage_fill + 15) & ~15ULL);
+        uint64_t room = at + 32 < c->stage_cap ? (c->stage_cap - 1 - at) & ~15ULL : 0;
+        if (room < std::min<uint64_t>((nbases - pos + 15) & ~15ULL, 65536))
+        {
+            c->stage_fill = cont ? at : c->stage_fill;
+            flush_staging(c);
+            at = 0;
+            if (cont)
+            {
+                const uint64_t keep = pos >= c->len - 1 ? pos - (c->len - 1) : 0;      // first position whose window is still to be counted
+                const uint64_t from = keep & ~15ULL;
+                kill = keep - from;
+                pos = from;
+            }
+            room = (c->stage_cap - 1) & ~15ULL;
+        }
+        else if (!cont && at > c->stage_fill)
+            HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->stream));      // (groups land on 16-byte boundaries)
+        const uint64_t n = std::min<uint64_t>({nbases - pos, kPiece, room});
+        const uint64_t groups = (n + 15) / 16;
+        uint32_t* dcodes = (uint32_t*)landing(c);
+        uint16_t* dbad = (uint16_t*)(landing(c) + groups * 4);
+        HIP_TRY(hipMemcpyAsync(dcodes, codes + pos / 16, groups * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dbad, nonbase + pos / 16, groups * 2, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups, kTB)), dim3(kTB), 0, c->stream, (const uint32_t*)dcodes,
+                           (const uint16_t*)dbad, groups, c->stage + at);
+        if (kill) { HIP_TRY(hipMemsetAsync(c->stage + at, '\n', kill, c->stream)); kill = 0; }
+        c->stage_fill = at + n;
+        pos += n;
+        cont = true;
+    }
+    // (positions of the last group beyond nbases hold whatever the caller's upper bits say: the separator and the next
+    // push overwrite them, and the staged string ends at stage_fill)
+    HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', 1, c->stream));
+    c->stage_fill += 1;
+    if (async) { note_pending(c, release, user); release_pending(c, false); }
+    else { HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, false); if (release) release(user); }
+}
+
 int goss_gpu_push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes)
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() {
-        if (nbytes < c->len) return;
-        ensure_arena(c);
-        if (!c->stage)
-        {
-            // 1/24 of the arena: with ~17 bytes of key workspace per base the staged bases then
-            // fill about three quarters of the rest when they are counted
-            c->stage_cap = std::max<uint64_t>(c->arena.avail() / 24, 1u << 20) & ~4095ULL;
-            c->stage = (uint8_t*)c->arena.temp(c->stage_cap + 16);
-            c->stage_fill = 0;
-        }
-        if (nbytes + 1 > c->stage_cap)
-        {
-            // larger than the staging buffer: count it on its own, in pieces that overlap by
-            // len-1 bytes so that no window is lost at a cut
-            flush_staging(c);
-            uint64_t done = 0;
-            const uint64_t nstarts_total = nbytes - c->len + 1;
-            while (done < nstarts_total)
-            {
-                uint64_t ns = std::min<uint64_t>(c->stage_cap - c->len, nstarts_total - done);
-                uint64_t nb = ns + c->len - 1;
-                HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->stream));
-                if (c->words == 1) push_device<Key1>(c, c->stage, nb); else push_device<Key2>(c, c->stage, nb);
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                done += ns;
-            }
-            return;
-        }
-        if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging(c);
-        HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));       // the caller may reuse its buffer
-        c->stage_fill += nbytes + 1;
-    });
+    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, false, nullptr, nullptr); });
+}
+
+int goss_gpu_push_bases_host_async(goss_gpu_ctx* c, const char* bases, uint64_t nbytes, goss_gpu_release_fn release, void* user)
+{
+    if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, true, release, user); });
+}
+
+int goss_gpu_push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases)
+{
+    if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, false, nullptr, nullptr); });
+}
+
+int goss_gpu_push_packed_host_async(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases,
+                                    goss_gpu_release_fn release, void* user)
+{
+    if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, true, release, user); });
+}
+
+int goss_gpu_flush(goss_gpu_ctx* c)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() { if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, true); });
 }
 
 int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
@@ -2709,6 +2842,7 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
     int rc = guarded(c, [&]() {
         ensure_arena(c);
         flush_staging(c);
+        release_pending(c, true);          // (every asynchronous push has been copied by now: the buffers go back)
         if (c->stage) { c->stage = nullptr; c->arena.hi = c->arena.size; }    // staging no longer needed
         if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
         if (!c->runs.empty() && c->runs[0].rep)
@@ -3197,6 +3331,7 @@ int goss_gpu_reset(goss_gpu_ctx* c)
     return guarded(c, [&]() {
         if (c->arena_thread.joinable()) ensure_arena(c);      // a background mapping (goss_gpu_prepare) ends first
         HIP_TRY(hipStreamSynchronize(c->stream));
+        release_pending(c, true);
         c->runs.clear();
         c->big_maps.clear();
         c->res_big.clear();

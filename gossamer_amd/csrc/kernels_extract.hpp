@@ -60,6 +60,37 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
     if ((threadIdx.x & 63u) == 0 && seen) { atomicAdd(&out[0], bad); atomicAdd(&out[1], seen); }
 }
 
+// 2-bit packed bases (goss_gpu_push_packed_host*: one u32 of codes and one u16 of non-base flags per 16 positions,
+// packed by the host's parser threads so that 3 bits per base cross PCIe instead of 8) -> the byte string the
+// extraction kernels read: "ACGT"[code], or a newline where the flag is set.  One thread per group of 16; `out` is
+// 16-byte aligned.  The role of GossReadBaseString's per-base encoder (GossReadBaseString.hh:133-188), inverted:
+// the device keeps ONE input form, and unpacking costs one write and one read of a byte per base in HBM.
+__global__ __launch_bounds__(kTB) void unpack_bases_kernel(const uint32_t* __restrict__ codes, const uint16_t* __restrict__ nonbase,
+                                                           uint64_t ngroups, uint8_t* __restrict__ out)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t c = codes[g];
+    const uint32_t b = nonbase[g];
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const uint32_t code = (c >> (2 * (4 * i + j))) & 3u;
+            // A C G T = 0x41 0x43 0x47 0x54
+            uint32_t ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
+            if ((b >> (4 * i + j)) & 1u) ch = 0x0Au;
+            x |= ch << (8 * j);
+        }
+        w[i] = x;
+    }
+    reinterpret_cast<uint4*>(out)[g] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // Strand representative of a k-mer for COUNTING: of {x, rc(x)} the one whose bits, rotated left
 // by len (the central bases first), are smaller.  It is a function of the unordered pair, so both
 // strands of a k-mer count as one key; the rotation makes the choice depend on the central bases,

@@ -93,6 +93,35 @@ int goss_gpu_prepare(goss_gpu_ctx* ctx);
 int goss_gpu_push_bases_host(goss_gpu_ctx* ctx, const char* bases, uint64_t nbytes);
 int goss_gpu_push_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes);
 
+/*
+ * Asynchronous form of goss_gpu_push_bases_host: returns as soon as the copy is queued.  The buffer belongs to the
+ * library until release(user) is called -- by the CALLER'S OWN THREAD, from inside a later call on this context
+ * (another push, goss_gpu_flush, finish, reset, destroy), once the bytes have left it; no thread is created.  The
+ * buffer should be page-locked (goss_gpu_host_alloc), else the copy is synchronous inside the driver.  With a
+ * pool of such buffers the parser threads keep filling while earlier batches cross PCIe: the per-push wait of the
+ * synchronous form is what bounded `goss build-kmer-set` on a large FASTQ file.  release may be NULL (the caller
+ * then finds out through goss_gpu_flush).  Same role as the synchronous form (BackgroundMultiConsumer<KmerBlockPtr>
+ * ::push_back, GossCmdBuildKmerSet.tcc:246-256, is likewise a hand-over of a block the producer does not touch again).
+ */
+typedef void (*goss_gpu_release_fn)(void* user);
+int goss_gpu_push_bases_host_async(goss_gpu_ctx* ctx, const char* bases, uint64_t nbytes, goss_gpu_release_fn release, void* user);
+
+/*
+ * 2-bit packed bases: codes = one u32 per 16 positions, position j of a group at bits [2j, 2j+2), A=0 C=1 G=2 T=3;
+ * nonbase = one u16 per 16 positions, bit j set where position j is NOT a base (read separators, N, ...: it ends the
+ * run of windows like any non-ACGT byte of the byte form).  nbases positions; the upper bits of a partial last
+ * group are ignored.  Packed by the host's parser threads this moves 3 bits per base over PCIe instead of 8
+ * (north_star: "2-bit read encoding"; the per-base encoder it stands for is GossReadBaseString.hh:133-188); on the
+ * device the groups are unpacked into the byte form the extraction kernels read (one more byte written and read per
+ * base in HBM, 1/8 of what a key costs).  Windows never span two pushes.  _async: as goss_gpu_push_bases_host_async,
+ * both arrays belong to the library until release(user).
+ */
+int goss_gpu_push_packed_host(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases);
+int goss_gpu_push_packed_host_async(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases,
+                                    goss_gpu_release_fn release, void* user);
+/* Wait for every queued copy and hand all buffers of asynchronous pushes back (release is called for each). */
+int goss_gpu_flush(goss_gpu_ctx* ctx);
+
 typedef struct {
     uint64_t windows;    /* valid k-windows seen (kmer-set: k-mers; graph: rho-mer windows) */
     uint64_t keys;       /* keys inserted (= windows, or 2*windows in graph mode) */

@@ -1,0 +1,62 @@
+"""goss_gpu_push_bases_host_async / goss_gpu_push_packed_host(_async) / goss_gpu_flush: the same key stream as the
+synchronous byte form (include/goss_gpu.h), whatever the size and number of the pushes; every lent buffer comes back."""
+import random
+
+import pytest
+
+import gossamer_amd as g
+from test_gpu_parity import make_reads, oracle_counts
+
+pytestmark = pytest.mark.gpu
+MB = 1 << 20
+
+
+def batches(rng, reads, nb):
+    per = (len(reads) + nb - 1) // nb
+    return [("\n".join(reads[i:i + per]) + rng.choice(["\n", "\n", "", "N"])).encode() for i in range(0, len(reads), per)]
+
+
+@pytest.mark.parametrize("k,mode", [(25, 0), (31, 1), (45, 0), (55, 1)])
+def test_async_and_packed_pushes_count_what_the_synchronous_push_counts(oracle, k, mode):
+    rng = random.Random(31 * k + mode)
+    reads = make_reads(rng, 3000, (max(5, k - 3), 160), 30000, lower=True)
+    length = k + 1 if mode else k
+    for nb in (1, 7, 200):
+        bs = batches(random.Random(nb), reads, nb)
+        # a batch that does not end with a separator must not join the next one: the oracle sees them apart
+        ek, ec, nwin = oracle_counts(oracle, [b.decode() for b in bs], length, mode)
+        for how in ("sync", "async", "packed", "packed-async", "mixed"):
+            released = []
+            with g.Context(k, mode, hbm_budget=(64 if nb == 200 else 256) * MB) as ctx:
+                for i, b in enumerate(bs):
+                    h = how if how != "mixed" else ("sync", "async", "packed", "packed-async")[i % 4]
+                    if h == "sync":
+                        ctx.push_host(b)
+                    elif h == "async":
+                        ctx.push_host_async(b, on_release=lambda i=i: released.append(i))
+                    else:
+                        ctx.push_packed_host(b, async_=(h == "packed-async"))
+                if how == "async" and nb == 7:
+                    ctx.flush()
+                    assert sorted(released) == list(range(len(bs)))
+                c = ctx.finish()
+                ks, cs = ctx.result()
+                assert not getattr(ctx, "_lent", None), "a buffer was not handed back by finish"
+            if how == "async":
+                assert sorted(released) == list(range(len(bs)))
+            assert c.windows == nwin, (how, nb)
+            assert ks == ek and [int(x) for x in cs] == ec, (how, nb)
+
+
+def test_packed_push_larger_than_the_staging_buffer(oracle):
+    """48 MB of positions into a context whose staging buffer holds ~10 MB: unpacked and counted piece by piece, no
+    window lost where the staging buffer is counted in between."""
+    k = 21
+    reads = g.synth_reads_host(320_000, 150, 400_000, seed=5)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "r", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    with g.Context(k, 0, hbm_budget=256 * MB) as ctx:
+        ctx.push_packed_host(reads)
+        c = ctx.finish()
+        assert c.windows == nwin
+        assert ctx.emit() == exp
