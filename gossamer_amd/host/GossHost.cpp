@@ -7,6 +7,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <sys/mman.h>
 
@@ -371,6 +374,67 @@ size_t guessRecordStart(const char* p, size_t n, size_t from)
     return (size_t)-1;
 }
 
+// ---- 2-bit packing of parsed bases (goss_gpu_push_packed_host: one u32 of codes + one u16 of non-base flags per 16
+// positions).  GossReadBaseString.hh:133-188 is the reference's per-base encoder; here the parser threads pack
+// whole chunks so that 3 bits per base cross PCIe instead of 8.  Two forms with the same result: a table-driven
+// loop, and an AVX2 + BMI2 one (32 positions per step) chosen at run time where the CPU has both.
+void packBasesScalar(const char* p, size_t n, uint32_t* codes, uint16_t* bad)
+{
+    static const struct Lut { uint8_t v[256]; Lut() { memset(v, 4, 256); v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } } lut;
+    const size_t groups = (n + 15) / 16;
+    for (size_t g = 0; g < groups; ++g)
+    {
+        uint32_t c = 0, b = 0;
+        const size_t lim = std::min<size_t>(16, n - g * 16);
+        for (size_t j = 0; j < lim; ++j)
+        {
+            const uint32_t v = lut.v[(uint8_t)p[g * 16 + j]];
+            c |= (v & 3u) << (2 * j);
+            b |= (v >> 2) << j;
+        }
+        if (lim < 16) b |= 0xFFFFu << lim;               // positions behind the end are no bases
+        codes[g] = c; bad[g] = (uint16_t)b;
+    }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2"))) void packBasesAvx2(const char* p, size_t n, uint32_t* codes, uint16_t* bad)
+{
+    const size_t whole = n / 32;                         // steps of two groups
+    const __m256i fold = _mm256_set1_epi8(0x20);
+    const __m256i ca = _mm256_set1_epi8('a'), cc = _mm256_set1_epi8('c'), cg = _mm256_set1_epi8('g'), ct = _mm256_set1_epi8('t');
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1);
+    for (size_t i = 0; i < whole; ++i)
+    {
+        const __m256i raw = _mm256_loadu_si256((const __m256i*)(p + 32 * i));
+        const __m256i l = _mm256_or_si256(raw, fold);
+        const __m256i good = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(l, ca), _mm256_cmpeq_epi8(l, cc)),
+                                             _mm256_or_si256(_mm256_cmpeq_epi8(l, cg), _mm256_cmpeq_epi8(l, ct)));
+        const uint32_t gm = (uint32_t)_mm256_movemask_epi8(good);
+        // code = ((l >> 1) & 3) ^ (((l >> 1) & 3) >> 1): a 0 c 1 g 3->2 t 2->3
+        __m256i x = _mm256_and_si256(_mm256_srli_epi16(l, 1), three);
+        x = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), one));
+        alignas(32) uint64_t w[4];
+        _mm256_store_si256((__m256i*)w, x);
+        const uint64_t m = 0x0303030303030303ULL;
+        const uint32_t c0 = (uint32_t)_pext_u64(w[0], m) | ((uint32_t)_pext_u64(w[1], m) << 16);
+        const uint32_t c1 = (uint32_t)_pext_u64(w[2], m) | ((uint32_t)_pext_u64(w[3], m) << 16);
+        codes[2 * i] = c0; codes[2 * i + 1] = c1;
+        bad[2 * i] = (uint16_t)~gm; bad[2 * i + 1] = (uint16_t)~(gm >> 16);
+    }
+    if (whole * 32 < n) packBasesScalar(p + whole * 32, n - whole * 32, codes + 2 * whole, bad + 2 * whole);
+}
+#endif
+
+void packBases(const char* p, size_t n, uint32_t* codes, uint16_t* bad)
+{
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !std::getenv("GOSS_PACK_SCALAR");
+    if (fast) { packBasesAvx2(p, n, codes, bad); return; }
+#endif
+    packBasesScalar(p, n, codes, bad);
+}
+
 struct ChunkResult {
     char* buf = nullptr;               // from the buffer pool (pinned when a GPU is attached)
     size_t len = 0;
@@ -379,6 +443,8 @@ struct ChunkResult {
     bool ok = false;
     FastqFail fail{};
     bool done = false;
+    uint32_t* codes = nullptr;         // packed form of buf[0, len) (behind the bytes in the same buffer), when asked for
+    uint16_t* bad = nullptr;
 };
 
 }  // namespace
@@ -597,10 +663,17 @@ struct HostAlloc {                       // how the chunk buffers are obtained (
 // pushOwned (optional): the consumer keeps the buffer until it calls `release` -- several devices then copy
 // from several buffers at once; without it `push` returns when the bytes are on their way.
 typedef std::function<void(const char*, size_t, std::function<void()>)> OwnedPush;
+// pushPacked (optional, one device): the workers also pack their bases (packBases) and the consumer hands the packed
+// arrays over without waiting -- `release` comes back later, on the consumer's own thread from inside a library call
+// (goss_gpu_push_packed_host_async); `drain` makes every outstanding release happen (goss_gpu_flush).
+struct PackedPush {
+    std::function<void(const uint32_t*, const uint16_t*, size_t, std::function<void()>)> push;
+    std::function<void()> drain;
+};
 
 uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t chunkBytes,
                             const std::function<void(const char*, size_t)>& push, const HostAlloc& ha,
-                            const OwnedPush* pushOwned = nullptr)
+                            const OwnedPush* pushOwned = nullptr, const PackedPush* pushPacked = nullptr)
 {
     // (compressed inputs are framed by the serial parser behind InFile's decompressor)
     if (threads < 2 || name == "-" || endsWith(name, ".gz") || endsWith(name, ".bz2")) return ~0ULL;
@@ -634,7 +707,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // of its own, one buffer after the other, while the workers already parse: a short file never
     // pays for buffers it does not use and a long one does not wait for them up front.
     const size_t bufCap = chunkBytes / 2 + (1u << 16);
-    const size_t nbuf = std::min<size_t>((size_t)threads + 4, nchunks + 1);
+    // (packed pushes: codes and flags behind the bytes -- 6 bytes per 16 positions)
+    const size_t packOff = (bufCap + 63) & ~(size_t)63, codesBytes = (bufCap / 16 + 2) * 4;
+    const size_t bufBytes = pushPacked ? packOff + codesBytes + (bufCap / 16 + 2) * 2 + 64 : bufCap;
+    const size_t nbuf = std::min<size_t>((size_t)threads + (pushPacked ? 12 : 4), nchunks + 1);
     std::vector<char*> freeBufs;
     std::vector<void*> allBufs;
     std::atomic<bool> allocFailed{false};
@@ -643,7 +719,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         for (size_t i = 0; i < nbuf && !abortAll.load() && nextChunk.load() < nchunks; ++i)
         {
             // (GOSS_TEST_FAIL_PARSER_ALLOC: fault injection for the test of this path -- the second buffer cannot be had)
-            void* b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufCap);
+            void* b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufBytes);
             if (!b)
             {
                 // (under the lock: a worker or the consumer between its predicate and its wait must not miss this)
@@ -660,6 +736,8 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     size_t lent = 0;
     struct WaitLent { std::mutex& m; std::condition_variable& cv; size_t& lent;
                       ~WaitLent() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return lent == 0; }); } } waitLent{m, cv, lent};
+    // (packed pushes give their buffers back from inside library calls of THIS thread: make them all happen before waiting)
+    struct Drain { const PackedPush* p; ~Drain() { if (p && p->drain) { try { p->drain(); } catch (...) {} } } } drainLent{pushPacked};
 
     auto worker = [&]() {
         for (;;)
@@ -689,6 +767,12 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 };
                 r.ok = fastqLoop(src, limit, sink, &r.reads, &r.lines, &r.fail);
                 r.end = src.valid() ? (size_t)src.offset() : size;
+                if (pushPacked && r.ok && r.len && r.len <= bufCap)
+                {
+                    r.codes = (uint32_t*)(r.buf + packOff);
+                    r.bad = (uint16_t*)(r.buf + packOff + codesBytes);
+                    packBases(r.buf, r.len, r.codes, r.bad);
+                }
             }
             r.done = true;
             {
@@ -743,7 +827,19 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         };
         if (r.start != expected || r.len > bufCap) { giveBack(); serialRest = true; break; }
         if (!r.ok) throw Error::Parse(name, r.fail.what + num(baseLine + r.fail.line - 1));
-        if (r.len && pushOwned)
+        if (r.len && pushPacked && r.codes)
+        {
+            char* b = r.buf;
+            r.buf = nullptr;
+            { std::lock_guard<std::mutex> lk(m); ++lent; }
+            const auto a = now();
+            pushPacked->push(r.codes, r.bad, r.len, [&m, &cv, &freeBufs, &lent, b]() {
+                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); --lent; }
+                cv.notify_all();
+            });
+            pushSeconds += std::chrono::duration<double>(now() - a).count();
+        }
+        else if (r.len && pushOwned)
         {
             char* b = r.buf;
             r.buf = nullptr;
@@ -765,6 +861,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         expected = r.end;
     }
     if (allocFailed.load()) throw Error::General("cannot allocate parser buffers\n");
+    if (pushPacked && pushPacked->drain) pushPacked->drain();
     if (serialRest || expected < size)
     {
         // a boundary guess did not line up (wrapped records, '@' starting quality lines, ...):
@@ -1006,8 +1103,19 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         { std::ostringstream o; o << "parsing sequences from " << f << " (contexts ready at "
             << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s)"; log(info, o.str()); }
         flush();
+        // one device: the workers pack their bases to 2 bits + a flag and the packed arrays are handed over without
+        // waiting for the copy (GOSS_HOST_ASCII=1: the byte form, one synchronous push per chunk, as before)
+        struct Cb { std::function<void()> fn; };
+        PackedPush packed;
+        packed.push = [&](const uint32_t* codes, const uint16_t* bad, size_t n, std::function<void()> release) {
+            Cb* cb = new Cb{std::move(release)};
+            const int rc = goss_gpu_push_packed_host_async(g.h, codes, bad, n, [](void* u) { Cb* c = (Cb*)u; c->fn(); delete c; }, cb);
+            if (rc != GOSS_OK) { cb->fn(); delete cb; g.check(rc, "counting k-mers"); }
+        };
+        packed.drain = [&]() { g.check(goss_gpu_flush(g.h), "counting k-mers"); };
+        const bool usePacked = !fed && !std::getenv("GOSS_HOST_ASCII");
         uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned,
-                                        fed ? &ownedPush : nullptr);
+                                        fed ? &ownedPush : nullptr, usePacked ? &packed : nullptr);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
@@ -1525,8 +1633,19 @@ int gossMain(int argc, char* argv[])
                 {
                     // -T > 1 exercises the parallel parser (same byte stream, file order)
                     HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }};
+                    // GOSS_DUMP_PACKED=1: the chunks go through the workers' 2-bit packer and are unpacked here the
+                    // way the device unpacks them (a base letter in upper case, a newline for every non-base)
+                    PackedPush viaPacked;
+                    viaPacked.push = [&](const uint32_t* codes, const uint16_t* bad, size_t n, std::function<void()> release) {
+                        std::string out(n, '\n');
+                        for (size_t i = 0; i < n; ++i)
+                            if (!((bad[i / 16] >> (i % 16)) & 1u)) out[i] = "ACGT"[(codes[i / 16] >> (2 * (i % 16))) & 3u];
+                        fwrite(out.data(), 1, n, stdout);
+                        release();
+                    };
                     uint64_t r = parseFastqParallel(f, (unsigned)T, parseChunkBytes(),
-                                                    [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); }, heap);
+                                                    [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); }, heap, nullptr,
+                                                    std::getenv("GOSS_DUMP_PACKED") ? &viaPacked : nullptr);
                     if (r == ~0ULL) r = parseFastq(f, sink);
                     reads += r;
                 }

@@ -293,3 +293,37 @@ def test_parallel_parser_reports_a_failed_buffer_allocation(tmp_path):
                        stderr=subprocess.PIPE, env=env, timeout=60)
     assert p.returncode == 1
     assert b"cannot allocate parser buffers" in p.stderr
+
+
+def test_parser_threads_pack_bases_to_two_bits(tmp_path):
+    """The parallel parser's workers pack their bases for goss_gpu_push_packed_host (2 bits per base + a non-base flag):
+    unpacked again -- the way unpack_bases_kernel does it -- the stream is the plain one with every base in upper case
+    and every non-base a newline.  Both packers (table-driven, AVX2 + BMI2 where the CPU has them) against
+    gossamer_amd.binding.pack_bases, the numpy statement of the format."""
+    import numpy as np
+    from gossamer_amd.binding import pack_bases
+    rng = random.Random(12)
+    reads = ["".join(rng.choice("ACGTacgtNn.-RY") if rng.random() < 0.1 else rng.choice("ACGT") for _ in range(rng.randint(1, 300)))
+             for _ in range(20000)]
+    fq = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
+    (tmp_path / "p.fq").write_text(fq)
+    plain = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(tmp_path / "p.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, GOSS_PARSE_CHUNK="65536"), timeout=120)
+    assert plain.returncode == 0, plain.stderr.decode()
+    want = bytes(c if c in b"ACGT" else 10 for c in plain.stdout.upper())
+    for scalar in (False, True):
+        env = dict(os.environ, GOSS_PARSE_CHUNK="65536", GOSS_DUMP_PACKED="1")
+        if scalar:
+            env["GOSS_PACK_SCALAR"] = "1"
+        p = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(tmp_path / "p.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=env, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == want, scalar
+    # the numpy statement of the format unpacks to the same bytes
+    codes, bad = pack_bases(plain.stdout)
+    n = len(plain.stdout)
+    idx = np.arange(n)
+    c = (codes[idx // 16] >> (2 * (idx % 16)).astype(np.uint32)) & 3
+    b = (bad[idx // 16] >> (idx % 16).astype(np.uint16)) & 1
+    got = np.where(b == 1, 10, np.frombuffer(b"ACGT", dtype=np.uint8)[c]).astype(np.uint8).tobytes()
+    assert got == want
