@@ -94,6 +94,7 @@ struct goss_gpu_ctx {
     bool has_emit_estimate = false;
     struct Pending { hipEvent_t ev; void (*fn)(void*); void* user; };
     std::vector<Pending> pending;       // asynchronous host pushes whose buffers the caller has not got back yet
+    uint64_t flush_wait_us = 0, flush_count_us = 0, flushes = 0;   // staging buffer counted: waiting for queued copies / counting (host wall)
     uint8_t* stage = nullptr;           // staging buffer for host pushes (top of the arena)
     uint64_t stage_cap = 0, stage_fill = 0;
     bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
@@ -2650,7 +2651,14 @@ static void flush_staging(goss_gpu_ctx* c)
     if (!c->stage || c->stage_fill == 0) return;
     const uint64_t n = c->stage_fill;
     c->stage_fill = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(c->stream));          // (the copies queued so far: counted apart from the chunk's own time)
+    const auto t1 = std::chrono::steady_clock::now();
     if (c->words == 1) push_device<Key1>(c, c->stage, n); else push_device<Key2>(c, c->stage, n);
+    const auto t2 = std::chrono::steady_clock::now();
+    c->flush_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(t1 - t0).count();
+    c->flush_count_us += (uint64_t)std::chrono::duration<double, std::micro>(t2 - t1).count();
+    c->flushes++;
 }
 
 int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes)
@@ -2696,6 +2704,7 @@ static void note_pending(goss_gpu_ctx* c, void (*fn)(void*), void* user)
 
 // positions unpacked per landing of a packed push (24 MB of packed bytes at most; a small arena lands less at a time)
 static inline uint64_t land_positions(const goss_gpu_ctx* c) { return std::min<uint64_t>(64ULL << 20, (c->stage_cap + 15) & ~15ULL); }
+// (landing: codes of a piece, then its flags)
 static void ensure_stage(goss_gpu_ctx* c)
 {
     ensure_arena(c);
@@ -2757,15 +2766,24 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
     // window is lost where one piece ends.  When the staging buffer must be counted in between, the last len - 1
     // positions are staged again in front of the rest -- their groups from the start, the positions whose windows
     // have been counted turned into separators.
+    // (the staged string always ends on a 16-byte boundary behind a group of separators -- the unpack kernel writes
+    // them -- so a push costs one copy (two when the caller's arrays do not lie back to back) and one launch)
     uint64_t pos = 0, kill = 0;
     bool cont = false;
+    if (c->stage_fill & 15ULL)          // (bytes staged by the byte form: pad to a boundary)
+    {
+        const uint64_t at = (c->stage_fill + 15) & ~15ULL;
+        if (at + 64 < c->stage_cap) { HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->stream)); c->stage_fill = at; }
+        else flush_staging(c);
+    }
     while (pos < nbases)
     {
-        uint64_t at = cont ? c->stage_fill : ((c->stage_fill + 15) & ~15ULL);
-        uint64_t room = at + 32 < c->stage_cap ? (c->stage_cap - 1 - at) & ~15ULL : 0;
+        // continuing a push: over the separator group of the piece before (whole groups but for the last piece)
+        uint64_t at = cont ? c->stage_fill - 16 : c->stage_fill;
+        uint64_t room = at + 64 < c->stage_cap ? (c->stage_cap - 32 - at) & ~15ULL : 0;
         if (room < std::min<uint64_t>((nbases - pos + 15) & ~15ULL, 65536))
         {
-            c->stage_fill = cont ? at : c->stage_fill;
+            c->stage_fill = at;
             flush_staging(c);
             at = 0;
             if (cont)
@@ -2775,27 +2793,28 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
                 kill = keep - from;
                 pos = from;
             }
-            room = (c->stage_cap - 1) & ~15ULL;
+            room = (c->stage_cap - 32) & ~15ULL;
         }
-        else if (!cont && at > c->stage_fill)
-            HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->stream));      // (groups land on 16-byte boundaries)
         const uint64_t n = std::min<uint64_t>({nbases - pos, kPiece, room});
         const uint64_t groups = (n + 15) / 16;
         uint32_t* dcodes = (uint32_t*)landing(c);
-        uint16_t* dbad = (uint16_t*)(landing(c) + groups * 4);
-        HIP_TRY(hipMemcpyAsync(dcodes, codes + pos / 16, groups * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dbad, nonbase + pos / 16, groups * 2, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups, kTB)), dim3(kTB), 0, c->stream, (const uint32_t*)dcodes,
-                           (const uint16_t*)dbad, groups, c->stage + at);
+        uint16_t* dbad = (uint16_t*)(dcodes + groups);
+        const uint32_t* hc = codes + pos / 16;
+        const uint16_t* hb = nonbase + pos / 16;
+        if ((const void*)hb == (const void*)(hc + groups))
+            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 6, hipMemcpyHostToDevice, c->stream));
+        else
+        {
+            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->stream));
+        }
+        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups + 1, kTB)), dim3(kTB), 0, c->stream, (const uint32_t*)dcodes,
+                           (const uint16_t*)dbad, groups, n, c->stage + at);
         if (kill) { HIP_TRY(hipMemsetAsync(c->stage + at, '\n', kill, c->stream)); kill = 0; }
-        c->stage_fill = at + n;
+        c->stage_fill = at + (groups + 1) * 16;
         pos += n;
         cont = true;
     }
-    // (positions of the last group beyond nbases hold whatever the caller's upper bits say: the separator and the next
-    // push overwrite them, and the staged string ends at stage_fill)
-    HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', 1, c->stream));
-    c->stage_fill += 1;
     if (async) { note_pending(c, release, user); release_pending(c, false); }
     else { HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, false); if (release) release(user); }
 }
@@ -3768,6 +3787,9 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "rep_chunks") *value = c->rep_chunks;
     else if (n == "rec_chunks") *value = c->rec_chunks;
+    else if (n == "flush_wait_us") *value = c->flush_wait_us;
+    else if (n == "flush_count_us") *value = c->flush_count_us;
+    else if (n == "flushes") *value = c->flushes;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;

@@ -66,12 +66,21 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
 // 16-byte aligned.  The role of GossReadBaseString's per-base encoder (GossReadBaseString.hh:133-188), inverted:
 // the device keeps ONE input form, and unpacking costs one write and one read of a byte per base in HBM.
 __global__ __launch_bounds__(kTB) void unpack_bases_kernel(const uint32_t* __restrict__ codes, const uint16_t* __restrict__ nonbase,
-                                                           uint64_t ngroups, uint8_t* __restrict__ out)
+                                                           uint64_t ngroups, uint64_t npos, uint8_t* __restrict__ out)
 {
+    // groups 0 .. ngroups-1 hold positions; positions at or beyond npos, and one more whole group behind the last
+    // (written by the thread ngroups), are separators: the string a push leaves behind ends on a 16-byte boundary
+    // with a separator, and the host issues no fill calls of its own
     const uint64_t g = (uint64_t)blockIdx.x * kTB + threadIdx.x;
-    if (g >= ngroups) return;
-    const uint32_t c = codes[g];
-    const uint32_t b = nonbase[g];
+    if (g > ngroups) return;
+    uint32_t c = 0, b = 0xFFFFu;
+    if (g < ngroups)
+    {
+        c = codes[g];
+        b = nonbase[g];
+        const uint64_t left = npos - g * 16;
+        if (left < 16) b |= 0xFFFFu << (uint32_t)left;
+    }
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -658,7 +658,12 @@ size_t parseChunkBytes()
 struct HostAlloc {                       // how the chunk buffers are obtained (pinned under a GPU)
     std::function<void*(size_t)> alloc;
     std::function<void(void*)> release;
+    // keep: buffers are not given back to the system when a file is done but kept for the next one (page-locked memory
+    // costs ~0.3 s/GB to obtain and milliseconds per buffer to return: a build ends faster without the returns)
+    bool keep = false;
 };
+std::mutex gKeptMutex;
+std::map<size_t, std::vector<void*>> gKeptBuffers;          // by size
 
 // pushOwned (optional): the consumer keeps the buffer until it calls `release` -- several devices then copy
 // from several buffers at once; without it `push` returns when the bytes are on their way.
@@ -714,12 +719,23 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     std::vector<char*> freeBufs;
     std::vector<void*> allBufs;
     std::atomic<bool> allocFailed{false};
-    struct FreeAll { std::vector<void*>& v; const HostAlloc& h; ~FreeAll() { for (void* b : v) h.release(b); } } freeAll{allBufs, ha};
+    struct FreeAll { std::vector<void*>& v; const HostAlloc& h; size_t bytes;
+                     ~FreeAll() {
+                         if (h.keep) { std::lock_guard<std::mutex> lk(gKeptMutex); auto& k = gKeptBuffers[bytes]; k.insert(k.end(), v.begin(), v.end()); }
+                         else for (void* b : v) h.release(b);
+                     } } freeAll{allBufs, ha, bufBytes};
     std::thread allocator([&]() {
         for (size_t i = 0; i < nbuf && !abortAll.load() && nextChunk.load() < nchunks; ++i)
         {
             // (GOSS_TEST_FAIL_PARSER_ALLOC: fault injection for the test of this path -- the second buffer cannot be had)
-            void* b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufBytes);
+            void* b = nullptr;
+            if (ha.keep)
+            {
+                std::lock_guard<std::mutex> lk(gKeptMutex);
+                auto it = gKeptBuffers.find(bufBytes);
+                if (it != gKeptBuffers.end() && !it->second.empty()) { b = it->second.back(); it->second.pop_back(); }
+            }
+            if (!b) b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufBytes);
             if (!b)
             {
                 // (under the lock: a worker or the consumer between its predicate and its wait must not miss this)
@@ -769,8 +785,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 r.end = src.valid() ? (size_t)src.offset() : size;
                 if (pushPacked && r.ok && r.len && r.len <= bufCap)
                 {
+                    // (flags right behind the codes: the library then moves both with one copy)
                     r.codes = (uint32_t*)(r.buf + packOff);
-                    r.bad = (uint16_t*)(r.buf + packOff + codesBytes);
+                    r.bad = (uint16_t*)(r.codes + (r.len + 15) / 16);
                     packBases(r.buf, r.len, r.codes, r.bad);
                 }
             }
@@ -1022,7 +1039,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     batch.reserve(cxt.batchBytes + (1u << 20));
     uint64_t reads = 0;
     HostAlloc pinned{[](size_t n) { void* p = nullptr; return goss_gpu_host_alloc(&p, n) == GOSS_OK ? p : nullptr; },
-                     [](void* p) { goss_gpu_host_free(p); }};
+                     [](void* p) { goss_gpu_host_free(p); }, true};
     double pushSeconds = 0;
     auto timedPush = [&](const char* p, size_t n) {
         auto a = std::chrono::steady_clock::now();
@@ -1133,6 +1150,10 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         if (P > 1) o << " of device " << devs[d];
         o << ": " << (bytes >> 30) << " GB mapped in " << ms / 1000.0 << "s";
         log(info, o.str());
+        uint64_t fw = 0, fc = 0, fn = 0;
+        goss_gpu_stat(gs[d]->h, "flush_wait_us", &fw); goss_gpu_stat(gs[d]->h, "flush_count_us", &fc); goss_gpu_stat(gs[d]->h, "flushes", &fn);
+        std::ostringstream o2; o2 << "staging buffer counted " << fn << " times: " << fw / 1e6 << "s waiting for queued copies, " << fc / 1e6 << "s counting";
+        log(info, o2.str());
     }
 
     log(info, "sorting the hashtable...");
@@ -1632,7 +1653,7 @@ int gossMain(int argc, char* argv[])
                 for (auto& f : fastqs)
                 {
                     // -T > 1 exercises the parallel parser (same byte stream, file order)
-                    HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }};
+                    HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }, false};
                     // GOSS_DUMP_PACKED=1: the chunks go through the workers' 2-bit packer and are unpacked here the
                     // way the device unpacks them (a base letter in upper case, a newline for every non-base)
                     PackedPush viaPacked;

@@ -1,14 +1,18 @@
 #!/bin/bash
-# C2 end to end: 100 M x 150 bp reads as a FASTQ file in /dev/shm -> KmerSet files, three runs, with the time split
-# of the parser's in-order consumer (the first run of a freshly written file is slower: cold page mappings).
+# C2 end to end: 100 M x 150 bp reads as a FASTQ file in /dev/shm -> KmerSet files, with the time split of the
+# parser's in-order consumer (the first run of a freshly written file is slower: cold page mappings).
+# usage: tools/e2e_c2.sh [reads] ["env settings to compare, one per run, e.g. 'GOSS_HOST_ASCII=1' ''"]
 N=${1:-100000000}
+shift
 D=$(mktemp -d /dev/shm/goss_e2e.XXXXXX)
 ./gossamer_amd/goss synth-reads $N 150 $N 1 $D/reads.fq
 ls -la $D/reads.fq
+nproc
 TIMEFORMAT="wall %R s  user %U s  sys %S s"
-for run in 1 2 3; do
-  echo "== -T 64, run $run"
-  time GOSS_PARSE_STATS=1 ./gossamer_amd/goss build-kmer-set -k 25 -T 64 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
-  grep -E "consumer|total build|parsed and|arena|contexts ready|merged at|written at" $D/log.txt | sed 's/^.*info//'
+if [ $# -eq 0 ]; then set -- "" "" ""; fi
+for e in "$@"; do
+  echo "== -T 64, env: [$e]"
+  time env $e GOSS_PARSE_STATS=1 ./gossamer_amd/goss build-kmer-set -k 25 -T 64 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
+  grep -E "staging buffer|consumer|total build|parsed and|arena|contexts ready|merged at|written at|parallel parser" $D/log.txt | sed 's/^.*info//'
 done
 rm -rf $D
