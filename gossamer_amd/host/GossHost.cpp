@@ -652,6 +652,15 @@ size_t parseChunkBytes()
     return 8u << 20;      // small enough that page-locking the buffer pool (threads + 4 buffers of half this size) takes ~0.1 s
 }
 
+// Bytes read behind a chunk for the record that crosses its end (GOSS_PARSE_SLACK overrides: the tests make it tiny so
+// that the re-reads with a larger window happen).
+size_t parseSlackBytes()
+{
+    const char* e = std::getenv("GOSS_PARSE_SLACK");
+    if (e && *e) { long v = atol(e); if (v >= 1) return (size_t)v; }
+    return 1u << 20;
+}
+
 // Parse a plain FASTQ file with `threads` workers (see "parallel FASTQ parsing" above).  Batches of
 // bases go to `push` in file order.  Returns the number of reads, or ~0 if the file is not eligible
 // (too small, not a regular file) and the caller should use the serial parser.
@@ -692,8 +701,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < 2 * chunkBytes) { ::close(fd); return ~0ULL; }
     const size_t size = (size_t)st.st_size;
+    // (the mapping serves the serial path below, should a chunk boundary not line up: untouched otherwise)
     void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
+    const int rfd = fd;
+    struct CloseFd { int f; ~CloseFd() { ::close(f); } } closeFd{fd};
     if (map == MAP_FAILED) return ~0ULL;
     madvise(map, size, MADV_SEQUENTIAL);
     const char* p = (const char*)map;
@@ -756,10 +767,12 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     struct Drain { const PackedPush* p; ~Drain() { if (p && p->drain) { try { p->drain(); } catch (...) {} } } } drainLent{pushPacked};
 
     auto worker = [&]() {
+        std::vector<char> raw;                  // the chunk's bytes as read from the file
         for (;;)
         {
             ChunkResult r;
             size_t i;
+            char* mybuf;
             {
                 // buffer first, chunk number second (both under the lock): every outstanding chunk
                 // then owns a buffer and the in-order consumer can always make progress
@@ -768,28 +781,57 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 if (abortAll.load()) return;
                 i = nextChunk.fetch_add(1);
                 if (i >= nchunks) return;
-                r.buf = freeBufs.back(); freeBufs.pop_back();
+                mybuf = freeBufs.back(); freeBufs.pop_back();
             }
             const size_t begin = i * chunkBytes, limit = std::min(size, begin + chunkBytes);
-            r.start = i == 0 ? 0 : guessRecordStart(p, size, begin);
-            if (r.start == (size_t)-1 || r.start >= limit) { r.end = r.start; r.ok = true; r.start = (size_t)-1; }
-            else
+            // The chunk's bytes are READ into a buffer of the worker's own (pread), with room behind `limit` for the
+            // record that crosses it: 64 threads faulting the pages of one mapping in serialise on the address space's
+            // lock (24 GB/s for the whole pool on the bench's box); copies out of the page cache do not.  A record
+            // that runs past the room is read again with eight times as much.
+            const size_t lo = begin ? begin - 1 : 0;              // (guessRecordStart looks at the byte in front)
+            for (size_t slack = parseSlackBytes();; slack *= 8)
             {
-                MemLines src(p, size, r.start);
+                const size_t hi = std::min(size, limit + slack);
+                if (raw.size() < hi - lo) raw.resize(hi - lo);
+                size_t got = 0;
+                while (got < hi - lo)
+                {
+                    const ssize_t k = pread(rfd, raw.data() + got, hi - lo - got, (off_t)(lo + got));
+                    if (k < 0) { if (errno == EINTR) continue; break; }
+                    if (k == 0) break;
+                    got += (size_t)k;
+                }
+                const char* lp = raw.data();
+                r = ChunkResult{};
+                r.buf = mybuf;
+                if (got != hi - lo) { r.start = begin; r.len = bufCap + 1; r.ok = true; break; }      // (a short read: the serial path reports it)
+                const size_t s0 = i == 0 ? 0 : guessRecordStart(lp, got, begin - lo);
+                if (s0 == (size_t)-1 || lo + s0 >= limit)
+                {
+                    // no record start in the chunk (fine when the record before runs past it) -- unless the window was short
+                    if (s0 == (size_t)-1 && hi < size && slack < size) continue;
+                    r.end = r.start; r.ok = true; r.start = (size_t)-1;
+                    break;
+                }
+                r.start = lo + s0;
+                MemLines src(lp, got, s0);
                 auto sink = [&](const char* seq, size_t len) {
                     // a chunk's reads are shorter than the chunk's bytes (titles, '+', qualities)
                     if (r.len + len + 1 <= bufCap) { memcpy(r.buf + r.len, seq, len); r.len += len; r.buf[r.len++] = '\n'; }
                     else r.len = bufCap + 1;                 // cannot happen for a record-aligned chunk
                 };
-                r.ok = fastqLoop(src, limit, sink, &r.reads, &r.lines, &r.fail);
-                r.end = src.valid() ? (size_t)src.offset() : size;
-                if (pushPacked && r.ok && r.len && r.len <= bufCap)
-                {
-                    // (flags right behind the codes: the library then moves both with one copy)
-                    r.codes = (uint32_t*)(r.buf + packOff);
-                    r.bad = (uint16_t*)(r.codes + (r.len + 15) / 16);
-                    packBases(r.buf, r.len, r.codes, r.bad);
-                }
+                r.ok = fastqLoop(src, limit - lo, sink, &r.reads, &r.lines, &r.fail);
+                // the parse must have ended inside the window (or at the end of the file): else a record was cut off
+                if (!src.good && hi < size) continue;
+                r.end = src.valid() ? lo + (size_t)src.offset() : size;
+                break;
+            }
+            if (pushPacked && r.ok && r.start != (size_t)-1 && r.len && r.len <= bufCap)
+            {
+                // (flags right behind the codes: the library then moves both with one copy)
+                r.codes = (uint32_t*)(r.buf + packOff);
+                r.bad = (uint16_t*)(r.codes + (r.len + 15) / 16);
+                packBases(r.buf, r.len, r.codes, r.bad);
             }
             r.done = true;
             {

@@ -223,6 +223,12 @@ def test_parallel_fastq_parser_matches_serial(tmp_path):
             par = subprocess.run([GOSS, "dump-bases", "-T", T, "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert par.returncode == 0, par.stderr
             assert par.stdout == serial.stdout, (name, T)
+        # the workers read their chunk plus some room for the record that crosses its end: with almost no room the
+        # record is cut off and the chunk read again with a larger window
+        par = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             env=dict(env, GOSS_PARSE_SLACK="7"))
+        assert par.returncode == 0, par.stderr
+        assert par.stdout == serial.stdout, (name, "slack")
     # an error deep in the file: same message, same line number
     bad = files["plain.fq"].split("\n")
     bad[4 * 4000 + 2] = "-"             # the '+' line of record 4000
