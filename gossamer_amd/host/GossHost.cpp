@@ -652,6 +652,8 @@ size_t parseChunkBytes()
     return 8u << 20;      // small enough that page-locking the buffer pool (threads + 4 buffers of half this size) takes ~0.1 s
 }
 
+constexpr uint64_t kMaxFramers = 32;      // worker threads of the parallel FASTQ parser, whatever -T says beyond it
+
 // Bytes read behind a chunk for the record that crosses its end (GOSS_PARSE_SLACK overrides: the tests make it tiny so
 // that the re-reads with a larger window happen).
 size_t parseSlackBytes()
@@ -1173,7 +1175,10 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         };
         packed.drain = [&]() { g.check(goss_gpu_flush(g.h), "counting k-mers"); };
         const bool usePacked = !fed && !std::getenv("GOSS_HOST_ASCII");
-        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, 64), parseChunkBytes(), timedPush, pinned,
+        // (at most 32 framing threads: measured on the bench's box -- 256 cores shared with other jobs -- the 31.5 GB of
+        // C2 take 0.5 s with 32 and 1.2 to 3.5 s with 64, whose system time is four to ten times higher; the pushes'
+        // driver calls slow down with them: 1.34 / 1.43 s for the build with -T 32 against 1.64 / 1.94 s with -T 64)
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, kMaxFramers), parseChunkBytes(), timedPush, pinned,
                                         fed ? &ownedPush : nullptr, usePacked ? &packed : nullptr);
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
@@ -1706,7 +1711,7 @@ int gossMain(int argc, char* argv[])
                         fwrite(out.data(), 1, n, stdout);
                         release();
                     };
-                    uint64_t r = parseFastqParallel(f, (unsigned)T, parseChunkBytes(),
+                    uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(T, kMaxFramers), parseChunkBytes(),
                                                     [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); }, heap, nullptr,
                                                     std::getenv("GOSS_DUMP_PACKED") ? &viaPacked : nullptr);
                     if (r == ~0ULL) r = parseFastq(f, sink);
