@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(*args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "1", "--warmup", "0", "--no-extra",
-                        "--e2e-reads", "0", "--no-cpu-baseline", "--hbm-budget-gb", "6"],
+                        "--e2e-reads", "0", "--no-cpu-baseline", "--hbm-budget-gb", "4"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
     return json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -29,6 +29,19 @@ def test_bench_launches_its_own_ranks():
     # value = the windows of BOTH ranks over the slowest rank's time
     windows = 2 * 2000000 * (150 - 25 + 1)
     assert abs(two["value"] * 1e6 * two["ms_per_step"] * 1e-3 / windows - 1) < 0.02
+
+
+@pytest.mark.gpu
+def test_c3_shape_with_eight_ranks():
+    """BASELINE config C3's shape -- eight ranks, every rank its own share of the reads of one genome, the exchange
+    before counting -- at a size one GPU holds eight contexts for: `bench.py --gpus 8` starts the eight rank processes
+    itself (gloo, the GPU shared), and the distinct-key count equals one context's over all the reads, for both forms of
+    the exchange."""
+    one = _bench("--gpus", "1", "--reads", "4000000", "--genome", "8000000")
+    for exchange in ("records", "counted"):
+        eight = _bench("--gpus", "8", "--backend", "gloo", "--reads", "500000", "--genome", "1000000", "--exchange", exchange)
+        assert eight["n_gpus"] == 8 and eight["config"]["exchange"] == exchange
+        assert eight["config"]["distinct_kmers"] == one["config"]["distinct_kmers"] > 0, exchange
 
 
 def test_launcher_fails_loudly_when_a_rank_fails():

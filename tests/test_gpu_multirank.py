@@ -142,10 +142,10 @@ def test_hip_path_with_several_ranks(oracle, world):
     _run(world, _build_cases(oracle, world))
 
 
-def test_set_algebra_with_two_ranks(oracle):
-    """C5 at test scale over 2 ranks: two k-mer sets counted and range-partitioned with common
+@pytest.mark.parametrize("world", [2, 8])
+def test_set_algebra_with_several_ranks(oracle, world):
+    """C5 at test scale over 2 and 8 ranks (BASELINE's split): two k-mer sets counted and range-partitioned with common
     splitters, intersected / subtracted range by range, assembled on rank 0."""
-    world = 2
     texts = [g.synth_reads_host(6000, 150, 400000, seed=71, first_read=f) for f in (0, 3000)]
     cases = []
     for k in (25, 45):
