@@ -146,11 +146,6 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
             return {"failed": "synth-reads: " + p.stderr.decode(errors="replace")[-300:]}
         gen_s = time.perf_counter() - t0
         nbytes = os.path.getsize(fq)
-        # the parser alone: the parallel FASTQ framer the build uses, bases written to /dev/null
-        t0 = time.perf_counter()
-        with open(os.devnull, "wb") as null:
-            subprocess.run([goss, "dump-bases", "-T", str(threads), "-i", fq], stdout=null, stderr=subprocess.PIPE)
-        parse_s = time.perf_counter() - t0
         runs, logs = [], []
         for _ in range(2):          # (the first run of a freshly written file maps cold pages)
             for f in os.listdir(d):
@@ -165,6 +160,15 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
                 return {"failed": logs[-1][-400:]}
         secs = min(runs)
         log = logs[runs.index(secs)]
+        # the parser alone: the parallel FASTQ framer the build uses, bases written to /dev/null (after the builds: the
+        # first pass over a freshly written file maps cold pages; the faster of two)
+        parse = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            with open(os.devnull, "wb") as null:
+                subprocess.run([goss, "dump-bases", "-T", str(threads), "-i", fq], stdout=null, stderr=subprocess.PIPE)
+            parse.append(time.perf_counter() - t0)
+        parse_s = min(parse)
         m = re.search(r"HBM arena: (\d+) GB mapped in ([0-9.]+)s", log)
         w = re.search(r"k-mer windows: (\d+)", log)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("ks"))
