@@ -290,9 +290,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed-by-the-headline C4 record (build-graph k=55, 200 M reads)")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
-    ap.add_argument("--exchange", default="records", choices=("records", "counted"),
+    ap.add_argument("--exchange", default="auto", choices=("auto", "records", "counted"),
                     help="N > 1: what travels in the first all-to-all -- super-k-mer records routed by minimizer BEFORE counting "
-                         "(each rank counts 1/N of the key space), or the (key,count) pairs of every rank's local count")
+                         "(each rank counts 1/N of the key space), or the (key,count) pairs of every rank's local count; auto: "
+                         "records from 4 ranks on (with 2 ranks one xGMI link would carry half of all records, and counting "
+                         "first is cheaper anyway: tools/scale_probe.sh)")
     ap.add_argument("--route-parts", type=int, default=0, help="with --force-dist on one rank: cut the records as a build over "
                     "this many ranks would (the rank then receives all its own parts: one rank's load of an N-rank build)")
     ap.add_argument("--graph", action="store_true", help="build-graph instead of build-kmer-set (windows are (k+1)-mers, "
@@ -306,6 +308,8 @@ def main():
         launch_ranks(args.gpus, sys.argv[1:])          # does not return
     if world != args.gpus:
         raise SystemExit("bench.py: WORLD_SIZE = %d but --gpus %d" % (world, args.gpus))
+    if args.exchange == "auto":
+        args.exchange = "records" if world >= 4 or args.route_parts >= 4 else "counted"
 
     import torch
     import torch.distributed as dist

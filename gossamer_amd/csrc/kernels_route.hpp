@@ -16,7 +16,7 @@
 //
 // Record (SkRec, 12 bytes): bits 0..91 = the run's (nwin + len - 1 <= 46) bases as 2-bit codes, base j of the
 // run at bits [2j, 2j + 2) (the bit order of the extraction kernels' window registers); bits 92..95 = nwin - 1.
-// A record never spans a non-base, a read boundary, or the 16 windows a routing thread owns.
+// A record never spans a non-base, a read boundary, or a routing tile (4 096 window starts).
 // Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp.
 #pragma once
 
@@ -71,9 +71,13 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
     __shared__ uint32_t cnt[kRouteMaxParts], win[kRouteMaxParts];
     __shared__ unsigned long long gbase[kRouteMaxParts];
     __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ int sh_max[kWaves];
+    __shared__ uint32_t lastd[kTB];                 // destination of the thread's last window, or ~0 when it is not valid
+    __shared__ uint16_t vmask[kTB], bmask[kTB];     // valid windows / windows that start a run, per thread
     const uint32_t tid = threadIdx.x;
     const uint32_t m = len - W + 1;
     const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    (void)maxwin;                                   // (records hold up to 16 windows in both modes)
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
@@ -143,8 +147,10 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
         const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;      // base j of this thread at bits [2j, 2j + 2)
         const uint64_t bhi = hi >> s2;
 
-        uint32_t nrec = 0, starts = 0;
+        uint32_t nrec = 0, starts = 0, bnd = 0, last = 0xFFFFFFFFu;
         uint32_t dest[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) dest[i] = 0;
         if (valid)
         {
             // hashed canonical m-mers at positions 0 .. NPOS-1: forward and reverse complement rolled; the first
@@ -192,20 +198,67 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
                     mn[i] = x;
                 }
             }
+            // destination: the low 16 bits of the minimizer's hash (the product's low half: a bijection of the m-mer's
+            // last 8 bases, independent of the high bits that made it the minimum), scaled to the parts
 #pragma unroll
-            for (int i = 0; i < P; ++i) dest[i] = __umulhi(route_mix(mn[i]), nparts);
-            // a record starts at a valid window whose predecessor is not valid, goes elsewhere, or filled a record
+            for (int i = 0; i < P; ++i) dest[i] = ((mn[i] & 0xFFFFu) * nparts) >> 16;
+            // windows 1 .. 15 that start a run: valid, and the window before is not or goes elsewhere
 #pragma unroll
-            for (int i = 0; i < P; ++i)
+            for (int i = 1; i < P; ++i)
             {
                 const uint32_t ok = (valid >> i) & 1u;
-                const uint32_t prev_ok = i ? (valid >> (i - 1)) & 1u : 0u;
-                const uint32_t same = i ? (dest[i] == dest[i - 1] ? 1u : 0u) : 0u;
-                const uint32_t forced = (maxwin < (uint32_t)P && i == (int)maxwin) ? 1u : 0u;      // (maxwin is 8 or 16)
-                starts |= (ok & (((prev_ok & same) ^ 1u) | forced)) << i;
+                const uint32_t prev_ok = (valid >> (i - 1)) & 1u;
+                const uint32_t same = dest[i] == dest[i - 1] ? 1u : 0u;
+                bnd |= (ok & ((prev_ok & same) ^ 1u)) << i;
             }
-            nrec = __popc(starts);
+            if ((valid >> (P - 1)) & 1u) last = dest[P - 1];
         }
+        // Runs are followed ACROSS threads (a record holds up to 16 windows of a run wherever its first lies): window 0
+        // starts a run unless the thread before ends in a valid window with the same destination; a record starts at a
+        // run's windows 0, 16, 32, ..; its length is bounded by the next run start or invalid window, which may lie
+        // among the next thread's windows (a thread has the bases of 64 positions: enough for 16 windows from any of
+        // its own).  Records never span tiles.
+        lastd[tid] = last;
+        vmask[tid] = (uint16_t)valid;
+        __syncthreads();
+        if (valid & 1u)
+        {
+            const uint32_t prev = tid ? lastd[tid - 1] : 0xFFFFFFFFu;
+            if (prev != dest[0]) bnd |= 1u;
+        }
+        bmask[tid] = (uint16_t)bnd;
+        // position (in the tile) of the last run start before this thread's windows, or -1
+        const int mine = bnd ? (int)(tid * P + (31 - __clz(bnd))) : -1;
+        int cur;
+        {
+            int inc = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const int o = __shfl_up(inc, d, 64);
+                if ((int)lane_id() >= d) inc = max(inc, o);
+            }
+            if (lane_id() == 63) sh_max[wave_id()] = inc;
+            __syncthreads();
+            int before = -1;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) if ((int)wave_id() > w) before = max(before, sh_max[w]);
+            const int up = __shfl_up(inc, 1, 64);
+            cur = max(before, lane_id() ? up : -1);
+        }
+        const uint32_t nb = tid + 1 < (uint32_t)kTB ? bmask[tid + 1] : 0xFFFFu;
+        const uint32_t nv = tid + 1 < (uint32_t)kTB ? vmask[tid + 1] : 0u;
+        // bit j set: window j (of this thread's 16 and the next thread's 16) starts a run or is not valid
+        const uint32_t stop32 = (bnd | (~valid & 0xFFFFu)) | ((nb | (~nv & 0xFFFFu)) << 16);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+        {
+            const int pos = (int)(tid * P) + i;
+            if ((bnd >> i) & 1u) cur = pos;
+            const uint32_t st = ((valid >> i) & 1u) & ((((uint32_t)(pos - cur)) & 15u) == 0u ? 1u : 0u);
+            starts |= st << i;
+        }
+        nrec = __popc(starts);
         uint32_t tot;
         const uint32_t at = block_excl_scan<uint32_t>(nrec, sh_scan, &tot);
         (void)tot;
@@ -217,8 +270,8 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
             {
                 const uint32_t s = __ffs(todo) - 1;
                 todo &= todo - 1;
-                const uint32_t stop = (todo | ~valid | (1u << P)) >> s;            // bit j set: window s + j ends the run
-                const uint32_t n = __ffs(stop & ~1u) - 1;                          // (bit 0 is the start itself)
+                const uint32_t stop = (stop32 >> s) & ~1u;                         // bit j set: window s + j ends the run
+                const uint32_t n = stop ? min(16u, (uint32_t)__ffs(stop) - 1u) : 16u;
                 uint32_t d = 0;
 #pragma unroll
                 for (int i = 0; i < P; ++i) if ((uint32_t)i == s) d = dest[i];
@@ -249,8 +302,8 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
             {
                 const uint32_t s = __ffs(todo) - 1;
                 todo &= todo - 1;
-                const uint32_t stop = (todo | ~valid | (1u << P)) >> s;
-                const uint32_t n = __ffs(stop & ~1u) - 1;
+                const uint32_t stop = (stop32 >> s) & ~1u;
+                const uint32_t n = stop ? min(16u, (uint32_t)__ffs(stop) - 1u) : 16u;
                 const uint32_t nbases = n + len - 1;                               // <= 46
                 // bases s .. s + nbases - 1 of this thread
                 const uint32_t ss = 2 * s;
