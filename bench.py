@@ -27,12 +27,11 @@ def algorithmic_bytes_per_window(k, read_len, key_bytes=8, keys_per_window=1):
 
 
 def kernels_hash():
-    """sha256 over the device sources the built library comes from (what profiles/traffic.json is keyed by)."""
-    import glob
+    """sha256 over the sources of the kernels profiles/traffic.json holds figures for (extraction, partition, counting)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gossamer_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "kernels_*.hpp")) + [os.path.join(d, "goss_key.hpp")]):
+    for f in [os.path.join(d, n) for n in ("goss_key.hpp", "kernels_common.hpp", "kernels_count.hpp", "kernels_extract.hpp", "kernels_partition.hpp")]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
     constexpr int NVEC = T / 16 + 4;
     constexpr int NPOS = P + W - 1;                 // m-mer positions a thread looks at
     __shared__ uint32_t pk[NVEC], iv[NVEC];
-    __shared__ uint16_t rkbuf[T];                   // rank of every record inside its part's share of the tile (a record per window at worst)
+    __shared__ uint32_t rkbuf[T];                   // part << 16 | rank of every record inside its part's share of the tile (a record per window at worst)
     __shared__ uint32_t cnt[kRouteMaxParts], win[kRouteMaxParts];
     __shared__ unsigned long long gbase[kRouteMaxParts];
     __shared__ uint32_t sh_scan[kWaves + 1];
@@ -259,6 +259,10 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
             starts |= st << i;
         }
         nrec = __popc(starts);
+        // the windows' destinations as bytes of two words: picked by shifting in the loops over the records
+        uint64_t dp0 = 0, dp1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dp0 |= (uint64_t)dest[i] << (8 * i); dp1 |= (uint64_t)dest[i + 8] << (8 * i); }
         uint32_t tot;
         const uint32_t at = block_excl_scan<uint32_t>(nrec, sh_scan, &tot);
         (void)tot;
@@ -272,10 +276,8 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
                 todo &= todo - 1;
                 const uint32_t stop = (stop32 >> s) & ~1u;                         // bit j set: window s + j ends the run
                 const uint32_t n = stop ? min(16u, (uint32_t)__ffs(stop) - 1u) : 16u;
-                uint32_t d = 0;
-#pragma unroll
-                for (int i = 0; i < P; ++i) if ((uint32_t)i == s) d = dest[i];
-                rkbuf[at + r] = (uint16_t)atomicAdd(&cnt[d], 1u);
+                const uint32_t d = (uint32_t)((s < 8 ? dp0 >> (8 * s) : dp1 >> (8 * (s - 8))) & 0xFFu);
+                rkbuf[at + r] = (d << 16) | atomicAdd(&cnt[d], 1u);
                 atomicAdd(&win[d], n);
                 ++r;
             }
@@ -312,14 +314,12 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
                 const uint32_t nb2 = 2 * nbases;
                 const uint64_t klo = nb2 >= 64 ? flo : (flo & ((1ULL << nb2) - 1ULL));
                 const uint32_t khi = nb2 > 64 ? (uint32_t)(fhi & ((1ULL << (nb2 - 64)) - 1ULL)) : 0u;
-                uint32_t d = 0;
-#pragma unroll
-                for (int i = 0; i < P; ++i) if ((uint32_t)i == s) d = dest[i];
-                const unsigned long long g = gbase[d];
+                const uint32_t dr = rkbuf[at + r];
+                const unsigned long long g = gbase[dr >> 16];
                 if (g != ~0ULL)
                 {
                     SkRec rec{(uint32_t)klo, (uint32_t)(klo >> 32), khi | ((n - 1) << 28)};
-                    out[g + rkbuf[at + r]] = rec;
+                    out[g + (dr & 0xFFFFu)] = rec;
                 }
                 ++r;
             }
