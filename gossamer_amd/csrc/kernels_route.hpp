@@ -144,8 +144,12 @@ __global__ __launch_bounds__(kTB, 4) void route_records_kernel(const uint8_t* __
         }
         const uint64_t lo = w0 | (w1 << 32), hi = w2 | (w3 << 32);
         const uint32_t s2 = 2 * sh;
-        const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;      // base j of this thread at bits [2j, 2j + 2)
-        const uint64_t bhi = hi >> s2;
+        // base j of this thread at bits [2j, 2j + 2) of (blo, bhi): all 64 of them -- a record that starts at the
+        // thread's last window and runs 16 windows into the next thread's needs up to 15 + 16 + len - 1 <= 61 bases,
+        // so where the thread does not start on a vector boundary the fifth vector fills the top
+        const uint64_t w4 = pk[v0 + 4];
+        const uint64_t blo = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+        const uint64_t bhi = s2 ? ((hi >> s2) | (w4 << (64 - s2))) : hi;
 
         uint32_t nrec = 0, starts = 0, bnd = 0, last = 0xFFFFFFFFu;
         uint32_t dest[P];

@@ -94,28 +94,30 @@ def test_small_part_buffers_are_reported_and_a_second_call_fits(oracle):
 
 
 def test_misaligned_bases_and_two_word_keys():
-    k = 21
+    """A base string that does not start on a 16-byte boundary (the pieces of a pipelined exchange start anywhere): a
+    routing thread's 64 bases then come from five vectors -- a record may run 16 windows into the next thread's."""
     rng = random.Random(77)
-    reads = make_reads(rng, 300, 100, 3000)
+    reads = make_reads(rng, 1500, (90, 160), 6000)
     text = ("\n".join(reads) + "\n").encode()
     dev = torch.device("cuda", 0)
-    with g.Context(k, 0, hbm_budget=64 * MB) as ctx:
-        ctx.push_host(text)
-        ctx.finish()
-        want = ctx.result()
-    for off in (1, 7, 13):
-        t = torch.zeros(len(text) + 32, dtype=torch.uint8, device=dev)
-        t[off:off + len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
-        buf = torch.empty((len(text) // 4) * 2 * REC, dtype=torch.uint8, device=dev)
-        cap = len(text) // 4
-        with g.Context(k, 0, hbm_budget=64 * MB) as ctx:
-            recs, wins, ok = ctx.route_records(t.data_ptr() + off, len(text), 2, buf.data_ptr(), [0, cap], [cap, cap])
-            assert ok
-            for p in range(2):
-                ctx.push_records(buf.data_ptr() + p * cap * REC, recs[p], wins[p])
+    for k, mode in ((21, 0), (25, 0), (31, 0), (27, 1), (30, 1)):
+        with g.Context(k, mode, hbm_budget=64 * MB) as ctx:
+            ctx.push_host(text)
             ctx.finish()
-            got = ctx.result()
-        assert got[0] == want[0] and list(got[1]) == list(want[1]), off
+            want = ctx.result()
+        for off in (1, 6, 7, 13, 15):
+            t = torch.zeros(len(text) + 32, dtype=torch.uint8, device=dev)
+            t[off:off + len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+            cap = len(text) // 4
+            buf = torch.empty(cap * 2 * REC, dtype=torch.uint8, device=dev)
+            with g.Context(k, mode, hbm_budget=64 * MB) as ctx:
+                recs, wins, ok = ctx.route_records(t.data_ptr() + off, len(text), 2, buf.data_ptr(), [0, cap], [cap, cap])
+                assert ok
+                for p in range(2):
+                    ctx.push_records(buf.data_ptr() + p * cap * REC, recs[p], wins[p])
+                ctx.finish()
+                got = ctx.result()
+            assert got[0] == want[0] and list(got[1]) == list(want[1]), (k, mode, off)
     with g.Context(40, 0, hbm_budget=64 * MB) as ctx:          # two-word keys do not route
         with pytest.raises(g.GossGpuError) as e:
             ctx.route_records(t.data_ptr(), len(text), 2, buf.data_ptr(), [0, cap], [cap, cap])
