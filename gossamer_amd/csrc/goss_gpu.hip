@@ -122,8 +122,6 @@ struct goss_gpu_ctx {
     uint32_t seg_merges = 0;            // merges done by segments
     uint32_t hash_merges = 0;           // ... of them through the counting table (seg_hash_merge96_kernel)
     uint64_t hash_merge_min = 1u << 20; // GOSS_GPU_HASH_MERGE_MIN=<entries>: smallest merge that goes that way (65 536 workgroups)
-    bool split_chunks = true;           // GOSS_GPU_NO_SPLIT=1: a chunk with too many distinct keys for the two-level form is not halved
-    uint32_t split_count = 0;           // chunks counted in halves for that reason
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
@@ -1072,8 +1070,7 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r)
 // Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
 // buffers of one key per window start).
-enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2, kFusedSplit = 3 };
-struct SplitChunk {};          // thrown by process_chunk: count this chunk in halves (push_device / push_records do)
+enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2 };
 constexpr uint32_t kFusedGrid = 768;                         // workgroups of extract1_part_kernel: 3 per CU (52 KB of LDS each)
 #ifndef GOSS_FUSED_NKEYS2
 #define GOSS_FUSED_NKEYS2 14          // keys per thread of extract2_part_kernel (tile of 3584 keys + carry = 70 KB of LDS)
@@ -1084,11 +1081,6 @@ constexpr uint32_t kFusedGrid = 768;                         // workgroups of ex
 constexpr uint32_t kFusedGrid2 = GOSS_FUSED_GRID2;                        // ... of extract2_part_kernel: 2 per CU (75 KB)
 constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
 constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
-
-inline bool msd_wanted_split(const goss_gpu_ctx* c, uint32_t segbits, int big_table)
-{
-    return c->fused_msd && segbits > (uint32_t)kSegBits && big_table == 0;
-}
 
 template <class K>
 int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, uint64_t navail, K* ka, uint64_t ka_slots,
@@ -1226,16 +1218,6 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             // between the two: the 6144-slot table, still one workgroup (and one read) per segment
             if (r == 0 && c->wide_table && (m_est >> kSegBits) <= (uint64_t)kSegWideLimit2 * 3 / 4) { segbits = kSegBits; big_table = -1; break; }
         }
-    // More distinct keys than the two-level form's largest tables take (reads with ~1 % of errors: every error makes up
-    // to k new k-mers): such keys grow with the chunk, so HALF the chunk fits where the whole does not -- two chunks
-    // through the two-level form and a merge of their runs cost less than one through three partition digits
-    // (profiles/r03/error_probe.jsonl).  GOSS_GPU_NO_SPLIT=1: the three-digit form as before.
-    if (kOne && c->split_chunks && msd_wanted_split(c, segbits, big_table) && nstarts >= std::max<uint64_t>(4 * c->fused_min, 1u << 18))
-    {
-        if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: %llu distinct keys estimated in %llu window starts: counted in halves\n",
-                                   (unsigned long long)m_est, (unsigned long long)nstarts);
-        return (int)kFusedSplit;
-    }
     if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
@@ -1605,7 +1587,6 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     K* kb = (K*)c->arena.temp(kb_slots * sizeof(K));
     int frc = process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots);
     if (frc == kFusedDone) { if (reduced) c->valid_sized_chunks++; c->arena.release(mark); return; }
-    if (frc == kFusedSplit) { c->arena.release(mark); c->split_count++; throw SplitChunk{}; }
     if (reduced)
     {
         c->valid_resizes++;
@@ -1615,11 +1596,10 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
         full_slots();
         ka = (K*)c->arena.temp(ka_slots * sizeof(K));
         kb = (K*)c->arena.temp(kb_slots * sizeof(K));
-        if (frc == kFusedNeedFull)
+        if (frc == kFusedNeedFull && process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots) == kFusedDone)
         {
-            const int frc2 = process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots);
-            if (frc2 == kFusedDone) { c->arena.release(mark); return; }
-            if (frc2 == kFusedSplit) { c->arena.release(mark); c->split_count++; throw SplitChunk{}; }
+            c->arena.release(mark);
+            return;
         }
     }
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
@@ -1925,11 +1905,6 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         {
             process_chunk<K>(c, d + done, ns, navail);
         }
-        catch (const SplitChunk&)
-        {
-            limit = ((ns + 1) / 2 + 4095) & ~4095ULL;
-            continue;
-        }
         catch (const StatusError& e)
         {
             if (e.status != GOSS_ERR_OOM || ns <= 8192) throw;
@@ -1996,11 +1971,6 @@ void push_records(goss_gpu_ctx* c, const uint8_t* d, uint64_t nrecs, uint64_t nw
         try
         {
             process_chunk<K>(c, d + (done / P) * sizeof(SkRec), ns, 0);
-        }
-        catch (const SplitChunk&)
-        {
-            limit = ((ns + 1) / 2 + 4095) & ~4095ULL;
-            continue;
         }
         catch (const StatusError& e)
         {
@@ -2615,7 +2585,6 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
-    { const char* e = std::getenv("GOSS_GPU_NO_SPLIT"); if (e && *e == '1') c->split_chunks = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }
@@ -3818,7 +3787,6 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "rep_chunks") *value = c->rep_chunks;
     else if (n == "rec_chunks") *value = c->rec_chunks;
-    else if (n == "split_chunks") *value = c->split_count;
     else if (n == "flush_wait_us") *value = c->flush_wait_us;
     else if (n == "flush_count_us") *value = c->flush_count_us;
     else if (n == "flushes") *value = c->flushes;

@@ -174,57 +174,3 @@ def test_c5_full_size_properties():
         rep = ctx.check_index({k[len(".kmers"):]: v for k, v in files.items() if k.startswith(".kmers")})
         assert rep["select"] == 0 and rep["rank"] == 0 and rep["access"] == 0 and rep["failures"] == 0, rep
 
-
-def test_reads_with_errors_counted_in_halves():
-    """50 M reads with 1.3 % of their bases substituted: ~1.8 G distinct k-mers in 6.3 G windows, more than the
-    two-level form's largest tables take for one chunk -- the chunk is counted in halves (two-level form twice, the
-    runs merged).  Same keys and counts as the three-digit form of the whole chunk (GOSS_GPU_NO_SPLIT=1), counts add
-    up to the windows."""
-    import torch
-    from gossamer_amd import dist as gd
-    free_b, total_b = torch.cuda.mem_get_info(0)
-    if total_b < 250 * (1 << 30):
-        pytest.skip("needs the 288 GB of an MI355X")
-    n, L, G, k = 50_000_000, 150, 50_000_000, 25
-    dev = torch.device("cuda", 0)
-    nbytes = n * (L + 1)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    budget = int((free_b - nbytes - (40 << 30)) * 0.9)
-    res = []
-    for env in ({}, {"GOSS_GPU_NO_SPLIT": "1"}):
-        old = {kk: os.environ.get(kk) for kk in env}
-        os.environ.update(env)
-        try:
-            ctx = g.Context(k, g.MODE_KMER_SET, hbm_budget=budget)
-        finally:
-            for kk, v in old.items():
-                if v is None:
-                    del os.environ[kk]
-                else:
-                    os.environ[kk] = v
-        if not res:
-            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=3)
-            torch.cuda.synchronize()
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(11)
-            lut = torch.tensor([ord(c) for c in "ACGT"], dtype=torch.uint8, device=dev)
-            step = 1 << 28
-            for at in range(0, nbytes, step):
-                v = buf[at:at + step]
-                hit = (torch.rand(v.numel(), device=dev, generator=gen) < 0.013) & (v != 10)
-                sub = lut[torch.randint(0, 4, (v.numel(),), device=dev, generator=gen)]
-                v[hit] = sub[hit]
-                del hit, sub
-            torch.cuda.synchronize()
-        ctx.push_device(buf.data_ptr(), nbytes)
-        c = ctx.finish()
-        keys, counts = gd.result_views(ctx, 1, dev)
-        res.append((keys.clone(), counts.clone(), c.windows, c.distinct, ctx.stat("split_chunks")))
-        del keys, counts
-        ctx.close()
-    (k0, c0, w0, m0, s0), (k1, c1, w1, m1, s1) = res
-    assert s0 >= 1 and s1 == 0, (s0, s1)
-    assert w0 == w1 and m0 == m1 > 1_400_000_000
-    assert torch.equal(k0, k1) and torch.equal(c0, c1)
-    assert int(c0.to(torch.int64).sum().item()) == w0
-    assert bool((k0[1:] > k0[:-1]).all())
