@@ -200,6 +200,33 @@ __global__ __launch_bounds__(kTB) void global_hist_kernel(const K* __restrict__ 
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
+// Histogram of the 16 bits at `shift` of every key (65 536 bins): the joint histogram of the two partition digits the
+// fused path sizes its sub-regions from (exact when the sample is the chunk).  One workgroup per CU with half of
+// the bins at a time in LDS (32 768 words = 128 KB), so two sweeps over the keys.
+constexpr int kJointThreads = 1024;
+template <class K>
+__global__ __launch_bounds__(kJointThreads) void joint_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift,
+                                                                   unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t lh[32768];
+    const uint64_t stride = (uint64_t)gridDim.x * kJointThreads;
+    for (uint32_t half = 0; half < 2; ++half)
+    {
+        for (uint32_t i = threadIdx.x; i < 32768; i += kJointThreads) lh[i] = 0;
+        __syncthreads();
+        for (uint64_t i = (uint64_t)blockIdx.x * kJointThreads + threadIdx.x; i < n; i += stride)
+        {
+            const uint32_t b = (uint32_t)key_shr64(keys[i], shift) & 0xFFFFu;
+            // (a bin of the other half: a spare word nobody reads, instead of a branch around the atomic)
+            atomicAdd(&lh[(b >> 15) == half ? (b & 32767u) : 32767u], (b >> 15) == half ? 1u : 0u);
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < 32768; j += kJointThreads)
+            if (lh[j]) atomicAdd(&hist[half * 32768u + j], (unsigned long long)lh[j]);
+        __syncthreads();
+    }
+}
+
 // In-place exclusive scan of each 256-entry row (one workgroup per row).
 __global__ __launch_bounds__(kTB) void scan_rows256_kernel(unsigned long long* __restrict__ hist)
 {

@@ -728,7 +728,11 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // (packed pushes: codes and flags behind the bytes -- 6 bytes per 16 positions)
     const size_t packOff = (bufCap + 63) & ~(size_t)63, codesBytes = (bufCap / 16 + 2) * 4;
     const size_t bufBytes = pushPacked ? packOff + codesBytes + (bufCap / 16 + 2) * 2 + 64 : bufCap;
-    const size_t nbuf = std::min<size_t>((size_t)threads + (pushPacked ? 12 : 4), nchunks + 1);
+    // (packed pushes keep their buffer until its copy has completed, and the consumer is away for ~25 ms whenever the
+    // staging buffer is counted: more buffers than workers, so that the workers go on meanwhile)
+    size_t extraBufs = pushPacked ? 12 : 4;
+    if (const char* e = std::getenv("GOSS_PARSE_POOL")) { const long v = atol(e); if (v >= 1) extraBufs = (size_t)v; }
+    const size_t nbuf = std::min<size_t>((size_t)threads + extraBufs, nchunks + 1);
     std::vector<char*> freeBufs;
     std::vector<void*> allBufs;
     std::atomic<bool> allocFailed{false};
