@@ -3068,12 +3068,16 @@ void group_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, uint32_t sample)
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->arena.release(mark);
     }
-    // 3. range j of every run -> buffers on context j's device (outside the arenas: the arenas are reset below)
-    struct Inbox { uint8_t* keys = nullptr; uint32_t* counts = nullptr; std::vector<uint64_t> off; };
+    // 3. range j of every run -> buffers on context j's device: at the top of context j's own arena where it has the
+    //    room (the arenas of a build without --hbm-budget may have grown to nearly all of HBM: device memory outside
+    //    them is then scarce), else memory of their own.  The top of an arena is temporary space: it is fenced off
+    //    while the context is reset and takes the runs in.
+    struct Inbox { uint8_t* keys = nullptr; uint32_t* counts = nullptr; std::vector<uint64_t> off; bool in_arena = false; uint64_t fence = 0; };
     std::vector<Inbox> inbox(n);
     auto free_all = [&]() {
         for (uint32_t j = 0; j < n; ++j)
         {
+            if (inbox[j].in_arena) continue;
             (void)hipSetDevice(ctxs[j]->device);
             if (inbox[j].keys) (void)hipFree(inbox[j].keys);
             if (inbox[j].counts) (void)hipFree(inbox[j].counts);
@@ -3090,8 +3094,19 @@ void group_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, uint32_t sample)
             const uint64_t tot = in.off[n];
             if (tot == 0) continue;
             HIP_TRY(hipSetDevice(d->device));
-            HIP_TRY(hipMalloc((void**)&in.keys, tot * ksz));
-            HIP_TRY(hipMalloc((void**)&in.counts, tot * 4));
+            // (room for the inbox above the result, and for the runs it becomes plus their merge below it)
+            if (d->arena.avail() >= 3 * tot * (ksz + 4) + (512ULL << 20))
+            {
+                in.counts = (uint32_t*)d->arena.temp(tot * 4);
+                in.keys = (uint8_t*)d->arena.temp(tot * ksz);
+                in.in_arena = true;
+                in.fence = d->arena.hi;
+            }
+            else
+            {
+                HIP_TRY(hipMalloc((void**)&in.keys, tot * ksz));
+                HIP_TRY(hipMalloc((void**)&in.counts, tot * 4));
+            }
             for (uint32_t i = 0; i < n; ++i)
             {
                 const uint64_t cnt = cut[i][j + 1] - cut[i][j];
@@ -3115,11 +3130,13 @@ void group_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, uint32_t sample)
                 goss_gpu_ctx* d = ctxs[j];
                 const uint64_t windows = d->windows, keys_total = d->keys_total;
                 int rc = goss_gpu_reset(d);
+                if (inbox[j].in_arena) d->arena.hi = inbox[j].fence;          // (the reset has given the whole arena back: the inbox lives on)
                 for (uint32_t i = 0; i < n && rc == GOSS_OK; ++i)
                 {
                     const uint64_t cnt = inbox[j].off[i + 1] - inbox[j].off[i];
                     if (cnt) rc = goss_gpu_push_run_device(d, inbox[j].keys + inbox[j].off[i] * ksz, inbox[j].counts + inbox[j].off[i], cnt);
                 }
+                if (inbox[j].in_arena) d->arena.hi = d->arena.size;           // (the runs are copies: the inbox is done)
                 d->windows = windows; d->keys_total = keys_total;
                 goss_gpu_counts cts;
                 if (rc == GOSS_OK) rc = goss_gpu_finish(d, &cts);
