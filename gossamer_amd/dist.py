@@ -289,9 +289,9 @@ _ROUTE_SIZES = {}          # (bases_ptr, nbytes, parts) -> records per part of t
 def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, pieces=0):
     """The exchange before counting: this rank's reads -> super-k-mer records routed by minimizer into one buffer
     per rank (goss_gpu_route_records_device) -> all-to-all(v) of record bytes -> the records this rank received are
-    counted (goss_gpu_push_records_device; not yet finished).  `pieces` (0 = by size): the reads go through these
-    steps in that many pieces, the all-to-all of one overlapping the routing of the next and the counting of the one
-    before.  Returns the windows of this rank's own reads."""
+    counted (goss_gpu_push_records_device; not yet finished).  `pieces` (0 = by size): the reads are routed and
+    exchanged in that many pieces, the all-to-all of one overlapping the routing of the next; what arrived is counted
+    in one go.  Returns the windows of this rank's own reads."""
     import os
     from .binding import RECORD_BYTES as RB
     world = dist.get_world_size(group)
@@ -314,8 +314,8 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         ctx.push_records(sbuf.data_ptr(), sum(recs), sum(wins))
         return sum(wins)
     # The reads are cut into pieces (window starts [s_i, s_i+1): piece i = bytes [s_i, s_i+1 + len - 1), so no window is
-    # lost or taken twice) and the pieces go through route -> all-to-all -> count as a pipeline: while the records of
-    # piece i travel (RCCL's stream), piece i + 1 is routed and piece i - 1 counted (the library's stream).
+    # lost or taken twice) and the pieces go through route -> all-to-all as a pipeline: while the records of piece i
+    # travel (RCCL's stream), piece i + 1 is routed (the library's stream).
     klen = ctx.k + (1 if ctx.mode == MODE_GRAPH else 0)
     nstarts = nbytes - klen + 1 if nbytes >= klen else 0
     if pieces <= 0:
@@ -329,18 +329,20 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         pieces = int(agreed.item())
     cuts = [nstarts * i // pieces for i in range(pieces + 1)]
     own_windows = 0
-    inflight = None          # (works, rbuf, total records, windows, buffers kept alive)
+    # What arrives is gathered in ONE buffer (sized from the first piece: the pieces are alike) and counted in one go
+    # after the last piece has landed: a push is at least one chunk of the counting pipeline, with its sample, its
+    # sizing and a run to merge -- eight pushes of an eighth each cost ~30 ms more per rank than two chunks of a half.
+    # The exchange of a piece hides behind the routing of the next (about the same time at 8 ranks); only the last
+    # piece's is exposed.
+    big, cap, used, windows_in = None, 0, 0, 0
+    extra = []               # pieces that did not fit the gathered buffer: (buffer, records, windows)
+    inflight = None          # (works, buffers kept alive)
 
     def land(job):
-        works, rbuf, total, nwin, keep = job
+        works, keep = job
         for w in works:
             w.wait()
-        if not on_gpu:
-            rbuf = rbuf.to(dev)
-        _sync(dev)
         del keep
-        if total:
-            ctx.push_records(rbuf.data_ptr(), total, nwin)
 
     for i in range(pieces):
         ptr = bases_ptr + cuts[i]
@@ -369,24 +371,39 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         total = sum(recv)
         parts = [sbuf[first[p] * RB:(first[p] + recs[p]) * RB] for p in range(world)]
         largest = max(max(row[:world]) for row in matrix) * RB
-        if on_gpu:
-            rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev)
-        else:
+        if not on_gpu:
             parts = [p.cpu() for p in parts]
-            rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8)
+        if big is None:
+            cap = int(total * pieces * 1.2) + 65536 if pieces > 1 else max(1, total)
+            big = torch.empty(cap * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+        if used + total <= cap:
+            rbuf = big[used * RB:(used + total) * RB]
+            used += total
+            windows_in += recv_windows
+        else:
+            rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+            extra.append((rbuf, total, recv_windows))
         outs, at = [], 0
         for m in recv:
             outs.append(rbuf[at * RB:(at + m) * RB])
             at += m
         # (views of both buffers: nothing is packed or copied on the GPU)
         works = all_to_all_views(outs, parts, largest, group, async_op=on_gpu and pieces > 1)
-        job = (works, rbuf, total, recv_windows, (sbuf, parts, outs))
+        job = (works, (sbuf, parts, outs, rbuf))
         del sbuf, parts, outs, rbuf
         if inflight is not None:
-            land(inflight)          # the previous piece has arrived meanwhile: count it while this one travels
+            land(inflight)          # (the piece before has arrived while this one was routed)
         inflight = job
     if inflight is not None:
         land(inflight)
+    _sync(dev)
+    for buf, nrec, nwin in [(big, used, windows_in)] + extra:
+        if nrec:
+            if not on_gpu:
+                buf = buf[:nrec * RB].to(dev)
+                _sync(dev)
+            ctx.push_records(buf.data_ptr(), nrec, nwin)
+    del big, extra
     return own_windows
 
 def result_views(ctx, words, device):
