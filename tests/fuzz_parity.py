@@ -85,7 +85,33 @@ def main():
         parts = rng.choice([1, 1, 2, 3]) if GROUPS else 1
         try:
             try:
-                if parts == 1:
+                # one-word keys, some cases: the reads go through the routing kernel (super-k-mer records for 1 .. 8
+                # parts) and the context counts the records of all parts -- the exchange before counting, on one GPU
+                via_records = parts == 1 and 2 * (k + (1 if graph else 0)) <= 62 and rng.random() < 0.4
+                if via_records:
+                    import torch
+                    nparts = rng.choice([1, 2, 3, 5, 8])
+                    dev = torch.device("cuda", 0)
+                    with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
+                        bases = torch.frombuffer(bytearray(reads), dtype=torch.uint8).to(dev)
+                        need = [1] * nparts
+                        for attempt in range(2):
+                            first = [sum(need[:p]) for p in range(nparts)]
+                            buf = torch.empty(sum(need) * 12, dtype=torch.uint8, device=dev)
+                            recs, wins, okr = ctx.route_records(bases.data_ptr(), bases.numel(), nparts, buf.data_ptr(), first, need)
+                            need = recs
+                        assert okr
+                        if rng.random() < 0.5:
+                            ctx.push_records(buf.data_ptr(), sum(recs), sum(wins))          # (exact sizes: the parts lie back to back)
+                        else:
+                            for p in range(nparts):
+                                if recs[p]:
+                                    ctx.push_records(buf.data_ptr() + first[p] * 12, recs[p], wins[p])
+                        c = ctx.finish()
+                        got = ctx.emit()
+                        windows = c.windows
+                        stats = {"records": sum(recs), "parts": nparts, "rec_chunks": ctx.stat("rec_chunks"), "fused_chunks": ctx.stat("fused_chunks")}
+                elif parts == 1:
                     with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
                         ctx.push_host(reads)
                         c = ctx.finish()
