@@ -95,7 +95,16 @@ struct goss_gpu_ctx {
     struct Pending { hipEvent_t ev; void (*fn)(void*); void* user; };
     std::vector<Pending> pending;       // asynchronous host pushes whose buffers the caller has not got back yet
     uint64_t flush_wait_us = 0, flush_count_us = 0, flushes = 0;   // staging buffer counted: waiting for queued copies / counting (host wall)
-    uint8_t* stage = nullptr;           // staging buffer for host pushes (top of the arena)
+    // Host pushes are staged in one of TWO buffers (device memory of their own, beside the arena) by copies on a stream of
+    // their own; a full buffer is counted by a thread of the library while the caller goes on filling the other
+    uint8_t* stage_buf[2] = {nullptr, nullptr};
+    int stage_cur = 0;
+    hipStream_t copy_stream = nullptr;
+    std::thread bg;                     // counts a full staging buffer (one at a time)
+    int bg_status = GOSS_OK;
+    std::string bg_error;
+    std::vector<hipEvent_t> pend_pool;  // events of `pending` (the counting thread has event_pool to itself)
+    uint8_t* stage = nullptr;           // the staging buffer being filled (= stage_buf[stage_cur])
     uint64_t stage_cap = 0, stage_fill = 0;
     bool cursor_pass0 = true;           // GOSS_GPU_NO_CURSOR_PASS0=1: look-back chain in every pass
     bool mute_timing = false;           // set around auxiliary launches (the distinct-count estimate)
@@ -247,15 +256,15 @@ void ensure_arena(goss_gpu_ctx* c)
 }
 
 // Grow the arena so that at least `want_avail` bytes are free (or double it when want_avail is 0),
-// up to budget_limit (0 = the budget is fixed): a new mapping, the permanent part and a live
-// staging buffer copied over, every pointer into the arena rebased.  Only legal where the staging
-// buffer is the only live temporary (start of a chunk, start of a merge).  False = not possible.
+// up to budget_limit (0 = the budget is fixed): a new mapping, the permanent part copied over, every
+// pointer into the arena rebased.  Only legal where no temporary is live (start of a chunk, start of a
+// merge; the staging buffers of host pushes are memory of their own).  False = not possible.
 bool grow_arena(goss_gpu_ctx* c, uint64_t want_avail)
 {
     Arena& a = c->arena;
     if (!a.base || c->budget_limit <= a.size) return false;
-    const uint64_t top = a.size - a.hi;                    // live temporaries at the top
-    if (top != 0 && !(c->stage && (uint64_t)(c->stage - a.base) == a.hi)) return false;
+    const uint64_t top = a.size - a.hi;                    // live temporaries at the top: none where growing is legal
+    if (top != 0) return false;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     uint64_t target = std::max<uint64_t>(a.size * 2, a.lo + top + want_avail + (1ULL << 30));
@@ -279,7 +288,6 @@ bool grow_arena(goss_gpu_ctx* c, uint64_t want_avail)
     for (auto& r : c->runs) { rebase(r.keys); rebase(r.counts); }
     rebase(c->res_keys); rebase(c->res_counts);
     for (auto& f : c->files) rebase(f.dev);          // file images already emitted (stand-alone SparseArray builds)
-    if (c->stage) c->stage = nb + target - top + (c->stage - (a.base + a.hi));
     (void)hipFree(a.base);
     a.base = nb; a.hi = target - top; a.size = target;
     c->budget = target;
@@ -1867,12 +1875,7 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
     }
     uint64_t done = 0;
     uint64_t limit = 0;                 // chunk size cap after an out-of-memory retry
-    // the bases may live in the context's own staging buffer, which moves when the arena grows
-    const uint8_t* stage0 = c->stage;
-    auto follow_stage = [&]() {
-        if (stage0 && c->stage != stage0 && d >= stage0 && d < stage0 + c->stage_cap + 16) d = c->stage + (d - stage0);
-        stage0 = c->stage;
-    };
+    auto follow_stage = [] {};          // (staging buffers are outside the arena: growing it moves nothing the bases live in)
     while (done < nstarts_total)
     {
         const bool optimistic = use_segment_path<K>(c);
@@ -2493,8 +2496,13 @@ void emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uin
     c->arena.release(mark);
 }
 
+void wait_background_thread(goss_gpu_ctx* c);
+
+// wait_bg: the call works on the arena or the runs -- the thread that counts a full staging buffer must have ended
+// (its failure becomes this call's).  Only the host pushes, which touch nothing but the other staging buffer, go on
+// beside it.
 template <class F>
-int guarded(goss_gpu_ctx* c, F&& f)
+int guarded(goss_gpu_ctx* c, F&& f, bool wait_bg = true)
 {
     try
     {
@@ -2502,6 +2510,7 @@ int guarded(goss_gpu_ctx* c, F&& f)
         // forget what the calling thread left behind (e.g. hipErrorNotReady from an event or stream
         // poll of the host process): from here on an error is ours
         (void)hipGetLastError();
+        if (c && wait_bg) wait_background_thread(c);
         f();
         // a refused kernel launch raises no exception by itself and leaves its outputs untouched:
         // no entry point returns success over one
@@ -2630,8 +2639,13 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
     if (!c) return;
     if (c->arena_thread.joinable()) c->arena_thread.join();
     (void)hipSetDevice(c->device);
+    if (c->bg.joinable()) c->bg.join();
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& pd : c->pending) { if (pd.fn) pd.fn(pd.user); (void)hipEventDestroy(pd.ev); }
+    for (auto e : c->pend_pool) (void)hipEventDestroy(e);
+    for (auto*& b : c->stage_buf) if (b) (void)hipFree(b);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& pe : c->events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -2645,19 +2659,73 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
 // Host pushes are gathered in a staging buffer in HBM and counted together: every counted chunk
 // becomes a sorted run that has to be merged later, so many small chunks are far more expensive
 // than one large one.  Pushes are separated by one non-base byte (windows never span pushes).
+// The counting thread's outcome, taken over by the caller's thread (every entry point but the host pushes does this
+// first: one thread at a time works on the context's arena and runs).
+static void wait_background(goss_gpu_ctx* c);
+namespace { void wait_background_thread(goss_gpu_ctx* c) { wait_background(c); } }
+static void wait_background(goss_gpu_ctx* c)
+{
+    if (!c->bg.joinable()) return;
+    c->bg.join();
+    if (c->bg_status != GOSS_OK)
+    {
+        const int st = c->bg_status;
+        c->bg_status = GOSS_OK;
+        throw StatusError{st, c->bg_error};
+    }
+}
+
+static void count_staged(goss_gpu_ctx* c, const uint8_t* buf, uint64_t n)
+{
+    const auto t1 = std::chrono::steady_clock::now();
+    if (c->words == 1) push_device<Key1>(c, buf, n); else push_device<Key2>(c, buf, n);
+    c->flush_count_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    c->flushes++;
+}
+
+// What is staged is counted now, on the caller's thread (finish, a device push, anything that needs the runs).
 static void flush_staging(goss_gpu_ctx* c)
 {
+    wait_background(c);
     if (!c->stage || c->stage_fill == 0) return;
     const uint64_t n = c->stage_fill;
     c->stage_fill = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(c->stream));          // (the copies queued so far: counted apart from the chunk's own time)
-    const auto t1 = std::chrono::steady_clock::now();
-    if (c->words == 1) push_device<Key1>(c, c->stage, n); else push_device<Key2>(c, c->stage, n);
-    const auto t2 = std::chrono::steady_clock::now();
-    c->flush_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(t1 - t0).count();
-    c->flush_count_us += (uint64_t)std::chrono::duration<double, std::micro>(t2 - t1).count();
-    c->flushes++;
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));      // (the copies queued so far: counted apart from the chunk's own time)
+    c->flush_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    count_staged(c, c->stage, n);
+}
+
+// A staging buffer is full while the caller keeps pushing: a thread of the library counts it -- its kernels wait on
+// the device for the copies that filled it -- and the caller goes on with the other buffer.
+static void flush_staging_background(goss_gpu_ctx* c)
+{
+    wait_background(c);                                  // (one buffer is counted at a time: this is where a producer that outruns the device waits)
+    if (!c->stage || c->stage_fill == 0) return;
+    const uint64_t n = c->stage_fill;
+    uint8_t* buf = c->stage;
+    hipEvent_t e;
+    if (!c->pend_pool.empty()) { e = c->pend_pool.back(); c->pend_pool.pop_back(); }
+    else HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(e, c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+    c->pend_pool.push_back(e);                           // (the wait has been queued: the event may be recorded again)
+    c->stage_cur ^= 1;
+    c->stage = c->stage_buf[c->stage_cur];
+    c->stage_fill = 0;
+    c->bg_status = GOSS_OK;
+    c->bg = std::thread([c, buf, n]() {
+        try
+        {
+            HIP_TRY(hipSetDevice(c->device));
+            (void)hipGetLastError();
+            count_staged(c, buf, n);
+            check_launch("a kernel launch was refused");
+        }
+        catch (const HipError& e) { c->bg_status = GOSS_ERR_HIP; c->bg_error = std::string(e.what) + ": " + hipGetErrorString(e.e); }
+        catch (const StatusError& e) { c->bg_status = e.status; c->bg_error = e.msg; }
+        catch (const std::bad_alloc&) { c->bg_status = GOSS_ERR_OOM; c->bg_error = "host allocation failed"; }
+    });
 }
 
 int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes)
@@ -2687,7 +2755,7 @@ static void release_pending(goss_gpu_ctx* c, bool wait)
             if (e != hipSuccess) throw HipError{e, "hipEventQuery(pending push)"};
         }
         if (pd.fn) pd.fn(pd.user);
-        c->event_pool.push_back(pd.ev);
+        c->pend_pool.push_back(pd.ev);
     }
     c->pending.erase(c->pending.begin(), c->pending.begin() + done);
 }
@@ -2695,9 +2763,9 @@ static void release_pending(goss_gpu_ctx* c, bool wait)
 static void note_pending(goss_gpu_ctx* c, void (*fn)(void*), void* user)
 {
     hipEvent_t e;
-    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    if (!c->pend_pool.empty()) { e = c->pend_pool.back(); c->pend_pool.pop_back(); }
     else HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipEventRecord(e, c->stream));
+    HIP_TRY(hipEventRecord(e, c->copy_stream));
     c->pending.push_back({e, fn, user});
 }
 
@@ -2706,13 +2774,19 @@ static inline uint64_t land_positions(const goss_gpu_ctx* c) { return std::min<u
 // (landing: codes of a piece, then its flags)
 static void ensure_stage(goss_gpu_ctx* c)
 {
-    ensure_arena(c);
     if (c->stage) return;
-    // 1/24 of the arena: with ~17 bytes of key workspace per base the staged bases then
-    // fill about three quarters of the rest when they are counted
+    wait_background(c);
+    ensure_arena(c);
+    // 1/24 of the arena each: with ~17 bytes of key workspace per base the staged bases then
+    // fill about three quarters of the arena when they are counted
     c->stage_cap = std::max<uint64_t>(c->arena.avail() / 24, 1u << 20) & ~4095ULL;
-    // (one block: the staging buffer, and behind it the landing area of packed pushes -- the arena moves them together when it grows)
-    c->stage = (uint8_t*)c->arena.temp(c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64);
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // (one block each: the staging buffer, and behind it the landing area of packed pushes)
+    const uint64_t bytes = c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64;
+    for (auto*& b : c->stage_buf)
+        if (!b && hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipGetLastError(); b = nullptr; throw StatusError{GOSS_ERR_OOM, "no device memory for the staging buffers"}; }
+    c->stage_cur = 0;
+    c->stage = c->stage_buf[0];
     c->stage_fill = 0;
 }
 static inline uint8_t* landing(goss_gpu_ctx* c) { return c->stage + ((c->stage_cap + 16 + 255) & ~255ULL); }
@@ -2736,22 +2810,23 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
         {
             uint64_t ns = std::min<uint64_t>(c->stage_cap - c->len, nstarts_total - done);
             uint64_t nb = ns + c->len - 1;
-            HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->stream));
-            if (c->words == 1) push_device<Key1>(c, c->stage, nb); else push_device<Key2>(c, c->stage, nb);
+            HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            count_staged(c, c->stage, nb);
             HIP_TRY(hipStreamSynchronize(c->stream));
             done += ns;
         }
         if (release) release(user);
         return;
     }
-    if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging(c);
-    HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging_background(c);
+    HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->copy_stream));
     // reads of two pushes must not join: a separator unless the caller's bytes end with one already
     const bool sep = is_base_byte(bases[nbytes - 1]);
-    if (sep) HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->stream));
+    if (sep) HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->copy_stream));
     c->stage_fill += nbytes + (sep ? 1 : 0);
     if (async) { note_pending(c, release, user); release_pending(c, false); }
-    else { HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, false); if (release) release(user); }
+    else { HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, false); if (release) release(user); }
 }
 
 // packed bases -> landing area -> unpacked into the staging buffer (unpack_bases_kernel), 16 positions per group
@@ -2772,8 +2847,8 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
     if (c->stage_fill & 15ULL)          // (bytes staged by the byte form: pad to a boundary)
     {
         const uint64_t at = (c->stage_fill + 15) & ~15ULL;
-        if (at + 64 < c->stage_cap) { HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->stream)); c->stage_fill = at; }
-        else flush_staging(c);
+        if (at + 64 < c->stage_cap) { HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->copy_stream)); c->stage_fill = at; }
+        else flush_staging_background(c);
     }
     while (pos < nbases)
     {
@@ -2783,7 +2858,7 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         if (room < std::min<uint64_t>((nbases - pos + 15) & ~15ULL, 65536))
         {
             c->stage_fill = at;
-            flush_staging(c);
+            flush_staging_background(c);
             at = 0;
             if (cont)
             {
@@ -2801,42 +2876,42 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         const uint32_t* hc = codes + pos / 16;
         const uint16_t* hb = nonbase + pos / 16;
         if ((const void*)hb == (const void*)(hc + groups))
-            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 6, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 6, hipMemcpyHostToDevice, c->copy_stream));
         else
         {
-            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 4, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->copy_stream));
         }
-        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups + 1, kTB)), dim3(kTB), 0, c->stream, (const uint32_t*)dcodes,
+        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups + 1, kTB)), dim3(kTB), 0, c->copy_stream, (const uint32_t*)dcodes,
                            (const uint16_t*)dbad, groups, n, c->stage + at);
-        if (kill) { HIP_TRY(hipMemsetAsync(c->stage + at, '\n', kill, c->stream)); kill = 0; }
+        if (kill) { HIP_TRY(hipMemsetAsync(c->stage + at, '\n', kill, c->copy_stream)); kill = 0; }
         c->stage_fill = at + (groups + 1) * 16;
         pos += n;
         cont = true;
     }
     if (async) { note_pending(c, release, user); release_pending(c, false); }
-    else { HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, false); if (release) release(user); }
+    else { HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, false); if (release) release(user); }
 }
 
 int goss_gpu_push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes)
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, false, nullptr, nullptr); });
+    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, false, nullptr, nullptr); }, false);
 }
 
 int goss_gpu_push_bases_host_async(goss_gpu_ctx* c, const char* bases, uint64_t nbytes, goss_gpu_release_fn release, void* user)
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, true, release, user); });
+    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, true, release, user); }, false);
 }
 
 int goss_gpu_push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases)
 {
     if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, false, nullptr, nullptr); });
+    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, false, nullptr, nullptr); }, false);
 }
 
 int goss_gpu_push_packed_host_async(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases,
@@ -2844,13 +2919,13 @@ int goss_gpu_push_packed_host_async(goss_gpu_ctx* c, const uint32_t* codes, cons
 {
     if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, true, release, user); });
+    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, true, release, user); }, false);
 }
 
 int goss_gpu_flush(goss_gpu_ctx* c)
 {
     if (!c) return GOSS_ERR_INVALID_ARG;
-    return guarded(c, [&]() { if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream)); release_pending(c, true); });
+    return guarded(c, [&]() { if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, true); }, false);
 }
 
 int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
@@ -2861,7 +2936,6 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
         ensure_arena(c);
         flush_staging(c);
         release_pending(c, true);          // (every asynchronous push has been copied by now: the buffers go back)
-        if (c->stage) { c->stage = nullptr; c->arena.hi = c->arena.size; }    // staging no longer needed
         if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
         if (!c->runs.empty() && c->runs[0].rep)
         {
@@ -3375,7 +3449,8 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         c->finished = c->emitted = false;
         c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;
         c->arena.lo = 0; c->arena.hi = c->arena.size;
-        c->stage = nullptr; c->stage_fill = 0;
+        if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        c->stage_cur = 0; c->stage = c->stage_buf[0]; c->stage_fill = 0;          // (the staging buffers stay)
         c->dump_live = false;
         HIP_TRY(hipMemsetAsync(c->d_flags, 0, 16, c->stream));
     });

@@ -866,6 +866,9 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
 // instead of three reads from three arrays, and 8192 slots fit a CU's LDS (128 KB) -- up to 6144
 // distinct keys per segment counted by one workgroup.  Slot word w: 0 = empty, kSegLock = being
 // written, otherwise the count of a published key (the protocol of seg_hash_reduce2_body).
+#ifndef GOSS_SEG96_PROBE
+#define GOSS_SEG96_PROBE 3          // (C4: 204 ms with 3, 209 with 2, 211 with 4)
+#endif
 struct __attribute__((aligned(16))) Slot96 { uint32_t r0, r1, r2, w; };
 __device__ __forceinline__ uint4 tbl4(const Slot96* t, uint32_t i) { return reinterpret_cast<const uint4*>(t)[i]; }
 
@@ -1031,15 +1034,16 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
         // wave-wide loop costs every lane of the wave its iterations.
         {
             constexpr int kQ = 2;
+            constexpr int kProbe = GOSS_SEG96_PROBE;          // slots read behind the home slot (the rest waits in the wave's queue)
             static_assert(kU % kQ == 0, "pairs");
 #pragma unroll
             for (int h = 0; h < kU / kQ; ++h)
             {
-                uint4 f[kQ][4];
+                uint4 f[kQ][kProbe];
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) f[j][q] = tbl4(tbl, (slots[h * kQ + j] + q) & (SLOTS - 1));
+                    for (int q = 0; q < kProbe; ++q) f[j][q] = tbl4(tbl, (slots[h * kQ + j] + q) & (SLOTS - 1));
 #pragma unroll
                 for (int j = 0; j < kQ; ++j)
                 {
@@ -1048,7 +1052,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
                     // the scalar instructions of exec-mask bookkeeping then outnumber the vector ones)
                     uint32_t off = 4;
 #pragma unroll
-                    for (int q = 3; q >= 0; --q)
+                    for (int q = kProbe - 1; q >= 0; --q)
                     {
                         const uint32_t diff = (f[j][q].x ^ r0[u]) | (f[j][q].y ^ r1[u]) | (f[j][q].z ^ r2[u]);
                         // a published slot: 1 <= w < kSegLock
