@@ -7,7 +7,10 @@
  * reference code whose role it takes over (paths relative to the reference's src/).
  *
  * Conventions: plain pointers and sizes only; every function returns 0 (GOSS_OK) or a
- * negative goss_status; no exceptions cross the boundary; one host thread per context;
+ * negative goss_status; no exceptions cross the boundary; one host thread per context
+ * (the library itself runs one more: a full staging buffer of host pushes is counted by a
+ * thread of its own while the caller fills a second buffer -- every other entry point waits
+ * for that thread first and reports its failure as its own);
  * the library fails loudly (GOSS_ERR_NO_DEVICE) when no gfx950 device is usable -- there is
  * no CPU fallback behind this ABI.
  */
@@ -85,7 +88,9 @@ int goss_gpu_prepare(goss_gpu_ctx* ctx);
  * Takes over: GossRead::Iterator / GossReadBaseString::{firstKmer,nextKmer,getBase,getEdge}
  * (GossRead.hh:57-114, GossReadBaseString.hh:52-188) and the insert loop
  * (GossCmdBuildKmerSet.tcc:246-256 + BackyardHash::insert BackyardHash.cc:115-242).
- * _host: bytes in host memory (pinned memory makes the copy asynchronous);
+ * _host: bytes in host memory (pinned memory makes the copy asynchronous).  Host pushes are gathered in one of two
+ *        staging buffers in device memory beside the arena (1/24 of the arena each) by copies on a stream of the
+ *        context's own; a full buffer is counted in the background while the next pushes fill the other;
  * _device: bytes already resident in HBM on the context's device (not modified).  The context
  *          works on its own stream and does not wait for any other: whatever produced the bytes
  *          (a copy, a kernel on another stream) must have completed before the call.
