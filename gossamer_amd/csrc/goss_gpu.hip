@@ -2780,6 +2780,14 @@ static void ensure_stage(goss_gpu_ctx* c)
     // 1/24 of the arena each: with ~17 bytes of key workspace per base the staged bases then
     // fill about three quarters of the arena when they are counted
     c->stage_cap = std::max<uint64_t>(c->arena.avail() / 24, 1u << 20) & ~4095ULL;
+    {
+        // (an arena that was given nearly all of the device leaves less than that beside it: smaller buffers then)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t room = free_b > (768ULL << 20) ? (free_b - (512ULL << 20)) / 2 : (64ULL << 20);
+        const uint64_t fits = room > (48ULL << 20) ? (room - (32ULL << 20)) * 8 / 11 : (1ULL << 20);      // (buffer + landing = 11/8 of it)
+        if (c->stage_cap > fits) c->stage_cap = std::max<uint64_t>(fits, 1u << 20) & ~4095ULL;
+    }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     // (one block each: the staging buffer, and behind it the landing area of packed pushes)
     const uint64_t bytes = c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64;

@@ -60,3 +60,20 @@ def test_packed_push_larger_than_the_staging_buffer(oracle):
         c = ctx.finish()
         assert c.windows == nwin
         assert ctx.emit() == exp
+
+
+def test_host_pushes_beside_an_arena_that_takes_nearly_all_memory(oracle):
+    """The two staging buffers of host pushes are device memory beside the arena: an arena that was given all but
+    a few GB of the device leaves less than 1/24 of itself twice -- the buffers shrink to what is there."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info(0)
+    k = 25
+    rng = random.Random(2)
+    reads = make_reads(rng, 2000, 150, 20000)
+    ek, ec, nwin = oracle_counts(oracle, reads, k, 0)
+    with g.Context(k, 0, hbm_budget=int(free_b * 0.9)) as ctx:
+        for i in range(0, len(reads), 500):
+            ctx.push_host_async("\n".join(reads[i:i + 500]) + "\n")
+        c = ctx.finish()
+        ks, cs = ctx.result()
+    assert c.windows == nwin and ks == ek and [int(x) for x in cs] == ec
