@@ -3592,7 +3592,7 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
         HIP_TRY(hipMemcpyAsync(dcap, part_cap, nparts * 8, hipMemcpyHostToDevice, c->stream));
         const uint64_t nstarts = nbytes - c->len + 1;
         const uint64_t ntiles = (nstarts + kTB * 16 - 1) / (kTB * 16);
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 4);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * GOSS_ROUTE_OCC);
         const uintptr_t addr = (uintptr_t)d_bases;
         const uint32_t mis = (uint32_t)(addr & 15u);
         const uint8_t* aligned = (const uint8_t*)(addr - mis);
