@@ -10,7 +10,7 @@
 // Routing function: the MINIMIZER of a window = the smallest (under a multiplicative hash) canonical m-mer
 // among its W = len - m + 1 m-mers, canonical = min(m-mer, reverse complement).  The set of canonical m-mers of
 // a window and of its reverse complement are the same set, so both strands of a k-mer have the same minimizer:
-// destination = second hash of the minimizer, scaled to [0, nparts).  Consecutive windows of a read mostly share
+// destination = the low 16 bits of the minimizer's hash, scaled to [0, nparts).  Consecutive windows of a read mostly share
 // their minimizer (~(W + 1) / 2 windows in a row), so a run of windows with one destination travels as ONE
 // record holding its bases once: 12 bytes for up to 16 windows instead of 8 bytes per window.
 //
@@ -46,12 +46,6 @@ __host__ __device__ inline uint32_t route_positions(uint32_t len)
     for (int i = 0; i < 5; ++i)
         if (len >= ws[i] && len - ws[i] + 1 >= (len < 7 ? len : 7) && len - ws[i] + 1 <= 15) return ws[i];
     return 1;      // (len <= 15: the window is its own minimizer)
-}
-
-__device__ __forceinline__ uint32_t route_mix(uint32_t x)
-{
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-    return x;
 }
 
 // reads (ASCII, any non-ACGT byte ends a run of windows) -> records appended to `nparts` buffers.
