@@ -183,6 +183,41 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def multi_gpu_probe(ranks=8):
+    """No multi-GPU node may be at hand: ONE rank's share of a `ranks`-GPU build (C3's share: 125 M reads per GPU),
+    measured on this GPU by child runs of this script (tools/scale_probe.sh does the same for 1 / 2 / 4 / 8):
+      counted_1   the rank alone: the multi-GPU code path with one rank (its N = 1 step);
+      records_N   the rank routes its reads into super-k-mer records as for N destinations and counts all its own
+                  parts: the windows (15.7 G) and distinct keys (125 M) one rank of the real build receives.
+    The projection adds the wire and the second exchange by arithmetic: it is not a measurement."""
+    import subprocess
+    common = ["--force-dist", "--reads", "125000000", "--genome", "125000000", "--steps", "2", "--warmup", "1", "--no-extra",
+              "--no-cpu-baseline", "--e2e-reads", "0"]
+    out = {"what": "one rank's share of a %d-GPU build (125 M reads per GPU) measured on one GPU; projection by arithmetic" % ranks}
+    for name, extra in (("counted_1", ["--exchange", "counted"]), ("records_%d" % ranks, ["--exchange", "records", "--route-parts", str(ranks)])):
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        try:
+            d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            out[name] = {"ms_per_step": d["ms_per_step"], "windows_per_step": d["value"] * 1e6 * d["ms_per_step"] * 1e-3,
+                         "device_ms_per_step": d["roofline"]["device_ms_per_step"]}
+        except (ValueError, IndexError, KeyError):
+            out[name] = {"failed": p.stderr.decode(errors="replace")[-300:]}
+    try:
+        rec, one = out["records_%d" % ranks], out["counted_1"]
+        bytes_per_window = 1.6          # measured: 7.5 windows per 12-byte record at 8 destinations
+        wire_gb = rec["windows_per_step"] * bytes_per_window * (ranks - 1) / ranks / 1e9
+        wire_ms = wire_gb / (ranks - 1) / 50.0 * 1e3          # one xGMI link per peer, 50 GB/s of its 76.8 achieved
+        exposed = wire_ms / 8 + 10.0                           # the last of 8 pieces, and the second exchange + merge
+        step = rec["ms_per_step"] + exposed
+        out["projection"] = {"per_rank_step_ms": step, "ratio_to_one_rank": step / one["ms_per_step"],
+                             "value_M_kmers_per_s": ranks * rec["windows_per_step"] / (step * 1e-3) / 1e6,
+                             "assumed": "records on the wire %.1f GB per rank over %d links at 50 GB/s = %.0f ms, hidden behind the "
+                                        "routing but for one piece of eight; second exchange and merge 10 ms" % (wire_gb, ranks - 1, wire_ms)}
+    except KeyError:
+        pass
+    return out
+
+
 def c4_record(g, torch, device, local_rank):
     """BASELINE config C4: build-graph k = 55 (112-bit edge keys, both strands), 200 M x 150 bp reads of a
     100 Mbp genome, one GPU, Graph emitted; one warm-up and one timed build, inputs resident in HBM."""
@@ -508,6 +543,8 @@ def main():
                 bases = None
                 torch.cuda.empty_cache()
                 out["extra"] = c4_record(g, torch, device, dev_index)
+                torch.cuda.empty_cache()
+                out["multi_gpu_probe"] = multi_gpu_probe(8)
         # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
         import ctypes
         ctypes.CDLL(None).fflush(None)
