@@ -1111,12 +1111,13 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     // same order as the reference: line, fasta, fastq (GossCmdBuildKmerSet.cc:118-141)
     for (auto& f : lines) { log(info, "parsing sequences from " + f); reads += parseLines(f, sink); }
     for (auto& f : fastas) { log(info, "parsing sequences from " + f); reads += parseFasta(f, sink); }
-    // Compressed FASTQ cannot be cut into chunks (one inflate stream per file), but several such
-    // files -- lanes, read pairs -- can be inflated and framed side by side: one worker per file,
+    // Compressed FASTQ (.gz, .bz2) cannot be cut into chunks (one stream per file), but several such
+    // files -- lanes, read pairs -- can be decompressed and framed side by side: one worker per file,
     // each with its own batch, pushes serialised.  The k-mer multiset does not depend on the
     // order in which reads arrive, so the output is the reference's.
     std::vector<std::string> gzFiles;
-    for (auto& f : fastqs) if (endsWith(f, ".gz")) gzFiles.push_back(f);
+    auto compressed = [](const std::string& f) { return endsWith(f, ".gz") || endsWith(f, ".bz2"); };
+    for (auto& f : fastqs) if (compressed(f)) gzFiles.push_back(f);
     if (gzFiles.size() > 1 && threads > 1)
     {
         flush();
@@ -1164,7 +1165,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     }
     for (auto& f : fastqs)
     {
-        if (gzFiles.size() > 1 && threads > 1 && endsWith(f, ".gz")) continue;      // done above
+        if (gzFiles.size() > 1 && threads > 1 && compressed(f)) continue;      // done above
         { std::ostringstream o; o << "parsing sequences from " << f << " (contexts ready at "
             << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s)"; log(info, o.str()); }
         flush();

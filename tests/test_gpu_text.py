@@ -115,7 +115,7 @@ def test_dump_restore_lint(oracle, tmp_path):
 
 
 def test_several_gz_inputs_side_by_side(oracle, tmp_path):
-    """Compressed FASTQ files are inflated and framed by one worker each (-T > 1): the objects must
+    """Compressed FASTQ files (.gz and .bz2) are decompressed and framed by one worker each (-T > 1): the objects must
     be the ones a serial pass over the same files gives, and a framing error in one of them must
     still surface as the reference's message."""
     import gzip
@@ -126,10 +126,13 @@ def test_several_gz_inputs_side_by_side(oracle, tmp_path):
     for i in range(4):
         reads = [genome[s:s + 100] for s in (rng.randrange(0, 4900) for _ in range(800))]
         fq = "".join("@r%d\n%s\n+\n%s\n" % (j, r, "I" * len(r)) for j, r in enumerate(reads))
-        name = "p%d.fq.gz" % i if i < 3 else "p3.fq"
-        if i < 3:
+        name = ("p%d.fq.gz" % i if i < 2 else "p2.fq.bz2") if i < 3 else "p3.fq"
+        if name.endswith(".gz"):
             with gzip.open(tmp_path / name, "wb") as f:
                 f.write(fq.encode())
+        elif name.endswith(".bz2"):
+            import bz2
+            (tmp_path / name).write_bytes(bz2.compress(fq.encode()))
         else:
             (tmp_path / name).write_text(fq)
         inputs.append((oracle.FASTQ, name, fq))
