@@ -14,7 +14,9 @@ show() {
 import json, sys
 try:
     r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("  ms/step %.1f  value %.0f  device %s" % (r["ms_per_step"], r["value"], {k: round(v, 1) for k, v in r["roofline"]["device_ms_per_step"].items()}))
+    dev = r["roofline"]["device_ms_per_step"]
+    print("  ms/step %.1f  value %.0f  device %s  outside the kernel classes (host, copies, exchange with itself) %.1f"
+          % (r["ms_per_step"], r["value"], {k: round(v, 1) for k, v in dev.items()}, r["ms_per_step"] - sum(dev.values())))
 except Exception as e:
     print("  no line:", e)
 PY
