@@ -146,7 +146,7 @@ struct goss_gpu_ctx {
     uint32_t big_table_chunks = 0;      // chunks counted that way
     uint32_t wide_table_chunks = 0;     // ... of them, two-word keys in the 6144-slot table
     bool rec_mode = false;              // the current push is a string of super-k-mer records (goss_gpu_push_records_device): "bases" point at
-                                        // SkRec records, a "window start" is one of a record's P window slots (16, graph mode 8)
+                                        // SkRec records, a "window start" is one of a record's 16 window slots
     uint32_t rec_chunks = 0;            // chunks counted from records by the fused path
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
@@ -1239,7 +1239,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (msd)
     {
         // the sample's joint histogram of both digits (kept out of the per-kernel timing): one pass over the sample
-        // with the bins in LDS (a 16-bit partition of the sample + segment bounds took 2.4 ms on C2, this 0.4)
+        // with the bins in LDS (a 16-bit partition of the sample + segment bounds took 2.4 ms on C2, this 0.9)
         c->mute_timing = true;
         unsigned long long* jh = (unsigned long long*)c->arena.temp(65536 * 8);
         HIP_TRY(hipMemsetAsync(jh, 0, 65536 * 8, c->stream));
@@ -1875,7 +1875,7 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
     }
     uint64_t done = 0;
     uint64_t limit = 0;                 // chunk size cap after an out-of-memory retry
-    auto follow_stage = [] {};          // (staging buffers are outside the arena: growing it moves nothing the bases live in)
+    // (staging buffers are outside the arena: growing it moves nothing the bases live in)
     while (done < nstarts_total)
     {
         const bool optimistic = use_segment_path<K>(c);
@@ -1884,8 +1884,8 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         if (capn < 4096)
         {
             // try to make room by merging what we have
-            if (c->runs.size() > 1) { merge_runs<K>(c); follow_stage(); capn = chunk_capacity(c, false); }
-            if (capn < 4096 && grow_arena(c, 0)) { follow_stage(); capn = chunk_capacity(c, false); }
+            if (c->runs.size() > 1) { merge_runs<K>(c); capn = chunk_capacity(c, false); }
+            if (capn < 4096 && grow_arena(c, 0)) capn = chunk_capacity(c, false);
             if (capn < 4096) throw StatusError{GOSS_ERR_OOM, "HBM budget too small for one chunk"};
         }
         if (limit && capn > limit) capn = limit;
@@ -1914,7 +1914,7 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->arena.lo = lo0; c->arena.hi = hi0;
             c->runs.resize(runs0);
-            if (grow_arena(c, 0)) { follow_stage(); continue; }
+            if (grow_arena(c, 0)) continue;
             limit = (ns / 2) & ~4095ULL;
             continue;
         }
@@ -1925,9 +1925,8 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         if (c->runs.size() > 1 && run_bytes > c->arena.size / 4)
         {
             // merging needs two more copies of the runs: possible now, or after growing; else the
-            // runs wait for finish (which can grow the arena once the staging buffer is gone)
+            // runs wait for finish
             if (c->arena.avail() >= 2 * run_bytes + (512ULL << 20) || grow_arena(c, 2 * run_bytes + (512ULL << 20))) merge_runs<K>(c);
-            follow_stage();
         }
     }
 }
