@@ -3596,11 +3596,13 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
         const uint32_t mis = (uint32_t)(addr & 15u);
         const uint8_t* aligned = (const uint8_t*)(addr - mis);
         const uint32_t maxwin = 16;          // (the counting side takes records of any length in both modes)
+        // slots a workgroup takes ahead per part: ~8 tiles' worth (a tile cuts ~550 records); what it does not use ends as pads
+        const uint32_t block = std::max<uint32_t>(32, std::min<uint32_t>(GOSS_ROUTE_BLOCK, 8 * GOSS_ROUTE_BLOCK / nparts));
         {
             PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
 #define GOSS_LAUNCH_ROUTE(W)                                                                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, nbytes, \
-                       c->len, maxwin, nparts, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles)
+                       c->len, maxwin, nparts, block, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles)
             switch (route_positions(c->len))
             {
                 case 17: GOSS_LAUNCH_ROUTE(17); break;

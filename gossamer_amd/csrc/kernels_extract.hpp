@@ -676,6 +676,10 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // tile it stages up to 512 of them in LDS, takes as many whole records as hold at most T windows (prefix sums of
 // their window counts), and thread t extracts windows 16 t .. 16 t + 15 of the tile's window sequence -- wherever the
 // record boundaries fall -- so every key register holds a valid window whatever the records' lengths are.
+// windows of a record from its third word: bits 28..31 = windows - 1; a PAD (word 1 << 27: a single window's bases end
+// below bit 64, so no record of windows has that bit without bits 28..31) holds none
+constexpr uint32_t kSkPadWord2 = 1u << 27;
+__host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27) == 1u ? 0u : (w2 >> 28) + 1u; }
 template <int MODE, int NH, bool ODD, bool REC = false>
 __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
@@ -774,12 +778,12 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
     uint32_t ra0 = 0, ra1 = 0, ra2 = 0, rb0 = 0, rb1 = 0, rb2 = 0, rna = 0, rnb = 0;      // the records the thread stages next
     uint32_t* rbuf = pk;                                     // [512][3] record words, then [513] prefix sums: phase A's share of `sorted`
     uint32_t* rpre = pk + 512 * 3;
-    uint32_t* rmark = rpre + 520;                            // [256] the record that holds thread g's first window; [256] = records that fit
+    uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
     auto fetch_recs = [&](uint64_t base) {
         const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
         ra0 = ra1 = ra2 = rb0 = rb1 = rb2 = rna = rnb = 0;
-        if (ia < rc_end) { ra0 = recw[3 * ia]; ra1 = recw[3 * ia + 1]; ra2 = recw[3 * ia + 2]; rna = (ra2 >> 28) + 1; }
-        if (ib < rc_end) { rb0 = recw[3 * ib]; rb1 = recw[3 * ib + 1]; rb2 = recw[3 * ib + 2]; rnb = (rb2 >> 28) + 1; }
+        if (ia < rc_end) { ra0 = recw[3 * ia]; ra1 = recw[3 * ia + 1]; ra2 = recw[3 * ia + 2]; rna = rec_windows(ra2); }
+        if (ib < rc_end) { rb0 = recw[3 * ib]; rb1 = recw[3 * ib + 1]; rb2 = recw[3 * ib + 2]; rnb = rec_windows(rb2); }
     };
     if constexpr (REC)
     {
@@ -810,26 +814,33 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
         uint32_t wt = 0;                          // (REC) windows of this tile
         if constexpr (REC)
         {
-            // the staged records and the running sum of their windows; R = the records that fit the tile
-            rbuf[6 * tid] = ra0; rbuf[6 * tid + 1] = ra1; rbuf[6 * tid + 2] = ra2;
-            rbuf[6 * tid + 3] = rb0; rbuf[6 * tid + 4] = rb1; rbuf[6 * tid + 5] = rb2;
-            if (tid == 0) rmark[kTB] = 512;                       // (records that fit: all, unless a thread finds the one that does not)
-            uint32_t tot;
-            const uint32_t ex = block_excl_scan<uint32_t>(rna + rnb, sh_scan, &tot);
+            // The records that hold windows are staged back to back (pads -- the unused ends of the routing kernel's
+            // blocks -- and what lies beyond the share's end hold none and take no place), with the running sum of
+            // their windows: one scan carries both sums (windows <= 8 192 in the low half, staged records above).
+            if (tid == 0) { rmark[kTB] = 512; rmark[kTB + 1] = 0xFFFFFFFFu; }     // (records that fit: all, unless a thread finds the one that does not)
+            const uint32_t pa = rna ? 1u : 0u, pb = rnb ? 1u : 0u;
+            uint32_t tot2;
+            const uint32_t sc = block_excl_scan<uint32_t>((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
+            const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
             const uint32_t ea = ex + rna, eb = ea + rnb;          // ends of the thread's two records in the window sequence
-            rpre[2 * tid] = ex; rpre[2 * tid + 1] = ea;
-            if (tid == kTB - 1) rpre[512] = tot;
-            // the first record that does not fit ends the tile (records beyond the share's end hold no window and fit)
-            if (ex <= (uint32_t)T && eb > (uint32_t)T) rmark[kTB] = 2 * tid + (ea <= (uint32_t)T ? 1u : 0u);
+            if (pa) { rbuf[3 * ca] = ra0; rbuf[3 * ca + 1] = ra1; rbuf[3 * ca + 2] = ra2; rpre[ca] = ex; }
+            if (pb) { rbuf[3 * cb] = rb0; rbuf[3 * cb + 1] = rb1; rbuf[3 * cb + 2] = rb2; rpre[cb] = ea; }
+            // the first record that does not fit ends the tile: records taken from the share, and their windows
+            if (ex <= (uint32_t)T && eb > (uint32_t)T)
+            {
+                const uint32_t one = ea <= (uint32_t)T ? 1u : 0u;
+                rmark[kTB] = 2 * tid + one;
+                rmark[kTB + 1] = one ? ea : ex;
+            }
             // thread g starts at window P g: a record of at most 16 windows holds at most one such window and tells g
             {
                 const uint32_t ga = (ex + P - 1) / P, gb = (ea + P - 1) / P;
-                if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = 2 * tid;
-                if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = 2 * tid + 1;
+                if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = ca;
+                if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = cb;
             }
             __syncthreads();
             const uint32_t nfit = rmark[kTB];
-            wt = rpre[nfit];
+            wt = rmark[kTB + 1] == 0xFFFFFFFFu ? (tot2 & 0xFFFFu) : rmark[kTB + 1];
             rc_next += nfit;
             more = rc_next < rc_end;
             if (more) fetch_recs(rc_next);
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
                 blo = (uint64_t)rbuf[3 * r_at] | ((uint64_t)rbuf[3 * r_at + 1] << 32);
                 const uint32_t w2 = rbuf[3 * r_at + 2];
                 bhi = w2 & 0x0FFFFFFFu;
-                r_nw = (w2 >> 28) + 1;
+                r_nw = (w2 >> 28) + 1;                             // (no pad is staged)
             };
             if constexpr (REC)
             {

@@ -28,8 +28,14 @@ namespace goss {
 #ifndef GOSS_ROUTE_OCC
 #define GOSS_ROUTE_OCC 5          // workgroups per CU the routing kernel is compiled for (96 VGPRs, 25 KB of LDS): 19.2 ms against 20.3 with 4
 #endif
+#ifndef GOSS_ROUTE_BLOCK
+#define GOSS_ROUTE_BLOCK 512      // record slots a routing workgroup takes ahead per part at 8 parts (fewer per part with more parts)
+#endif
 struct SkRec { uint32_t w0, w1, w2; };
 static_assert(sizeof(SkRec) == 12, "records are 12 bytes");
+// A PAD holds no window: words 0, 0, 1 << 27 -- one window (bits 92..95 zero) whose bases would end below bit 64, and a
+// bit above them, which no record of windows has.  The routing kernel fills the unused ends of its blocks with them.
+// (kSkPadWord2, rec_windows: kernels_extract.hpp)
 
 constexpr int kRouteMaxParts = 256;
 struct RouteCounters {
@@ -48,13 +54,36 @@ __host__ __device__ inline uint32_t route_positions(uint32_t len)
     return 1;      // (len <= 15: the window is its own minimizer)
 }
 
+#ifndef GOSS_ROUTE_MUL24
+#define GOSS_ROUTE_MUL24 1
+#endif
+// order of the canonical m-mers / scaling of a 16-bit hash to the parts
+__device__ __forceinline__ uint32_t route_hash(uint32_t c, uint32_t m)
+{
+#if GOSS_ROUTE_MUL24
+    const uint32_t h = __umul24(c, 0x3779B1u);
+    return m > 12 ? h ^ __umul24(c >> 12, 0x5BD1E9u) : h;
+#else
+    (void)m;
+    return c * 0x9E3779B1u;
+#endif
+}
+__device__ __forceinline__ uint32_t route_scale(uint32_t h16, uint32_t nparts)
+{
+#if GOSS_ROUTE_MUL24
+    return __umul24(h16, nparts);
+#else
+    return h16 * nparts;
+#endif
+}
+
 // reads (ASCII, any non-ACGT byte ends a run of windows) -> records appended to `nparts` buffers.
 // out + part_first[p] = first record slot of part p, part_cap[p] its capacity.  Tile = 4096 window starts,
 // 16 per thread; phase A (bytes -> 2-bit codes + non-base flags in LDS) is the extraction kernels'.
 template <int W>
 __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                uint64_t nstarts, uint64_t navail, uint32_t len, uint32_t maxwin,
-                                                               uint32_t nparts, SkRec* __restrict__ out,
+                                                               uint32_t nparts, uint32_t block, SkRec* __restrict__ out,
                                                                const unsigned long long* __restrict__ part_first,
                                                                const unsigned long long* __restrict__ part_cap,
                                                                RouteCounters* __restrict__ rc, uint64_t ntiles)
@@ -66,12 +95,16 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
     __shared__ uint32_t pk[NVEC], iv[NVEC];
     __shared__ uint32_t rkbuf[T];                   // part << 16 | rank of every record inside its part's share of the tile (a record per window at worst)
     __shared__ uint32_t cnt[kRouteMaxParts], win[kRouteMaxParts];
-    __shared__ unsigned long long gbase[kRouteMaxParts];
+    __shared__ unsigned long long gbase[kRouteMaxParts], gbase2[kRouteMaxParts];   // first slot (minus rank) of a tile's records: in the block's rest / in the new room
+    __shared__ uint32_t grem[kRouteMaxParts];                                       // records of the tile that fit the block's rest
+    __shared__ unsigned long long bpos[kRouteMaxParts];                             // the workgroup's block: next free slot of the part
+    __shared__ uint32_t bleft[kRouteMaxParts], wintot[kRouteMaxParts];              // slots left in it | bit 31: it lies inside the part's buffer; the workgroup's windows so far
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ int sh_max[kWaves];
     __shared__ uint32_t lastd[kTB];                 // destination of the thread's last window, or ~0 when it is not valid
     __shared__ uint16_t vmask[kTB], bmask[kTB];     // valid windows / windows that start a run, per thread
     const uint32_t tid = threadIdx.x;
+    if (tid < nparts) { bpos[tid] = 0; wintot[tid] = 0; bleft[tid] = 0; }
     const uint32_t m = len - W + 1;
     const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     (void)maxwin;                                   // (records hold up to 16 windows in both modes)
@@ -154,26 +187,29 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         for (int i = 0; i < P; ++i) dest[i] = 0;
         if (valid)
         {
-            // hashed canonical m-mers at positions 0 .. NPOS-1: forward and reverse complement rolled; the first
-            // m - 1 bases prime the roll, then position `pos` takes base pos + m - 1
+            // hashed canonical m-mers at positions 0 .. NPOS-1
             uint32_t val[NPOS];
-            uint32_t fm = 0, rm = 0;
-            for (uint32_t j = 0; j + 1 < m; ++j)
+            // forward m-mer: rolled (first base most significant); primed with the first m - 1 bases = their 2-bit
+            // groups in reverse order.  Reverse complement at position pos = the complemented bases pos .. pos + m - 1
+            // as they lie in the registers (first base least significant): no roll
+            uint32_t fm;
             {
-                const uint32_t nb = (uint32_t)(blo >> (2 * j)) & 3u;          // (m - 1 <= 14 bases: all in blo)
-                fm = ((fm << 2) | nb) & mmask;
-                rm = (rm >> 2) | ((nb ^ 3u) << (2 * (m - 1)));
+                const uint32_t x = (uint32_t)blo & (mmask >> 2);                     // (m - 1 <= 14 bases: all in blo)
+                const uint32_t r = m > 1 ? __brev(x) >> (32 - 2 * (m - 1)) : 0u;
+                fm = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
             }
             const uint32_t ms = 2 * (m - 1);
             const uint64_t clo = ms ? ((blo >> ms) | (bhi << (64 - ms))) : blo;
             const uint64_t chi = bhi >> ms;
+            const uint32_t nw[4] = {~(uint32_t)blo, ~(uint32_t)(blo >> 32), ~(uint32_t)bhi, ~(uint32_t)(bhi >> 32)};
 #pragma unroll
             for (int pos = 0; pos < NPOS; ++pos)
             {
                 const uint32_t nb = (uint32_t)(pos < 32 ? (clo >> (2 * pos)) : (chi >> (2 * (pos - 32)))) & 3u;
                 fm = ((fm << 2) | nb) & mmask;
-                rm = (rm >> 2) | ((nb ^ 3u) << (2 * (m - 1)));
-                val[pos] = (fm < rm ? fm : rm) * 0x9E3779B1u;
+                const int wi = (2 * pos) >> 5, bs = (2 * pos) & 31;
+                const uint32_t rm = (bs ? __builtin_amdgcn_alignbit(nw[wi + 1 < 4 ? wi + 1 : 3], nw[wi], bs) : nw[wi]) & mmask;
+                val[pos] = route_hash(fm < rm ? fm : rm, m);
             }
             // minimum over W positions for every window
             uint32_t mn[P];
@@ -202,16 +238,12 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             // destination: the low 16 bits of the minimizer's hash (the product's low half: a bijection of the m-mer's
             // last 8 bases, independent of the high bits that made it the minimum), scaled to the parts
 #pragma unroll
-            for (int i = 0; i < P; ++i) dest[i] = ((mn[i] & 0xFFFFu) * nparts) >> 16;
+            for (int i = 0; i < P; ++i) dest[i] = route_scale(mn[i] & 0xFFFFu, nparts) >> 16;
             // windows 1 .. 15 that start a run: valid, and the window before is not or goes elsewhere
+            uint32_t neq = 0;
 #pragma unroll
-            for (int i = 1; i < P; ++i)
-            {
-                const uint32_t ok = (valid >> i) & 1u;
-                const uint32_t prev_ok = (valid >> (i - 1)) & 1u;
-                const uint32_t same = dest[i] == dest[i - 1] ? 1u : 0u;
-                bnd |= (ok & ((prev_ok & same) ^ 1u)) << i;
-            }
+            for (int i = 1; i < P; ++i) neq |= (dest[i] != dest[i - 1] ? 1u : 0u) << i;
+            bnd = valid & (~(valid << 1) | neq) & 0xFFFEu;
             if ((valid >> (P - 1)) & 1u) last = dest[P - 1];
         }
         // Runs are followed ACROSS threads (a record holds up to 16 windows of a run wherever its first lies): window 0
@@ -251,13 +283,13 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         const uint32_t nv = tid + 1 < (uint32_t)kTB ? vmask[tid + 1] : 0u;
         // bit j set: window j (of this thread's 16 and the next thread's 16) starts a run or is not valid
         const uint32_t stop32 = (bnd | (~valid & 0xFFFFu)) | ((nb | (~nv & 0xFFFFu)) << 16);
-#pragma unroll
-        for (int i = 0; i < P; ++i)
+        // records start at a run's windows 0, 16, 32, ..: the run starts among this thread's windows, and the one
+        // window at that distance from the run that comes in from the threads before (cur), unless a run of this
+        // thread starts at or before it
         {
-            const int pos = (int)(tid * P) + i;
-            if ((bnd >> i) & 1u) cur = pos;
-            const uint32_t st = ((valid >> i) & 1u) & ((((uint32_t)(pos - cur)) & 15u) == 0u ? 1u : 0u);
-            starts |= st << i;
+            const uint32_t i0 = (uint32_t)cur & 15u;
+            const uint32_t inc = (cur >= 0 && (bnd & ((2u << i0) - 1u)) == 0u) ? 1u << i0 : 0u;
+            starts = valid & (bnd | inc);
         }
         nrec = __popc(starts);
         // the windows' destinations as bytes of two words: picked by shifting in the loops over the records
@@ -284,19 +316,38 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             }
         }
         __syncthreads();
-        // ---- phase D: room in every part's buffer (one atomic per part and tile), then the records leave --------
+        // ---- phase D: room in every part's buffer, then the records leave ------------------------------------------
+        // A workgroup takes room in blocks: what the tile needs beyond the rest of its block, and `block` slots for the
+        // tiles to come (none after its last tile), with ONE atomic -- one returning atomic per part and tile on 2 nparts
+        // addresses was a third of the kernel's time (13.5 ms against 19 per 40 M reads without them).  A tile's records
+        // of a part are split between the old block's rest (ranks < rem) and the new room.  A block that does not fit the
+        // part's buffer is walked through all the same (nothing stored), so that records[] ends as what a big enough
+        // buffer would have taken, pads included: the caller learns the need.
         if (tid < nparts)
         {
             const uint32_t c = cnt[tid];
-            unsigned long long g = ~0ULL;
+            unsigned long long g0 = ~0ULL, g1 = ~0ULL;
+            uint32_t rem = 0;
             if (c)
             {
-                g = atomicAdd(&rc->records[tid], (unsigned long long)c);
-                if (g + c > part_cap[tid]) { g = ~0ULL; atomicOr(&rc->overflow, 1ULL); }
-                else g += part_first[tid];
-                if (win[tid]) atomicAdd(&rc->windows[tid], (unsigned long long)win[tid]);
+                unsigned long long pos = bpos[tid];
+                uint32_t left = bleft[tid] & 0x7FFFFFFFu, ok = bleft[tid] >> 31;
+                rem = c < left ? c : left;
+                if (rem) { g0 = ok ? part_first[tid] + pos : ~0ULL; pos += rem; left -= rem; }
+                if (c > rem)
+                {
+                    const uint32_t more = c - rem;
+                    const uint32_t take = more + (tile + gridDim.x < ntiles ? block : 0u);
+                    const unsigned long long g = atomicAdd(&rc->records[tid], (unsigned long long)take);
+                    ok = g + take <= part_cap[tid] ? 1u : 0u;
+                    if (!ok) atomicOr(&rc->overflow, 1ULL);
+                    g1 = ok ? part_first[tid] + g - rem : ~0ULL;             // (rank r >= rem goes to slot g + r - rem)
+                    pos = g + more; left = take - more;
+                }
+                bpos[tid] = pos; bleft[tid] = left | (ok << 31);
+                wintot[tid] += win[tid];
             }
-            gbase[tid] = g;
+            gbase[tid] = g0; gbase2[tid] = g1; grem[tid] = rem;
         }
         __syncthreads();
         {
@@ -316,17 +367,29 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
                 const uint64_t klo = nb2 >= 64 ? flo : (flo & ((1ULL << nb2) - 1ULL));
                 const uint32_t khi = nb2 > 64 ? (uint32_t)(fhi & ((1ULL << (nb2 - 64)) - 1ULL)) : 0u;
                 const uint32_t dr = rkbuf[at + r];
-                const unsigned long long g = gbase[dr >> 16];
+                const uint32_t rank = dr & 0xFFFFu;
+                const unsigned long long g = rank < grem[dr >> 16] ? gbase[dr >> 16] : gbase2[dr >> 16];
                 if (g != ~0ULL)
                 {
                     SkRec rec{(uint32_t)klo, (uint32_t)(klo >> 32), khi | ((n - 1) << 28)};
-                    out[g + (dr & 0xFFFFu)] = rec;
+                    out[g + rank] = rec;
                 }
                 ++r;
             }
         }
         __syncthreads();
     }
+    // what is left of the workgroup's blocks is filled with pads (records of no window), and the windows are told
+    for (uint32_t p = 0; p < nparts; ++p)
+    {
+        const uint32_t left = bleft[p] & 0x7FFFFFFFu;
+        if (left && (bleft[p] >> 31))
+        {
+            SkRec* o = out + part_first[p] + bpos[p];
+            for (uint32_t i = tid; i < left; i += kTB) o[i] = SkRec{0u, 0u, kSkPadWord2};
+        }
+    }
+    if (tid < nparts && wintot[tid]) atomicAdd(&rc->windows[tid], (unsigned long long)wintot[tid]);
 }
 
 // records -> keys, densely (the role of extract1_kernel for a record source): one thread per record, its
@@ -355,7 +418,7 @@ __global__ __launch_bounds__(kTB) void extract_records_kernel(const SkRec* __res
         const uint64_t ri = r0 + tid;
         uint32_t nw = 0;
         SkRec rec{0, 0, 0};
-        if (ri < nrecs) { rec = recs[ri]; nw = (rec.w2 >> 28) + 1; }
+        if (ri < nrecs) { rec = recs[ri]; nw = rec_windows(rec.w2); }
         uint32_t tot;
         const uint32_t at = block_excl_scan<uint32_t>(nw * S, sh_scan, &tot);
         if (tid == 0) sh_base = tot ? atomicAdd(&ctr->keys_out, (unsigned long long)tot) : 0ULL;

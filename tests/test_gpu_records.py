@@ -134,6 +134,13 @@ def test_records_at_a_size_the_fused_path_takes_by_itself(oracle):
         _, _, need, _, _ = route(rctx, reads, 8, caps=[1] * 8)
         buf, first, recs, wins, ok = route(rctx, reads, 8, caps=need)          # exact sizes: the parts lie back to back
     assert ok and sum(wins) == nwin and recs == need
+    # the routing workgroups take room in blocks and fill what they do not use with pads (third word 1 << 27, no
+    # window): counted as records, skipped by the counting side
+    w2 = buf.view(torch.int32).view(-1, 3)[:, 2].to(torch.int64) & 0xFFFFFFFF
+    pads = (w2 >> 27) == 1
+    npads = int(pads.sum())
+    assert 0 < npads <= 8 * 1280 * 512, npads
+    assert int(((w2 >> 28) + 1)[~pads].sum()) == nwin
     # one push of everything, as a rank pushes the segments it received from all ranks
     recs, wins, first = [sum(recs)], [sum(wins)], [0]
     ks, cs, c, files, stats = count_parts(k, 0, buf, first, recs, wins, [0], budget=6 << 30)
