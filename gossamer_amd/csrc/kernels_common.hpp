@@ -131,4 +131,21 @@ __global__ __launch_bounds__(kTB) void scan_apply_kernel(uint64_t* __restrict__ 
     }
 }
 
+// Four input bytes -> their 2-bit codes, one per byte (A 0, C 1, G 2, T 3: bits 1-2 of the lower-cased letter, G and T
+// put in order), and `bad` = 0x80 in every byte that is not one of ACGTacgt: the letter the code stands for is
+// looked up by a byte permute and compared -- one non-zero test instead of one per letter.
+// (GossReadBaseString::getBase, GossReadBaseString.hh:52-103: A/a C/c G/g T/t, anything else ends the windows.)
+__device__ __forceinline__ uint32_t base_codes(uint32_t w, uint32_t& bad)
+{
+    const uint32_t l = w | 0x20202020u;
+    uint32_t x = (l >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    const uint32_t v = l ^ __builtin_amdgcn_perm(0u, 0x74676361u, x);        // byte i of the second operand = "acgt"[code i]
+    bad = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+    return x;
+}
+// the codes of four bytes -> 8 bits, their flags -> 4 bits: a multiplication gathers one field per byte in the top byte
+__device__ __forceinline__ uint32_t pack_codes(uint32_t x) { return (x * 0x01041040u) >> 24; }
+__device__ __forceinline__ uint32_t pack_flags(uint32_t bad) { return ((bad >> 7) * 0x01020408u) >> 24; }
+
 }  // namespace goss

@@ -39,7 +39,6 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
                                                              unsigned long long* __restrict__ out)
 {
     unsigned long long bad = 0, seen = 0;
-    auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
     for (uint64_t s = blockIdx.x; s < nslices; s += gridDim.x)
     {
         const uint4* p = reinterpret_cast<const uint4*>(aligned + s * stride);
@@ -50,8 +49,9 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
 #pragma unroll
             for (int i = 0; i < 4; ++i)
             {
-                const uint32_t l = w[i] | 0x20202020u;
-                bad += __popc(nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u));
+                uint32_t b;
+                (void)base_codes(w[i], b);
+                bad += __popc(b);
             }
             seen += 16;
         }
@@ -186,13 +186,9 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i)
         {
-            // SWAR over 4 bytes: lower-case, 2-bit code, validity.
-            uint32_t l = w[i] | 0x20202020u;
-            uint32_t x = (l >> 1) & 0x03030303u;
-            x ^= (x >> 1) & 0x01010101u;
-            // nz(v): 0x80 in every byte of v that is non-zero
-            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
+            // SWAR over 4 bytes: 2-bit code per byte, 0x80 where the byte is no base
+            uint32_t bad;
+            const uint32_t x = base_codes(w[i], bad);
             // bad byte -> code 4
             uint32_t badm = (bad >> 7) * 0xFFu;      // 0xFF in bad bytes
             o[i] = (x & ~badm) | ((bad >> 5) & 0x04040404u);
@@ -340,17 +336,10 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i)
         {
-            uint32_t l = w[i] | 0x20202020u;
-            uint32_t x = (l >> 1) & 0x03030303u;
-            x ^= (x >> 1) & 0x01010101u;
-            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-            // four code bytes -> 8 bits, four bad flags -> 4 bits
-            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-            uint32_t b1 = bad >> 7;
-            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-            codes |= c8 << (8 * i);
-            bads |= b4 << (4 * i);
+            uint32_t bad;
+            const uint32_t x = base_codes(w[i], bad);
+            codes |= pack_codes(x) << (8 * i);
+            bads |= pack_flags(bad) << (4 * i);
         }
         pk[v] = codes;
         iv[v] = bads;
@@ -507,16 +496,10 @@ __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i)
             {
-                uint32_t l = w[i] | 0x20202020u;
-                uint32_t x = (l >> 1) & 0x03030303u;
-                x ^= (x >> 1) & 0x01010101u;
-                auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-                uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-                uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-                uint32_t b1 = bad >> 7;
-                uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-                codes |= c8 << (8 * i);
-                bads |= b4 << (4 * i);
+                uint32_t bad;
+                const uint32_t x = base_codes(w[i], bad);
+                codes |= pack_codes(x) << (8 * i);
+                bads |= pack_flags(bad) << (4 * i);
             }
             pk[v] = codes;
             iv[v] = bads;
@@ -753,16 +736,10 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i)
         {
-            uint32_t l = w[i] | 0x20202020u;
-            uint32_t x = (l >> 1) & 0x03030303u;
-            x ^= (x >> 1) & 0x01010101u;
-            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-            uint32_t b1 = bad >> 7;
-            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-            codes |= c8 << (8 * i);
-            bads |= b4 << (4 * i);
+            uint32_t bad;
+            const uint32_t x = base_codes(w[i], bad);
+            codes |= pack_codes(x) << (8 * i);
+            bads |= pack_flags(bad) << (4 * i);
         }
     };
     // The bytes of a tile are fetched one tile ahead and wait, encoded, in registers: the load's
@@ -1209,16 +1186,10 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i)
         {
-            uint32_t l = w[i] | 0x20202020u;
-            uint32_t x = (l >> 1) & 0x03030303u;
-            x ^= (x >> 1) & 0x01010101u;
-            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
-            uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-            uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-            uint32_t b1 = bad >> 7;
-            uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-            codes |= c8 << (8 * i);
-            bads |= b4 << (4 * i);
+            uint32_t bad;
+            const uint32_t x = base_codes(w[i], bad);
+            codes |= pack_codes(x) << (8 * i);
+            bads |= pack_flags(bad) << (4 * i);
         }
     };
     constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..5 also vector NV0 + tid

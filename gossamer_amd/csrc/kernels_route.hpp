@@ -61,8 +61,9 @@ __host__ __device__ inline uint32_t route_positions(uint32_t len)
 __device__ __forceinline__ uint32_t route_hash(uint32_t c, uint32_t m)
 {
 #if GOSS_ROUTE_MUL24
-    const uint32_t h = __umul24(c, 0x3779B1u);
-    return m > 12 ? h ^ __umul24(c >> 12, 0x5BD1E9u) : h;
+    // (the low 12 bases of a longer m-mer order it: m-mers that agree there tie, and ties go to the same part)
+    (void)m;
+    return __umul24(c, 0x3779B1u);
 #else
     (void)m;
     return c * 0x9E3779B1u;
@@ -135,16 +136,10 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
 #pragma unroll
             for (int i = 0; i < 4; ++i)
             {
-                const uint32_t l = w[i] | 0x20202020u;
-                uint32_t x = (l >> 1) & 0x03030303u;
-                x ^= (x >> 1) & 0x01010101u;
-                auto nz = [](uint32_t u) { return (((u & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | u) & 0x80808080u; };
-                const uint32_t bad = nz(l ^ 0x61616161u) & nz(l ^ 0x63636363u) & nz(l ^ 0x67676767u) & nz(l ^ 0x74747474u);
-                const uint32_t c8 = (x & 0x3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-                const uint32_t b1 = bad >> 7;
-                const uint32_t b4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-                codes |= c8 << (8 * i);
-                bads |= b4 << (4 * i);
+                uint32_t bad;
+                const uint32_t x = base_codes(w[i], bad);
+                codes |= pack_codes(x) << (8 * i);
+                bads |= pack_flags(bad) << (4 * i);
             }
             if (byte0 < mis) bads |= (1u << (uint32_t)(mis - byte0 > 16 ? 16 : mis - byte0)) - 1u;
             pk[v] = codes; iv[v] = bads;
@@ -310,7 +305,8 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
                 const uint32_t stop = (stop32 >> s) & ~1u;                         // bit j set: window s + j ends the run
                 const uint32_t n = stop ? min(16u, (uint32_t)__ffs(stop) - 1u) : 16u;
                 const uint32_t d = (uint32_t)((s < 8 ? dp0 >> (8 * s) : dp1 >> (8 * (s - 8))) & 0xFFu);
-                rkbuf[at + r] = (d << 16) | atomicAdd(&cnt[d], 1u);
+                // rank in the part's share of the tile (< 4 096) | windows - 1 << 12 | part << 16 | first window << 24
+                rkbuf[at + r] = atomicAdd(&cnt[d], 1u) | ((n - 1) << 12) | (d << 16) | (s << 24);
                 atomicAdd(&win[d], n);
                 ++r;
             }
@@ -351,30 +347,24 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         }
         __syncthreads();
         {
-            uint32_t todo = starts, r = 0;
-            while (todo)
+            const uint32_t b0 = (uint32_t)blo, b1 = (uint32_t)(blo >> 32), b2 = (uint32_t)bhi, b3 = (uint32_t)(bhi >> 32);
+            for (uint32_t r = 0; r < nrec; ++r)
             {
-                const uint32_t s = __ffs(todo) - 1;
-                todo &= todo - 1;
-                const uint32_t stop = (stop32 >> s) & ~1u;
-                const uint32_t n = stop ? min(16u, (uint32_t)__ffs(stop) - 1u) : 16u;
-                const uint32_t nbases = n + len - 1;                               // <= 46
-                // bases s .. s + nbases - 1 of this thread
-                const uint32_t ss = 2 * s;
-                const uint64_t flo = ss ? ((blo >> ss) | (bhi << (64 - ss))) : blo;
-                const uint64_t fhi = bhi >> ss;
-                const uint32_t nb2 = 2 * nbases;
-                const uint64_t klo = nb2 >= 64 ? flo : (flo & ((1ULL << nb2) - 1ULL));
-                const uint32_t khi = nb2 > 64 ? (uint32_t)(fhi & ((1ULL << (nb2 - 64)) - 1ULL)) : 0u;
                 const uint32_t dr = rkbuf[at + r];
-                const uint32_t rank = dr & 0xFFFFu;
-                const unsigned long long g = rank < grem[dr >> 16] ? gbase[dr >> 16] : gbase2[dr >> 16];
+                const uint32_t rank = dr & 0xFFFu, n1 = (dr >> 12) & 15u, d = (dr >> 16) & 0xFFu, ss = (dr >> 24) * 2;
+                // bases s .. s + n + len - 2 of this thread (2 s <= 30: three funnel shifts)
+                const uint32_t f0 = __builtin_amdgcn_alignbit(b1, b0, ss), f1 = __builtin_amdgcn_alignbit(b2, b1, ss);
+                const uint32_t f2 = __builtin_amdgcn_alignbit(b3, b2, ss);
+                const uint32_t nb2 = 2 * (n1 + len);                               // <= 92
+                const uint64_t flo = (uint64_t)f0 | ((uint64_t)f1 << 32);
+                const uint64_t klo = nb2 >= 64 ? flo : (flo & ((1ULL << nb2) - 1ULL));
+                const uint32_t khi = nb2 > 64 ? (f2 & ((1u << (nb2 - 64)) - 1u)) : 0u;
+                const unsigned long long g = rank < grem[d] ? gbase[d] : gbase2[d];
                 if (g != ~0ULL)
                 {
-                    SkRec rec{(uint32_t)klo, (uint32_t)(klo >> 32), khi | ((n - 1) << 28)};
+                    SkRec rec{(uint32_t)klo, (uint32_t)(klo >> 32), khi | (n1 << 28)};
                     out[g + rank] = rec;
                 }
-                ++r;
             }
         }
         __syncthreads();
