@@ -207,12 +207,18 @@ def multi_gpu_probe(ranks=8):
         bytes_per_window = 1.6          # measured: 7.5 windows per 12-byte record at 8 destinations
         wire_gb = rec["windows_per_step"] * bytes_per_window * (ranks - 1) / ranks / 1e9
         wire_ms = wire_gb / (ranks - 1) / 50.0 * 1e3          # one xGMI link per peer, 50 GB/s of its 76.8 achieved
-        exposed = wire_ms / 8 + 10.0                           # the last of 8 pieces, and the second exchange + merge
+        # gossamer_amd/dist.py: the pieces are routed back to back, their all-to-alls queue on RCCL's stream, and the
+        # first half of the records is counted while the second half travels: the wire runs beside device work unless
+        # it is longer than half of the step; while it is busy RCCL's copy kernels hold about a tenth of the CUs
+        exposed = max(0.0, wire_ms - 0.5 * rec["ms_per_step"]) + 0.1 * wire_ms + 10.0          # + the second exchange and merge
         step = rec["ms_per_step"] + exposed
         out["projection"] = {"per_rank_step_ms": step, "ratio_to_one_rank": step / one["ms_per_step"],
                              "value_M_kmers_per_s": ranks * rec["windows_per_step"] / (step * 1e-3) / 1e6,
-                             "assumed": "records on the wire %.1f GB per rank over %d links at 50 GB/s = %.0f ms, hidden behind the "
-                                        "routing but for one piece of eight; second exchange and merge 10 ms" % (wire_gb, ranks - 1, wire_ms)}
+                             "assumed": "records on the wire %.1f GB per rank over %d links at 50 GB/s = %.0f ms, beside the routing of "
+                                        "the later pieces and the counting of the first half of the records (exposed: what exceeds "
+                                        "half of the step, here %.0f ms; a tenth of the wire time for RCCL's kernels on the CUs); "
+                                        "second exchange and merge 10 ms"
+                                        % (wire_gb, ranks - 1, wire_ms, max(0.0, wire_ms - 0.5 * rec["ms_per_step"]))}
     except KeyError:
         pass
     return out

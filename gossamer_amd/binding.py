@@ -280,11 +280,13 @@ class Context:
         self._L.goss_gpu_push_keys_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         self._check(self._L.goss_gpu_push_keys_device(self._h, C.c_void_p(ptr), n))
 
-    def route_records(self, bases_ptr, nbytes, nparts, records_ptr, part_first, part_cap):
+    def route_records(self, bases_ptr, nbytes, nparts, records_ptr, part_first, part_cap, ready=False):
         """goss_gpu_route_records_device: the windows of a device-resident base string as super-k-mer records in
-        nparts buffers.  Returns (records per part, windows per part, ok); ok False = some part_cap was too small
-        and `records` holds what every part needs."""
-        _torch_ready()
+        nparts buffers.  Returns (record slots filled per part -- pads, records of no window, included --, windows per
+        part, ok); ok False = some part_cap was too small and `records` holds what every part needs.  ready: the
+        caller has waited for whatever wrote the bases (no device-wide synchronisation here)."""
+        if not ready:
+            _torch_ready()
         U = C.c_uint64 * nparts
         first, cap, recs, wins = U(*part_first), U(*part_cap), U(), U()
         self._L.goss_gpu_route_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
@@ -296,9 +298,11 @@ class Context:
             self._check(rc)
         return [int(x) for x in recs], [int(x) for x in wins], rc == 0
 
-    def push_records(self, records_ptr, nrecords, nwindows=0):
-        """goss_gpu_push_records_device: count the windows of super-k-mer records resident in HBM."""
-        _torch_ready()
+    def push_records(self, records_ptr, nrecords, nwindows=0, ready=False):
+        """goss_gpu_push_records_device: count the windows of super-k-mer records resident in HBM.  ready: the caller
+        has waited for whatever wrote the records (no device-wide synchronisation here: other streams go on)."""
+        if not ready:
+            _torch_ready()
         self._L.goss_gpu_push_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         self._check(self._L.goss_gpu_push_records_device(self._h, C.c_void_p(records_ptr), nrecords, nwindows))
 

@@ -166,6 +166,7 @@ struct goss_gpu_ctx {
     std::vector<OutFile> files;
     ExtractCounters* d_ctr = nullptr;     // device counters
     uint32_t* d_flags = nullptr;          // device error flags [0]=count overflow [1]=ef overflow
+    void* d_route = nullptr;              // RouteCounters + the parts' first slots and capacities (goss_gpu_route_records_device)
     void* h_pinned = nullptr;             // pinned scratch (>= 64 bytes)
     std::vector<PhaseEvents> events;
     std::vector<hipEvent_t> event_pool;
@@ -2650,6 +2651,7 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_route) (void)hipFree(c->d_route);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -3579,12 +3581,13 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
     return guarded(c, [&]() {
         for (uint32_t p = 0; p < nparts; ++p) { part_records[p] = 0; if (part_windows) part_windows[p] = 0; }
         if (nbytes < c->len) return;
-        // counters and the parts' places: a small device block of its own (the arena may not be mapped yet, and need not be)
-        struct Dev { void* p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } dev;
+        // counters and the parts' places: a small device block of its own (the arena may not be mapped yet, and need not
+        // be), kept for the context's life -- hipFree waits for the whole device, also for a collective of the caller
+        // that is still moving the records of the piece before
         const size_t tab = (size_t)kRouteMaxParts * 8;
-        HIP_TRY(hipMalloc(&dev.p, sizeof(RouteCounters) + 2 * tab));
-        RouteCounters* rc = (RouteCounters*)dev.p;
-        unsigned long long* dfirst = (unsigned long long*)((uint8_t*)dev.p + sizeof(RouteCounters));
+        if (!c->d_route) HIP_TRY(hipMalloc(&c->d_route, sizeof(RouteCounters) + 2 * tab));
+        RouteCounters* rc = (RouteCounters*)c->d_route;
+        unsigned long long* dfirst = (unsigned long long*)((uint8_t*)c->d_route + sizeof(RouteCounters));
         unsigned long long* dcap = dfirst + kRouteMaxParts;
         HIP_TRY(hipMemsetAsync(rc, 0, sizeof(RouteCounters), c->stream));
         HIP_TRY(hipMemcpyAsync(dfirst, part_first, nparts * 8, hipMemcpyHostToDevice, c->stream));

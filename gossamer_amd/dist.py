@@ -329,20 +329,21 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         pieces = int(agreed.item())
     cuts = [nstarts * i // pieces for i in range(pieces + 1)]
     own_windows = 0
-    # What arrives is gathered in ONE buffer (sized from the first piece: the pieces are alike) and counted in one go
-    # after the last piece has landed: a push is at least one chunk of the counting pipeline, with its sample, its
-    # sizing and a run to merge -- eight pushes of an eighth each cost ~30 ms more per rank than two chunks of a half.
-    # The exchange of a piece hides behind the routing of the next (about the same time at 8 ranks); only the last
-    # piece's is exposed.
-    big, cap, used, windows_in = None, 0, 0, 0
-    extra = []               # pieces that did not fit the gathered buffer: (buffer, records, windows)
-    inflight = None          # (works, buffers kept alive)
-
-    def land(job):
-        works, keep = job
-        for w in works:
-            w.wait()
-        del keep
+    _sync(dev)               # the bases are there; from here on only single streams are waited for
+    # What arrives is gathered in TWO buffers -- the first half of the pieces and the rest -- and each is counted in one
+    # go: a push is at least one chunk of the counting pipeline, with its sample, its sizing and a run to merge (eight
+    # pushes of an eighth each cost ~30 ms more per rank than two chunks of a half), and 125 M reads per rank are two
+    # chunks anyway.  Schedule at 8 ranks: the pieces are routed back to back (~5 ms each) and their all-to-alls queue up
+    # on RCCL's stream (~8 ms each: the wire is the slower of the two); the first half has landed when the last piece is
+    # routed and is counted WHILE the second half travels; only then is the second half waited for.  For that the sizes
+    # of a piece (a matrix of 2 x world numbers) must not queue behind the previous piece's records: they go through a
+    # group of their own (_meta_group: gloo beside RCCL).
+    side = world > 1 and (on_gpu or os.environ.get("GOSS_DIST_META_GROUP") == "1")          # (the variable: for the tests under gloo)
+    meta = _meta_group(group) if side else group
+    mdev = torch.device("cpu") if side else xdev
+    halves = [list(range((pieces + 1) // 2)), list(range((pieces + 1) // 2, pieces))] if pieces >= 2 else [list(range(pieces))]
+    gather = [{"buf": None, "cap": 0, "used": 0, "windows": 0, "extra": []} for _ in halves]
+    jobs = [None] * pieces       # (works, buffers kept alive)
 
     for i in range(pieces):
         ptr = bases_ptr + cuts[i]
@@ -354,7 +355,7 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         for attempt in range(2):
             first = [sum(caps[:p]) for p in range(world)]
             sbuf = torch.empty(max(1, sum(caps)) * RB, dtype=torch.uint8, device=dev)
-            recs, wins, ok = ctx.route_records(ptr, n, world, sbuf.data_ptr(), first, caps)
+            recs, wins, ok = ctx.route_records(ptr, n, world, sbuf.data_ptr(), first, caps, ready=True)
             if ok:
                 break
             del sbuf
@@ -362,9 +363,9 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         else:
             raise RuntimeError("routing did not fit the sizes it asked for")
         own_windows += sum(wins)
-        mine = torch.tensor(recs + wins, dtype=torch.int64, device=xdev)
+        mine = torch.tensor(recs + wins, dtype=torch.int64, device=mdev)
         rows = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(rows, mine, group=group)
+        dist.all_gather(rows, mine, group=meta)
         matrix = torch.stack(rows).cpu().tolist()
         recv = [int(matrix[q][rank]) for q in range(world)]
         recv_windows = sum(int(matrix[q][world + rank]) for q in range(world))
@@ -373,38 +374,59 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         largest = max(max(row[:world]) for row in matrix) * RB
         if not on_gpu:
             parts = [p.cpu() for p in parts]
-        if big is None:
-            cap = int(total * pieces * 1.2) + 65536 if pieces > 1 else max(1, total)
-            big = torch.empty(cap * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
-        if used + total <= cap:
-            rbuf = big[used * RB:(used + total) * RB]
-            used += total
-            windows_in += recv_windows
+        h = 0 if i in halves[0] else 1
+        g = gather[h]
+        if g["buf"] is None:          # sized from the half's first piece: the pieces are alike
+            g["cap"] = int(total * len(halves[h]) * 1.2) + 65536 if len(halves[h]) > 1 else max(1, total)
+            g["buf"] = torch.empty(g["cap"] * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+        if g["used"] + total <= g["cap"]:
+            rbuf = g["buf"][g["used"] * RB:(g["used"] + total) * RB]
+            g["used"] += total
+            g["windows"] += recv_windows
         else:
             rbuf = torch.empty(max(1, total) * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
-            extra.append((rbuf, total, recv_windows))
+            g["extra"].append((rbuf, total, recv_windows))
         outs, at = [], 0
         for m in recv:
             outs.append(rbuf[at * RB:(at + m) * RB])
             at += m
         # (views of both buffers: nothing is packed or copied on the GPU)
         works = all_to_all_views(outs, parts, largest, group, async_op=on_gpu and pieces > 1)
-        job = (works, (sbuf, parts, outs, rbuf))
+        jobs[i] = (works, (sbuf, parts, outs, rbuf))
         del sbuf, parts, outs, rbuf
-        if inflight is not None:
-            land(inflight)          # (the piece before has arrived while this one was routed)
-        inflight = job
-    if inflight is not None:
-        land(inflight)
-    _sync(dev)
-    for buf, nrec, nwin in [(big, used, windows_in)] + extra:
-        if nrec:
-            if not on_gpu:
-                buf = buf[:nrec * RB].to(dev)
-                _sync(dev)
-            ctx.push_records(buf.data_ptr(), nrec, nwin)
-    del big, extra
+    for h, g in enumerate(gather):
+        for i in halves[h]:
+            works, keep = jobs[i]
+            for w in works:
+                w.wait()          # (RCCL: the current stream waits for the collective; the host goes on)
+            jobs[i] = None
+            del keep
+        # the host waits for THIS half only: what is still queued on RCCL's stream travels while the half is counted
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        for buf, nrec, nwin in [(g["buf"], g["used"], g["windows"])] + g["extra"]:
+            if nrec:
+                if not on_gpu:
+                    buf = buf[:nrec * RB].to(dev)
+                    _sync(dev)
+                ctx.push_records(buf.data_ptr(), nrec, nwin, ready=True)
+        g["buf"] = None
+        g["extra"] = []
     return own_windows
+
+
+_META_GROUPS = {}
+
+
+def _meta_group(group):
+    """A gloo group with the ranks of `group`, for the few numbers that must not wait behind bulk data queued on
+    RCCL's stream (collectives of one communicator run in order).  Made once per group, by all its ranks together."""
+    key = id(group) if group is not None else 0
+    if key not in _META_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        _META_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _META_GROUPS[key]
+
 
 def result_views(ctx, words, device):
     """zero-copy views of the context's result: valid until its next emit, reset, push or close"""

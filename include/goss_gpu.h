@@ -474,8 +474,9 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  * (2*len <= 62, len = k or k + 1) route; others get GOSS_ERR_INVALID_ARG.
  *   d_records           device memory for the records of all parts
  *   part_first[p]       first record slot of part p inside d_records, part_cap[p] the slots it may use
- *   part_records[p]     (out) records of part p -- what it NEEDS when the call returns GOSS_ERR_BUFFER because some
- *                       part_cap was too small (nothing usable was written for that part: call again with room)
+ *   part_records[p]     (out) record slots of part p that were filled, pads included (below) -- what it NEEDS when the
+ *                       call returns GOSS_ERR_BUFFER because some part_cap was too small (nothing usable was written
+ *                       for that part: call again with room; the need of an input is the same in every call)
  *   part_windows[p]     (out, may be NULL) windows routed to part p
  * The context only lends its device, stream and (k, mode): nothing is counted and no state changes.
  *
@@ -484,7 +485,11 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  * which sizes the key buffers.  Records and bases may be mixed in one build.
  *
  * Record layout (little endian, three u32): bits 0..91 the run's nwin + len - 1 <= 46 bases as 2-bit codes
- * (A=0 C=1 G=2 T=3), base j at bits [2j, 2j+2); bits 92..95 nwin - 1.
+ * (A=0 C=1 G=2 T=3), base j at bits [2j, 2j+2), zero above them; bits 92..95 nwin - 1.
+ * A PAD is the record {0, 0, 1 << 27} -- no window: the routing kernel takes room in blocks (<= 512 slots per
+ * workgroup and part) and fills what it does not use with pads; they are slots of the part like any record, travel
+ * with it and are dropped by goss_gpu_push_records_device (no record of windows has bit 91 set with bits 92..95 zero:
+ * a single window's bases end below bit 64).  About 0.1 % of the slots of a large input.
  */
 #define GOSS_RECORD_BYTES 12
 int goss_gpu_route_records_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t nparts, void* d_records,

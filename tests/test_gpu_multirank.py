@@ -43,6 +43,8 @@ def _worker(rank, world, port, cases, q):
             kind, k, name = case["kind"], case["k"], case["name"]
             graph = kind == "graph"
             key_bits = 2 * (k + 1 if graph else k)
+            # (the sizes of a piece of records through a gloo group beside the data's group, as under RCCL)
+            os.environ["GOSS_DIST_META_GROUP"] = "1" if case.get("meta_group") else "0"
             with gg.Context(k, gg.MODE_GRAPH if graph else gg.MODE_KMER_SET, device=0, hbm_budget=768 << 20) as ctx:
                 if kind in ("kmer", "graph"):
                     buf = torch.frombuffer(bytearray(case["shards"][rank]), dtype=torch.uint8).to(dev)
@@ -132,6 +134,7 @@ def _build_cases(oracle, world):
     # ... in three pieces: the all-to-all of one piece overlaps the routing of the next and the counting of the one before
     cases.append(dict(cases[0], name="kmer k=25, records in 3 pieces", exchange="records", pieces=3))
     cases.append(dict(cases[2], name="graph k=27, records in 3 pieces", exchange="records", pieces=3))
+    cases.append(dict(cases[0], name="kmer k=25, records in 5 pieces, sizes through a side group", exchange="records", pieces=5, meta_group=True))
     return cases
 
 
