@@ -339,19 +339,38 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
     # of a piece (a matrix of 2 x world numbers) must not queue behind the previous piece's records: they go through a
     # group of their own (_meta_group: gloo beside RCCL).
     side = world > 1 and (on_gpu or os.environ.get("GOSS_DIST_META_GROUP") == "1")          # (the variable: for the tests under gloo)
-    meta = _meta_group(group) if side else group
+    meta = _meta_group(group) if side else None
+    if meta is None:
+        meta, side = group, False
     mdev = torch.device("cpu") if side else xdev
     halves = [list(range((pieces + 1) // 2)), list(range((pieces + 1) // 2, pieces))] if pieces >= 2 else [list(range(pieces))]
     gather = [{"buf": None, "cap": 0, "used": 0, "windows": 0, "extra": []} for _ in halves]
     jobs = [None] * pieces       # (works, buffers kept alive)
+    depth = 4                    # pieces on their way at once: their send buffers are the memory this loop holds
 
+    def landed(i):
+        """piece i has arrived (the host waits for ITS all-to-all, not for the device); its send buffer is let go"""
+        if jobs[i] is None:
+            return
+        works, keep = jobs[i]
+        for w in works:
+            w.wait()              # (RCCL: the current stream waits for the collective ...)
+        if works and dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()          # (... and the host for the current stream)
+        jobs[i] = None
+        del keep
+
+    last_recs = None
     for i in range(pieces):
+        if i >= depth:
+            landed(i - depth)
         ptr = bases_ptr + cuts[i]
         n = nbytes - cuts[i] if i == pieces - 1 else min(cuts[i + 1] - cuts[i] + klen - 1, nbytes - cuts[i])
-        # room per part: ~6 windows per record at 8 parts (fewer parts cut less often), a third of slack; a part that
-        # needs more is reported by the library and the routing is redone with exact sizes
+        # room per part: ~6 windows per record at 8 parts (fewer parts cut less often), a third of slack -- after the
+        # first piece what that piece took and a twentieth (the pieces are alike); a part that needs more is reported
+        # by the library and the routing is redone with exact sizes
         guess = n // 5 // world + n // 15 // world + 4096
-        caps = [guess] * world
+        caps = [guess] * world if last_recs is None else [r + r // 20 + 4096 for r in last_recs]
         for attempt in range(2):
             first = [sum(caps[:p]) for p in range(world)]
             sbuf = torch.empty(max(1, sum(caps)) * RB, dtype=torch.uint8, device=dev)
@@ -363,6 +382,7 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         else:
             raise RuntimeError("routing did not fit the sizes it asked for")
         own_windows += sum(wins)
+        last_recs = recs
         mine = torch.tensor(recs + wins, dtype=torch.int64, device=mdev)
         rows = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(rows, mine, group=meta)
@@ -377,7 +397,7 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         h = 0 if i in halves[0] else 1
         g = gather[h]
         if g["buf"] is None:          # sized from the half's first piece: the pieces are alike
-            g["cap"] = int(total * len(halves[h]) * 1.2) + 65536 if len(halves[h]) > 1 else max(1, total)
+            g["cap"] = int(total * len(halves[h]) * 1.08) + 65536 if len(halves[h]) > 1 else max(1, total)
             g["buf"] = torch.empty(g["cap"] * RB, dtype=torch.uint8, device=dev if on_gpu else "cpu")
         if g["used"] + total <= g["cap"]:
             rbuf = g["buf"][g["used"] * RB:(g["used"] + total) * RB]
@@ -395,13 +415,9 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         jobs[i] = (works, (sbuf, parts, outs, rbuf))
         del sbuf, parts, outs, rbuf
     for h, g in enumerate(gather):
-        for i in halves[h]:
-            works, keep = jobs[i]
-            for w in works:
-                w.wait()          # (RCCL: the current stream waits for the collective; the host goes on)
-            jobs[i] = None
-            del keep
         # the host waits for THIS half only: what is still queued on RCCL's stream travels while the half is counted
+        for i in halves[h]:
+            landed(i)
         if dev.type == "cuda":
             torch.cuda.current_stream(dev).synchronize()
         for buf, nrec, nwin in [(g["buf"], g["used"], g["windows"])] + g["extra"]:
@@ -424,7 +440,10 @@ def _meta_group(group):
     key = id(group) if group is not None else 0
     if key not in _META_GROUPS:
         ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-        _META_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+        try:
+            _META_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+        except Exception:          # no gloo here (all ranks of a node fail alike): the sizes queue behind the data
+            _META_GROUPS[key] = None
     return _META_GROUPS[key]
 
 
