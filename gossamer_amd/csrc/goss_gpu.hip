@@ -1080,7 +1080,7 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r)
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
 // buffers of one key per window start).
 enum { kFusedDeclined = 0, kFusedDone = 1, kFusedNeedFull = 2 };
-constexpr uint32_t kFusedGrid = 768;                         // workgroups of extract1_part_kernel: 3 per CU (52 KB of LDS each)
+constexpr uint32_t kFusedGrid = 256 * GOSS_E1_OCC;                         // workgroups of extract1_part_kernel: 3 per CU (52 KB of LDS each)
 #ifndef GOSS_FUSED_NKEYS2
 #define GOSS_FUSED_NKEYS2 14          // keys per thread of extract2_part_kernel (tile of 3584 keys + carry = 70 KB of LDS)
 #endif
@@ -1308,7 +1308,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // chunk gets fewer workgroups, then smaller blocks.  Workgroups per CU: 3 for one-word keys (52 KB of
     // LDS each), 2 for two-word keys (75 KB).
     const uint32_t kGranule = kOne ? 8 : 4;                       // keys per 64 bytes
-    const uint64_t kSuperFused = kOne ? (uint64_t)kTB * (graph_mode ? 8 : 16)
+    const uint64_t kSuperFused = kOne ? (uint64_t)kTB * (graph_mode ? GOSS_E1_NK / 2 : GOSS_E1_NK)
                                       : (uint64_t)kTB * (graph_mode ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
     const double pad_budget = 0.03 * (double)n_exp;
     uint32_t fgrid = (uint32_t)std::min<uint64_t>((nstarts + kSuperFused - 1) / kSuperFused, (uint64_t)(kOne ? kFusedGrid : kFusedGrid2));
@@ -1356,7 +1356,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 #define GOSS_FUSED_G 1
 #endif
         const bool graph = c->mode == GOSS_MODE_GRAPH;
-        const uint64_t kSuper = kOne ? (uint64_t)kTB * (graph ? 8 : 16)
+        const uint64_t kSuper = kOne ? (uint64_t)kTB * (graph ? GOSS_E1_NK / 2 : GOSS_E1_NK)
                                      : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
         uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 1024);

@@ -663,8 +663,18 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // below bit 64, so no record of windows has that bit without bits 28..31) holds none
 constexpr uint32_t kSkPadWord2 = 1u << 27;
 __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27) == 1u ? 0u : (w2 >> 28) + 1u; }
+// keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads: 16 / 3 (52 KB of LDS, 168 VGPRs)
+// 18.5 ms; 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
+// scans, ten barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
+// workgroups per CU: 22.5.  The record form needs 16.
+#ifndef GOSS_E1_NK
+#define GOSS_E1_NK 16
+#endif
+#ifndef GOSS_E1_OCC
+#define GOSS_E1_OCC 3
+#endif
 template <int MODE, int NH, bool ODD, bool REC = false>
-__global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
+__global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
                                                             const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
@@ -673,7 +683,8 @@ __global__ __launch_bounds__(kTB, 3) void extract1_part_kernel(const uint8_t* __
     // MODE 0: one key per window, 16 windows per thread.  MODE 1 (graph): forward key and
     // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
     constexpr int S = MODE == 1 ? 2 : 1;
-    constexpr int P = 16 / S;
+    constexpr int P = GOSS_E1_NK / S;
+    static_assert(!REC || GOSS_E1_NK == 16, "a record of 16 windows holds at most one thread's first window");
     constexpr int T = kTB * P;                   // window starts per tile
     constexpr int NVEC = T / 16 + 4;
     constexpr int NK = P * S;                    // keys per thread
