@@ -665,7 +665,7 @@ constexpr uint32_t kSkPadWord2 = 1u << 27;
 __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27) == 1u ? 0u : (w2 >> 28) + 1u; }
 // keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads: 16 / 3 (52 KB of LDS, 168 VGPRs)
 // 18.5 ms; 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
-// scans, ten barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
+// scans, seven barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
 // workgroups per CU: 22.5.  The record form needs 16.
 #ifndef GOSS_E1_NK
 #define GOSS_E1_NK 16

@@ -489,7 +489,7 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  * A PAD is the record {0, 0, 1 << 27} -- no window: the routing kernel takes room in blocks (<= 512 slots per
  * workgroup and part) and fills what it does not use with pads; they are slots of the part like any record, travel
  * with it and are dropped by goss_gpu_push_records_device (no record of windows has bit 91 set with bits 92..95 zero:
- * a single window's bases end below bit 64).  About 0.1 % of the slots of a large input.
+ * a single window's bases end below bit 64).  0.1-0.3 % of the slots of a large input.
  */
 #define GOSS_RECORD_BYTES 12
 int goss_gpu_route_records_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t nparts, void* d_records,
