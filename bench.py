@@ -27,13 +27,19 @@ def algorithmic_bytes_per_window(k, read_len, key_bytes=8, keys_per_window=1):
 
 
 def kernels_hash():
-    """sha256 over the sources of the kernels profiles/traffic.json holds figures for (extraction, partition, counting)."""
+    """sha256 over the sources of the kernels profiles/traffic.json holds figures for (extraction, partition, counting):
+    their code, not their comments or layout (the kernel sources hold no string literal with comment marks)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gossamer_amd", "csrc")
     for f in [os.path.join(d, n) for n in ("goss_key.hpp", "kernels_common.hpp", "kernels_count.hpp", "kernels_extract.hpp", "kernels_partition.hpp")]:
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+        with open(f, "r", encoding="utf-8") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        text = " ".join(text.split())
+        h.update(os.path.basename(f).encode() + b"\0" + text.encode())
     return h.hexdigest()[:16]
 
 
