@@ -148,3 +148,15 @@ def test_records_at_a_size_the_fused_path_takes_by_itself(oracle):
     assert stats["rec_chunks"] >= 1, stats
     assert files == exp
     print("windows per record: %.2f, record bytes per window: %.2f" % (nwin / sum(recs), 12.0 * sum(recs) / nwin))
+    # one and three parts: a tile's records of a part outnumber the block a workgroup takes ahead (512 slots at one
+    # part: ~550 records per tile), so tiles are split between the rest of a block and new room, several blocks at once
+    for nparts in (1, 3):
+        with g.Context(k, 0, hbm_budget=64 * MB) as rctx:
+            _, _, need, _, _ = route(rctx, reads, nparts, caps=[1] * nparts)
+            buf, first, recs, wins, ok = route(rctx, reads, nparts, caps=need)
+        assert ok and sum(wins) == nwin and recs == need
+        w2 = buf.view(torch.int32).view(-1, 3)[:, 2].to(torch.int64) & 0xFFFFFFFF
+        pads = (w2 >> 27) == 1
+        assert int(((w2 >> 28) + 1)[~pads].sum()) == nwin
+        ks, cs, c, files, stats = count_parts(k, 0, buf, [0], [sum(recs)], [sum(wins)], [0], budget=6 << 30)
+        assert c.windows == nwin and files == exp
