@@ -666,7 +666,8 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 // keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads: 16 / 3 (52 KB of LDS, 168 VGPRs)
 // 18.5 ms; 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
 // scans, seven barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
-// workgroups per CU: 22.5.  The record form needs 16.
+// workgroups per CU: 22.5; 512 threads of 8 keys (the same tile, two workgroups per CU, four waves per SIMD): 27.7.  The
+// record form needs 16.
 #ifndef GOSS_E1_NK
 #define GOSS_E1_NK 16
 #endif
