@@ -160,3 +160,20 @@ def test_records_at_a_size_the_fused_path_takes_by_itself(oracle):
         assert int(((w2 >> 28) + 1)[~pads].sum()) == nwin
         ks, cs, c, files, stats = count_parts(k, 0, buf, [0], [sum(recs)], [sum(wins)], [0], budget=6 << 30)
         assert c.windows == nwin and files == exp
+
+
+@pytest.mark.parametrize("nparts", [64, 256])
+def test_many_parts_small_blocks(oracle, nparts):
+    """64 and 256 parts (the most the boundary takes): the routing workgroups take room in blocks of 64 / 32 slots, a tile
+    brings a handful of records per part; everything pushed in one go equals the oracle's build."""
+    k = 21
+    reads = g.synth_reads_host(120_000, 150, 700_000, seed=9)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "r", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    with g.Context(k, 0, hbm_budget=64 * MB) as rctx:
+        _, _, need, _, _ = route(rctx, reads, nparts, caps=[1] * nparts)
+        buf, first, recs, wins, ok = route(rctx, reads, nparts, caps=need)
+    assert ok and sum(wins) == nwin and recs == need
+    assert max(wins) < 3 * nwin / nparts          # (no part far above its share)
+    ks, cs, c, files, stats = count_parts(k, 0, buf, [0], [sum(recs)], [sum(wins)], [0], budget=2 << 30)
+    assert c.windows == nwin and files == exp
