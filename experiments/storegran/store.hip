@@ -111,6 +111,54 @@ static void run_t(uint64_t* d, uint64_t total_keys, uint32_t nb)
     }
 }
 
+// 16 bytes per lane (two keys): does the store path take lanes or bytes?
+template <int RUN, int OCC>
+__global__ __launch_bounds__(256, OCC) void store_kernel_x4(uint4* out, uint64_t region_pairs, uint32_t tiles, uint32_t nb_log2)
+{
+    constexpr uint32_t kRunPairs = RUN / 16;
+    constexpr uint32_t kTile = 2048;                           // pairs per tile = 4096 keys
+    constexpr uint32_t kRunsPerTile = kTile / kRunPairs;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nb = 1u << nb_log2;
+    const uint64_t share = (region_pairs / gridDim.x) & ~7ULL;
+    uint4* mine = out + (uint64_t)blockIdx.x * share;
+    for (uint32_t t = 0; t < tiles; ++t)
+    {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+        {
+            const uint32_t i = tid + 256 * u;
+            const uint32_t run = i / kRunPairs, in = i % kRunPairs;
+            const uint32_t b = (run + 7u * t) & (nb - 1);
+            const uint32_t visits = (t * kRunsPerTile + run) >> nb_log2;
+            mine[(uint64_t)b * region_pairs + visits * kRunPairs + in] = make_uint4(t, i, t, i);
+        }
+    }
+}
+
+template <int RUN, int OCC>
+static void run_x4(uint64_t* d, uint64_t total_keys, uint32_t nb)
+{
+    uint32_t nb_log2 = 0;
+    while ((1u << nb_log2) < nb) ++nb_log2;
+    const uint32_t grid = 256 * OCC;
+    const uint64_t region_pairs = total_keys / 2 / nb;
+    const uint32_t tiles = (uint32_t)(total_keys / grid / 4096 / 2);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep)
+    {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(store_kernel_x4<RUN, OCC>), dim3(grid), dim3(256), 0, 0, (uint4*)d, region_pairs, tiles, nb_log2);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double bytes = (double)grid * tiles * 32768.0;
+        if (rep == 2) std::printf("%d x 256 threads, 16 bytes per lane, tile 4096 keys, run %4d B, buckets %4u: %.1f GB in %.2f ms = %.2f TB/s\n", grid, RUN, nb, bytes / 1e9, ms, bytes / ms / 1e9);
+    }
+}
+
 int main()
 {
     const uint64_t total_keys = 5ULL << 30;            // 40 GB of room
@@ -136,6 +184,9 @@ int main()
     run_t<128, 256, 16, 2>(d, total_keys, 256);
     run_t<256, 512, 16, 2>(d, total_keys, 256);
     run_t<256, 768, 16, 1>(d, total_keys, 256);
+    run_x4<64, 3>(d, total_keys, 256);
+    run_x4<128, 3>(d, total_keys, 256);
+    run_x4<64, 1>(d, total_keys, 256);
     CHECK(hipFree(d));
     return 0;
 }

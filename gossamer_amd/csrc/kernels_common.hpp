@@ -61,6 +61,25 @@ __device__ __forceinline__ T block_excl_scan(T v, T* sh, T* total)
     return base + inc - v;
 }
 
+// The same without the closing barrier: for a caller that passes another barrier before `sh` is written again.
+template <class T>
+__device__ __forceinline__ T block_excl_scan_open(T v, T* sh, T* total)
+{
+    T inc = wave_incl_scan(v);
+    if (lane_id() == 63) sh[wave_id()] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+    {
+        T s = sh[w];
+        if ((int)wave_id() > w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // The same for a workgroup of NW waves.
 template <class T, int NW>
 __device__ __forceinline__ T block_excl_scan_n(T v, T* sh, T* total)
