@@ -648,7 +648,7 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 //     on the way: 1.4-1.5 x the bytes when runs start anywhere), so a tile stores only whole
 //     granules: per bucket the keys beyond a multiple of 8 wait in the registers of the thread that
 //     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket; in LDS the
-//     stored parts of all buckets lie back to back, each a multiple of 8 keys, so that 8 aligned
+//     stored parts of all buckets lie back to back, each a multiple of 8 keys, so that 4 aligned
 //     lanes of ONE store instruction cover one aligned granule;
 //   * MODE 0 stores the strand representative (strand_rep) instead of the canonical form.
 // The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
@@ -664,7 +664,7 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 constexpr uint32_t kSkPadWord2 = 1u << 27;
 __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27) == 1u ? 0u : (w2 >> 28) + 1u; }
 // keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads: 16 / 3 (52 KB of LDS, 168 VGPRs)
-// 18.5 ms; 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
+// 18.5 ms (17.0 since the stores take two keys per lane); 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
 // scans, seven barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
 // workgroups per CU: 22.5; 512 threads of 8 keys (the same tile, two workgroups per CU, four waves per SIMD): 27.7.  The
 // record form needs 16.
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        // ---- phase D: whole granules to the bucket blocks; every 8 aligned lanes store one -------
+        // ---- phase D: whole granules to the bucket blocks; every 4 aligned lanes store one (two keys each) -------
         // (two keys per lane and store: the store path takes 16 bytes per lane as quickly as 8 --
         // experiments/storegran: 4.5 against 4.1 TB/s for this pattern alone -- and the loop has half the instructions)
         if (sh_ovf == 0)
