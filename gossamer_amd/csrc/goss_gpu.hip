@@ -133,6 +133,9 @@ struct goss_gpu_ctx {
     uint64_t hash_merge_min = 1u << 20; // GOSS_GPU_HASH_MERGE_MIN=<entries>: smallest merge that goes that way (65 536 workgroups)
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
+    bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
+    int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
+    uint32_t rem32_chunks = 0;          // chunks counted in that form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
@@ -945,6 +948,57 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     return 0;
 }
 
+// The same for the 32-bit-remainder form (subpart32_kernel's output): 131 072 segments of u32 remainders, counted by
+// seg_hash_reduce32_kernel in tables of `slots` slots; `spare` (n one-word keys) is the staging area.
+// Returns 0, 1 (a table overflowed) or 2 (staging area too small) like segment_reduce.
+int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_t n, Run* out, const uint64_t* seg_beg,
+                     const uint64_t* seg_end, int slots, bool squeeze, uint32_t rbits, uint32_t sqbit)
+{
+    const uint32_t nseg = kSub32Regions;
+    uint64_t mark = c->arena.mark();
+    PhaseTimer t(c, GOSS_T_REDUCE, n);
+    uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
+    uint64_t* seg_cnt = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+    uint64_t* seg_dst = (uint64_t*)c->arena.temp(((uint64_t)nseg + 1) * 8);
+    SegOut* so = (SegOut*)c->arena.temp(sizeof(SegOut));
+    const uint64_t cap = n * sizeof(Key1) / (sizeof(Key1) + 4);
+    Key1* stage_keys = spare;
+    uint32_t* stage_counts = (uint32_t*)(spare + cap);
+    SegOut hso{};
+    hso.stage_cap = cap;
+    HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
+#define GOSS_LAUNCH_R32(SLOTS, SQ)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_hash_reduce32_kernel<SLOTS, SQ>), unit_grid(nseg), dim3(kTB), 0, c->stream, rems, seg_beg, \
+                       seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rbits, sqbit)
+    if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(2048, true); else GOSS_LAUNCH_R32(2048, false); }
+    else { if (squeeze) GOSS_LAUNCH_R32(4096, true); else GOSS_LAUNCH_R32(4096, false); }
+#undef GOSS_LAUNCH_R32
+    check_launch("32-bit segment counting kernel");
+    SegOut* h = (SegOut*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h->overflow)
+    {
+        const int why = (h->overflow & 1u) ? 1 : 2;
+        t.stop();
+        c->arena.release(mark);
+        return why;
+    }
+    const uint64_t m = h->cursor;
+    HIP_TRY(hipMemcpyAsync(seg_dst, seg_cnt, (uint64_t)nseg * 8, hipMemcpyDeviceToDevice, c->stream));
+    exclusive_scan_u64(c, seg_dst, nseg);
+    out->m = m;
+    out->keys = c->arena.perm(std::max<uint64_t>(m, 1) * sizeof(Key1));
+    out->counts = (uint32_t*)c->arena.perm(std::max<uint64_t>(m, 1) * 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_gather_kernel<Key1>), unit_grid(nseg), dim3(kTB), 0, c->stream,
+                       (const Key1*)stage_keys, (const uint32_t*)stage_counts, (const uint64_t*)seg_pos,
+                       (const uint64_t*)seg_dst, (const uint64_t*)seg_cnt, (Key1*)out->keys, out->counts);
+    t.stop();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+    return 0;
+}
+
 // Count a chunk of n extracted keys (in ka): segment path with as many partition bits as the
 // estimated number of distinct keys asks for, more bits after an overflow, finally the full
 // LSD sort + run compaction.
@@ -1227,7 +1281,22 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             // between the two: the 6144-slot table, still one workgroup (and one read) per segment
             if (r == 0 && c->wide_table && (m_est >> kSegBits) <= (uint64_t)kSegWideLimit2 * 3 / 4) { segbits = kSegBits; big_table = -1; break; }
         }
-    if ((!big_table && (m_est >> segbits) > limit) || segbits + 8 > keybits)
+    // one-word keys whose bits below a 17-bit prefix fit 32 (an odd-length k-mer's strand representative has one bit
+    // that is always clear): 9 bits at the second level, which then writes -- and the counting kernel reads -- 4-byte
+    // remainders instead of 8-byte keys (kernels_partition.hpp: subpart32_kernel)
+    const uint32_t rbits32 = keybits > 17 ? keybits - 17 : 0;
+    const bool squeeze = kOne && !graph_mode && (c->len & 1u) && rbits32 == 33;
+    const uint32_t sqbit32 = c->len - 1;
+    int r32_slots = 0;
+    if (kOne && c->rem32 && c->fused_msd && c->big_rounds_min == 0 && rbits32 >= 8 && rbits32 - (squeeze ? 1u : 0u) <= 32)
+    {
+        const uint64_t per = m_est >> 17;
+        if (c->rem32_slots) r32_slots = c->rem32_slots;
+        else if (per <= 2048 / 4 * 3 * 3 / 4) r32_slots = 2048;
+        else if (per <= 4096 / 4 * 3 * 3 / 4) r32_slots = 4096;
+        if (r32_slots) { segbits = kSegBits; big_table = 0; }
+    }
+    if ((!big_table && !r32_slots && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
     const uint32_t npass = (segbits + 7) / 8;
@@ -1236,21 +1305,32 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     //    first partition digit only
     std::vector<unsigned long long> hh(256, 0);          // the fused kernel's digit
     std::vector<uint64_t> joint;                         // [high*256 + low], two-level form only
+    std::vector<uint64_t> joint17;                       // [high*512 + low9], 32-bit-remainder form
     bool msd = want_msd && segbits == 16;
+    if (!msd) r32_slots = 0;
     if (msd)
     {
         // the sample's joint histogram of both digits (kept out of the per-kernel timing): one pass over the sample
-        // with the bins in LDS (a 16-bit partition of the sample + segment bounds took 2.4 ms on C2, this 0.9)
+        // with the bins in LDS (a 16-bit partition of the sample + segment bounds took 2.4 ms on C2, this 0.9);
+        // 17 bits (four sweeps) for the 32-bit-remainder form, whose pairs of bins are the 16-bit form's
+        const uint32_t jbins = r32_slots ? kSub32Regions : 65536u;
         c->mute_timing = true;
-        unsigned long long* jh = (unsigned long long*)c->arena.temp(65536 * 8);
-        HIP_TRY(hipMemsetAsync(jh, 0, 65536 * 8, c->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(joint_hist_kernel<K>), dim3(256), dim3(kJointThreads), 0, c->stream, (const K*)ka, ns, shift, jh);
+        unsigned long long* jh = (unsigned long long*)c->arena.temp((uint64_t)jbins * 8);
+        HIP_TRY(hipMemsetAsync(jh, 0, (uint64_t)jbins * 8, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(joint_hist_kernel<K>), dim3(256), dim3(kJointThreads), 0, c->stream, (const K*)ka, ns,
+                           r32_slots ? rbits32 : shift, jh, jbins / 32768u);
         c->mute_timing = false;
-        std::vector<uint64_t> ho(65536);
-        HIP_TRY(hipMemcpyAsync(ho.data(), jh, 65536 * 8, hipMemcpyDeviceToHost, c->stream));
+        std::vector<uint64_t> ho(jbins);
+        HIP_TRY(hipMemcpyAsync(ho.data(), jh, (uint64_t)jbins * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         joint.resize(65536);
-        for (uint32_t i = 0; i < 65536; ++i) { joint[i] = ho[i]; hh[i >> 8] += joint[i]; }
+        if (r32_slots)
+        {
+            joint17.swap(ho);
+            for (uint32_t i = 0; i < 65536; ++i) joint[i] = joint17[2 * i] + joint17[2 * i + 1];
+        }
+        else joint.swap(ho);
+        for (uint32_t i = 0; i < 65536; ++i) hh[i >> 8] += joint[i];
     }
     else
     {
@@ -1266,7 +1346,33 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // sub-regions of the second buffer (two-level form): expected size + six standard deviations
     // of the sample count; they must fit, else the one-level form is used
     std::vector<SubTable> hsub;
-    if (msd)
+    std::vector<SubTable32> hsub32;
+    if (msd && r32_slots)
+    {
+        // 131 072 sub-regions of 4-byte slots in the second key buffer; every start a multiple of four slots (the
+        // counting kernel loads 16 bytes per lane)
+        hsub32.resize(1);
+        uint64_t at = 0;
+        bool fits = true;
+        for (uint32_t i = 0; i < kSub32Regions; ++i)
+        {
+            const double h = (double)joint17[i];
+            const uint64_t cap = exact ? (((uint64_t)(h * c->fused_capscale)) + 3) & ~3ULL
+                                       : (((uint64_t)(((h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0) * c->fused_capscale) + 15) & ~15ULL);
+            if (cap > 0xFFFF0000ULL) fits = false;
+            hsub32[0].start[i] = at; hsub32[0].cap[i] = (uint32_t)cap;
+            at += cap;
+        }
+        if (!fits || at > 2 * kb_slots)
+        {
+            if (c->debug) std::fprintf(stderr, "libgossgpu: 32-bit sub-regions need %llu slots of %llu: 8-byte form\n",
+                                       (unsigned long long)at, (unsigned long long)(2 * kb_slots));
+            r32_slots = 0;
+            hsub32.clear();
+            if ((m_est >> segbits) > limit) return decline("too many distinct keys per segment");
+        }
+    }
+    if (msd && !r32_slots)
     {
         hsub.resize(1);
         uint64_t at = 0;
@@ -1446,7 +1552,54 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     LookbackCtl* hctl = (LookbackCtl*)((uint8_t*)c->h_pinned + 128);
     HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(LookbackCtl), c->stream));
     Run r{nullptr, nullptr, 0};
-    if (msd)
+    if (msd && r32_slots)
+    {
+        // 4a'. second level, 32-bit-remainder form: keys of region b go to sub-region (b, next 9 bits) as u32 remainders
+        SubTable32* dsub = (SubTable32*)c->arena.temp(sizeof(SubTable32));
+        unsigned long long* cur2 = (unsigned long long*)c->arena.temp((uint64_t)kSub32Regions * 4);     // pairs of 32-bit cursors
+        uint64_t* seg_beg = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
+        uint64_t* seg_end = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
+        HIP_TRY(hipMemcpyAsync(dsub, hsub32.data(), sizeof(SubTable32), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)kSub32Regions * 4, c->stream));
+        {
+            PhaseTimer t(c, GOSS_T_SCATTER, n);
+            const dim3 g2((uint32_t)((tiles + 7) / 8 * 8));
+            if (squeeze)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<true>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
+                                   sqbit32, cur2, (const GapTable*)dgt, (const SubTable32*)dsub, ctl);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<false>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
+                                   sqbit32, cur2, (const GapTable*)dgt, (const SubTable32*)dsub, ctl);
+            t.stop();
+        }
+        hipLaunchKernelGGL(sub_bounds32_kernel, dim3(kSub32Regions / 256), dim3(256), 0, c->stream, (const SubTable32*)dsub,
+                           (const uint32_t*)cur2, seg_beg, seg_end);
+        HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hctl->error) { c->fused_overflows++; return decline("a 32-bit sub-region overflowed"); }
+        lap("second level (32-bit remainders)");
+        int rc;
+        for (;;)
+        {
+            rc = segment_reduce32(c, (const uint32_t*)kb, (Key1*)ka, n, &r, seg_beg, seg_end, r32_slots, squeeze, rbits32, sqbit32);
+            if (rc != 1 || r32_slots == 4096) break;
+            // the remainders are still in their sub-regions: only the counting is redone, in the larger table
+            c->segment_retries++;
+            r32_slots = 4096;
+        }
+        if (rc != 0)
+        {
+            // more distinct keys per segment than this form takes: the chunk again in the 8-byte form and its ladder of tables
+            c->segment_retries++;
+            c->rem32 = false;
+            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: 32-bit form overflowed (%d), redoing the chunk in the 8-byte form\n", rc);
+            c->arena.release(mark);
+            return process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots);
+        }
+        c->fused_msd_chunks++;
+        c->rem32_chunks++;
+    }
+    else if (msd)
     {
         // 4a. second level: keys of region b go to sub-region (b, low digit) by atomic cursors
         SubTable* dsub = (SubTable*)c->arena.temp(sizeof(SubTable));
@@ -2593,6 +2746,8 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
+    { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }
@@ -3895,6 +4050,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "flushes") *value = c->flushes;
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
+    else if (n == "rem32_chunks") *value = c->rem32_chunks;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;
     else if (n == "wide_table_chunks") *value = c->wide_table_chunks;
     else if (n == "table96_chunks") *value = c->table96_chunks;

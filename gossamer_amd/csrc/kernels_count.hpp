@@ -546,6 +546,277 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_shared_kernel(
     seg_hash_reduce_body<kSegBigThreads, kSegBigSlots, true>(keys, seg_off, seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rem_bits, round_bits);
 }
 
+// --------------------------------------------------------------------------------------
+// Counting of 32-bit remainders (subpart32_kernel's output): 131 072 segments, one workgroup each
+// --------------------------------------------------------------------------------------
+//
+// A slot is ONE 64-bit word, remainder in the low half and count in the high half; count 0 = empty (every 32-bit
+// pattern is a remainder, so there is no spare key value).  A key is inserted with its first occurrence counted
+// (64-bit CAS of 0 -> rem | 1 << 32); a hit adds 1 to the high half (32-bit LDS atomic).  Buckets of two slots as in
+// seg_hash_reduce_kernel: the home bucket and an independent second one are read with one 16-byte LDS load each and
+// compared without a branch; what they do not hold waits in the lane's queue for the slow path.  The table is a
+// quarter (SLOTS = 2048: 16 KB, eight workgroups per CU) or half (4096) of the 8-byte form's, the keys half the bytes.
+// Remainders are loaded four per lane (16 bytes); a sub-region starts on a 16-byte boundary and its capacity is a
+// multiple of four, so the last vector may be read whole.
+#ifndef GOSS_R32_OCC
+#define GOSS_R32_OCC 5
+#endif
+template <int SLOTS, bool SQ>
+__global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_hash_reduce32_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
+                                                                const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                uint32_t rbits, uint32_t sqbit)
+{
+    constexpr int NT = kTB;
+    constexpr int kLimit = SLOTS / 4 * 3;
+    constexpr int kBucketBits = SLOTS == 4096 ? 11 : SLOTS == 2048 ? 10 : -1;       // log2(SLOTS / 2)
+    static_assert(kBucketBits > 0, "table size");
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS];
+    __shared__ uint32_t ndist, ovf;
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = unit_block(), tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_end[s];
+    if (b == e)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    if (e - b > 0xFFFFFFFFULL)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    for (uint32_t i = tid; i < SLOTS; i += NT) tab[i] = 0;
+    if (tid == 0) { ndist = 0; ovf = 0; }
+    __syncthreads();
+
+    uint32_t* const tw = reinterpret_cast<uint32_t*>(tab);          // word 2 i = remainder, 2 i + 1 = count of slot i
+    auto key_mix = [](uint32_t k) -> uint32_t { return (k ^ (k >> 15)) * 0x9E3779B1u; };
+    auto second_bucket = [](uint32_t f, uint32_t b1) -> uint32_t {
+        const uint32_t x = (f >> (32 - 2 * kBucketBits)) & (uint32_t)(SLOTS / 2 - 1);
+        return x == b1 ? ((b1 + 1u) & (uint32_t)(SLOTS / 2 - 1)) : x;
+    };
+    lds_vu32 vovf = (lds_vu32)&ovf;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4* lds_bucket_plain;
+    typedef const volatile __attribute__((address_space(3))) u32x4* lds_bucket_ptr;
+    const lds_bucket_plain pt2 = (lds_bucket_plain)tab;
+    const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
+
+    constexpr int kVec = 4;                                  // 16-byte loads in flight per lane
+    constexpr int kU = 4 * kVec;                             // remainders per lane and batch
+    const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + b);         // (b is a multiple of 4)
+    const uint32_t n = (uint32_t)(e - b);
+    const uint32_t nvec = (n + 3u) >> 2;
+    u32x4 nxt[kVec];
+#pragma unroll
+    for (int u = 0; u < kVec; ++u)
+    {
+        const uint32_t i = (uint32_t)u * NT + tid;
+        nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
+    }
+    for (uint32_t i0 = 0; i0 < nvec; i0 += (uint32_t)NT * kVec)
+    {
+        uint32_t kv[kU];
+        uint32_t livem = 0;                                  // bit u: remainder u of this batch exists
+#pragma unroll
+        for (int u = 0; u < kVec; ++u)
+        {
+            kv[4 * u] = nxt[u].x; kv[4 * u + 1] = nxt[u].y; kv[4 * u + 2] = nxt[u].z; kv[4 * u + 3] = nxt[u].w;
+            const uint32_t i = i0 + (uint32_t)u * NT + tid;
+            const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
+            livem |= ((1u << have) - 1u) << (4 * u);
+        }
+        // software pipeline: the next batch's loads are in flight while this one is inserted
+#pragma unroll
+        for (int u = 0; u < kVec; ++u)
+        {
+            const uint32_t i = i0 + (uint32_t)(kVec + u) * NT + tid;
+            nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
+        }
+        uint32_t bkt[kU];
+        uint32_t pend = 0, stm = 0;
+        constexpr int kHalf = kU / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            u32x4 q[kHalf], q2[kHalf];
+            uint32_t b2[kHalf];
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j)
+            {
+                const int u = h * kHalf + j;
+                const uint32_t f = key_mix(kv[u]);
+                bkt[u] = f >> (32 - kBucketBits);
+                b2[j] = second_bucket(f, bkt[u]);
+                q[j] = pt2[bkt[u]];
+                q2[j] = pt2[b2[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j)
+            {
+                const int u = h * kHalf + j;
+                const uint32_t live = (livem >> u) & 1u;
+                // (a slot matches when it is occupied and holds the remainder: integer forms, no branch per term)
+                const uint32_t h0 = (q[j].x == kv[u] ? 1u : 0u) & (q[j].y != 0u ? 1u : 0u);
+                const uint32_t h1 = (q[j].z == kv[u] ? 1u : 0u) & (q[j].w != 0u ? 1u : 0u);
+                const uint32_t h2 = (q2[j].x == kv[u] ? 1u : 0u) & (q2[j].y != 0u ? 1u : 0u);
+                const uint32_t h3 = (q2[j].z == kv[u] ? 1u : 0u) & (q2[j].w != 0u ? 1u : 0u);
+                const uint32_t hit = (h0 | h1 | h2 | h3) & live;
+                const uint32_t second = h2 | h3;
+                const uint32_t slot = 2 * (second ? b2[j] : bkt[u]) + (h1 | h3);
+                atomicAdd(&tw[2 * slot + 1], hit);
+                const uint32_t miss = live & (hit ^ 1u);
+                pend |= miss << u;
+                const uint32_t full = (q[j].y != 0u ? 1u : 0u) & (q[j].w != 0u ? 1u : 0u) & miss;
+                bkt[u] = full ? b2[j] : bkt[u];
+                stm |= full << u;
+            }
+        }
+        // slow path: every lane walks its own queue of leftover keys, one probe per wave iteration
+        uint32_t key = 0, bk = 0, st = 0;
+        bool busy = false;
+        for (;;)
+        {
+            if (!busy && pend)
+            {
+                const uint32_t u = __ffs(pend) - 1;
+                pend &= pend - 1;
+                st = (stm >> u) & 1u;
+#pragma unroll
+                for (int uu = 0; uu < kU; ++uu)
+                    if (u == (uint32_t)uu) { key = kv[uu]; bk = bkt[uu]; }
+                busy = true;
+            }
+            if (!__ballot(busy)) break;
+            if (busy)
+            {
+                const u32x4 q01 = vt2[bk];
+                uint32_t hit = ~0u;                       // slot that holds (or now holds) the key; ~0 - 1: inserted with its count
+                if (q01.y != 0u && q01.x == key) hit = 2 * bk;
+                else if (q01.w != 0u && q01.z == key) hit = 2 * bk + 1;
+                else if (q01.y == 0u || q01.w == 0u)
+                {
+                    const uint32_t slot = 2 * bk + (q01.y == 0u ? 0u : 1u);
+                    const unsigned long long old = atomicCAS(&tab[slot], 0ULL, (unsigned long long)key | (1ULL << 32));
+                    if (old == 0ULL)
+                    {
+                        const uint32_t nd = atomicAdd(&ndist, 1u);
+                        if (nd + 1 > (uint32_t)kLimit) *vovf = 1;
+                        busy = false;                     // (counted by the insertion itself)
+                    }
+                    else if ((uint32_t)old == key) hit = slot;
+                    // else: somebody else took the slot; look at this bucket again
+                }
+                else if (st == 0) { bk = second_bucket(key_mix(key), bk); st = 1; }
+                else bk = (bk + 1) & (SLOTS / 2 - 1);
+                if (hit != ~0u) { atomicAdd(&tw[2 * hit + 1], 1u); busy = false; }
+            }
+            if (*vovf) break;
+        }
+        if (*vovf) break;
+    }
+    __syncthreads();
+    if (ovf)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+
+    // Order the occupied slots on the remainder: every thread takes its slots into registers, a bucket sort on the top
+    // bits of the remainder (rank inside the bin by an LDS atomic, scan of the bin sizes, scatter as remainder << 32 |
+    // count so that a 64-bit compare orders by remainder), an insertion sort of every bin (1.5 entries on average at
+    // half the limit); a bin of more than 24 entries (skewed low bits) -> bitonic sort of the compacted entries.
+    constexpr int kPer = SLOTS / NT;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kBucketBits - 1;
+    __shared__ uint32_t bins[kBins];
+    __shared__ uint32_t sh_scan2[NT / 64 + 1];
+    __shared__ uint32_t big;
+    unsigned long long ck[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) ck[j] = tab[tid * kPer + j];
+    for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
+    if (tid == 0) big = 0;
+    __syncthreads();
+    const uint32_t rem_bits = rbits - (SQ ? 1u : 0u);
+    const uint32_t bsh = rem_bits > (uint32_t)kBinBits ? rem_bits - kBinBits : 0;
+    uint32_t rnk[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if ((ck[j] >> 32) != 0) rnk[j] = atomicAdd(&bins[((uint32_t)ck[j] >> bsh) & (kBins - 1)], 1u);
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
+    lds_vu32 vbig = (lds_vu32)&big;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        if (bn[q] > 24) *vbig = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if ((ck[j] >> 32) != 0)
+            tab[bins[((uint32_t)ck[j] >> bsh) & (kBins - 1)] + rnk[j]] = (ck[j] << 32) | (ck[j] >> 32);
+    __syncthreads();
+    if (!big)
+    {
+#pragma unroll
+        for (int q = 0; q < kBinsPer; ++q)
+            for (uint32_t i = 1; i < bn[q]; ++i)
+            {
+                const unsigned long long kk = tab[bs[q] + i];
+                uint32_t j = i;
+                while (j > 0 && tab[bs[q] + j - 1] > kk) { tab[bs[q] + j] = tab[bs[q] + j - 1]; --j; }
+                tab[bs[q] + j] = kk;
+            }
+        __syncthreads();
+    }
+    else
+    {
+        uint32_t nsort = 512;
+        while (nsort < tot_occ) nsort <<= 1;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += NT) tab[i] = ~0ULL;
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += NT)
+                {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t p = i + j;
+                    const bool up = (i & k2) == 0;
+                    const unsigned long long a = tab[i], c2 = tab[p];
+                    if ((a > c2) == up) { tab[i] = c2; tab[p] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    const uint32_t d = ndist;
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
+    const uint64_t prefix = (uint64_t)s << rbits;
+    for (uint32_t i = tid; i < d; i += NT)
+    {
+        const unsigned long long v = tab[i];
+        stage_keys[ob + i].lo = prefix | rem32_unpack<SQ>((uint32_t)(v >> 32), sqbit);
+        stage_counts[ob + i] = (uint32_t)v;
+    }
+}
+
 // Two-word keys.  LDS has no 128-bit compare-and-swap, so a slot is claimed through its state
 // word: 0 = empty, kSegLock = being written, otherwise the count of a published key.  The
 // insert loop is a per-lane state machine with exactly one probe per wave iteration and no

@@ -821,11 +821,16 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 rmark[kTB] = 2 * tid + one;
                 rmark[kTB + 1] = one ? ea : ex;
             }
-            // thread g starts at window P g: a record of at most 16 windows holds at most one such window and tells g
+            // thread g starts at window P g: a record of at most 16 windows holds at most 16 / P such windows (one for
+            // k-mer sets, two in graph mode where a thread takes 8 windows) and tells every one of those threads
             {
-                const uint32_t ga = (ex + P - 1) / P, gb = (ea + P - 1) / P;
-                if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = ca;
-                if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = cb;
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)(16 / P); ++j)
+                {
+                    const uint32_t ga = (ex + P - 1) / P + j, gb = (ea + P - 1) / P + j;
+                    if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = ca;
+                    if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = cb;
+                }
             }
             __syncthreads();
             const uint32_t nfit = rmark[kTB];

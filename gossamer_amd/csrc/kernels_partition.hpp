@@ -200,29 +200,30 @@ __global__ __launch_bounds__(kTB) void global_hist_kernel(const K* __restrict__ 
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
-// Histogram of the 16 bits at `shift` of every key (65 536 bins): the joint histogram of the two partition digits the
-// fused path sizes its sub-regions from (exact when the sample is the chunk).  One workgroup per CU with half of
-// the bins at a time in LDS (32 768 words = 128 KB), so two sweeps over the keys.
+// Histogram of the 16 (nsweeps = 2) or 17 (nsweeps = 4) bits at `shift` of every key (65 536 / 131 072 bins): the joint
+// histogram of the two partition digits the fused path sizes its sub-regions from (exact when the sample is the
+// chunk).  One workgroup per CU with 32 768 of the bins at a time in LDS (128 KB), so nsweeps sweeps over the keys.
 constexpr int kJointThreads = 1024;
 template <class K>
 __global__ __launch_bounds__(kJointThreads) void joint_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift,
-                                                                   unsigned long long* __restrict__ hist)
+                                                                   unsigned long long* __restrict__ hist, uint32_t nsweeps)
 {
     __shared__ uint32_t lh[32768];
     const uint64_t stride = (uint64_t)gridDim.x * kJointThreads;
-    for (uint32_t half = 0; half < 2; ++half)
+    const uint32_t mask = 32768u * nsweeps - 1u;
+    for (uint32_t sweep = 0; sweep < nsweeps; ++sweep)
     {
         for (uint32_t i = threadIdx.x; i < 32768; i += kJointThreads) lh[i] = 0;
         __syncthreads();
         for (uint64_t i = (uint64_t)blockIdx.x * kJointThreads + threadIdx.x; i < n; i += stride)
         {
-            const uint32_t b = (uint32_t)key_shr64(keys[i], shift) & 0xFFFFu;
-            // (a bin of the other half: a spare word nobody reads, instead of a branch around the atomic)
-            atomicAdd(&lh[(b >> 15) == half ? (b & 32767u) : 32767u], (b >> 15) == half ? 1u : 0u);
+            const uint32_t b = (uint32_t)key_shr64(keys[i], shift) & mask;
+            // (a bin of another sweep: a spare word nobody reads, instead of a branch around the atomic)
+            atomicAdd(&lh[(b >> 15) == sweep ? (b & 32767u) : 32767u], (b >> 15) == sweep ? 1u : 0u);
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < 32768; j += kJointThreads)
-            if (lh[j]) atomicAdd(&hist[half * 32768u + j], (unsigned long long)lh[j]);
+            if (lh[j]) atomicAdd(&hist[sweep * 32768u + j], (unsigned long long)lh[j]);
         __syncthreads();
     }
 }
@@ -535,6 +536,131 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
         keys_out[o] = k;
         if (HAS_VAL) vals_out[o] = vstage[i];
     }
+}
+
+// --------------------------------------------------------------------------------------
+// Second level, 32-bit-remainder form (one-word keys whose bits below a 17-bit prefix fit 32)
+// --------------------------------------------------------------------------------------
+//
+// What the second level writes and the counting kernel reads need not be the key: inside sub-region (b, d) the top
+// bits are implied.  With NINE bits at the second level -- 256 x 512 = 131 072 sub-regions -- a k-mer of k = 25 has
+// 33 bits left, and the strand representative of an odd-length k-mer has one bit that is always clear (bit len - 1,
+// the low bit of its middle base: extract1_part_kernel picks the strand by it), which is squeezed out: 32 bits.
+// This kernel reads 8-byte keys and writes 4-byte remainders; seg_hash_reduce32_kernel counts those: 12 + 4 bytes per
+// key behind the first level instead of 16 + 8.  Applies while 2 len - 17 - (odd k-mer set ? 1 : 0) <= 32.
+constexpr int kSub32Bits = 9;
+constexpr uint32_t kSub32Digits = 1u << kSub32Bits;          // 512 second-level digits
+constexpr uint32_t kSub32Regions = 256u * kSub32Digits;      // 131 072 sub-regions = segments
+struct SubTable32 {
+    unsigned long long start[kSub32Regions];     // first u32 slot of sub-region (b, d), index b * 512 + d; a multiple of 4
+    uint32_t cap[kSub32Regions];
+};
+
+// low `rbits` bits of a key, bit `sqbit` (always clear) taken out when SQ
+template <bool SQ>
+__host__ __device__ __forceinline__ uint32_t rem32_pack(uint64_t key, uint32_t rbits, uint32_t sqbit)
+{
+    const uint64_t x = key & ((1ULL << rbits) - 1ULL);
+    if (!SQ) return (uint32_t)x;
+    return (uint32_t)(((x >> (sqbit + 1)) << sqbit) | (x & ((1ULL << sqbit) - 1ULL)));
+}
+template <bool SQ>
+__host__ __device__ __forceinline__ uint64_t rem32_unpack(uint32_t r, uint32_t sqbit)
+{
+    if (!SQ) return r;
+    return (((uint64_t)r >> sqbit) << (sqbit + 1)) | ((uint64_t)r & ((1ULL << sqbit) - 1ULL));
+}
+
+// Tile = 5 632 keys of ONE first-level region (the same 52 KB of LDS and three workgroups per CU as the 8-byte form;
+// tiles dealt out by XCD for the same reason: the ~44-byte runs a tile appends to a sub-region meet their neighbours
+// in one L2).  Rank by one LDS atomic per key on 512 digit counters; a thread owns two neighbouring digits and takes
+// the tile's room in both sub-regions with ONE 64-bit atomic on the pair of 32-bit cursors (a wave's 64 atomics cover
+// 512 contiguous bytes); keys to their digit-sorted place in LDS; remainders out in coalesced runs.
+template <bool SQ>
+__global__ __launch_bounds__(kTB, 3) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
+                                                           uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
+                                                           const GapTable* __restrict__ gt, const SubTable32* __restrict__ sub,
+                                                           LookbackCtl* __restrict__ ctl)
+{
+    constexpr int kItems = SubCfg<Key1>::kItems;
+    constexpr int kTile = kTB * kItems;
+    __shared__ Key1 stage[kTile];
+    __shared__ uint32_t hist[kSub32Digits];                  // keys per digit, then the digit's first slot in `stage`
+    __shared__ unsigned long long gbase[kSub32Digits];       // the digit's first slot in `out` minus its first slot in `stage`
+    __shared__ uint32_t sh_scan[kWaves + 1];
+    __shared__ uint32_t sh_bucket, sh_skip, sh_total;
+
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t total_tiles = (uint32_t)gt->tile_first[256];
+    const uint32_t per = (total_tiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (tile >= total_tiles) return;
+    if (gt->tile_first[tid] <= tile && tile < gt->tile_first[tid + 1]) sh_bucket = tid;
+    if (tid == 0) sh_skip = 0;
+    hist[tid] = 0; hist[tid + 256] = 0;
+    __syncthreads();
+    const uint32_t b = sh_bucket;
+    const uint64_t j = (uint64_t)tile - gt->tile_first[b];
+    const uint64_t left = gt->cnt[b] - j * kTile;
+    const uint64_t tile_base = gt->reg_start[b] + j * kTile;
+    const uint32_t tile_n = (uint32_t)(left < (uint64_t)kTile ? left : (uint64_t)kTile);
+
+    Key1 key[kItems];
+    uint16_t rank[kItems];
+    uint32_t have = 0;
+    const uint32_t wbase = w * 64 * kItems;
+#pragma unroll
+    for (int r = 0; r < kItems; ++r)
+    {
+        const uint32_t li = wbase + r * 64 + lane;
+        if (li < tile_n) { key[r] = keys_in[tile_base + li]; have |= 1u << r; }
+    }
+    // (a second loop: looking at a key inside the load loop would wait for every load in turn)
+#pragma unroll
+    for (int r = 0; r < kItems; ++r)
+        if (((have >> r) & 1u) && is_pad_key(key[r])) have &= ~(1u << r);
+#pragma unroll
+    for (int r = 0; r < kItems; ++r)
+        if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u)], 1u);
+    __syncthreads();
+    {
+        // thread tid owns digits 2 tid and 2 tid + 1
+        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+        const uint32_t sidx = b * kSub32Digits + 2 * tid;
+        unsigned long long old = 0;
+        if (c0 | c1) old = atomicAdd(&cursors[sidx >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+        const uint32_t e0 = (uint32_t)old, e1 = (uint32_t)(old >> 32);
+        // too small a sub-region: nothing of this tile is stored, the host redoes the chunk
+        if ((c0 && e0 + c0 > sub->cap[sidx]) || (c1 && e1 + c1 > sub->cap[sidx + 1])) { atomicOr(&ctl->error, 2u); sh_skip = 1; }
+        uint32_t tile_total;
+        const uint32_t start = block_excl_scan<uint32_t>(c0 + c1, sh_scan, &tile_total);
+        hist[2 * tid] = start; hist[2 * tid + 1] = start + c0;
+        gbase[2 * tid] = sub->start[sidx] + e0 - start;
+        gbase[2 * tid + 1] = sub->start[sidx + 1] + e1 - (start + c0);
+        if (tid == 0) sh_total = tile_total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kItems; ++r)
+        if ((have >> r) & 1u) stage[hist[(uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u)] + rank[r]] = key[r];
+    __syncthreads();
+    if (sh_skip) return;
+    const uint32_t tile_keys = sh_total;
+    for (uint32_t i = tid; i < tile_keys; i += kTB)
+    {
+        const uint64_t k = stage[i].lo;
+        out[gbase[(uint32_t)(k >> rbits) & (kSub32Digits - 1u)] + i] = rem32_pack<SQ>(k, rbits, sqbit);
+    }
+}
+
+// Segment bounds of the 32-bit-remainder layout: segment s holds (the 32-bit half s of the cursor words) remainders from start[s].
+__global__ void sub_bounds32_kernel(const SubTable32* __restrict__ sub, const uint32_t* __restrict__ cursors,
+                                    uint64_t* __restrict__ seg_beg, uint64_t* __restrict__ seg_end)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= kSub32Regions) return;
+    seg_beg[s] = sub->start[s];
+    seg_end[s] = sub->start[s] + cursors[s];
 }
 
 // out[q] = first index of the sorted array whose key is >= query[q] (one thread per query).

@@ -177,3 +177,33 @@ def test_many_parts_small_blocks(oracle, nparts):
     assert max(wins) < 3 * nwin / nparts          # (no part far above its share)
     ks, cs, c, files, stats = count_parts(k, 0, buf, [0], [sum(recs)], [sum(wins)], [0], budget=2 << 30)
     assert c.windows == nwin and files == exp
+
+
+@pytest.mark.parametrize("k,mode,env", [(27, 1, {}), (24, 1, {}), (30, 1, {}), (22, 0, {}), (16, 0, {}), (25, 0, {"GOSS_GPU_NO_MSD": "1"}),
+                                        (27, 1, {"GOSS_GPU_NO_MSD": "1"}), (31, 0, {}), (21, 0, {"GOSS_GPU_NO_REM32": "1"})])
+def test_fused_record_kernel_variants_at_its_own_size(oracle, k, mode, env):
+    """The record form of the fused extraction in every variant it is compiled in: graph mode (a thread takes 8
+    windows, so a record of up to 16 holds the first window of TWO threads), even k (strand_rep instead of the middle
+    base), the one-level form (digit histograms in the kernel, GOSS_GPU_NO_MSD) -- at a size the fused path takes by
+    itself (300 k reads: ~100 M window slots), against the oracle's files.  rec_chunks says the kernel ran."""
+    reads = g.synth_reads_host(300_000, 150, 1_500_000, seed=40 + k + mode)
+    build = oracle.build_graph if mode else oracle.build_kmer_set
+    exp, nwin = build([(oracle.LINE, "r", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    with g.Context(k, mode, hbm_budget=64 * MB) as rctx:
+        _, _, need, _, _ = route(rctx, reads, 4, caps=[1] * 4)
+        buf, first, recs, wins, ok = route(rctx, reads, 4, caps=need)
+    assert ok and sum(wins) == nwin and recs == need
+    old = {n: os.environ.get(n) for n in env}
+    os.environ.update(env)
+    try:
+        ks, cs, c, files, stats = count_parts(k, mode, buf, [0], [sum(recs)], [sum(wins)], [0], budget=6 << 30)
+    finally:
+        for n, v in old.items():
+            if v is None:
+                os.environ.pop(n, None)
+            else:
+                os.environ[n] = v
+    assert c.windows == nwin and c.keys == nwin * (2 if mode else 1)
+    assert stats["rec_chunks"] >= 1, stats
+    assert files == exp
