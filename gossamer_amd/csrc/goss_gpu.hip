@@ -1362,6 +1362,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             if (cap > 0xFFFF0000ULL) fits = false;
             hsub32[0].start[i] = at; hsub32[0].cap[i] = (uint32_t)cap;
             at += cap;
+            // (the second level addresses a region's sub-regions with 32-bit offsets from the region's first)
+            if ((i & (kSub32Digits - 1u)) == kSub32Digits - 1u && at - hsub32[0].start[i - (kSub32Digits - 1u)] > 0xFFFF0000ULL) fits = false;
         }
         if (!fits || at > 2 * kb_slots)
         {
@@ -1559,17 +1561,20 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         unsigned long long* cur2 = (unsigned long long*)c->arena.temp((uint64_t)kSub32Regions * 4);     // pairs of 32-bit cursors
         uint64_t* seg_beg = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
         uint64_t* seg_end = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
+        Tile32* tdesc = (Tile32*)c->arena.temp(std::max<uint64_t>(tiles, 1) * sizeof(Tile32));
         HIP_TRY(hipMemcpyAsync(dsub, hsub32.data(), sizeof(SubTable32), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)kSub32Regions * 4, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<SubCfg<Key1>::kTile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+                           (const GapTable*)dgt, tdesc, (uint32_t)tiles);
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
             const dim3 g2((uint32_t)((tiles + 7) / 8 * 8));
             if (squeeze)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<true>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
-                                   sqbit32, cur2, (const GapTable*)dgt, (const SubTable32*)dsub, ctl);
+                                   sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<false>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
-                                   sqbit32, cur2, (const GapTable*)dgt, (const SubTable32*)dsub, ctl);
+                                   sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl);
             t.stop();
         }
         hipLaunchKernelGGL(sub_bounds32_kernel, dim3(kSub32Regions / 256), dim3(256), 0, c->stream, (const SubTable32*)dsub,

@@ -550,19 +550,33 @@ __global__ __launch_bounds__(kSegBigThreads) void seg_hash_reduce_shared_kernel(
 // Counting of 32-bit remainders (subpart32_kernel's output): 131 072 segments, one workgroup each
 // --------------------------------------------------------------------------------------
 //
-// A slot is ONE 64-bit word, remainder in the low half and count in the high half; count 0 = empty (every 32-bit
-// pattern is a remainder, so there is no spare key value).  A key is inserted with its first occurrence counted
-// (64-bit CAS of 0 -> rem | 1 << 32); a hit adds 1 to the high half (32-bit LDS atomic).  Buckets of two slots as in
-// seg_hash_reduce_kernel: the home bucket and an independent second one are read with one 16-byte LDS load each and
-// compared without a branch; what they do not hold waits in the lane's queue for the slow path.  The table is a
-// quarter (SLOTS = 2048: 16 KB, eight workgroups per CU) or half (4096) of the 8-byte form's, the keys half the bytes.
+// A slot is two 32-bit words, remainder and count; count 0 = empty.  A bucket is two slots = 16 bytes, read with one
+// LDS load.  A key has a home bucket and an independent second one (both from one 32-bit mix; second = home ^ an odd
+// field of the mix, so never the home); behind the second the buckets that follow it.  A key is inserted with its first
+// occurrence counted (64-bit CAS of {marker, 0} -> {rem, 1}); a hit adds 1 to the count word (32-bit LDS atomic).
+//
+// Every 32-bit pattern is a remainder, so "empty" cannot be a key value -- but it can be a value that never MATCHES:
+// the empty slots of bucket b hold the key E_b whose home is b ^ 1 and whose second bucket is b ^ 2.  The fast path
+// compares a key only with the slots of its own two buckets, so it can never take an empty slot for its key, and
+// needs no look at the counts: four compares pick the address of the count word to bump (or a word of the lane's own
+// behind the table, for a miss), one unconditional LDS add does the rest.  ~28 vector instructions per key where the
+// 8-byte form takes 56 -- these kernels are bound by what they issue, not by what they read (profiles/r04).
+// Misses wait in the lane's bit mask for the slow path, which looks at counts and starts at the home bucket.
+// The table is a quarter (SLOTS = 2048: 16 KB) or half (4096) of the 8-byte form's, the keys half the bytes.
 // Remainders are loaded four per lane (16 bytes); a sub-region starts on a 16-byte boundary and its capacity is a
 // multiple of four, so the last vector may be read whole.
+constexpr uint32_t kR32Mul = 0x9E3779B1u, kR32MulInv = 0x0E8B2F51u;          // kR32Mul * kR32MulInv = 1 mod 2^32
+__host__ __device__ __forceinline__ uint32_t r32_mix(uint32_t k) { return (k ^ (k >> 15)) * kR32Mul; }
+__host__ __device__ __forceinline__ uint32_t r32_unmix(uint32_t f) { const uint32_t y = f * kR32MulInv; return y ^ (y >> 15) ^ (y >> 30); }
+
 #ifndef GOSS_R32_OCC
 #define GOSS_R32_OCC 5
 #endif
+#ifndef GOSS_R32_G
+#define GOSS_R32_G 4
+#endif
 template <int SLOTS, bool SQ>
-__global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_hash_reduce32_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
+__global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_hash_reduce32_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
                                                                 const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                 uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
                                                                 Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
@@ -570,9 +584,11 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_has
 {
     constexpr int NT = kTB;
     constexpr int kLimit = SLOTS / 4 * 3;
-    constexpr int kBucketBits = SLOTS == 4096 ? 11 : SLOTS == 2048 ? 10 : -1;       // log2(SLOTS / 2)
-    static_assert(kBucketBits > 0, "table size");
-    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS];
+    constexpr int BB = SLOTS == 4096 ? 11 : SLOTS == 2048 ? 10 : -1;       // log2(buckets)
+    constexpr uint32_t NB = SLOTS / 2;
+    static_assert(BB > 0, "table size");
+    // the table, then 64 pairs of words nobody reads: lane l's misses "count" at word 2 (SLOTS + l) + 1
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS + 64];
     __shared__ uint32_t ndist, ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = unit_block(), tid = threadIdx.x;
@@ -587,28 +603,33 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_has
         if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    for (uint32_t i = tid; i < SLOTS; i += NT) tab[i] = 0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
+    typedef const __attribute__((address_space(3))) u32x4* lds_bucket_plain;
+    typedef const volatile __attribute__((address_space(3))) u32x4* lds_bucket_ptr;
+    typedef __attribute__((address_space(3))) uint32_t* lds_word;
+    const lds_bytes tb = (lds_bytes)tab;
+    // (f of the marker: home b ^ 1, odd field 3 -> second bucket b ^ 2)
+    auto marker = [](uint32_t bkt) -> uint32_t { return r32_unmix(((bkt ^ 1u) << (32 - BB)) | (3u << (32 - 2 * BB))); };
+    for (uint32_t i = tid; i < NB; i += NT)
+    {
+        const uint32_t m = marker(i);
+        *(__attribute__((address_space(3))) u32x4*)(tb + 16 * i) = u32x4{m, 0u, m, 0u};
+    }
+    if (tid < 64) tab[SLOTS + tid] = 0;
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
-    uint32_t* const tw = reinterpret_cast<uint32_t*>(tab);          // word 2 i = remainder, 2 i + 1 = count of slot i
-    auto key_mix = [](uint32_t k) -> uint32_t { return (k ^ (k >> 15)) * 0x9E3779B1u; };
-    auto second_bucket = [](uint32_t f, uint32_t b1) -> uint32_t {
-        const uint32_t x = (f >> (32 - 2 * kBucketBits)) & (uint32_t)(SLOTS / 2 - 1);
-        return x == b1 ? ((b1 + 1u) & (uint32_t)(SLOTS / 2 - 1)) : x;
-    };
     lds_vu32 vovf = (lds_vu32)&ovf;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(3))) u32x4* lds_bucket_plain;
-    typedef const volatile __attribute__((address_space(3))) u32x4* lds_bucket_ptr;
-    const lds_bucket_plain pt2 = (lds_bucket_plain)tab;
-    const lds_bucket_ptr vt2 = (lds_bucket_ptr)tab;
+    const uint32_t dummy = 8u * ((uint32_t)SLOTS + (tid & 63u)) + 4u;       // byte address of the lane's own word
+    auto home_of = [](uint32_t f) -> uint32_t { return f >> (32 - BB); };
+    auto second_of = [](uint32_t f, uint32_t h) -> uint32_t { return h ^ (((f >> (32 - 2 * BB)) & (NB - 1u)) | 1u); };
 
     constexpr int kVec = 4;                                  // 16-byte loads in flight per lane
-    constexpr int kU = 4 * kVec;                             // remainders per lane and batch
+    constexpr int kG = GOSS_R32_G;                           // keys whose buckets are read together
     const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + b);         // (b is a multiple of 4)
     const uint32_t n = (uint32_t)(e - b);
-    const uint32_t nvec = (n + 3u) >> 2;
+    const uint32_t nvec = (n + 3u) >> 2, nfull = n >> 2;      // vectors, and vectors of four live remainders
     u32x4 nxt[kVec];
 #pragma unroll
     for (int u = 0; u < kVec; ++u)
@@ -618,16 +639,9 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_has
     }
     for (uint32_t i0 = 0; i0 < nvec; i0 += (uint32_t)NT * kVec)
     {
-        uint32_t kv[kU];
-        uint32_t livem = 0;                                  // bit u: remainder u of this batch exists
+        u32x4 cur[kVec];
 #pragma unroll
-        for (int u = 0; u < kVec; ++u)
-        {
-            kv[4 * u] = nxt[u].x; kv[4 * u + 1] = nxt[u].y; kv[4 * u + 2] = nxt[u].z; kv[4 * u + 3] = nxt[u].w;
-            const uint32_t i = i0 + (uint32_t)u * NT + tid;
-            const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
-            livem |= ((1u << have) - 1u) << (4 * u);
-        }
+        for (int u = 0; u < kVec; ++u) cur[u] = nxt[u];
         // software pipeline: the next batch's loads are in flight while this one is inserted
 #pragma unroll
         for (int u = 0; u < kVec; ++u)
@@ -635,85 +649,107 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_has
             const uint32_t i = i0 + (uint32_t)(kVec + u) * NT + tid;
             nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
         }
-        uint32_t bkt[kU];
-        uint32_t pend = 0, stm = 0;
-        constexpr int kHalf = kU / 2;
+#if defined(GOSS_R32_EXP) && GOSS_R32_EXP == 1
+        // (timing experiment: the loads alone)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int u = 0; u < kVec; ++u) asm volatile("" ::"v"(cur[u].x), "v"(cur[u].y), "v"(cur[u].z), "v"(cur[u].w));
+        continue;
+#endif
+        // every vector of the batch whole?  (all but a segment's last batch: no validity arithmetic in the fast path)
+        const bool whole = i0 + (uint32_t)NT * kVec <= nfull;
+        uint32_t pend = 0;                                   // bit 4 u + j: remainder j of vector u missed
+#pragma unroll
+        for (int u = 0; u < kVec; ++u)
         {
-            u32x4 q[kHalf], q2[kHalf];
-            uint32_t b2[kHalf];
-#pragma unroll
-            for (int j = 0; j < kHalf; ++j)
+            const uint32_t kk[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+            uint32_t live = 0xFu;
+            if (!whole)
             {
-                const int u = h * kHalf + j;
-                const uint32_t f = key_mix(kv[u]);
-                bkt[u] = f >> (32 - kBucketBits);
-                b2[j] = second_bucket(f, bkt[u]);
-                q[j] = pt2[bkt[u]];
-                q2[j] = pt2[b2[j]];
+                const uint32_t i = i0 + (uint32_t)u * NT + tid;
+                const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
+                live = (1u << have) - 1u;
             }
+            // kG keys at a time: their two buckets each read, then looked at
 #pragma unroll
-            for (int j = 0; j < kHalf; ++j)
+            for (int g0 = 0; g0 < 4; g0 += kG)
             {
-                const int u = h * kHalf + j;
-                const uint32_t live = (livem >> u) & 1u;
-                // (a slot matches when it is occupied and holds the remainder: integer forms, no branch per term)
-                const uint32_t h0 = (q[j].x == kv[u] ? 1u : 0u) & (q[j].y != 0u ? 1u : 0u);
-                const uint32_t h1 = (q[j].z == kv[u] ? 1u : 0u) & (q[j].w != 0u ? 1u : 0u);
-                const uint32_t h2 = (q2[j].x == kv[u] ? 1u : 0u) & (q2[j].y != 0u ? 1u : 0u);
-                const uint32_t h3 = (q2[j].z == kv[u] ? 1u : 0u) & (q2[j].w != 0u ? 1u : 0u);
-                const uint32_t hit = (h0 | h1 | h2 | h3) & live;
-                const uint32_t second = h2 | h3;
-                const uint32_t slot = 2 * (second ? b2[j] : bkt[u]) + (h1 | h3);
-                atomicAdd(&tw[2 * slot + 1], hit);
-                const uint32_t miss = live & (hit ^ 1u);
-                pend |= miss << u;
-                const uint32_t full = (q[j].y != 0u ? 1u : 0u) & (q[j].w != 0u ? 1u : 0u) & miss;
-                bkt[u] = full ? b2[j] : bkt[u];
-                stm |= full << u;
+                uint32_t a1[kG], a2[kG];
+                u32x4 q[kG], q2[kG];
+#pragma unroll
+                for (int j = 0; j < kG; ++j)
+                {
+                    const uint32_t f = r32_mix(kk[g0 + j]);
+                    const uint32_t h = home_of(f);
+                    a1[j] = h << 4;
+                    a2[j] = second_of(f, h) << 4;
+                    q[j] = *(lds_bucket_plain)(tb + a1[j]);
+                    q2[j] = *(lds_bucket_plain)(tb + a2[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < kG; ++j)
+                {
+                    // the count word of the slot that holds the key, else the lane's own word
+                    const uint32_t k1 = kk[g0 + j];
+                    uint32_t at = dummy;
+                    at = q2[j].z == k1 ? a2[j] + 12u : at;
+                    at = q2[j].x == k1 ? a2[j] + 4u : at;
+                    at = q[j].z == k1 ? a1[j] + 12u : at;
+                    at = q[j].x == k1 ? a1[j] + 4u : at;
+                    uint32_t miss = at == dummy ? 1u : 0u;
+                    if (!whole) { const uint32_t lv = (live >> (g0 + j)) & 1u; at = lv ? at : dummy; miss &= lv; }
+                    __hip_atomic_fetch_add((lds_word)(tb + at), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pend |= miss << (4 * u + g0 + j);
+                }
             }
         }
         // slow path: every lane walks its own queue of leftover keys, one probe per wave iteration
-        uint32_t key = 0, bk = 0, st = 0;
-        bool busy = false;
-        for (;;)
+        if (__ballot(pend != 0))
         {
-            if (!busy && pend)
+            uint32_t key = 0, bk = 0, st = 0;
+            bool busy = false;
+            for (;;)
             {
-                const uint32_t u = __ffs(pend) - 1;
-                pend &= pend - 1;
-                st = (stm >> u) & 1u;
-#pragma unroll
-                for (int uu = 0; uu < kU; ++uu)
-                    if (u == (uint32_t)uu) { key = kv[uu]; bk = bkt[uu]; }
-                busy = true;
-            }
-            if (!__ballot(busy)) break;
-            if (busy)
-            {
-                const u32x4 q01 = vt2[bk];
-                uint32_t hit = ~0u;                       // slot that holds (or now holds) the key; ~0 - 1: inserted with its count
-                if (q01.y != 0u && q01.x == key) hit = 2 * bk;
-                else if (q01.w != 0u && q01.z == key) hit = 2 * bk + 1;
-                else if (q01.y == 0u || q01.w == 0u)
+                if (!busy && pend)
                 {
-                    const uint32_t slot = 2 * bk + (q01.y == 0u ? 0u : 1u);
-                    const unsigned long long old = atomicCAS(&tab[slot], 0ULL, (unsigned long long)key | (1ULL << 32));
-                    if (old == 0ULL)
-                    {
-                        const uint32_t nd = atomicAdd(&ndist, 1u);
-                        if (nd + 1 > (uint32_t)kLimit) *vovf = 1;
-                        busy = false;                     // (counted by the insertion itself)
-                    }
-                    else if ((uint32_t)old == key) hit = slot;
-                    // else: somebody else took the slot; look at this bucket again
+                    const uint32_t u = __ffs(pend) - 1;
+                    pend &= pend - 1;
+#pragma unroll
+                    for (int uu = 0; uu < kVec; ++uu)
+                        if ((u >> 2) == (uint32_t)uu)
+                        {
+                            const uint32_t j = u & 3u;
+                            key = j == 0 ? cur[uu].x : j == 1 ? cur[uu].y : j == 2 ? cur[uu].z : cur[uu].w;
+                        }
+                    bk = home_of(r32_mix(key));
+                    st = 0;
+                    busy = true;
                 }
-                else if (st == 0) { bk = second_bucket(key_mix(key), bk); st = 1; }
-                else bk = (bk + 1) & (SLOTS / 2 - 1);
-                if (hit != ~0u) { atomicAdd(&tw[2 * hit + 1], 1u); busy = false; }
+                if (!__ballot(busy)) break;
+                if (busy)
+                {
+                    const u32x4 q01 = *(lds_bucket_ptr)(tb + 16u * bk);
+                    uint32_t hit = ~0u;                       // slot that holds the key
+                    if (q01.y != 0u && q01.x == key) hit = 2 * bk;
+                    else if (q01.w != 0u && q01.z == key) hit = 2 * bk + 1;
+                    else if (q01.y == 0u || q01.w == 0u)
+                    {
+                        const uint32_t slot = 2 * bk + (q01.y == 0u ? 0u : 1u);
+                        const unsigned long long old = atomicCAS(&tab[slot], (unsigned long long)marker(bk), (unsigned long long)key | (1ULL << 32));
+                        if (old == (unsigned long long)marker(bk))
+                        {
+                            const uint32_t nd = atomicAdd(&ndist, 1u);
+                            if (nd + 1 > (uint32_t)kLimit) *vovf = 1;
+                            busy = false;                     // (counted by the insertion itself)
+                        }
+                        else if ((uint32_t)old == key && (old >> 32) != 0) hit = slot;
+                        // else: somebody else took the slot; look at this bucket again
+                    }
+                    else if (st == 0) { bk = second_of(r32_mix(key), bk); st = 1; }
+                    else bk = (bk + 1) & (NB - 1u);
+                    if (hit != ~0u) { atomicAdd(reinterpret_cast<uint32_t*>(tab) + 2 * hit + 1, 1u); busy = false; }
+                }
+                if (*vovf) break;
             }
-            if (*vovf) break;
         }
         if (*vovf) break;
     }
@@ -729,7 +765,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 3) void seg_has
     // count so that a 64-bit compare orders by remainder), an insertion sort of every bin (1.5 entries on average at
     // half the limit); a bin of more than 24 entries (skewed low bits) -> bitonic sort of the compacted entries.
     constexpr int kPer = SLOTS / NT;
-    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = kBucketBits - 1;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = BB - 1;
     __shared__ uint32_t bins[kBins];
     __shared__ uint32_t sh_scan2[NT / 64 + 1];
     __shared__ uint32_t big;

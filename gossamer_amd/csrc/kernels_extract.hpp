@@ -1054,8 +1054,16 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                     {
                         const uint32_t p = i - (tl[u].x & 0xFFFFu);
                         const uint32_t thr = tl[u].y >> 16;
-                        const uint64_t o = p < thr ? ((uint64_t)tb[u].x << 3) + p : ((uint64_t)tb[u].y << 3) + (p - thr);
+                        uint64_t o = p < thr ? ((uint64_t)tb[u].x << 3) + p : ((uint64_t)tb[u].y << 3) + (p - thr);
+#if defined(GOSS_E1_EXP) && GOSS_E1_EXP == 1
+                        // (timing experiment: everything but the stores themselves)
+                        asm volatile("" ::"v"(kk[u].x), "v"(kk[u].y), "v"(kk[u].z), "v"(kk[u].w), "v"((uint32_t)o), "v"((uint32_t)(o >> 32)));
+#else
+#if defined(GOSS_E1_EXP) && GOSS_E1_EXP == 2
+                        o &= (1ULL << 21) - 2ULL;          // (timing experiment: the same stores into a 16 MB window)
+#endif
                         *reinterpret_cast<uint4*>(&out[o]) = kk[u];
+#endif
                     }
                 }
             }

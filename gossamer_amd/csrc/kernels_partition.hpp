@@ -209,17 +209,31 @@ __global__ __launch_bounds__(kJointThreads) void joint_hist_kernel(const K* __re
                                                                    unsigned long long* __restrict__ hist, uint32_t nsweeps)
 {
     __shared__ uint32_t lh[32768];
+    __shared__ uint32_t spare[64];               // one word per lane for the keys of other sweeps (ONE word for all of them is a 64-way conflict)
     const uint64_t stride = (uint64_t)gridDim.x * kJointThreads;
     const uint32_t mask = 32768u * nsweeps - 1u;
+    uint32_t* const mine = &spare[threadIdx.x & 63u];
     for (uint32_t sweep = 0; sweep < nsweeps; ++sweep)
     {
         for (uint32_t i = threadIdx.x; i < 32768; i += kJointThreads) lh[i] = 0;
         __syncthreads();
-        for (uint64_t i = (uint64_t)blockIdx.x * kJointThreads + threadIdx.x; i < n; i += stride)
+        // (eight independent loads per thread in flight: with one, a sweep is a chain of memory latencies -- 0.56 ms per
+        // sweep over 196 M keys, 2.3 ms for the four of the 17-bit form)
+        constexpr int kU = 8;
+        for (uint64_t i0 = (uint64_t)blockIdx.x * kJointThreads + threadIdx.x; i0 < n; i0 += stride * kU)
         {
-            const uint32_t b = (uint32_t)key_shr64(keys[i], shift) & mask;
-            // (a bin of another sweep: a spare word nobody reads, instead of a branch around the atomic)
-            atomicAdd(&lh[(b >> 15) == sweep ? (b & 32767u) : 32767u], (b >> 15) == sweep ? 1u : 0u);
+            uint32_t bb[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+            {
+                const uint64_t i = i0 + (uint64_t)u * stride;
+                // (beyond the end: the last key again, counted in no bin)
+                bb[u] = i < n ? ((uint32_t)key_shr64(keys[i], shift) & mask) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                // (a bin of another sweep: a word of the lane's own that nobody reads, instead of a branch around the atomic)
+                atomicAdd((bb[u] >> 15) == sweep ? &lh[bb[u] & 32767u] : mine, 1u);
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < 32768; j += kJointThreads)
@@ -571,39 +585,59 @@ __host__ __device__ __forceinline__ uint64_t rem32_unpack(uint32_t r, uint32_t s
     return (((uint64_t)r >> sqbit) << (sqbit + 1)) | ((uint64_t)r & ((1ULL << sqbit) - 1ULL));
 }
 
-// Tile = 5 632 keys of ONE first-level region (the same 52 KB of LDS and three workgroups per CU as the 8-byte form;
-// tiles dealt out by XCD for the same reason: the ~44-byte runs a tile appends to a sub-region meet their neighbours
-// in one L2).  Rank by one LDS atomic per key on 512 digit counters; a thread owns two neighbouring digits and takes
-// the tile's room in both sub-regions with ONE 64-bit atomic on the pair of 32-bit cursors (a wave's 64 atomics cover
-// 512 contiguous bytes); keys to their digit-sorted place in LDS; remainders out in coalesced runs.
+// Where the second level's tiles lie: tile t is the (t - tile_first[b])-th run of kTile slots of region b.  Worked out once
+// per tile by this kernel (a binary search) so that a tile's workgroup learns its place with ONE scalar load
+// instead of a search over the regions, a barrier and a second round of loads before its first key load is issued.
+struct Tile32 { unsigned long long base; uint32_t n, bucket; };
+template <int TILE>
+__global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restrict__ desc, uint32_t total)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = 255;                   // the last region whose first tile is <= t
+    while (lo < hi)
+    {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (gt->tile_first[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t j = (uint64_t)t - gt->tile_first[lo];
+    const uint64_t left = gt->cnt[lo] - j * TILE;
+    desc[t] = Tile32{gt->reg_start[lo] + j * TILE, (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE), lo};
+}
+
+// Tile = 5 632 keys of ONE first-level region; tiles dealt out by XCD (the ~44-byte runs a tile appends to a sub-region
+// meet their neighbours in one L2).  Rank by one LDS atomic per key on 512 digit counters; a thread owns two
+// neighbouring digits and takes the tile's room in both sub-regions with ONE 64-bit atomic on the pair of 32-bit
+// cursors (a wave's 64 atomics cover 512 contiguous bytes); the REMAINDERS (4 bytes) and their digits (2 bytes) go to
+// their digit-sorted place in LDS -- 40 KB per workgroup, four per CU where the 8-byte staging of the other form
+// allows three; remainders out in coalesced runs.
+#ifndef GOSS_S32_OCC
+#define GOSS_S32_OCC 4
+#endif
 template <bool SQ>
-__global__ __launch_bounds__(kTB, 3) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
                                                            uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
-                                                           const GapTable* __restrict__ gt, const SubTable32* __restrict__ sub,
-                                                           LookbackCtl* __restrict__ ctl)
+                                                           const Tile32* __restrict__ desc, uint32_t total_tiles,
+                                                           const SubTable32* __restrict__ sub, LookbackCtl* __restrict__ ctl)
 {
     constexpr int kItems = SubCfg<Key1>::kItems;
     constexpr int kTile = kTB * kItems;
-    __shared__ Key1 stage[kTile];
+    __shared__ uint32_t stage[kTile];
+    __shared__ uint16_t sdig[kTile];
     __shared__ uint32_t hist[kSub32Digits];                  // keys per digit, then the digit's first slot in `stage`
-    __shared__ unsigned long long gbase[kSub32Digits];       // the digit's first slot in `out` minus its first slot in `stage`
+    __shared__ uint32_t gbase[kSub32Digits];                 // the digit's first slot in `out` minus its first slot in `stage`, relative to the region's first sub-region
     __shared__ uint32_t sh_scan[kWaves + 1];
-    __shared__ uint32_t sh_bucket, sh_skip, sh_total;
+    __shared__ uint32_t sh_skip, sh_total;
 
     const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t total_tiles = (uint32_t)gt->tile_first[256];
     const uint32_t per = (total_tiles + 7u) / 8u;
     const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (tile >= total_tiles) return;
-    if (gt->tile_first[tid] <= tile && tile < gt->tile_first[tid + 1]) sh_bucket = tid;
+    const Tile32 td = desc[tile];                            // (uniform: one scalar load)
+    const uint32_t b = td.bucket, tile_n = td.n;
+    const uint64_t tile_base = td.base;
     if (tid == 0) sh_skip = 0;
     hist[tid] = 0; hist[tid + 256] = 0;
-    __syncthreads();
-    const uint32_t b = sh_bucket;
-    const uint64_t j = (uint64_t)tile - gt->tile_first[b];
-    const uint64_t left = gt->cnt[b] - j * kTile;
-    const uint64_t tile_base = gt->reg_start[b] + j * kTile;
-    const uint32_t tile_n = (uint32_t)(left < (uint64_t)kTile ? left : (uint64_t)kTile);
 
     Key1 key[kItems];
     uint16_t rank[kItems];
@@ -615,6 +649,7 @@ __global__ __launch_bounds__(kTB, 3) void subpart32_kernel(const Key1* __restric
         const uint32_t li = wbase + r * 64 + lane;
         if (li < tile_n) { key[r] = keys_in[tile_base + li]; have |= 1u << r; }
     }
+    __syncthreads();
     // (a second loop: looking at a key inside the load loop would wait for every load in turn)
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
@@ -623,6 +658,7 @@ __global__ __launch_bounds__(kTB, 3) void subpart32_kernel(const Key1* __restric
     for (int r = 0; r < kItems; ++r)
         if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u)], 1u);
     __syncthreads();
+    const uint64_t region_first = sub->start[b * kSub32Digits];          // (uniform)
     {
         // thread tid owns digits 2 tid and 2 tid + 1
         const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
@@ -635,21 +671,33 @@ __global__ __launch_bounds__(kTB, 3) void subpart32_kernel(const Key1* __restric
         uint32_t tile_total;
         const uint32_t start = block_excl_scan<uint32_t>(c0 + c1, sh_scan, &tile_total);
         hist[2 * tid] = start; hist[2 * tid + 1] = start + c0;
-        gbase[2 * tid] = sub->start[sidx] + e0 - start;
-        gbase[2 * tid + 1] = sub->start[sidx + 1] + e1 - (start + c0);
+        // (a region's sub-regions span less than 2^32 slots: the host checks it)
+        gbase[2 * tid] = (uint32_t)(sub->start[sidx] - region_first) + e0 - start;
+        gbase[2 * tid + 1] = (uint32_t)(sub->start[sidx + 1] - region_first) + e1 - (start + c0);
         if (tid == 0) sh_total = tile_total;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
-        if ((have >> r) & 1u) stage[hist[(uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u)] + rank[r]] = key[r];
+        if ((have >> r) & 1u)
+        {
+            const uint32_t d = (uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u);
+            const uint32_t at = hist[d] + rank[r];
+            stage[at] = rem32_pack<SQ>(key[r].lo, rbits, sqbit);
+            sdig[at] = (uint16_t)d;
+        }
     __syncthreads();
     if (sh_skip) return;
     const uint32_t tile_keys = sh_total;
+    uint32_t* const out_r = out + region_first;
     for (uint32_t i = tid; i < tile_keys; i += kTB)
     {
-        const uint64_t k = stage[i].lo;
-        out[gbase[(uint32_t)(k >> rbits) & (kSub32Digits - 1u)] + i] = rem32_pack<SQ>(k, rbits, sqbit);
+#if defined(GOSS_S32_EXP) && GOSS_S32_EXP == 1
+        // (timing experiment: everything but the stores)
+        asm volatile("" ::"v"(gbase[sdig[i]]), "v"(stage[i]));
+#else
+        out_r[(uint32_t)(gbase[sdig[i]] + i)] = stage[i];
+#endif
     }
 }
 

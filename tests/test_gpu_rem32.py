@@ -133,11 +133,11 @@ def test_rem32_tables_overflow_in_turn():
 
 def test_rem32_gives_way_to_the_8_byte_form(oracle):
     """Reads = one fixed 16-base prefix + 9 random bases, 1.2 M of them (the fused path wants a million keys): every
-    forward 25-mer lies under ONE 17-bit prefix, ~130 000 distinct ones are their own strand representative -- both
+    forward 25-mer lies under ONE 17-bit prefix and is its own strand representative (262 144 distinct ones) -- both
     32-bit tables overflow, the chunk is redone in the 8-byte form, whose own ladder ends in the full sort.  Files
     against the oracle."""
     rng = random.Random(12)
-    prefix = "ACGTTGCAAGCTTAGG"
+    prefix = "ACGTTGCAAGCTGAGG"          # (base 12, the middle of the 25-mer, is a G: the forward strand is the representative)
     reads = [prefix + "".join(rng.choice("ACGT") for _ in range(9)) for _ in range(1_200_000)]
     txt = ("\n".join(reads) + "\n").encode()
     exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", txt)], 25, out="o")
@@ -154,7 +154,7 @@ def test_rem32_skewed_low_bits(oracle):
     fallback of seg_hash_reduce32_kernel.  One fixed prefix + 5 random bases (1 024 distinct forward keys, fewer than
     a table takes), 1.1 M reads; k = 25 (squeezed remainders) and graph k = 20."""
     rng = random.Random(8)
-    for k, mode, prefix in ((25, 0, "ACGTTGCAAGCTTAGGCATC"), (20, 1, "ACGTTGCAAGCTTAGG")):
+    for k, mode, prefix in ((25, 0, "ACGTTGCAAGCTGAGGCATC"), (20, 1, "ACGTTGCAAGCTTAGG")):
         tails = ["".join(rng.choice("ACGT") for _ in range(5)) for _ in range(1_100_000)]
         txt = ("\n".join(prefix + t for t in tails) + "\n").encode()
         build_o = oracle.build_graph if mode else oracle.build_kmer_set
