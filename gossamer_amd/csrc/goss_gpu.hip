@@ -1536,7 +1536,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (n == 0) return kFusedDeclined;
     if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");
     uint64_t tiles = 0, sum = 0;
-    const uint64_t tile_keys = msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
+    const uint64_t tile_keys = (msd && r32_slots) ? (uint64_t)kSub32Tile : msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
     for (int d = 0; d < 256; ++d)
     {
         // one-word keys: slots handed out in whole blocks, padding included (the next pass skips it)
@@ -1564,7 +1564,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         Tile32* tdesc = (Tile32*)c->arena.temp(std::max<uint64_t>(tiles, 1) * sizeof(Tile32));
         HIP_TRY(hipMemcpyAsync(dsub, hsub32.data(), sizeof(SubTable32), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)kSub32Regions * 4, c->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<SubCfg<Key1>::kTile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32Tile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
                            (const GapTable*)dgt, tdesc, (uint32_t)tiles);
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);

@@ -587,8 +587,8 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
     constexpr int BB = SLOTS == 4096 ? 11 : SLOTS == 2048 ? 10 : -1;       // log2(buckets)
     constexpr uint32_t NB = SLOTS / 2;
     static_assert(BB > 0, "table size");
-    // the table, then 64 pairs of words nobody reads: lane l's misses "count" at word 2 (SLOTS + l) + 1
-    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS + 64];
+    // the table, then a bucket per lane (64 x 16 bytes) for the accesses that must not land in the table
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS + 128];
     __shared__ uint32_t ndist, ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = unit_block(), tid = threadIdx.x;
@@ -616,12 +616,14 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
         const uint32_t m = marker(i);
         *(__attribute__((address_space(3))) u32x4*)(tb + 16 * i) = u32x4{m, 0u, m, 0u};
     }
-    if (tid < 64) tab[SLOTS + tid] = 0;
+    if (tid < 128) tab[SLOTS + tid] = 0;
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
 
     lds_vu32 vovf = (lds_vu32)&ovf;
-    const uint32_t dummy = 8u * ((uint32_t)SLOTS + (tid & 63u)) + 4u;       // byte address of the lane's own word
+    // behind the table: a bucket (16 bytes) per lane that nobody else touches -- its second word takes the lane's misses
+    const uint32_t own16 = 8u * (uint32_t)SLOTS + 16u * (tid & 63u);
+    const uint32_t dummy = own16 + 4u;
     auto home_of = [](uint32_t f) -> uint32_t { return f >> (32 - BB); };
     auto second_of = [](uint32_t f, uint32_t h) -> uint32_t { return h ^ (((f >> (32 - 2 * BB)) & (NB - 1u)) | 1u); };
 
@@ -669,12 +671,14 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
                 const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
                 live = (1u << have) - 1u;
             }
-            // kG keys at a time: their two buckets each read, then looked at
+            // kG keys at a time: their home buckets read and looked at; the second bucket only by the lanes whose key
+            // was not at home (6 % at a load of 0.37): a 16-byte LDS read costs what its busiest bank takes, and with a
+            // few lanes active that is one cycle per lane group instead of three -- the LDS pipe is this kernel's bound
 #pragma unroll
             for (int g0 = 0; g0 < 4; g0 += kG)
             {
-                uint32_t a1[kG], a2[kG];
-                u32x4 q[kG], q2[kG];
+                uint32_t a1[kG], a2[kG], at[kG];
+                u32x4 q[kG];
 #pragma unroll
                 for (int j = 0; j < kG; ++j)
                 {
@@ -683,21 +687,46 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
                     a1[j] = h << 4;
                     a2[j] = second_of(f, h) << 4;
                     q[j] = *(lds_bucket_plain)(tb + a1[j]);
-                    q2[j] = *(lds_bucket_plain)(tb + a2[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < kG; ++j)
                 {
                     // the count word of the slot that holds the key, else the lane's own word
                     const uint32_t k1 = kk[g0 + j];
-                    uint32_t at = dummy;
-                    at = q2[j].z == k1 ? a2[j] + 12u : at;
-                    at = q2[j].x == k1 ? a2[j] + 4u : at;
-                    at = q[j].z == k1 ? a1[j] + 12u : at;
-                    at = q[j].x == k1 ? a1[j] + 4u : at;
-                    uint32_t miss = at == dummy ? 1u : 0u;
-                    if (!whole) { const uint32_t lv = (live >> (g0 + j)) & 1u; at = lv ? at : dummy; miss &= lv; }
-                    __hip_atomic_fetch_add((lds_word)(tb + at), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t t = dummy;
+                    t = q[j].z == k1 ? a1[j] + 12u : t;
+                    t = q[j].x == k1 ? a1[j] + 4u : t;
+                    at[j] = t;
+                }
+                {
+                    // (a lane whose key was at home reads a bucket of its own behind the table instead: 64 such reads
+                    // are one conflict-free sweep, so the instruction costs what the few lanes that missed make it cost)
+                    u32x4 q2[kG];
+#pragma unroll
+                    for (int j = 0; j < kG; ++j)
+                    {
+#if !defined(GOSS_R32_BOTH)
+                        a2[j] = at[j] == dummy ? a2[j] : own16;
+#endif
+                        q2[j] = *(lds_bucket_plain)(tb + a2[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kG; ++j)
+                    {
+                        const uint32_t k1 = kk[g0 + j];
+                        uint32_t t = dummy;
+                        t = q2[j].z == k1 ? a2[j] + 12u : t;
+                        t = q2[j].x == k1 ? a2[j] + 4u : t;
+                        at[j] = at[j] == dummy ? t : at[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kG; ++j)
+                {
+                    uint32_t t = at[j];
+                    uint32_t miss = t == dummy ? 1u : 0u;
+                    if (!whole) { const uint32_t lv = (live >> (g0 + j)) & 1u; t = lv ? t : dummy; miss &= lv; }
+                    __hip_atomic_fetch_add((lds_word)(tb + t), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     pend |= miss << (4 * u + g0 + j);
                 }
             }

@@ -791,6 +791,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         if (tid < 4) encode(q1, c1, b1);
     }
 
+#if defined(GOSS_E1_STAGGER)
+    // (timing experiment: the workgroups that share a CU start a third of a tile apart)
+    for (uint32_t z = 0; z < (blockIdx.x >> 8) * GOSS_E1_STAGGER; ++z) __builtin_amdgcn_s_sleep(100);
+#endif
     for (uint64_t st = blockIdx.x;; st += gridDim.x)
     {
         if constexpr (REC) { if (rc_next >= rc_end) break; }

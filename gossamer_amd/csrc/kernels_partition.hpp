@@ -200,46 +200,45 @@ __global__ __launch_bounds__(kTB) void global_hist_kernel(const K* __restrict__ 
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
-// Histogram of the 16 (nsweeps = 2) or 17 (nsweeps = 4) bits at `shift` of every key (65 536 / 131 072 bins): the joint
+// Histogram of the 16 (nparts = 2) or 17 (nparts = 4) bits at `shift` of every key (65 536 / 131 072 bins): the joint
 // histogram of the two partition digits the fused path sizes its sub-regions from (exact when the sample is the
-// chunk).  One workgroup per CU with 32 768 of the bins at a time in LDS (128 KB), so nsweeps sweeps over the keys.
+// chunk).  A workgroup holds 32 768 of the bins in LDS (128 KB, one workgroup per CU), so the bins are cut into nparts
+// parts and the grid (a multiple of 8 * nparts workgroups) into groups of nparts workgroups that read the SAME keys,
+// each counting its own part of the bins.  The members of a group are 8 apart in blockIdx -- one XCD -- and do the
+// same amount of work, so they run side by side and the keys come from HBM once and from that XCD's L2 nparts - 1
+// times (as nparts sweeps of every workgroup over all keys the four parts took 2.1 ms on C2's 196 M sample keys: 6.3 GB).
 constexpr int kJointThreads = 1024;
 template <class K>
 __global__ __launch_bounds__(kJointThreads) void joint_hist_kernel(const K* __restrict__ keys, uint64_t n, uint32_t shift,
-                                                                   unsigned long long* __restrict__ hist, uint32_t nsweeps)
+                                                                   unsigned long long* __restrict__ hist, uint32_t nparts)
 {
     __shared__ uint32_t lh[32768];
-    __shared__ uint32_t spare[64];               // one word per lane for the keys of other sweeps (ONE word for all of them is a 64-way conflict)
-    const uint64_t stride = (uint64_t)gridDim.x * kJointThreads;
-    const uint32_t mask = 32768u * nsweeps - 1u;
+    __shared__ uint32_t spare[64];               // one word per lane for the keys of other parts (ONE word for all of them is a 64-way conflict)
+    const uint32_t mask = 32768u * nparts - 1u;
+    const uint32_t part = (blockIdx.x >> 3) % nparts;
+    const uint32_t stream = (blockIdx.x & 7u) + 8u * (blockIdx.x / (8u * nparts)), nstreams = gridDim.x / nparts;
+    const uint64_t stride = (uint64_t)nstreams * kJointThreads;
     uint32_t* const mine = &spare[threadIdx.x & 63u];
-    for (uint32_t sweep = 0; sweep < nsweeps; ++sweep)
+    for (uint32_t i = threadIdx.x; i < 32768; i += kJointThreads) lh[i] = 0;
+    __syncthreads();
+    constexpr int kU = 8;                        // independent loads per thread in flight
+    for (uint64_t i0 = (uint64_t)stream * kJointThreads + threadIdx.x; i0 < n; i0 += stride * kU)
     {
-        for (uint32_t i = threadIdx.x; i < 32768; i += kJointThreads) lh[i] = 0;
-        __syncthreads();
-        // (eight independent loads per thread in flight: with one, a sweep is a chain of memory latencies -- 0.56 ms per
-        // sweep over 196 M keys, 2.3 ms for the four of the 17-bit form)
-        constexpr int kU = 8;
-        for (uint64_t i0 = (uint64_t)blockIdx.x * kJointThreads + threadIdx.x; i0 < n; i0 += stride * kU)
+        uint32_t bb[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
         {
-            uint32_t bb[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u)
-            {
-                const uint64_t i = i0 + (uint64_t)u * stride;
-                // (beyond the end: the last key again, counted in no bin)
-                bb[u] = i < n ? ((uint32_t)key_shr64(keys[i], shift) & mask) : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u)
-                // (a bin of another sweep: a word of the lane's own that nobody reads, instead of a branch around the atomic)
-                atomicAdd((bb[u] >> 15) == sweep ? &lh[bb[u] & 32767u] : mine, 1u);
+            const uint64_t i = i0 + (uint64_t)u * stride;
+            bb[u] = i < n ? ((uint32_t)key_shr64(keys[i], shift) & mask) : 0xFFFFFFFFu;          // (beyond the end: no bin)
         }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < 32768; j += kJointThreads)
-            if (lh[j]) atomicAdd(&hist[sweep * 32768u + j], (unsigned long long)lh[j]);
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            // (a bin of another part: a word of the lane's own that nobody reads, instead of a branch around the atomic)
+            atomicAdd((bb[u] >> 15) == part ? &lh[bb[u] & 32767u] : mine, 1u);
     }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < 32768; j += kJointThreads)
+        if (lh[j]) atomicAdd(&hist[part * 32768u + j], (unsigned long long)lh[j]);
 }
 
 // In-place exclusive scan of each 256-entry row (one workgroup per row).
@@ -589,6 +588,11 @@ __host__ __device__ __forceinline__ uint64_t rem32_unpack(uint32_t r, uint32_t s
 // per tile by this kernel (a binary search) so that a tile's workgroup learns its place with ONE scalar load
 // instead of a search over the regions, a barrier and a second round of loads before its first key load is issued.
 struct Tile32 { unsigned long long base; uint32_t n, bucket; };
+#ifndef GOSS_S32_ITEMS
+#define GOSS_S32_ITEMS 22
+#endif
+constexpr int kSub32Items = GOSS_S32_ITEMS;          // keys per thread of subpart32_kernel
+constexpr int kSub32Tile = kTB * kSub32Items;
 template <int TILE>
 __global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restrict__ desc, uint32_t total)
 {
@@ -620,8 +624,8 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
                                                            const Tile32* __restrict__ desc, uint32_t total_tiles,
                                                            const SubTable32* __restrict__ sub, LookbackCtl* __restrict__ ctl)
 {
-    constexpr int kItems = SubCfg<Key1>::kItems;
-    constexpr int kTile = kTB * kItems;
+    constexpr int kItems = kSub32Items;
+    constexpr int kTile = kSub32Tile;
     __shared__ uint32_t stage[kTile];
     __shared__ uint16_t sdig[kTile];
     __shared__ uint32_t hist[kSub32Digits];                  // keys per digit, then the digit's first slot in `stage`
