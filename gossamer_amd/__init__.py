@@ -5,4 +5,4 @@ the C++ host command `goss` (build-kmer-set / build-graph).  This Python package
 the C ABI for tests and bench.py.
 """
 from .binding import (Context, GossGpuError, MODE_GRAPH, MODE_KMER_SET, SYMBOLS,  # noqa: F401
-                      group_emit, group_exchange, load, synth_reads_host)
+                      group_emit, group_exchange, group_route_exchange, load, synth_reads_host)

@@ -25,6 +25,7 @@ SYMBOLS = [
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
+    "goss_gpu_set_deferred", "goss_gpu_stage_room", "goss_gpu_group_route_exchange",
     "goss_gpu_push_keys_host", "goss_gpu_push_keys_device",
     "goss_gpu_route_records_device", "goss_gpu_push_records_device",
     "goss_gpu_push_bases_host_async", "goss_gpu_push_packed_host", "goss_gpu_push_packed_host_async", "goss_gpu_flush",
@@ -161,6 +162,24 @@ def group_exchange(contexts, sample_per_context=0):
     _torch_ready()
     contexts[0]._check(L.goss_gpu_group_exchange(arr, n, sample_per_context, sizes))
     return [int(x) for x in sizes]
+
+
+class GroupXStats(C.Structure):
+    _fields_ = [("transport", C.c_uint32), ("rounds", C.c_uint32), ("records", C.c_uint64), ("windows", C.c_uint64),
+                ("record_bytes", C.c_uint64), ("route_ms", C.c_double), ("wire_ms", C.c_double), ("count_ms", C.c_double)]
+
+
+def group_route_exchange(contexts, transport=0):
+    """goss_gpu_group_route_exchange: what the (deferred) contexts have staged is cut into super-k-mer records routed by
+    minimizer, part p of every context moved to context p and counted there.  Returns the call's statistics as a dict."""
+    L = load()
+    n = len(contexts)
+    arr = (C.c_void_p * n)(*[c._h for c in contexts])
+    st = GroupXStats()
+    L.goss_gpu_group_route_exchange.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_int, C.POINTER(GroupXStats)]
+    _torch_ready()
+    contexts[0]._check(L.goss_gpu_group_route_exchange(arr, n, transport, C.byref(st)))
+    return {f: getattr(st, f) for f, _ in GroupXStats._fields_}
 
 
 def group_emit(contexts, estimate=0):
@@ -374,6 +393,18 @@ class Context:
         """Let the arena grow up to max_bytes when a chunk or a merge needs it (goss_gpu_set_budget_limit)."""
         self._L.goss_gpu_set_budget_limit.argtypes = [C.c_void_p, C.c_uint64]
         self._check(self._L.goss_gpu_set_budget_limit(self._h, max_bytes))
+
+    def set_deferred(self, on=True):
+        """goss_gpu_set_deferred: host pushes only stage; a full staging buffer is reported (GOSS_ERR_BUFFER)."""
+        self._L.goss_gpu_set_deferred.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._L.goss_gpu_set_deferred(self._h, 1 if on else 0))
+
+    def stage_room(self):
+        """goss_gpu_stage_room -> (bytes the staging buffer still takes, its capacity)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._L.goss_gpu_stage_room.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self._check(self._L.goss_gpu_stage_room(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def stat(self, name):
         """A diagnostic counter of the context (goss_gpu_stat)."""

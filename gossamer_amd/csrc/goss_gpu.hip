@@ -4,6 +4,7 @@
 #include "../../include/goss_gpu.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -12,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -151,6 +153,13 @@ struct goss_gpu_ctx {
     bool rec_mode = false;              // the current push is a string of super-k-mer records (goss_gpu_push_records_device): "bases" point at
                                         // SkRec records, a "window start" is one of a record's 16 window slots
     uint32_t rec_chunks = 0;            // chunks counted from records by the fused path
+    bool deferred = false;              // goss_gpu_set_deferred: host pushes only stage; a full staging buffer is reported, not counted
+                                        // (the caller then runs goss_gpu_group_route_exchange: the exchange before counting)
+    uint8_t* grp_send = nullptr;        // goss_gpu_group_route_exchange: this member's routed records (device memory of its own) ...
+    uint64_t grp_send_cap = 0;          // ... record slots
+    uint8_t* grp_inbox = nullptr;       // ... and what the other members sent it
+    uint64_t grp_inbox_cap = 0;
+    hipStream_t xstream = nullptr;      // stream of the transfers into this member's inbox
     double valid_frac = 1.0;            // estimated valid windows per window start of the current push (sizes the key buffers)
     bool size_by_valid = true;          // GOSS_GPU_NO_VALID_SIZING=1: key buffers always hold one key per window start
     uint64_t budget = 0;
@@ -2812,6 +2821,9 @@ void goss_gpu_destroy(goss_gpu_ctx* c)
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_route) (void)hipFree(c->d_route);
+    if (c->grp_send) (void)hipFree(c->grp_send);
+    if (c->grp_inbox) (void)hipFree(c->grp_inbox);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2861,6 +2873,8 @@ static void flush_staging(goss_gpu_ctx* c)
 // the device for the copies that filled it -- and the caller goes on with the other buffer.
 static void flush_staging_background(goss_gpu_ctx* c)
 {
+    if (c->deferred && c->stage && c->stage_fill)
+        throw StatusError{GOSS_ERR_BUFFER, "the staging buffer is full and counting is deferred: goss_gpu_group_route_exchange first (goss_gpu_stage_room says how much fits)"};
     wait_background(c);                                  // (one buffer is counted at a time: this is where a producer that outruns the device waits)
     if (!c->stage || c->stage_fill == 0) return;
     const uint64_t n = c->stage_fill;
@@ -2949,6 +2963,12 @@ static void ensure_stage(goss_gpu_ctx* c)
         const uint64_t fits = room > (48ULL << 20) ? (room - (32ULL << 20)) * 8 / 11 : (1ULL << 20);      // (buffer + landing = 11/8 of it)
         if (c->stage_cap > fits) c->stage_cap = std::max<uint64_t>(fits, 1u << 20) & ~4095ULL;
     }
+    // (tests: a small staging buffer makes a small input take several flushes / exchange rounds)
+    if (const char* e = std::getenv("GOSS_GPU_STAGE_CAP"))
+    {
+        const uint64_t v = std::strtoull(e, nullptr, 10);
+        if (v) c->stage_cap = std::min<uint64_t>(c->stage_cap, std::max<uint64_t>(v, 1u << 16) & ~4095ULL);
+    }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     // (one block each: the staging buffer, and behind it the landing area of packed pushes)
     const uint64_t bytes = c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64;
@@ -2970,6 +2990,7 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
     ensure_stage(c);
     if (nbytes + 1 > c->stage_cap)
     {
+        if (c->deferred) throw StatusError{GOSS_ERR_BUFFER, "a push larger than the staging buffer while counting is deferred"};
         // larger than the staging buffer: count it on its own, in pieces that overlap by
         // len-1 bytes so that no window is lost at a cut
         flush_staging(c);
@@ -3504,6 +3525,259 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
     });
     if (d_high) { (void)hipSetDevice(c0->device); (void)hipFree(d_high); }
     return rc;
+}
+
+// ---- the exchange BEFORE counting for one process that owns several GPUs ---------------------------------
+// (gossamer_amd/dist.py: route_and_exchange_records does the same between processes)
+
+extern "C++" {
+namespace {
+
+// RCCL, loaded at run time (the library links against nothing but HIP): point-to-point sends and receives inside one
+// group call are an all-to-all at full xGMI bandwidth.  Absent library, communicators that cannot be made (the same
+// device twice) or GOSS_GROUP_TRANSPORT=peer -> hipMemcpyPeerAsync.
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool tried = false;
+    std::map<std::vector<int>, std::vector<void*>> comms;          // device list -> one communicator per member
+    std::mutex m;
+};
+Rccl g_rccl;
+
+bool rccl_load()
+{
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+    {
+        void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!h) continue;
+        Rccl r;
+        r.lib = h;
+        r.CommInitAll = (int (*)(void**, int, const int*))dlsym(h, "ncclCommInitAll");
+        r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        r.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        r.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+        r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+        r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+        r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        if (r.CommInitAll && r.GroupStart && r.GroupEnd && r.Send && r.Recv)
+        {
+            g_rccl.lib = r.lib; g_rccl.CommInitAll = r.CommInitAll; g_rccl.CommDestroy = r.CommDestroy; g_rccl.GroupStart = r.GroupStart;
+            g_rccl.GroupEnd = r.GroupEnd; g_rccl.Send = r.Send; g_rccl.Recv = r.Recv; g_rccl.GetErrorString = r.GetErrorString;
+            return true;
+        }
+        dlclose(h);
+    }
+    return false;
+}
+
+// communicators of a device list (made once per list and process); nullptr = not to be had
+const std::vector<void*>* rccl_comms(const std::vector<int>& devs)
+{
+    std::lock_guard<std::mutex> lk(g_rccl.m);
+    if (!rccl_load()) return nullptr;
+    auto it = g_rccl.comms.find(devs);
+    if (it != g_rccl.comms.end()) return it->second.empty() ? nullptr : &it->second;
+    std::vector<int> sorted = devs;
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<void*> cs;
+    if (std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end())          // (a device twice: no communicators)
+    {
+        cs.assign(devs.size(), nullptr);
+        if (g_rccl.CommInitAll(cs.data(), (int)devs.size(), devs.data()) != 0) cs.clear();
+    }
+    auto& slot = g_rccl.comms[devs];
+    slot = cs;
+    return slot.empty() ? nullptr : &slot;
+}
+
+constexpr uint64_t kRecBytes = sizeof(SkRec);
+constexpr uint64_t kXferRound = 512ULL << 20;          // bytes per (source, destination) pair and round (RCCL 2.26 drops the second half of segments above 1 GiB)
+
+void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, goss_gpu_group_xstats* st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    // 1. every member routes what it has staged into n parts (side by side: one host thread per device)
+    std::vector<std::vector<uint64_t>> recs(n, std::vector<uint64_t>(n, 0)), wins(n, std::vector<uint64_t>(n, 0)), first(n, std::vector<uint64_t>(n, 0));
+    std::vector<int> status(n, GOSS_OK);
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < n; ++i)
+            pool.emplace_back([&, i]() {
+                goss_gpu_ctx* c = ctxs[i];
+                status[i] = guarded(c, [&]() {
+                    if (!c->stage || c->stage_fill == 0) return;
+                    HIP_TRY(hipStreamSynchronize(c->copy_stream));          // (the copies that filled the buffer)
+                    const uint64_t nb = c->stage_fill;
+                    // room per part: ~7 windows per record, a third of slack; a part that needs more is reported and the
+                    // routing is redone with what every part asked for
+                    std::vector<uint64_t> cap(n, nb / 5 / n + nb / 15 / n + 4096);
+                    for (int attempt = 0;; ++attempt)
+                    {
+                        uint64_t tot = 0;
+                        for (uint32_t p = 0; p < n; ++p) { first[i][p] = tot; tot += cap[p]; }
+                        if (tot > c->grp_send_cap)
+                        {
+                            if (c->grp_send) { HIP_TRY(hipFree(c->grp_send)); c->grp_send = nullptr; c->grp_send_cap = 0; }
+                            if (hipMalloc((void**)&c->grp_send, tot * kRecBytes) != hipSuccess)
+                            { (void)hipGetLastError(); throw StatusError{GOSS_ERR_OOM, "no device memory for the routed records"}; }
+                            c->grp_send_cap = tot;
+                        }
+                        const int rc = goss_gpu_route_records_device(c, c->stage, nb, n, c->grp_send, first[i].data(), cap.data(), recs[i].data(), wins[i].data());
+                        if (rc == GOSS_OK) break;
+                        if (rc != GOSS_ERR_BUFFER || attempt) throw StatusError{rc, "routing the staged reads: " + c->last_error};
+                        for (uint32_t p = 0; p < n; ++p) cap[p] = recs[i][p] + 1;
+                    }
+                    c->stage_fill = 0;          // (the windows of these bases now live in the records)
+                });
+            });
+        for (auto& t : pool) t.join();
+        for (uint32_t i = 0; i < n; ++i)
+            if (status[i] != GOSS_OK) throw StatusError{status[i], "member " + std::to_string(i) + ": " + ctxs[i]->last_error};
+    }
+    const double route_ms = ms_since(t0);
+    // 2. part p of every member -> member p's inbox
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<std::vector<uint64_t>> in_off(n, std::vector<uint64_t>(n + 1, 0));          // in_off[p][i]: where member i's records start in p's inbox
+    uint64_t total_recs = 0, total_wins = 0;
+    for (uint32_t p = 0; p < n; ++p)
+    {
+        for (uint32_t i = 0; i < n; ++i) { in_off[p][i + 1] = in_off[p][i] + recs[i][p]; total_wins += wins[i][p]; }
+        total_recs += in_off[p][n];
+        goss_gpu_ctx* d = ctxs[p];
+        HIP_TRY(hipSetDevice(d->device));
+        if (!d->xstream) HIP_TRY(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+        if (in_off[p][n] > d->grp_inbox_cap)
+        {
+            if (d->grp_inbox) { HIP_TRY(hipFree(d->grp_inbox)); d->grp_inbox = nullptr; d->grp_inbox_cap = 0; }
+            const uint64_t want = in_off[p][n] + in_off[p][n] / 8 + 4096;
+            if (hipMalloc((void**)&d->grp_inbox, want * kRecBytes) != hipSuccess)
+            { (void)hipGetLastError(); throw StatusError{GOSS_ERR_OOM, "no device memory for the received records"}; }
+            d->grp_inbox_cap = want;
+        }
+    }
+    std::vector<int> devs(n);
+    for (uint32_t i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+    const std::vector<void*>* comms = nullptr;
+    if (transport != 2) comms = rccl_comms(devs);
+    if (transport == 1 && !comms) throw StatusError{GOSS_ERR_STATE, "RCCL transport asked for, but librccl or its communicators for these devices are not to be had"};
+    uint32_t rounds = 0;
+    if (comms)
+    {
+        uint64_t largest = 0;
+        for (uint32_t i = 0; i < n; ++i) for (uint32_t p = 0; p < n; ++p) largest = std::max(largest, recs[i][p] * kRecBytes);
+        for (uint64_t off = 0; off < std::max<uint64_t>(largest, 1); off += kXferRound, ++rounds)
+        {
+            if (largest == 0) break;
+            auto nccl_check = [&](int rc, const char* what) {
+                if (rc != 0) throw StatusError{GOSS_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error")};
+            };
+            nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+            for (uint32_t i = 0; i < n; ++i)
+                for (uint32_t p = 0; p < n; ++p)
+                {
+                    const uint64_t bytes = recs[i][p] * kRecBytes;
+                    if (off >= bytes) continue;
+                    const uint64_t len = std::min<uint64_t>(kXferRound, bytes - off);
+                    nccl_check(g_rccl.Send(ctxs[i]->grp_send + first[i][p] * kRecBytes + off, len, 0 /* ncclInt8 */, (int)p, (*comms)[i], ctxs[i]->xstream), "ncclSend");
+                    nccl_check(g_rccl.Recv(ctxs[p]->grp_inbox + in_off[p][i] * kRecBytes + off, len, 0, (int)i, (*comms)[p], ctxs[p]->xstream), "ncclRecv");
+                }
+            nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        }
+    }
+    else
+    {
+        for (uint32_t p = 0; p < n; ++p)
+        {
+            goss_gpu_ctx* d = ctxs[p];
+            HIP_TRY(hipSetDevice(d->device));
+            for (uint32_t i = 0; i < n; ++i)
+                if (recs[i][p])
+                    HIP_TRY(hipMemcpyPeerAsync(d->grp_inbox + in_off[p][i] * kRecBytes, d->device, ctxs[i]->grp_send + first[i][p] * kRecBytes, ctxs[i]->device,
+                                               recs[i][p] * kRecBytes, d->xstream));
+        }
+        rounds = 1;
+    }
+    for (uint32_t p = 0; p < n; ++p)
+    {
+        HIP_TRY(hipSetDevice(ctxs[p]->device));
+        HIP_TRY(hipStreamSynchronize(ctxs[p]->xstream));
+    }
+    const double wire_ms = ms_since(t1);
+    // 3. every member counts what it received (side by side)
+    const auto t2 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t p = 0; p < n; ++p)
+            pool.emplace_back([&, p]() {
+                uint64_t w = 0;
+                for (uint32_t i = 0; i < n; ++i) w += wins[i][p];
+                status[p] = in_off[p][n] ? goss_gpu_push_records_device(ctxs[p], ctxs[p]->grp_inbox, in_off[p][n], w) : GOSS_OK;
+            });
+        for (auto& t : pool) t.join();
+        for (uint32_t p = 0; p < n; ++p)
+            if (status[p] != GOSS_OK) throw StatusError{status[p], "member " + std::to_string(p) + " counting its records: " + ctxs[p]->last_error};
+    }
+    if (st)
+    {
+        st->transport = comms ? 1u : 2u;
+        st->rounds = rounds;
+        st->records = total_recs; st->windows = total_wins; st->record_bytes = total_recs * kRecBytes;
+        st->route_ms = route_ms; st->wire_ms = wire_ms; st->count_ms = ms_since(t2);
+    }
+}
+
+}  // namespace
+}  // extern "C++"
+
+int goss_gpu_set_deferred(goss_gpu_ctx* c, int on)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    if (c->finished) { c->last_error = "deferred counting is set before the pushes"; return GOSS_ERR_STATE; }
+    c->deferred = on != 0;
+    return GOSS_OK;
+}
+
+int goss_gpu_stage_room(goss_gpu_ctx* c, uint64_t* free_bytes, uint64_t* capacity)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    return guarded(c, [&]() {
+        ensure_stage(c);
+        // (a push of n bytes takes n + 1: the separator behind it)
+        if (free_bytes) *free_bytes = c->stage_cap > c->stage_fill + 64 ? c->stage_cap - c->stage_fill - 64 : 0;
+        if (capacity) *capacity = c->stage_cap;
+    }, false);
+}
+
+int goss_gpu_group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, goss_gpu_group_xstats* out)
+{
+    if (!ctxs || n == 0 || n > (uint32_t)kRouteMaxParts || transport < 0 || transport > 2) return GOSS_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i) if (!ctxs[i]) return GOSS_ERR_INVALID_ARG;
+    goss_gpu_ctx* c0 = ctxs[0];
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        goss_gpu_ctx* c = ctxs[i];
+        if (c->k != c0->k || c->mode != c0->mode) { c0->last_error = "group: contexts of different k or mode"; return GOSS_ERR_INVALID_ARG; }
+        if (c->finished) { c0->last_error = "group route exchange after finish"; return GOSS_ERR_STATE; }
+        if (c->words != 1) { c0->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+        for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == c) { c0->last_error = "group: the same context twice"; return GOSS_ERR_INVALID_ARG; }
+    }
+    if (out) std::memset(out, 0, sizeof(*out));
+    if (const char* e = std::getenv("GOSS_GROUP_TRANSPORT"))
+    {
+        if (!std::strcmp(e, "peer")) transport = 2;
+        else if (!std::strcmp(e, "rccl")) transport = 1;
+    }
+    return guarded(c0, [&]() { group_route_exchange(ctxs, n, transport, out); });
 }
 
 int goss_gpu_file_device(goss_gpu_ctx* c, uint32_t i, const void** d_ptr)

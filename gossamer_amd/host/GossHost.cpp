@@ -1061,9 +1061,53 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     auto feedError = [&]() {
         for (auto& f : feeders) { std::lock_guard<std::mutex> lk(f->m); if (!f->error.empty()) throw Error::General(f->error + "\n"); }
     };
+    // Several devices: the exchange BEFORE counting (goss_gpu_group_route_exchange) for one-word keys from four devices
+    // on -- every context only stages its batches; when a staging buffer is full, and once at the end, every context's
+    // reads are cut into super-k-mer records routed by minimizer, part p goes to device p (RCCL or peer copies) and is
+    // counted there: the work per device stays what one device's share of the windows costs, however many devices
+    // there are.  With two or three devices, or two-word keys, every device counts its own reads and only the counted
+    // ranges are exchanged (GOSS_GROUP_EXCHANGE=records|counted overrides).
+    const bool oneWord = 2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) <= 62;
+    bool useRecords = fed && oneWord && P >= 4;
+    if (const char* e = std::getenv("GOSS_GROUP_EXCHANGE"))
+    {
+        if (!std::strcmp(e, "records")) useRecords = fed && oneWord;
+        else if (!std::strcmp(e, "counted")) useRecords = false;
+    }
+    std::vector<uint64_t> stagedBytes(P, 0), stageCap(P, 0);
+    uint64_t xRounds = 0, xRecords = 0, xWindows = 0;
+    double xRouteMs = 0, xWireMs = 0, xCountMs = 0;
+    uint32_t xTransport = 0;
+    if (useRecords)
+        for (size_t d = 0; d < P; ++d) gs[d]->check(goss_gpu_set_deferred(gs[d]->h, 1), "deferring the count");
+    std::function<void()> drainForRound;          // (drainFeeders, defined below)
+    auto exchangeRound = [&]() {
+        drainForRound();
+        std::vector<goss_gpu_ctx*> hs;
+        for (auto& x : gs) hs.push_back(x->h);
+        goss_gpu_group_xstats st;
+        gs[0]->check(goss_gpu_group_route_exchange(hs.data(), (uint32_t)P, 0, &st), "exchanging the reads' records");
+        ++xRounds; xRecords += st.records; xWindows += st.windows; xRouteMs += st.route_ms; xWireMs += st.wire_ms; xCountMs += st.count_ms;
+        xTransport = st.transport;
+        std::fill(stagedBytes.begin(), stagedBytes.end(), 0);
+    };
     // hand a batch to the next device; `done` runs when the device has taken the bytes (wait = until then)
     auto feed = [&](const char* p, size_t n, std::function<void()> done, bool wait) {
         if (feedFailed.load()) { if (done) done(); feedError(); }
+        if (useRecords)
+        {
+            // (what a device has staged is tracked here: the feeders run behind, and a push that does not fit is refused)
+            const size_t d = nextDev;
+            if (stageCap[d] == 0)
+            {
+                uint64_t room = 0, cap = 0;
+                gs[d]->check(goss_gpu_stage_room(gs[d]->h, &room, &cap), "sizing the staging buffer");
+                stageCap[d] = cap > 4096 ? cap - 4096 : cap;
+            }
+            if (n + 1 > stageCap[d]) { if (done) done(); throw Error::General("a batch of reads larger than a device's staging buffer (--hbm-budget too small for --devices)\n"); }
+            if (stagedBytes[d] + n + 1 > stageCap[d]) exchangeRound();
+            stagedBytes[d] += n + 1;
+        }
         Feeder* f = feeders[nextDev].get();
         nextDev = (nextDev + 1) % P;
         {
@@ -1082,6 +1126,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         for (auto& f : feeders) { std::unique_lock<std::mutex> lk(f->m); f->cv.wait(lk, [&] { return f->q.empty() && !f->busy; }); }
         feedError();
     };
+    drainForRound = drainFeeders;
 
     std::vector<char> batch;
     batch.reserve(cxt.batchBytes + (1u << 20));
@@ -1192,6 +1237,14 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     flush();
     if (fed) drainFeeders();
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (useRecords)
+    {
+        exchangeRound();          // (what is still staged)
+        std::ostringstream o;
+        o << "records routed by minimizer: " << xRecords << " records (" << xWindows << " windows) exchanged in " << xRounds << " round(s) over "
+          << (xTransport == 1 ? "RCCL" : "peer copies") << ": routing " << xRouteMs / 1e3 << "s, transfer " << xWireMs / 1e3 << "s, counting " << xCountMs / 1e3 << "s";
+        log(info, o.str());
+    }
     { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "
         << pushSeconds << "s)"; log(info, o.str()); }
     for (size_t d = 0; d < P; ++d)

@@ -369,6 +369,44 @@ int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_high, uint32_t high_
  */
 int goss_gpu_group_exchange(goss_gpu_ctx* const* contexts, uint32_t n, uint32_t sample_per_context, uint64_t* range_sizes);
 int goss_gpu_group_emit(goss_gpu_ctx* const* contexts, uint32_t n, uint64_t estimate);
+
+/*
+ * The exchange BEFORE counting for the same group (one process, one context per GPU): what keeps the work per GPU
+ * constant as GPUs are added -- with the exchange after counting every GPU counts a set that approaches the whole
+ * k-mer set.  Replaces nothing in the reference (its scale-out is build-parts-then-merge, docs/goss.md:314-321); it
+ * stands where GossCmdBuildKmerSet::operator() hands its reads to ONE BackyardHash (GossCmdBuildKmerSet.cc:112-149,
+ * .tcc:226-256) and keeps that command's result: the windows are the reference's (KmerizingAdapter.hh:20-86 /
+ * ReverseComplementAdapter.hh:20-93), only WHICH device counts a window is decided by its minimizer.
+ *
+ * goss_gpu_set_deferred(ctx, 1): host pushes of that context only stage their bases; a push that does not fit the
+ * staging buffer returns GOSS_ERR_BUFFER (nothing of it was taken) instead of counting the buffer.
+ * goss_gpu_stage_room: bytes the staging buffer still takes (a push of n bytes needs n + 1) and its capacity.
+ * finish / emit / a device push on a deferred context count what is staged locally, as ever: the result of the
+ * group is the same (goss_gpu_group_exchange merges equal keys), only the balance is lost.
+ *
+ * goss_gpu_group_route_exchange(contexts, n, transport, stats): every context cuts the windows of its staged bases
+ * into super-k-mer records routed by minimizer into n parts (goss_gpu_route_records_device), part p of every context
+ * is moved to context p's device, and every context counts what it received (goss_gpu_push_records_device).  All
+ * copies of a key -- either strand -- reach ONE context, so the contexts' counted sets are disjoint.  The staging
+ * buffers are empty afterwards; call it whenever a buffer is full and once before the finishes, then
+ * goss_gpu_group_exchange (range partition of the counted sets) and goss_gpu_group_emit as above.
+ *   transport   0 = RCCL when librccl.so can be loaded at run time and communicators for the contexts' devices can
+ *               be made (ncclCommInitAll; not with one device twice): ncclSend / ncclRecv of all n x n parts inside
+ *               one ncclGroupStart / ncclGroupEnd, at most 512 MiB per pair and round -- else hipMemcpyPeerAsync;
+ *               1 = RCCL or fail (GOSS_ERR_STATE); 2 = peer copies.  GOSS_GROUP_TRANSPORT=rccl|peer overrides.
+ *   stats       (may be NULL) what the call moved and how long its three steps took on the host's clock.
+ * One-word keys only (2 * len <= 62: records carry those); other contexts: GOSS_ERR_INVALID_ARG.
+ */
+typedef struct goss_gpu_group_xstats {
+    uint32_t transport;            /* 1 = RCCL send / recv, 2 = peer copies */
+    uint32_t rounds;               /* transfer rounds (<= 512 MiB per pair each) */
+    uint64_t records, windows;     /* moved by this call, all members */
+    uint64_t record_bytes;
+    double route_ms, wire_ms, count_ms;
+} goss_gpu_group_xstats;
+int goss_gpu_set_deferred(goss_gpu_ctx* ctx, int on);
+int goss_gpu_stage_room(goss_gpu_ctx* ctx, uint64_t* free_bytes, uint64_t* capacity);
+int goss_gpu_group_route_exchange(goss_gpu_ctx* const* contexts, uint32_t n, int transport, goss_gpu_group_xstats* stats);
 /* Device address of file i's image (NULL when the file was built on the host): for moving slices
  * between GPUs without a host copy.  Valid until the next emit, reset, push or destroy. */
 int goss_gpu_file_device(goss_gpu_ctx* ctx, uint32_t i, const void** d_ptr);

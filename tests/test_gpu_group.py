@@ -82,6 +82,109 @@ def test_group_refuses_mixed_contexts():
             g.group_exchange([a, a])
 
 
+def _record_group_build(shards, k, mode, rounds=2, transport=0, stage_cap=None):
+    """the exchange before counting: deferred contexts, the shards pushed in `rounds` portions with a
+    goss_gpu_group_route_exchange behind each, then finish / range exchange / emission as above"""
+    import os
+    old = os.environ.get("GOSS_GPU_STAGE_CAP")
+    if stage_cap:
+        os.environ["GOSS_GPU_STAGE_CAP"] = str(stage_cap)
+    ctxs = [g.Context(k, mode, hbm_budget=768 << 20) for _ in shards]
+    try:
+        for c in ctxs:
+            c.set_deferred(True)
+        stats = []
+        pieces = [[b"".join(l + b"\n" for l in s.split(b"\n")[:-1][r::rounds]) for r in range(rounds)] for s in shards]
+        for r in range(rounds):
+            for c, ps in zip(ctxs, pieces):
+                if ps[r]:
+                    c.push_host(ps[r])
+            stats.append(g.group_route_exchange(ctxs, transport))
+        windows = sum(c.finish().windows for c in ctxs)
+        rec_chunks = [c.stat("rec_chunks") + c.stat("fused_chunks") for c in ctxs]
+        # the members' counted sets are disjoint: no key in two of them
+        seen = set()
+        for c in ctxs:
+            ks, _ = c.result()
+            assert not (seen & set(ks))
+            seen |= set(ks)
+        sizes = g.group_exchange(ctxs, sample_per_context=256)
+        g.group_emit(ctxs)
+        return gd.assemble_files([c.files() for c in ctxs]), sizes, windows, stats, rec_chunks
+    finally:
+        for c in ctxs:
+            c.close()
+        if old is None:
+            os.environ.pop("GOSS_GPU_STAGE_CAP", None)
+        else:
+            os.environ["GOSS_GPU_STAGE_CAP"] = old
+
+
+@pytest.mark.parametrize("kind,k,parts", [("kmer", 25, 4), ("graph", 27, 4), ("kmer", 21, 3), ("graph", 30, 2), ("kmer", 31, 8)])
+def test_group_route_exchange_builds_the_oracles_object(oracle, kind, k, parts):
+    """goss_gpu_group_route_exchange (what `goss --devices` with four and more devices drives): the members' reads cut
+    into records routed by minimizer, part p counted by member p -- here all on cuda:0, so the parts travel by peer
+    copies of the one device.  Files equal to the oracle's single build of all reads."""
+    reads = g.synth_reads_host(18000, 150, 120000, seed=31)
+    build = oracle.build_graph if kind == "graph" else oracle.build_kmer_set
+    exp, nwin = build([(oracle.LINE, "reads", reads)], k, out="ob")
+    exp = _suffix_map(exp, "ob")
+    got, sizes, windows, stats, _ = _record_group_build(_split_reads(reads, parts), k, g.MODE_GRAPH if kind == "graph" else g.MODE_KMER_SET)
+    assert windows == nwin == sum(st["windows"] for st in stats)
+    assert all(st["transport"] == 2 and st["records"] > 0 for st in stats), stats          # (one device several times: no communicators)
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
+def test_deferred_context_reports_a_full_staging_buffer(oracle):
+    """A deferred context refuses the push that does not fit (nothing of it taken) and says how much fits; what is
+    staged when it is finished without an exchange is counted locally -- same result."""
+    import os
+    reads = g.synth_reads_host(4000, 150, 50000, seed=5)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="o")
+    os.environ["GOSS_GPU_STAGE_CAP"] = str(256 << 10)
+    try:
+        with g.Context(25, 0, hbm_budget=512 << 20) as ctx:
+            ctx.set_deferred(True)
+            room, cap = ctx.stage_room()
+            assert cap == 256 << 10 and 0 < room <= cap
+            lines = reads.split(b"\n")[:-1]
+            chunk = b"".join(l + b"\n" for l in lines[:1000])          # 151 000 bytes
+            ctx.push_host(chunk)
+            room2, _ = ctx.stage_room()
+            assert room2 == room - len(chunk)          # (the chunk ends with its own separator)
+            with pytest.raises(g.GossGpuError) as e:
+                ctx.push_host(chunk)
+            assert e.value.status == -9
+            assert ctx.stage_room()[0] == room2
+            st = g.group_route_exchange([ctx])
+            assert 990 * 126 < st["windows"] <= 1000 * 126 and ctx.stage_room()[0] == room          # (a read in 97 holds an N)
+            for i in range(1, 4):
+                ctx.push_host(b"".join(l + b"\n" for l in lines[1000 * i:1000 * (i + 1)]))
+                if i < 3:
+                    g.group_route_exchange([ctx])
+            c = ctx.finish()          # (the last thousand reads are still staged: counted here)
+            assert c.windows == nwin
+            got = ctx.emit()
+        assert {n: d for n, d in got.items()} == {n[1:]: d for n, d in exp.items()}
+    finally:
+        os.environ.pop("GOSS_GPU_STAGE_CAP", None)
+
+
+def test_group_route_exchange_over_rccl_with_one_member(oracle):
+    """The RCCL transport (librccl.so loaded at run time, ncclCommInitAll, ncclSend / ncclRecv inside one group call) on
+    the one GPU a test box has: a group of one member sends its single part to itself.  Two rounds; files against the
+    oracle.  (More than one RCCL rank needs more than one GPU: not here.)"""
+    reads = g.synth_reads_host(12000, 150, 90000, seed=77)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ob")
+    exp = _suffix_map(exp, "ob")
+    got, sizes, windows, stats, _ = _record_group_build([reads], 25, g.MODE_KMER_SET, rounds=2, transport=1)
+    assert windows == nwin and all(st["transport"] == 1 for st in stats), stats
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
 def test_goss_devices_option(oracle, tmp_path):
     """`goss build-kmer-set / build-graph --devices 0,0[,0]`: one context per listed device (here the same GPU
     several times), batches dealt round the contexts by feeder threads, ranges exchanged, every context's slices
@@ -107,18 +210,29 @@ def test_goss_devices_option(oracle, tmp_path):
     (tmp_path / "c.txt").write_text(ln)
     inputs = [(oracle.LINE, "c.txt", ln), (oracle.FASTA, "b.fa", fa), (oracle.FASTQ, "a.fq", fq)]
     env = dict(os.environ, GOSS_PARSE_CHUNK="65536")
-    for cmd, k, obuild, base, devices in (("build-kmer-set", 25, oracle.build_kmer_set, "ks", "0,0"),
-                                          ("build-graph", 27, oracle.build_graph, "gr", "0,0,0"),
-                                          ("build-graph", 55, oracle.build_graph, "g55", "0,0")):
+    # (four devices and more, one-word keys: the exchange before counting -- records routed by minimizer; a staging
+    # buffer of 256 KB makes the 1 MB of reads take several exchange rounds; two-word keys and fewer devices: the
+    # counted ranges are exchanged)
+    for cmd, k, obuild, base, devices, records in (("build-kmer-set", 25, oracle.build_kmer_set, "ks", "0,0", False),
+                                                   ("build-graph", 27, oracle.build_graph, "gr", "0,0,0", False),
+                                                   ("build-graph", 55, oracle.build_graph, "g55", "0,0", False),
+                                                   ("build-kmer-set", 25, oracle.build_kmer_set, "ks4", "0,0,0,0", True),
+                                                   ("build-graph", 27, oracle.build_graph, "gr4", "0,0,0,0", True),
+                                                   ("build-graph", 55, oracle.build_graph, "g554", "0,0,0,0", False)):
         exp, nwin = obuild(inputs, k, out=base)
         out = tmp_path / base
         p = subprocess.run([goss, cmd, "-k", str(k), "-i", str(tmp_path / "a.fq"), "-I", str(tmp_path / "b.fa"),
                             "--line-in", str(tmp_path / "c.txt"), "-O", str(out), "--hbm-budget", "1", "-T", "4", "-v",
                             "--devices", devices],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(env, GOSS_GPU_STAGE_CAP=str(256 << 10)))
         assert p.returncode == 0, p.stderr.decode()
         assert ("counted on %d devices" % len(devices.split(","))).encode() in p.stderr
         assert ("k-mer windows: %d," % nwin).encode() in p.stderr
+        assert (b"records routed by minimizer" in p.stderr) == records, p.stderr.decode()
+        if records:
+            import re
+            m = re.search(rb"\((\d+) windows\) exchanged in (\d+) round\(s\) over peer copies", p.stderr)
+            assert m and int(m.group(1)) == nwin and int(m.group(2)) >= 2, p.stderr.decode()
         got = {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
         assert sorted(got) == sorted(exp)
         for name in exp:
