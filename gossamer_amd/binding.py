@@ -31,7 +31,13 @@ SYMBOLS = [
     "goss_gpu_push_bases_host_async", "goss_gpu_push_packed_host", "goss_gpu_push_packed_host_async", "goss_gpu_flush",
 ]
 
-RECORD_BYTES = 12
+RECORD_BYTES = 12          # one-word keys (2 * len <= 62); two-word keys: 20 (record_bytes)
+
+
+def record_bytes(k, mode=0):
+    """bytes of a super-k-mer record of a (k, mode) context: SkRec (12) for one-word keys, SkRec2 (20) for two-word keys"""
+    length = k + (1 if mode == 1 else 0)
+    return 12 if 2 * length <= 62 else 20
 
 
 RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)

@@ -602,6 +602,8 @@ void launch_extract1(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
 }
 // window slots of a record (the most windows one holds): a string of n records counts as 16 n window starts
 inline uint32_t rec_slots(const goss_gpu_ctx*) { return 16u; }
+// bytes of a record: 12 for one-word keys (SkRec), 20 for two-word keys (SkRec2)
+inline uint64_t rec_bytes(const goss_gpu_ctx* c) { return c->words == 1 ? sizeof(SkRec) : sizeof(SkRec2); }
 
 // records -> keys with the plain kernel: all records (slice_groups = 0) or slices of them (the fused path's sample)
 void launch_extract_records(goss_gpu_ctx* c, const SkRec* recs, uint64_t nrecs, Key1* out, uint64_t ngroups, uint64_t slice_groups,
@@ -664,6 +666,18 @@ void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
 template <>
 void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out)
 {
+    if (c->rec_mode)
+    {
+        // two-word records -> keys with the plain kernel (their counting goes through the unfused sequence)
+        const uint64_t nrecs = nstarts / rec_slots(c);
+        const uint64_t ngroups = (nrecs + kRecGroup - 1) / kRecGroup;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ngroups, 1), 256 * 16);
+        if (c->mode == GOSS_MODE_GRAPH)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<1>), dim3(grid), dim3(kTB), 0, c->stream, (const SkRec2*)aligned, nrecs, c->len, out, c->d_ctr, ngroups);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<0>), dim3(grid), dim3(kTB), 0, c->stream, (const SkRec2*)aligned, nrecs, c->len, out, c->d_ctr, ngroups);
+        return;
+    }
     if (c->extract_v1)
     {
         if (c->mode == GOSS_MODE_KMER_SET) launch_extract<Key2, 0, 8>(c, aligned, mis, nstarts, navail, out);
@@ -1160,6 +1174,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 {
     constexpr bool kOne = std::is_same<K, Key1>::value;          // one-word keys
     const uint32_t keybits = 2 * c->len;
+    if (c->rec_mode && !kOne) return kFusedDeclined;             // (two-word records: the plain record kernel + the unfused sequence)
     if (!c->fused || c->path != 0 || !c->lookback || c->ordered_tiles ||
         c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
         return kFusedDeclined;
@@ -2139,7 +2154,7 @@ void push_records(goss_gpu_ctx* c, const uint8_t* d, uint64_t nrecs, uint64_t nw
         const size_t runs0 = c->runs.size();
         try
         {
-            process_chunk<K>(c, d + (done / P) * sizeof(SkRec), ns, 0);
+            process_chunk<K>(c, d + (done / P) * rec_bytes(c), ns, 0);
         }
         catch (const StatusError& e)
         {
@@ -3599,11 +3614,11 @@ const std::vector<void*>* rccl_comms(const std::vector<int>& devs)
     return slot.empty() ? nullptr : &slot;
 }
 
-constexpr uint64_t kRecBytes = sizeof(SkRec);
 constexpr uint64_t kXferRound = 512ULL << 20;          // bytes per (source, destination) pair and round (RCCL 2.26 drops the second half of segments above 1 GiB)
 
 void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, goss_gpu_group_xstats* st)
 {
+    const uint64_t kRecBytes = rec_bytes(ctxs[0]);          // (all members have one k and mode)
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     // 1. every member routes what it has staged into n parts (side by side: one host thread per device)
@@ -3768,7 +3783,7 @@ int goss_gpu_group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int tra
         goss_gpu_ctx* c = ctxs[i];
         if (c->k != c0->k || c->mode != c0->mode) { c0->last_error = "group: contexts of different k or mode"; return GOSS_ERR_INVALID_ARG; }
         if (c->finished) { c0->last_error = "group route exchange after finish"; return GOSS_ERR_STATE; }
-        if (c->words != 1) { c0->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+        if (c->len > 63) { c0->last_error = "records carry windows of at most 63 bases"; return GOSS_ERR_INVALID_ARG; }
         for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == c) { c0->last_error = "group: the same context twice"; return GOSS_ERR_INVALID_ARG; }
     }
     if (out) std::memset(out, 0, sizeof(*out));
@@ -4011,7 +4026,7 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
 {
     if (!c || (!d_bases && nbytes) || nparts == 0 || nparts > (uint32_t)kRouteMaxParts || !part_first || !part_cap || !part_records)
         return GOSS_ERR_INVALID_ARG;
-    if (c->words != 1) { c->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+    if (c->len > 63) { c->last_error = "records carry windows of at most 63 bases"; return GOSS_ERR_INVALID_ARG; }
     return guarded(c, [&]() {
         for (uint32_t p = 0; p < nparts; ++p) { part_records[p] = 0; if (part_windows) part_windows[p] = 0; }
         if (nbytes < c->len) return;
@@ -4040,6 +4055,12 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
 #define GOSS_LAUNCH_ROUTE(W)                                                                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, nbytes, \
                        c->len, maxwin, nparts, block, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles)
+            if (c->words == 2)
+                // two-word keys: 20-byte records, the minimizer taken over the central 31 / 30 bases of a window (17 positions)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records2_kernel<17>), dim3((uint32_t)std::min<uint64_t>(ntiles, 256 * 4)), dim3(kTB), 0, c->stream, aligned, mis,
+                                   nstarts, nbytes, c->len, nparts, block, (SkRec2*)d_records, (const unsigned long long*)dfirst,
+                                   (const unsigned long long*)dcap, rc, ntiles);
+            else
             switch (route_positions(c->len))
             {
                 case 17: GOSS_LAUNCH_ROUTE(17); break;
@@ -4064,10 +4085,11 @@ int goss_gpu_push_records_device(goss_gpu_ctx* c, const void* d_records, uint64_
 {
     if (!c || (nrecords && !d_records)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    if (c->words != 1) { c->last_error = "records carry one-word keys (2*len <= 62)"; return GOSS_ERR_INVALID_ARG; }
+    if (c->len > 63) { c->last_error = "records carry windows of at most 63 bases"; return GOSS_ERR_INVALID_ARG; }
     return guarded(c, [&]() {
         flush_staging(c);
-        push_records<Key1>(c, (const uint8_t*)d_records, nrecords, nwindows);
+        if (c->words == 1) push_records<Key1>(c, (const uint8_t*)d_records, nrecords, nwindows);
+        else push_records<Key2>(c, (const uint8_t*)d_records, nrecords, nwindows);
     });
 }
 

@@ -17,7 +17,8 @@ Two forms of the first step (count_range, `exchange=`):
              them, and each rank counts only the keys of its minimizer class -- 1/P of the key space at the
              single-GPU cost, whatever P is.  The classes are not key ranges, so the (now final, disjoint) counted
              sets are range-partitioned afterwards by the same splitter exchange, which then moves 1/P as much.
-             One-word keys only (2*len <= 62); wider keys take "counted".
+             12-byte records for one-word keys (2*len <= 62), 20-byte records for two-word keys (len <= 63: the
+             minimizer of a long window is taken over its central 31 / 30 bases).
 
 Per exchange of counted runs there are three collectives and one host synchronisation: an all-gather of the
 P x P matrix of run lengths (every rank then knows what it receives), and an all-to-all(v) each for the keys and
@@ -293,7 +294,8 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
     exchanged in that many pieces, the all-to-all of one overlapping the routing of the next; what arrived is counted
     in one go.  Returns the windows of this rank's own reads."""
     import os
-    from .binding import RECORD_BYTES as RB
+    from .binding import record_bytes
+    RB = record_bytes(ctx.k, ctx.mode)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device(device)
@@ -503,7 +505,7 @@ def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters=
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ctx.reset()
-    if exchange == "records" and key_bits <= 62:
+    if exchange == "records" and key_bits <= 126:
         windows = route_and_exchange_records(ctx, bases_ptr, nbytes, device, group, record_pieces)
         c = ctx.finish()
     else:

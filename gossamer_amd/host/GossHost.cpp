@@ -1061,17 +1061,16 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     auto feedError = [&]() {
         for (auto& f : feeders) { std::lock_guard<std::mutex> lk(f->m); if (!f->error.empty()) throw Error::General(f->error + "\n"); }
     };
-    // Several devices: the exchange BEFORE counting (goss_gpu_group_route_exchange) for one-word keys from four devices
-    // on -- every context only stages its batches; when a staging buffer is full, and once at the end, every context's
+    // Several devices: the exchange BEFORE counting (goss_gpu_group_route_exchange) from four devices on -- every
+    // context only stages its batches; when a staging buffer is full, and once at the end, every context's
     // reads are cut into super-k-mer records routed by minimizer, part p goes to device p (RCCL or peer copies) and is
     // counted there: the work per device stays what one device's share of the windows costs, however many devices
-    // there are.  With two or three devices, or two-word keys, every device counts its own reads and only the counted
-    // ranges are exchanged (GOSS_GROUP_EXCHANGE=records|counted overrides).
-    const bool oneWord = 2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) <= 62;
-    bool useRecords = fed && oneWord && P >= 4;
+    // there are.  With two or three devices every device counts its own reads and only the counted ranges are
+    // exchanged (GOSS_GROUP_EXCHANGE=records|counted overrides).
+    bool useRecords = fed && P >= 4;
     if (const char* e = std::getenv("GOSS_GROUP_EXCHANGE"))
     {
-        if (!std::strcmp(e, "records")) useRecords = fed && oneWord;
+        if (!std::strcmp(e, "records")) useRecords = fed;
         else if (!std::strcmp(e, "counted")) useRecords = false;
     }
     std::vector<uint64_t> stagedBytes(P, 0), stageCap(P, 0);

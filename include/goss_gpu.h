@@ -395,7 +395,7 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* contexts, uint32_t n, uint64_t esti
  *               one ncclGroupStart / ncclGroupEnd, at most 512 MiB per pair and round -- else hipMemcpyPeerAsync;
  *               1 = RCCL or fail (GOSS_ERR_STATE); 2 = peer copies.  GOSS_GROUP_TRANSPORT=rccl|peer overrides.
  *   stats       (may be NULL) what the call moved and how long its three steps took on the host's clock.
- * One-word keys only (2 * len <= 62: records carry those); other contexts: GOSS_ERR_INVALID_ARG.
+ * Both key widths: 12-byte records for one-word keys, 20-byte records for two-word keys (below).
  */
 typedef struct goss_gpu_group_xstats {
     uint32_t transport;            /* 1 = RCCL send / recv, 2 = peer copies */
@@ -504,12 +504,14 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  *
  * goss_gpu_route_records_device cuts the windows of a base string (as goss_gpu_push_bases_device takes it) into
  * SUPER-K-MER RECORDS and appends each to one of nparts buffers: a record is a run of up to 16 consecutive windows
- * that have the same destination, with the run's bases stored once -- 12 bytes (GOSS_RECORD_BYTES)
- * instead of 8 bytes per window.  The destination of a window is a hash of its MINIMIZER (the smallest canonical
- * m-mer inside it, m = 7..15 depending on the window length), scaled to [0, nparts): a window and its reverse
- * complement have the same minimizer, so every occurrence of a k-mer -- and of a graph edge and its reverse
- * complement -- reaches the same part, and the counts of a part are final.  Only contexts with one-word keys
- * (2*len <= 62, len = k or k + 1) route; others get GOSS_ERR_INVALID_ARG.
+ * that have the same destination, with the run's bases stored once -- 12 bytes (GOSS_RECORD_BYTES) for one-word
+ * keys (2*len <= 62, len = k or k + 1) instead of 8 bytes per window, 20 bytes (GOSS_RECORD2_BYTES) for two-word keys
+ * (32 <= len <= 63) instead of 16 per window.  The destination of a window is a hash of its MINIMIZER (the smallest
+ * canonical m-mer inside it, m = 7..15 depending on the window length; for len >= 32 inside its central 31 -- odd
+ * len -- or 30 bases, whose reverse complement is the central part of the window's reverse complement), scaled to
+ * [0, nparts): a window and its reverse complement have the same minimizer, so every occurrence of a k-mer -- and of
+ * a graph edge and its reverse complement (ReverseComplementAdapter.hh:34-55) -- reaches the same part, and the counts
+ * of a part are final.
  *   d_records           device memory for the records of all parts
  *   part_first[p]       first record slot of part p inside d_records, part_cap[p] the slots it may use
  *   part_records[p]     (out) record slots of part p that were filled, pads included (below) -- what it NEEDS when the
@@ -528,8 +530,11 @@ int goss_gpu_push_keys_device(goss_gpu_ctx* ctx, const void* d_keys, uint64_t n)
  * workgroup and part) and fills what it does not use with pads; they are slots of the part like any record, travel
  * with it and are dropped by goss_gpu_push_records_device (no record of windows has bit 91 set with bits 92..95 zero:
  * a single window's bases end below bit 64).  0.1-0.3 % of the slots of a large input.
+ * Two-word keys (five u32): bits 0..155 the run's nwin + len - 1 <= 78 bases, bits 156..159 nwin - 1; PAD =
+ * {0, 0, 0, 0, 1 << 27}.
  */
 #define GOSS_RECORD_BYTES 12
+#define GOSS_RECORD2_BYTES 20
 int goss_gpu_route_records_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t nparts, void* d_records,
                                   const uint64_t* part_first, const uint64_t* part_cap, uint64_t* part_records,
                                   uint64_t* part_windows);

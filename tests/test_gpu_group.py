@@ -120,7 +120,8 @@ def _record_group_build(shards, k, mode, rounds=2, transport=0, stage_cap=None):
             os.environ["GOSS_GPU_STAGE_CAP"] = old
 
 
-@pytest.mark.parametrize("kind,k,parts", [("kmer", 25, 4), ("graph", 27, 4), ("kmer", 21, 3), ("graph", 30, 2), ("kmer", 31, 8)])
+@pytest.mark.parametrize("kind,k,parts", [("kmer", 25, 4), ("graph", 27, 4), ("kmer", 21, 3), ("graph", 30, 2), ("kmer", 31, 8),
+                                          ("kmer", 45, 4), ("graph", 55, 4), ("graph", 31, 3), ("kmer", 63, 2)])
 def test_group_route_exchange_builds_the_oracles_object(oracle, kind, k, parts):
     """goss_gpu_group_route_exchange (what `goss --devices` with four and more devices drives): the members' reads cut
     into records routed by minimizer, part p counted by member p -- here all on cuda:0, so the parts travel by peer
@@ -210,15 +211,15 @@ def test_goss_devices_option(oracle, tmp_path):
     (tmp_path / "c.txt").write_text(ln)
     inputs = [(oracle.LINE, "c.txt", ln), (oracle.FASTA, "b.fa", fa), (oracle.FASTQ, "a.fq", fq)]
     env = dict(os.environ, GOSS_PARSE_CHUNK="65536")
-    # (four devices and more, one-word keys: the exchange before counting -- records routed by minimizer; a staging
-    # buffer of 256 KB makes the 1 MB of reads take several exchange rounds; two-word keys and fewer devices: the
-    # counted ranges are exchanged)
+    # (four devices and more: the exchange before counting -- records routed by minimizer, 12 bytes for one-word keys
+    # and 20 for two-word keys; a staging buffer of 256 KB makes the 1 MB of reads take several exchange rounds; fewer
+    # devices: the counted ranges are exchanged)
     for cmd, k, obuild, base, devices, records in (("build-kmer-set", 25, oracle.build_kmer_set, "ks", "0,0", False),
                                                    ("build-graph", 27, oracle.build_graph, "gr", "0,0,0", False),
                                                    ("build-graph", 55, oracle.build_graph, "g55", "0,0", False),
                                                    ("build-kmer-set", 25, oracle.build_kmer_set, "ks4", "0,0,0,0", True),
                                                    ("build-graph", 27, oracle.build_graph, "gr4", "0,0,0,0", True),
-                                                   ("build-graph", 55, oracle.build_graph, "g554", "0,0,0,0", False)):
+                                                   ("build-graph", 55, oracle.build_graph, "g554", "0,0,0,0", True)):
         exp, nwin = obuild(inputs, k, out=base)
         out = tmp_path / base
         p = subprocess.run([goss, cmd, "-k", str(k), "-i", str(tmp_path / "a.fq"), "-I", str(tmp_path / "b.fa"),

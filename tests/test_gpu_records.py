@@ -23,16 +23,17 @@ def route(ctx, text, nparts, caps=None):
     if caps is None:
         caps = [len(text) + 64] * nparts          # one record per window is the worst case (short k: a window is its own minimizer)
     first = [sum(caps[:p]) for p in range(nparts)]
-    buf = torch.empty(max(1, sum(caps)) * REC, dtype=torch.uint8, device=dev)
+    buf = torch.empty(max(1, sum(caps)) * g.binding.record_bytes(ctx.k, ctx.mode), dtype=torch.uint8, device=dev)
     recs, wins, ok = ctx.route_records(bases.data_ptr(), bases.numel(), nparts, buf.data_ptr(), first, caps)
     return buf, first, recs, wins, ok
 
 
 def count_parts(k, mode, buf, first, recs, wins, parts, budget=256 * MB):
+    rb = g.binding.record_bytes(k, mode)
     with g.Context(k, mode, hbm_budget=budget) as ctx:
         for p in parts:
             if recs[p]:
-                ctx.push_records(buf.data_ptr() + first[p] * REC, recs[p], wins[p])
+                ctx.push_records(buf.data_ptr() + first[p] * rb, recs[p], wins[p])
         c = ctx.finish()
         ks, cs = ctx.result()
         files = ctx.emit()
@@ -40,11 +41,13 @@ def count_parts(k, mode, buf, first, recs, wins, parts, budget=256 * MB):
     return ks, [int(x) for x in cs], c, files, stats
 
 
-@pytest.mark.parametrize("k,mode", [(25, 0), (11, 0), (15, 0), (19, 0), (21, 0), (31, 0), (7, 0), (3, 0), (24, 1), (15, 1), (30, 1), (9, 1)])
+@pytest.mark.parametrize("k,mode", [(25, 0), (11, 0), (15, 0), (19, 0), (21, 0), (31, 0), (7, 0), (3, 0), (24, 1), (15, 1), (30, 1), (9, 1),
+                                    # two-word keys: 20-byte records, the minimizer of the window's central 31 / 30 bases
+                                    (32, 0), (33, 0), (45, 0), (63, 0), (62, 0), (31, 1), (32, 1), (55, 1), (62, 1), (44, 1)])
 @pytest.mark.parametrize("nparts", [1, 3, 8])
 def test_records_of_all_parts_hold_every_window_once(oracle, k, mode, nparts):
     rng = random.Random(900 + 7 * k + mode + nparts)
-    reads = make_reads(rng, 500, (max(4, k - 2), 170), 5000, lower=True)
+    reads = make_reads(rng, 500, (max(4, k - 2), 170 if k < 40 else 230), 5000, lower=True)
     text = ("\n".join(reads) + "\n").encode()
     length = k + 1 if mode else k
     ek, ec, nwin = oracle_counts(oracle, reads, length, mode)
@@ -93,14 +96,15 @@ def test_small_part_buffers_are_reported_and_a_second_call_fits(oracle):
     assert ks == ek and cs == ec
 
 
-def test_misaligned_bases_and_two_word_keys():
+def test_misaligned_bases_both_key_widths():
     """A base string that does not start on a 16-byte boundary (the pieces of a pipelined exchange start anywhere): a
     routing thread's 64 bases then come from five vectors -- a record may run 16 windows into the next thread's."""
     rng = random.Random(77)
     reads = make_reads(rng, 1500, (90, 160), 6000)
     text = ("\n".join(reads) + "\n").encode()
     dev = torch.device("cuda", 0)
-    for k, mode in ((21, 0), (25, 0), (31, 0), (27, 1), (30, 1)):
+    for k, mode in ((21, 0), (25, 0), (31, 0), (27, 1), (30, 1), (45, 0), (55, 1), (63, 0), (32, 0)):
+        REC = g.binding.record_bytes(k, mode)
         with g.Context(k, mode, hbm_budget=64 * MB) as ctx:
             ctx.push_host(text)
             ctx.finish()
@@ -118,10 +122,6 @@ def test_misaligned_bases_and_two_word_keys():
                 ctx.finish()
                 got = ctx.result()
             assert got[0] == want[0] and list(got[1]) == list(want[1]), (k, mode, off)
-    with g.Context(40, 0, hbm_budget=64 * MB) as ctx:          # two-word keys do not route
-        with pytest.raises(g.GossGpuError) as e:
-            ctx.route_records(t.data_ptr(), len(text), 2, buf.data_ptr(), [0, cap], [cap, cap])
-        assert e.value.status == -1
 
 
 def test_records_at_a_size_the_fused_path_takes_by_itself(oracle):
