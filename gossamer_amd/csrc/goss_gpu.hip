@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -2900,10 +2901,14 @@ static void flush_staging_background(goss_gpu_ctx* c)
     HIP_TRY(hipEventRecord(e, c->copy_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
     c->pend_pool.push_back(e);                           // (the wait has been queued: the event may be recorded again)
+    // (the caller's next copies go to the other buffer: the background run below reads this one.  The buffer being
+    // switched to is free: wait_background above returned only after the run that read it had synchronised its stream)
+    const int cur0 = c->stage_cur;
     c->stage_cur ^= 1;
     c->stage = c->stage_buf[c->stage_cur];
     c->stage_fill = 0;
     c->bg_status = GOSS_OK;
+    try {
     c->bg = std::thread([c, buf, n]() {
         try
         {
@@ -2916,6 +2921,15 @@ static void flush_staging_background(goss_gpu_ctx* c)
         catch (const StatusError& e) { c->bg_status = e.status; c->bg_error = e.msg; }
         catch (const std::bad_alloc&) { c->bg_status = GOSS_ERR_OOM; c->bg_error = "host allocation failed"; }
     });
+    }
+    catch (const std::system_error& e)
+    {
+        // no thread to be had: nothing was counted and nothing may be lost -- the staged bases are the current buffer's again
+        c->stage_cur = cur0;
+        c->stage = c->stage_buf[cur0];
+        c->stage_fill = n;
+        throw StatusError{GOSS_ERR_OOM, std::string("no thread for the counting of a staging buffer: ") + e.what()};
+    }
 }
 
 int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes)
@@ -2957,6 +2971,26 @@ static void note_pending(goss_gpu_ctx* c, void (*fn)(void*), void* user)
     else HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(e, c->copy_stream));
     c->pending.push_back({e, fn, user});
+}
+
+// An asynchronous push registers its buffer and hands back the buffers of earlier pushes whose copies are done.  The
+// contract of a failed push (include/goss_gpu.h): the library does NOT call release for it -- the buffer is the
+// caller's again on return -- so when handing back fails, the entry just registered is taken out again, after the
+// copies queued from the buffer have run (the caller may free it at once).
+static void note_pending_checked(goss_gpu_ctx* c, void (*fn)(void*), void* user)
+{
+    note_pending(c, fn, user);
+    try { release_pending(c, false); }
+    catch (...)
+    {
+        (void)hipStreamSynchronize(c->copy_stream);
+        if (!c->pending.empty() && c->pending.back().fn == fn && c->pending.back().user == user)
+        {
+            c->pend_pool.push_back(c->pending.back().ev);
+            c->pending.pop_back();
+        }
+        throw;
+    }
 }
 
 // positions unpacked per landing of a packed push (24 MB of packed bytes at most; a small arena lands less at a time)
@@ -3030,7 +3064,7 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
     const bool sep = is_base_byte(bases[nbytes - 1]);
     if (sep) HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill + nbytes, '\n', 1, c->copy_stream));
     c->stage_fill += nbytes + (sep ? 1 : 0);
-    if (async) { note_pending(c, release, user); release_pending(c, false); }
+    if (async) { note_pending_checked(c, release, user); }
     else { HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, false); if (release) release(user); }
 }
 
@@ -3094,7 +3128,7 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         pos += n;
         cont = true;
     }
-    if (async) { note_pending(c, release, user); release_pending(c, false); }
+    if (async) { note_pending_checked(c, release, user); }
     else { HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, false); if (release) release(user); }
 }
 
@@ -3109,7 +3143,11 @@ int goss_gpu_push_bases_host_async(goss_gpu_ctx* c, const char* bases, uint64_t 
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_bases_host(c, bases, nbytes, true, release, user); }, false);
+    return guarded(c, [&]() {
+        // (a failed push hands the buffer back to the caller on return: what was queued from it must have run)
+        try { push_bases_host(c, bases, nbytes, true, release, user); }
+        catch (...) { if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); throw; }
+    }, false);
 }
 
 int goss_gpu_push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases)
@@ -3124,7 +3162,10 @@ int goss_gpu_push_packed_host_async(goss_gpu_ctx* c, const uint32_t* codes, cons
 {
     if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
-    return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, true, release, user); }, false);
+    return guarded(c, [&]() {
+        try { push_packed_host(c, codes, nonbase, nbases, true, release, user); }
+        catch (...) { if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); throw; }
+    }, false);
 }
 
 int goss_gpu_flush(goss_gpu_ctx* c)

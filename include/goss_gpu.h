@@ -101,7 +101,12 @@ int goss_gpu_push_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t 
 /*
  * Asynchronous form of goss_gpu_push_bases_host: returns as soon as the copy is queued.  The buffer belongs to the
  * library until release(user) is called -- by the CALLER'S OWN THREAD, from inside a later call on this context
- * (another push, goss_gpu_flush, finish, reset, destroy), once the bytes have left it; no thread is created.  The
+ * (another push, goss_gpu_flush, finish, reset, destroy), once the bytes have left it: release never runs on a thread
+ * of the library (the library does keep ONE thread of its own per context, which counts a full staging buffer while the
+ * caller fills the other; it touches no buffer of the caller).  OWNERSHIP ON FAILURE: when the call returns anything but
+ * GOSS_OK the library does not call release for this push, now or later -- the buffer is the caller's again when the
+ * call returns (copies already queued from it have completed by then); buffers of EARLIER pushes are still released
+ * by later calls, and by goss_gpu_destroy at the latest.  The
  * buffer should be page-locked (goss_gpu_host_alloc), else the copy is synchronous inside the driver.  With a
  * pool of such buffers the parser threads keep filling while earlier batches cross PCIe: the per-push wait of the
  * synchronous form is what bounded `goss build-kmer-set` on a large FASTQ file.  release may be NULL (the caller

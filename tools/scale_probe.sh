@@ -29,3 +29,14 @@ for n in $ns; do
       --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/records_n$n.json" 2> "$out/records_n$n.err"
   echo "records N=$n rc=$?"; show "$out/records_n$n.json"
 done
+# C4's shape (build-graph k = 55: 112-bit edge keys, 20-byte records) through the same two forms: 200 M reads of a 100 Mbp
+# genome per rank -- one rank's share of an N-GPU build of N x 200 M reads (GRAPH_READS overrides the size)
+if [ -n "${WITH_C4:-1}" ]; then
+  gr=${GRAPH_READS:-200000000}
+  python bench.py --graph -k 55 --force-dist --exchange counted --reads $gr --genome 100000000 --steps 1 --warmup 1 \
+      --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/c4_counted_n1.json" 2> "$out/c4_counted_n1.err"
+  echo "C4 counted N=1 rc=$?"; show "$out/c4_counted_n1.json"
+  python bench.py --graph -k 55 --force-dist --exchange records --route-parts 8 --reads $gr --genome 100000000 --steps 1 --warmup 1 \
+      --no-extra --no-cpu-baseline --e2e-reads 0 > "$out/c4_records_n8.json" 2> "$out/c4_records_n8.err"
+  echo "C4 records N=8 rc=$?"; show "$out/c4_records_n8.json"
+fi
