@@ -115,6 +115,8 @@ struct goss_gpu_ctx {
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_rep = false;           // the next one-word k-mer extraction stores strand representatives (fused path's sample)
     uint32_t rep_chunks = 0;            // chunks counted in strand-representative space and mapped to canonical order afterwards
+    int canon_l1 = 1;                   // GOSS_GPU_CANON_L1=0|1|2: the fused first level computes gossamer's canonical form itself never / from 10 % distinct keys on / always
+    uint32_t canon_chunks = 0;          // chunks counted that way
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
     uint64_t fused_min = 32u << 20;     // GOSS_GPU_FUSED_MIN=<window starts>: smallest chunk the fused path takes
@@ -139,6 +141,10 @@ struct goss_gpu_ctx {
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
     int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
+    uint32_t rem32_bits_min = 0;        // GOSS_GPU_REM32_BITS=<9..12>: at least that many second-level bits (tests)
+    uint32_t rem32_bits_last = 0;       // second-level bits of the last chunk counted in that form
+    uint32_t rem32_split_min = 0;       // GOSS_GPU_REM32_SPLIT=<0..4>: at least that many third-level bits (tests; raised when tables overflow)
+    uint32_t rem32_split_last = 0;      // third-level bits of the last chunk counted in that form
     uint32_t fused_chunks = 0;          // chunks counted by the fused path
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
@@ -972,13 +978,12 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     return 0;
 }
 
-// The same for the 32-bit-remainder form (subpart32_kernel's output): 131 072 segments of u32 remainders, counted by
+// The same for the 32-bit-remainder form (subpart32_kernel's output): nseg = 2^17 .. 2^20 segments of u32 remainders, counted by
 // seg_hash_reduce32_kernel in tables of `slots` slots; `spare` (n one-word keys) is the staging area.
 // Returns 0, 1 (a table overflowed) or 2 (staging area too small) like segment_reduce.
 int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_t n, Run* out, const uint64_t* seg_beg,
-                     const uint64_t* seg_end, int slots, bool squeeze, uint32_t rbits, uint32_t sqbit)
+                     const uint64_t* seg_end, int slots, bool squeeze, uint32_t rbits, uint32_t sqbit, uint32_t nseg, uint32_t split_bits)
 {
-    const uint32_t nseg = kSub32Regions;
     uint64_t mark = c->arena.mark();
     PhaseTimer t(c, GOSS_T_REDUCE, n);
     uint64_t* seg_pos = (uint64_t*)c->arena.temp((uint64_t)nseg * 8);
@@ -993,7 +998,7 @@ int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_
     HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
 #define GOSS_LAUNCH_R32(SLOTS, SQ)                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_hash_reduce32_kernel<SLOTS, SQ>), unit_grid(nseg), dim3(kTB), 0, c->stream, rems, seg_beg, \
-                       seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rbits, sqbit)
+                       seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rbits, sqbit, split_bits)
     if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(2048, true); else GOSS_LAUNCH_R32(2048, false); }
     else { if (squeeze) GOSS_LAUNCH_R32(4096, true); else GOSS_LAUNCH_R32(4096, false); }
 #undef GOSS_LAUNCH_R32
@@ -1218,6 +1223,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const bool reduced = ka_slots < nstarts * kps || kb_slots < nstarts * kps;
     if (reduced && (nslices == 1 || nslices * slice_starts * kps > std::min(ka_slots, kb_slots))) return (int)kFusedNeedFull;
     const uint64_t slice_stride = nslices > 1 ? ((nstarts - slice_starts) / (nslices - 1)) & ~15ULL : 0;
+    // rep: one-word k-mer sets in strand-representative space (what the fused kernel counts in, unless canon_l1 below)
+    auto extract_sample = [&](bool rep) {
     c->mute_timing = true;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(ExtractCounters), c->stream));
     {
@@ -1225,7 +1232,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         const uint32_t mis0 = c->rec_mode ? 0u : (uint32_t)(addr0 & 15u);          // (records are taken where they lie)
         if (nslices == 1)
         {
-            c->extract_rep = kOne && !graph_mode;
+            c->extract_rep = kOne && !graph_mode && rep;
             extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
             c->extract_rep = false;
         }
@@ -1243,7 +1250,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             const uint64_t P = rec_slots(c);
             const uint64_t slice_groups = slice_starts / P / kRecGroup;
             launch_extract_records(c, (const SkRec*)d_bases, nstarts / P, (Key1*)ka, slice_groups * nslices, slice_groups, slice_stride / P,
-                                   !graph_mode);
+                                   !graph_mode && rep);
         }
         else
         {
@@ -1253,18 +1260,24 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<1, 8, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
                                    (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
                                    slice_tiles, slice_stride);
-            else      // strand representatives: the key space the fused kernel counts in
+            else if (rep)      // strand representatives: the key space the fused kernel counts in
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, 8, true>), dim3(grid), dim3(kTB), 0, c->stream,
+                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
+                                   slice_tiles, slice_stride);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, 8, false>), dim3(grid), dim3(kTB), 0, c->stream,
                                    (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
                                    slice_tiles, slice_stride);
         }
     }
     c->extract_hist_shift = 0xFFFFFFFFu;
-    ExtractCounters* hc = (ExtractCounters*)c->h_pinned;
-    HIP_TRY(hipMemcpyAsync(hc, c->d_ctr, 16, hipMemcpyDeviceToHost, c->stream));
+    ExtractCounters* hcs = (ExtractCounters*)c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hcs, c->d_ctr, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint64_t ns = hc->keys_out;
     c->mute_timing = false;
+    return (uint64_t)hcs->keys_out;
+    };
+    const uint64_t ns = extract_sample(true);
     if (ns < (1u << 20)) return decline("mostly non-bases");
     lap("sample extracted");
     const bool exact = nslices == 1;                                   // the sample is the chunk
@@ -1274,6 +1287,19 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (c->est_scale != 1.0) m_est = (uint64_t)((double)m_est * c->est_scale);      // tests: a wrong estimate on purpose
     lap("distinct keys estimated");
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
+    // One-word k-mer sets are counted as strand representatives and mapped to gossamer's canonical form afterwards -- a
+    // re-ordering of the DISTINCT keys (0.06 ms per million), cheap beside two FNV hashes per WINDOW in the first level
+    // (+ ~2.4 ms per 10^9 windows) while distinct keys are few.  Reads with many errors turn that round (2e9 distinct
+    // 25-mers of 12.6e9 windows: 116 ms of re-ordering against ~30 ms of hashing): from 10 % distinct keys on the first
+    // level computes the canonical form itself and the run needs no re-ordering.
+    const bool canon_l1 = kOne && !graph_mode && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > 0.10 * (double)n_exp));
+    if (canon_l1)
+    {
+        // (the regions are sized from the sample: it must be in the key space the first level writes)
+        const uint64_t ns2 = extract_sample(false);
+        if (ns2 != ns) throw StatusError{GOSS_ERR_HIP, "fused path: the sample changed between two extractions"};
+        lap("sample extracted again (canonical forms)");
+    }
     // buffers sized from the estimated share of valid windows must hold what the sample promises
     {
         if (reduced && ((double)n_exp * 1.035 + 262144.0 > (double)ka_slots || (double)n_exp * 1.02 + 6.0e6 > (double)kb_slots))
@@ -1306,21 +1332,42 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             // between the two: the 6144-slot table, still one workgroup (and one read) per segment
             if (r == 0 && c->wide_table && (m_est >> kSegBits) <= (uint64_t)kSegWideLimit2 * 3 / 4) { segbits = kSegBits; big_table = -1; break; }
         }
-    // one-word keys whose bits below a 17-bit prefix fit 32 (an odd-length k-mer's strand representative has one bit
-    // that is always clear): 9 bits at the second level, which then writes -- and the counting kernel reads -- 4-byte
-    // remainders instead of 8-byte keys (kernels_partition.hpp: subpart32_kernel)
-    const uint32_t rbits32 = keybits > 17 ? keybits - 17 : 0;
-    const bool squeeze = kOne && !graph_mode && (c->len & 1u) && rbits32 == 33;
+    // one-word keys whose bits below a 17- to 20-bit prefix fit 32 (an odd-length k-mer's strand representative has one
+    // bit that is always clear): 9 to 12 bits at the second level, which then writes -- and the counting kernel reads --
+    // 4-byte remainders instead of 8-byte keys (kernels_partition.hpp: subpart32_kernel).  The fewest bits whose
+    // segments hold the estimated distinct keys in an LDS table (2048 slots at 9 bits when they do, else 4096).
+    uint32_t r32_bits = 0, rbits32 = 0, r32_split = 0;
+    bool squeeze = false;
     const uint32_t sqbit32 = c->len - 1;
     int r32_slots = 0;
-    if (kOne && c->rem32 && c->fused_msd && c->big_rounds_min == 0 && rbits32 >= 8 && rbits32 - (squeeze ? 1u : 0u) <= 32)
+    if (kOne && c->rem32 && c->fused_msd && c->big_rounds_min == 0)
     {
-        const uint64_t per = m_est >> 17;
-        if (c->rem32_slots) r32_slots = c->rem32_slots;
-        else if (per <= 2048 / 4 * 3 * 3 / 4) r32_slots = 2048;
-        else if (per <= 4096 / 4 * 3 * 3 / 4) r32_slots = 4096;
-        if (r32_slots) { segbits = kSegBits; big_table = 0; }
+        // (second-level bits, third-level bits) in the order of what they cost on C2's 12.6 G keys: the second level 31 ms
+        // with 9 bits and 46 with 10 (shorter runs), the third level ~30 ms whatever it splits into -- so ten bits before a
+        // third level, and nine bits + a third level before ten + a third level.  The first pair whose remainder fits 32
+        // bits and whose segments hold the estimated distinct keys in an LDS table (2048 slots at (9, 0) when they
+        // do, else 4096 with a quarter to spare).
+        static const uint32_t order[][2] = {{9, 0}, {10, 0}, {9, 1}, {9, 2}, {9, 3}, {9, 4}, {10, 1}, {10, 2}, {10, 3}, {10, 4}};
+        for (const auto& cand : order)
+        {
+            const uint32_t b2 = cand[0], b3 = cand[1];
+            if (b2 < c->rem32_bits_min || b3 < c->rem32_split_min) continue;
+            if (keybits < 8 + b2 + 8) continue;
+            const uint32_t rb = keybits - 8 - b2;
+            const bool sq = !graph_mode && !canon_l1 && (c->len & 1u) && rb == 33;
+            if (rb - (sq ? 1u : 0u) > 32 || rb - (sq ? 1u : 0u) < b3 + 8) continue;
+            const uint64_t per = m_est >> (8 + b2 + b3);
+            int slots = 0;
+            if (c->rem32_slots) slots = per <= (uint64_t)(c->rem32_slots / 4 * 3) || (b2 == 10 && b3 == (uint32_t)kSub32SplitMax) ? c->rem32_slots : 0;
+            else if (per <= 2048 / 4 * 3 * 3 / 4 && b3 == 0 && b2 == (uint32_t)kSub32BitsMin) slots = 2048;
+            else if (per <= 4096 / 4 * 3 * 3 / 4) slots = 4096;
+            if (!slots) continue;
+            r32_slots = slots; r32_bits = b2; rbits32 = rb; squeeze = sq; r32_split = b3;
+            break;
+        }
     }
+    if (r32_slots) { segbits = kSegBits; big_table = 0; }
+    const uint32_t r32_digits = 1u << r32_bits, r32_regions = 256u << r32_bits;
     if ((!big_table && !r32_slots && (m_est >> segbits) > limit) || segbits + 8 > keybits)
         return decline("too many distinct keys per segment");
     const uint32_t shift = keybits - segbits;
@@ -1338,7 +1385,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         // the sample's joint histogram of both digits (kept out of the per-kernel timing): one pass over the sample
         // with the bins in LDS (a 16-bit partition of the sample + segment bounds took 2.4 ms on C2, this 0.9);
         // 17 bits (four sweeps) for the 32-bit-remainder form, whose pairs of bins are the 16-bit form's
-        const uint32_t jbins = r32_slots ? kSub32Regions : 65536u;
+        const uint32_t jbins = r32_slots ? r32_regions : 65536u;
         c->mute_timing = true;
         unsigned long long* jh = (unsigned long long*)c->arena.temp((uint64_t)jbins * 8);
         HIP_TRY(hipMemsetAsync(jh, 0, (uint64_t)jbins * 8, c->stream));
@@ -1352,7 +1399,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if (r32_slots)
         {
             joint17.swap(ho);
-            for (uint32_t i = 0; i < 65536; ++i) joint[i] = joint17[2 * i] + joint17[2 * i + 1];
+            const uint32_t fold = r32_regions / 65536u;          // bins of this form per bin of the 16-bit form
+            for (uint32_t i = 0; i < 65536; ++i) { uint64_t a = 0; for (uint32_t j = 0; j < fold; ++j) a += joint17[i * fold + j]; joint[i] = a; }
         }
         else joint.swap(ho);
         for (uint32_t i = 0; i < 65536; ++i) hh[i >> 8] += joint[i];
@@ -1371,31 +1419,33 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // sub-regions of the second buffer (two-level form): expected size + six standard deviations
     // of the sample count; they must fit, else the one-level form is used
     std::vector<SubTable> hsub;
-    std::vector<SubTable32> hsub32;
+    std::vector<uint64_t> hsub32_start;          // 32-bit-remainder form: first slot and capacity of every sub-region
+    std::vector<uint32_t> hsub32_cap;
     if (msd && r32_slots)
     {
-        // 131 072 sub-regions of 4-byte slots in the second key buffer; every start a multiple of four slots (the
+        // 2^17 .. 2^20 sub-regions of 4-byte slots in the second key buffer; every start a multiple of four slots (the
         // counting kernel loads 16 bytes per lane)
-        hsub32.resize(1);
+        hsub32_start.resize(r32_regions);
+        hsub32_cap.resize(r32_regions);
         uint64_t at = 0;
         bool fits = true;
-        for (uint32_t i = 0; i < kSub32Regions; ++i)
+        for (uint32_t i = 0; i < r32_regions; ++i)
         {
             const double h = (double)joint17[i];
             const uint64_t cap = exact ? (((uint64_t)(h * c->fused_capscale)) + 3) & ~3ULL
                                        : (((uint64_t)(((h + 6.0 * std::sqrt(h + 1.0) + 4.0) * scale + 64.0) * c->fused_capscale) + 15) & ~15ULL);
             if (cap > 0xFFFF0000ULL) fits = false;
-            hsub32[0].start[i] = at; hsub32[0].cap[i] = (uint32_t)cap;
+            hsub32_start[i] = at; hsub32_cap[i] = (uint32_t)cap;
             at += cap;
             // (the second level addresses a region's sub-regions with 32-bit offsets from the region's first)
-            if ((i & (kSub32Digits - 1u)) == kSub32Digits - 1u && at - hsub32[0].start[i - (kSub32Digits - 1u)] > 0xFFFF0000ULL) fits = false;
+            if ((i & (r32_digits - 1u)) == r32_digits - 1u && at - hsub32_start[i - (r32_digits - 1u)] > 0xFFFF0000ULL) fits = false;
         }
-        if (!fits || at > 2 * kb_slots)
+        if (!fits || at > 2 * kb_slots || (r32_split && at > 2 * ka_slots))          // (the third level writes the remainders into the first buffer)
         {
             if (c->debug) std::fprintf(stderr, "libgossgpu: 32-bit sub-regions need %llu slots of %llu: 8-byte form\n",
                                        (unsigned long long)at, (unsigned long long)(2 * kb_slots));
             r32_slots = 0;
-            hsub32.clear();
+            hsub32_start.clear(); hsub32_cap.clear();
             if ((m_est >> segbits) > limit) return decline("too many distinct keys per segment");
         }
     }
@@ -1510,23 +1560,30 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     } while (0)
             if (graph)
             {
-                if (nh == 0) GOSS_LAUNCH_EP3(1, 0, false);
-                else if (nh == 1) GOSS_LAUNCH_EP3(1, 1, false);
-                else GOSS_LAUNCH_EP3(1, 2, false);
+                if (nh == 0) GOSS_LAUNCH_EP3(1, 0, 0);
+                else if (nh == 1) GOSS_LAUNCH_EP3(1, 1, 0);
+                else GOSS_LAUNCH_EP3(1, 2, 0);
+            }
+            else if (canon_l1)
+            {
+                // gossamer's canonical form computed per window (many distinct keys: above)
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, 2);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, 2);
+                else GOSS_LAUNCH_EP3(0, 2, 2);
             }
             else if (c->len & 1u)
             {
                 // k-mer sets are counted as strand representatives and mapped to the canonical form
                 // afterwards (canonicalize_run); odd k: the central base picks the strand
-                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, true);
-                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, true);
-                else GOSS_LAUNCH_EP3(0, 2, true);
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, 1);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, 1);
+                else GOSS_LAUNCH_EP3(0, 2, 1);
             }
             else
             {
-                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, false);
-                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, false);
-                else GOSS_LAUNCH_EP3(0, 2, false);
+                if (nh == 0) GOSS_LAUNCH_EP3(0, 0, 0);
+                else if (nh == 1) GOSS_LAUNCH_EP3(0, 1, 0);
+                else GOSS_LAUNCH_EP3(0, 2, 0);
             }
 #undef GOSS_LAUNCH_EP3
         }
@@ -1583,36 +1640,61 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     {
         // 4a'. second level, 32-bit-remainder form: keys of region b go to sub-region (b, next 9 bits) as u32 remainders
         SubTable32* dsub = (SubTable32*)c->arena.temp(sizeof(SubTable32));
-        unsigned long long* cur2 = (unsigned long long*)c->arena.temp((uint64_t)kSub32Regions * 4);     // pairs of 32-bit cursors
-        uint64_t* seg_beg = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
-        uint64_t* seg_end = (uint64_t*)c->arena.temp((uint64_t)kSub32Regions * 8);
+        unsigned long long* cur2 = (unsigned long long*)c->arena.temp((uint64_t)r32_regions * 4);     // pairs of 32-bit cursors
+        uint64_t* seg_beg = (uint64_t*)c->arena.temp((uint64_t)r32_regions * 8);
+        uint64_t* seg_end = (uint64_t*)c->arena.temp((uint64_t)r32_regions * 8);
         Tile32* tdesc = (Tile32*)c->arena.temp(std::max<uint64_t>(tiles, 1) * sizeof(Tile32));
-        HIP_TRY(hipMemcpyAsync(dsub, hsub32.data(), sizeof(SubTable32), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)kSub32Regions * 4, c->stream));
+        // (only the used part of the table travels: the starts, then the capacities)
+        HIP_TRY(hipMemcpyAsync(dsub->start, hsub32_start.data(), (uint64_t)r32_regions * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dsub->cap, hsub32_cap.data(), (uint64_t)r32_regions * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)r32_regions * 4, c->stream));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32Tile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
                            (const GapTable*)dgt, tdesc, (uint32_t)tiles);
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
             const dim3 g2((uint32_t)((tiles + 7) / 8 * 8));
-            if (squeeze)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<true>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
-                                   sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<false>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32,
-                                   sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl);
+#define GOSS_LAUNCH_S32(SQ, B2)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<SQ, B2>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32, \
+                       sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl)
+            if (squeeze) GOSS_LAUNCH_S32(true, 9);          // (only the 9-bit form of an odd k-mer set needs the squeeze)
+            else if (r32_bits == 9) GOSS_LAUNCH_S32(false, 9);
+            else GOSS_LAUNCH_S32(false, 10);
+#undef GOSS_LAUNCH_S32
             t.stop();
         }
-        hipLaunchKernelGGL(sub_bounds32_kernel, dim3(kSub32Regions / 256), dim3(256), 0, c->stream, (const SubTable32*)dsub,
-                           (const uint32_t*)cur2, seg_beg, seg_end);
+        hipLaunchKernelGGL(sub_bounds32_kernel, dim3(r32_regions / 256), dim3(256), 0, c->stream, (const SubTable32*)dsub,
+                           (const uint32_t*)cur2, r32_regions, seg_beg, seg_end);
         HIP_TRY(hipMemcpyAsync(hctl, ctl, sizeof(LookbackCtl), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hctl->error) { c->fused_overflows++; return decline("a 32-bit sub-region overflowed"); }
         lap("second level (32-bit remainders)");
+        // third level: every segment split into 2^r32_split sub-segments, from kb into ka (same offsets); the counts are
+        // then staged in kb
+        const uint32_t* rems = (const uint32_t*)kb;
+        Key1* spare32 = (Key1*)ka;
+        uint32_t nseg32 = r32_regions;
+        if (r32_split)
+        {
+            nseg32 = r32_regions << r32_split;
+            uint64_t* sub_beg = (uint64_t*)c->arena.temp((uint64_t)nseg32 * 8);
+            uint64_t* sub_end = (uint64_t*)c->arena.temp((uint64_t)nseg32 * 8);
+            {
+                PhaseTimer t(c, GOSS_T_SCATTER, n);
+                hipLaunchKernelGGL(subsplit32_kernel, unit_grid(r32_regions), dim3(kTB), 0, c->stream, (const uint32_t*)kb, (uint32_t*)ka,
+                                   (const uint64_t*)seg_beg, (const uint64_t*)seg_end, rbits32 - (squeeze ? 1u : 0u), r32_split, sub_beg, sub_end);
+                t.stop();
+            }
+            check_launch("third-level split kernel");
+            seg_beg = sub_beg; seg_end = sub_end;
+            rems = (const uint32_t*)ka;
+            spare32 = (Key1*)kb;
+            lap("third level (sub-segments)");
+        }
         int rc;
         for (;;)
         {
-            rc = segment_reduce32(c, (const uint32_t*)kb, (Key1*)ka, n, &r, seg_beg, seg_end, r32_slots, squeeze, rbits32, sqbit32);
-            if (rc != 1 || r32_slots == 4096) break;
+            rc = segment_reduce32(c, rems, spare32, n, &r, seg_beg, seg_end, r32_slots, squeeze, rbits32, sqbit32, nseg32, r32_split);
+            if (rc != 1 || r32_slots == 4096 || c->rem32_slots) break;
             // the remainders are still in their sub-regions: only the counting is redone, in the larger table
             c->segment_retries++;
             r32_slots = 4096;
@@ -1621,13 +1703,19 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             // more distinct keys per segment than this form takes: the chunk again in the 8-byte form and its ladder of tables
             c->segment_retries++;
-            c->rem32 = false;
-            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: 32-bit form overflowed (%d), redoing the chunk in the 8-byte form\n", rc);
+            // more second-level bits while the remainder allows them (the chunk's first level is redone: the staging of
+            // the counts has overwritten its regions), else the 8-byte form and its ladder of tables
+            if (rc == 1 && r32_split < (uint32_t)kSub32SplitMax) c->rem32_split_min = r32_split + 1;
+            else c->rem32 = false;
+            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: 32-bit form with %u + %u bits overflowed (%d), redoing the chunk %s\n", r32_bits, r32_split, rc,
+                                       c->rem32 ? "with more sub-segments" : "in the 8-byte form");
             c->arena.release(mark);
             return process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots);
         }
         c->fused_msd_chunks++;
         c->rem32_chunks++;
+        c->rem32_bits_last = r32_bits;
+        c->rem32_split_last = r32_split;
     }
     else if (msd)
     {
@@ -1728,7 +1816,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         if (rc != 0) { c->segment_retries++; return decline("a segment table overflowed"); }
     }
     lap("segments counted");
-    if (kOne && !graph_mode)
+    if (canon_l1) c->canon_chunks++;
+    if (kOne && !graph_mode && !canon_l1)
     {
         // the run stays in representative space: it is mapped to gossamer's canonical forms when it meets a run
         // that is not, or at finish -- a build of several chunks pays for the re-ordering once, on the merged run
@@ -2776,7 +2865,10 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_CANON_L1"); if (e && *e >= '0' && *e <= '2') c->canon_l1 = *e - '0'; }
     { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
+    { const char* e = std::getenv("GOSS_GPU_REM32_BITS"); if (e && std::atoi(e) >= 9 && std::atoi(e) <= 10) c->rem32_bits_min = (uint32_t)std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_REM32_SPLIT"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 4) c->rem32_split_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
@@ -4386,6 +4478,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     const std::string n = name;
     if (n == "fused_chunks") *value = c->fused_chunks;
     else if (n == "rep_chunks") *value = c->rep_chunks;
+    else if (n == "canon_chunks") *value = c->canon_chunks;
     else if (n == "rec_chunks") *value = c->rec_chunks;
     else if (n == "flush_wait_us") *value = c->flush_wait_us;
     else if (n == "flush_count_us") *value = c->flush_count_us;
@@ -4393,6 +4486,8 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
+    else if (n == "rem32_bits") *value = c->rem32_bits_last;
+    else if (n == "rem32_split") *value = c->rem32_split_last;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;
     else if (n == "wide_table_chunks") *value = c->wide_table_chunks;
     else if (n == "table96_chunks") *value = c->table96_chunks;

@@ -580,8 +580,10 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
                                                                 const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                 uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
                                                                 Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
-                                                                uint32_t rbits, uint32_t sqbit)
+                                                                uint32_t rbits, uint32_t sqbit, uint32_t split_bits)
 {
+    // split_bits: the segments are the sub-segments of subsplit32_kernel -- 2^split_bits per second-level segment, told
+    // apart by the top split_bits bits of the remainder (which they keep) and starting anywhere, not on a 16-byte boundary
     constexpr int NT = kTB;
     constexpr int kLimit = SLOTS / 4 * 3;
     constexpr int BB = SLOTS == 4096 ? 11 : SLOTS == 2048 ? 10 : -1;       // log2(buckets)
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
         if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
     }
-    if (e - b > 0xFFFFFFFFULL)
+    if (e - b > 0xFFFFFFF0ULL)
     {
         if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
         return;
@@ -629,8 +631,10 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
 
     constexpr int kVec = 4;                                  // 16-byte loads in flight per lane
     constexpr int kG = GOSS_R32_G;                           // keys whose buckets are read together
-    const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + b);         // (b is a multiple of 4)
-    const uint32_t n = (uint32_t)(e - b);
+    // (vectors from the 16-byte boundary at or below the segment's start: the first `head` elements are not its own)
+    const uint32_t head = (uint32_t)(b & 3ULL);
+    const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + (b - head));
+    const uint32_t n = (uint32_t)(e - b) + head;
     const uint32_t nvec = (n + 3u) >> 2, nfull = n >> 2;      // vectors, and vectors of four live remainders
     u32x4 nxt[kVec];
 #pragma unroll
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
         continue;
 #endif
         // every vector of the batch whole?  (all but a segment's last batch: no validity arithmetic in the fast path)
-        const bool whole = i0 + (uint32_t)NT * kVec <= nfull;
+        const bool whole = i0 + (uint32_t)NT * kVec <= nfull && (i0 != 0 || head == 0);
         uint32_t pend = 0;                                   // bit 4 u + j: remainder j of vector u missed
 #pragma unroll
         for (int u = 0; u < kVec; ++u)
@@ -670,6 +674,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
                 const uint32_t i = i0 + (uint32_t)u * NT + tid;
                 const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
                 live = (1u << have) - 1u;
+                if (i == 0) live &= ~((1u << head) - 1u);
             }
             // kG keys at a time: their home buckets read and looked at; the second bucket only by the lanes whose key
             // was not at home (6 % at a load of 0.37): a 16-byte LDS read costs what its busiest bank takes, and with a
@@ -805,7 +810,8 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
     if (tid == 0) big = 0;
     __syncthreads();
     const uint32_t rem_bits = rbits - (SQ ? 1u : 0u);
-    const uint32_t bsh = rem_bits > (uint32_t)kBinBits ? rem_bits - kBinBits : 0;
+    // (the top split_bits bits are the same for the whole sub-segment: the bins are cut below them)
+    const uint32_t bsh = rem_bits > (uint32_t)kBinBits + split_bits ? rem_bits - split_bits - kBinBits : 0;
     uint32_t rnk[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
     __syncthreads();
     const uint64_t ob = sh_base;
     if (ob == ~0ULL) return;
-    const uint64_t prefix = (uint64_t)s << rbits;
+    const uint64_t prefix = (uint64_t)(s >> split_bits) << rbits;
     for (uint32_t i = tid; i < d; i += NT)
     {
         const unsigned long long v = tab[i];

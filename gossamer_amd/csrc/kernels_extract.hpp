@@ -674,7 +674,10 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 #ifndef GOSS_E1_OCC
 #define GOSS_E1_OCC 3
 #endif
-template <int MODE, int NH, bool ODD, bool REC = false>
+// REPK (MODE 0): which strand of a k-mer is stored -- 0: strand_rep (even k), 1: the strand whose middle base has a clear
+// low bit (odd k), 2: gossamer's canonical form (the smaller FNV-1a hash: two hash chains per window; chunks with many
+// distinct keys, whose re-ordering after counting would cost more)
+template <int MODE, int NH, int REPK, bool REC = false>
 __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 if (MODE == 0)
                 {
                     // odd length: the central base decides (its low bit differs between the strands)
-                    const Key1 k = ODD ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
+                    const Key1 k = REPK == 2 ? canonical(fk, rck) : REPK == 1 ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
                     kreg[i] = k;
                     bin[i] = ok ? ((uint32_t)(k.lo >> shift) & 0xFFu) : spare;
                 }

@@ -561,12 +561,17 @@ __global__ __launch_bounds__(kTB) void radix_onesweep_kernel(const K* __restrict
 // the low bit of its middle base: extract1_part_kernel picks the strand by it), which is squeezed out: 32 bits.
 // This kernel reads 8-byte keys and writes 4-byte remainders; seg_hash_reduce32_kernel counts those: 12 + 4 bytes per
 // key behind the first level instead of 16 + 8.  Applies while 2 len - 17 - (odd k-mer set ? 1 : 0) <= 32.
-constexpr int kSub32Bits = 9;
-constexpr uint32_t kSub32Digits = 1u << kSub32Bits;          // 512 second-level digits
-constexpr uint32_t kSub32Regions = 256u * kSub32Digits;      // 131 072 sub-regions = segments
+// Ten bits at the second level (2^18 sub-regions) where nine leave 33 bits and there is no bit to squeeze out (graphs of
+// k = 24, k-mer sets of k = 26 would need twelve: not served).  More distinct keys than the tables of 2^17 / 2^18 segments
+// hold (reads with sequencing errors: every error makes up to k new k-mers) do NOT get more second-level bits -- runs of
+// a few bytes per sub-region made that pass 1.5 x (10 bits), 3 x (11) and 7 x (12) slower -- but a THIRD level inside
+// every segment (subsplit32_kernel below), which is exact and cheap.
+constexpr int kSub32BitsMin = 9, kSub32BitsMax = 10;
+constexpr int kSub32SplitMax = 4;                                    // third-level bits at most: 16 sub-segments per segment
+constexpr uint32_t kSub32RegionsMax = 256u << kSub32BitsMax;         // 2^18 sub-regions = second-level segments at most
 struct SubTable32 {
-    unsigned long long start[kSub32Regions];     // first u32 slot of sub-region (b, d), index b * 512 + d; a multiple of 4
-    uint32_t cap[kSub32Regions];
+    unsigned long long start[kSub32RegionsMax];  // first u32 slot of sub-region (b, d), index (b << bits) + d; a multiple of 4
+    uint32_t cap[kSub32RegionsMax];
 };
 
 // low `rbits` bits of a key, bit `sqbit` (always clear) taken out when SQ
@@ -618,7 +623,7 @@ __global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restri
 #ifndef GOSS_S32_OCC
 #define GOSS_S32_OCC 4
 #endif
-template <bool SQ>
+template <bool SQ, int B2>
 __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
                                                            uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
                                                            const Tile32* __restrict__ desc, uint32_t total_tiles,
@@ -626,10 +631,13 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
 {
     constexpr int kItems = kSub32Items;
     constexpr int kTile = kSub32Tile;
+    constexpr uint32_t ND = 1u << B2;                        // second-level digits
+    constexpr int DPT = ND / kTB;                            // digits a thread owns: 2, 4, 8 or 16 neighbours
+    static_assert(DPT >= 2 && DPT % 2 == 0, "a thread owns pairs of digits");
     __shared__ uint32_t stage[kTile];
     __shared__ uint16_t sdig[kTile];
-    __shared__ uint32_t hist[kSub32Digits];                  // keys per digit, then the digit's first slot in `stage`
-    __shared__ uint32_t gbase[kSub32Digits];                 // the digit's first slot in `out` minus its first slot in `stage`, relative to the region's first sub-region
+    __shared__ uint32_t hist[ND];                            // keys per digit, then the digit's first slot in `stage`
+    __shared__ uint32_t gbase[ND];                           // the digit's first slot in `out` minus its first slot in `stage`, relative to the region's first sub-region
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ uint32_t sh_skip, sh_total;
 
@@ -641,7 +649,8 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
     const uint32_t b = td.bucket, tile_n = td.n;
     const uint64_t tile_base = td.base;
     if (tid == 0) sh_skip = 0;
-    hist[tid] = 0; hist[tid + 256] = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) hist[tid + j * kTB] = 0;
 
     Key1 key[kItems];
     uint16_t rank[kItems];
@@ -660,24 +669,36 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
         if (((have >> r) & 1u) && is_pad_key(key[r])) have &= ~(1u << r);
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
-        if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u)], 1u);
+        if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(uint32_t)(key[r].lo >> rbits) & (ND - 1u)], 1u);
     __syncthreads();
-    const uint64_t region_first = sub->start[b * kSub32Digits];          // (uniform)
+    const uint64_t region_first = sub->start[b * ND];       // (uniform)
     {
-        // thread tid owns digits 2 tid and 2 tid + 1
-        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-        const uint32_t sidx = b * kSub32Digits + 2 * tid;
-        unsigned long long old = 0;
-        if (c0 | c1) old = atomicAdd(&cursors[sidx >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
-        const uint32_t e0 = (uint32_t)old, e1 = (uint32_t)(old >> 32);
-        // too small a sub-region: nothing of this tile is stored, the host redoes the chunk
-        if ((c0 && e0 + c0 > sub->cap[sidx]) || (c1 && e1 + c1 > sub->cap[sidx + 1])) { atomicOr(&ctl->error, 2u); sh_skip = 1; }
+        // thread tid owns digits DPT tid .. DPT tid + DPT - 1; a pair of neighbouring 32-bit cursors is one 64-bit atomic
+        uint32_t cn[DPT], ex[DPT], mine = 0;
+        const uint32_t sidx = b * ND + DPT * tid;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) { cn[j] = hist[DPT * tid + j]; mine += cn[j]; }
+        bool over = false;
+#pragma unroll
+        for (int j = 0; j < DPT; j += 2)
+        {
+            unsigned long long old = 0;
+            if (cn[j] | cn[j + 1]) old = atomicAdd(&cursors[(sidx + j) >> 1], (unsigned long long)cn[j] | ((unsigned long long)cn[j + 1] << 32));
+            ex[j] = (uint32_t)old; ex[j + 1] = (uint32_t)(old >> 32);
+            // too small a sub-region: nothing of this tile is stored, the host redoes the chunk
+            over |= (cn[j] && ex[j] + cn[j] > sub->cap[sidx + j]) || (cn[j + 1] && ex[j + 1] + cn[j + 1] > sub->cap[sidx + j + 1]);
+        }
+        if (over) { atomicOr(&ctl->error, 2u); sh_skip = 1; }
         uint32_t tile_total;
-        const uint32_t start = block_excl_scan<uint32_t>(c0 + c1, sh_scan, &tile_total);
-        hist[2 * tid] = start; hist[2 * tid + 1] = start + c0;
+        uint32_t start = block_excl_scan<uint32_t>(mine, sh_scan, &tile_total);
         // (a region's sub-regions span less than 2^32 slots: the host checks it)
-        gbase[2 * tid] = (uint32_t)(sub->start[sidx] - region_first) + e0 - start;
-        gbase[2 * tid + 1] = (uint32_t)(sub->start[sidx + 1] - region_first) + e1 - (start + c0);
+#pragma unroll
+        for (int j = 0; j < DPT; ++j)
+        {
+            hist[DPT * tid + j] = start;
+            gbase[DPT * tid + j] = (mine ? (uint32_t)(sub->start[sidx + j] - region_first) : 0u) + ex[j] - start;
+            start += cn[j];
+        }
         if (tid == 0) sh_total = tile_total;
     }
     __syncthreads();
@@ -685,7 +706,7 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
     for (int r = 0; r < kItems; ++r)
         if ((have >> r) & 1u)
         {
-            const uint32_t d = (uint32_t)(key[r].lo >> rbits) & (kSub32Digits - 1u);
+            const uint32_t d = (uint32_t)(key[r].lo >> rbits) & (ND - 1u);
             const uint32_t at = hist[d] + rank[r];
             stage[at] = rem32_pack<SQ>(key[r].lo, rbits, sqbit);
             sdig[at] = (uint16_t)d;
@@ -706,13 +727,109 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
 }
 
 // Segment bounds of the 32-bit-remainder layout: segment s holds (the 32-bit half s of the cursor words) remainders from start[s].
-__global__ void sub_bounds32_kernel(const SubTable32* __restrict__ sub, const uint32_t* __restrict__ cursors,
+__global__ void sub_bounds32_kernel(const SubTable32* __restrict__ sub, const uint32_t* __restrict__ cursors, uint32_t nseg,
                                     uint64_t* __restrict__ seg_beg, uint64_t* __restrict__ seg_end)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= kSub32Regions) return;
+    if (s >= nseg) return;
     seg_beg[s] = sub->start[s];
     seg_end[s] = sub->start[s] + cursors[s];
+}
+
+// Third level of the 32-bit-remainder form: every second-level segment (a contiguous run of remainders, ~96 K of them on
+// C2) is split on the top b3 <= 4 bits of its remainders into 2^b3 sub-segments -- the segments the counting kernel
+// then takes, when a second-level segment holds more distinct keys than an LDS table (reads with sequencing errors).
+// One workgroup per segment, two passes over it: counts per wave and digit (every lane keeps its own counters in LDS:
+// no atomics), then every wave appends its keys of digit d to ITS OWN share of sub-segment d (rank inside the wave by
+// ballots over the digit's bits).  The output is a permutation of the segment at the same offsets of another buffer:
+// exact sizes, no slack, no overflow.  A wave's 2^b3 append streams advance by a few keys per instruction and meet
+// again in the L2 at once; 4 + 4 bytes read (the second time mostly from the Infinity Cache) and 4 written per key.
+__global__ __launch_bounds__(kTB) void subsplit32_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                         const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
+                                                         uint32_t rem_bits, uint32_t b3, uint64_t* __restrict__ sub_beg,
+                                                         uint64_t* __restrict__ sub_end)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t cnt[kWaves][64][17];             // per lane: its count of every digit (17: rows on different banks)
+    __shared__ uint32_t wcnt[kWaves][16];                // per wave and digit: count, then the wave's cursor inside the segment
+    const uint32_t s = unit_block(), tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t nd = 1u << b3, dsh = rem_bits - b3;
+    const uint64_t b = seg_beg[s], e = seg_end[s];
+    if (b == e)
+    {
+        if (tid < nd) { sub_beg[(uint64_t)s * nd + tid] = b; sub_end[(uint64_t)s * nd + tid] = b; }
+        return;
+    }
+    for (uint32_t j = 0; j < 17; ++j) cnt[w][lane][j] = 0;
+    const uint64_t n = e - b;
+    const uint64_t nvec = (n + 3) >> 2;
+    const u32x4* const in4 = reinterpret_cast<const u32x4*>(in + b);          // (a second-level sub-region starts on a 16-byte boundary)
+    // ---- pass 1: how many keys of every digit each wave will see ----
+    for (uint64_t i = tid; i < nvec; i += kTB)
+    {
+        const u32x4 v = in4[i];
+        const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * i + j < n) cnt[w][lane][(kk[j] >> dsh) & (nd - 1u)] += 1u;          // (the lane's own row: no atomic)
+    }
+    __syncthreads();
+    if (tid < (uint32_t)kWaves * 16u)
+    {
+        const uint32_t ww = tid >> 4, d = tid & 15u;
+        uint32_t sum = 0;
+        for (uint32_t l = 0; l < 64; ++l) sum += cnt[ww][l][d];
+        wcnt[ww][d] = d < nd ? sum : 0u;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        // sub-segment d = the waves' shares one after the other; the sub-segments in digit order
+        uint64_t at = 0;
+        for (uint32_t d = 0; d < nd; ++d)
+        {
+            sub_beg[(uint64_t)s * nd + d] = b + at;
+            for (uint32_t ww = 0; ww < (uint32_t)kWaves; ++ww) { const uint32_t c = wcnt[ww][d]; wcnt[ww][d] = (uint32_t)at; at += c; }
+            sub_end[(uint64_t)s * nd + d] = b + at;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: the same keys in the same order, every wave appending to its shares ----
+    uint32_t* const o = out + b;
+    lds_vu32 cur = (lds_vu32)wcnt[w];
+    const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+    for (uint64_t base = 0; base < nvec; base += kTB)
+    {
+        const uint64_t i = base + tid;
+        const bool have = i < nvec;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (have) v = __builtin_nontemporal_load(&in4[i]);
+        const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const bool live = have && 4 * i + j < n;
+            const uint32_t d = (kk[j] >> dsh) & (nd - 1u);
+            uint64_t peers = __ballot(live);
+            for (uint32_t bit = 0; bit < b3; ++bit)
+            {
+                const bool one = (d >> bit) & 1u;
+                const uint64_t m = __ballot(one);
+                peers &= one ? m : ~m;
+            }
+            const uint32_t rank = __popcll(peers & lt_mask);
+            uint32_t at = 0;
+            if (live) at = cur[d];
+            // (all reads of this round happen before the leader's update: one wave, in order)
+            __builtin_amdgcn_wave_barrier();
+            if (live)
+            {
+                o[at + rank] = kk[j];
+                if (rank == 0) cur[d] = at + (uint32_t)__popcll(peers);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // out[q] = first index of the sorted array whose key is >= query[q] (one thread per query).

@@ -41,18 +41,21 @@ def build(reads, k, mode, budget=8 << 30):
     return c, files, st
 
 
-@pytest.mark.parametrize("k,mode", [(25, 0), (21, 0), (24, 0), (13, 0), (17, 0), (24, 1), (20, 1), (15, 1)])
+@pytest.mark.parametrize("k,mode", [(25, 0), (21, 0), (24, 0), (13, 0), (17, 0), (24, 1), (20, 1), (15, 1), (26, 0), (27, 0), (25, 1)])
 def test_rem32_form_matches_the_oracle(oracle, k, mode):
     """300 k reads of 150 bp (45 M window starts: the fused path takes them by itself), ~30x coverage.  k = 25: 33 bits
-    below the prefix, the clear bit 24 squeezed out; graph k = 24: 33 bits and no clear bit, the 8-byte form must take
-    it; the others: narrower remainders."""
+    below a 17-bit prefix, the clear bit 24 squeezed out; graph k = 24: 33 bits and no clear bit -- ten bits at the second
+    level leave 32; k = 26, 27 and graph k = 25: no form fits, the 8-byte form takes them; the others: narrower
+    remainders."""
     reads = g.synth_reads_host(300_000, 150, 1_500_000, seed=100 + k + mode)
     build_o = oracle.build_graph if mode else oracle.build_kmer_set
     exp, nwin = build_o([(oracle.LINE, "reads", reads)], k, out="o")
     exp = {n[1:]: d for n, d in exp.items()}
     c, got, st = build(reads, k, mode)
     length = k + 1 if mode else k
-    fits = 2 * length - 17 - (1 if (not mode and length % 2 == 1 and 2 * length - 17 == 33) else 0) <= 32 and 2 * length - 17 >= 8
+    # some number of second-level bits (9 .. 12) leaves a remainder of 8 .. 32 bits (33 at 9 bits for an odd k-mer set: squeezed)
+    fits = any(8 <= 2 * length - 8 - b2 and 2 * length - 8 - b2 - (1 if (not mode and length % 2 == 1 and 2 * length - 8 - b2 == 33) else 0) <= 32
+               for b2 in (9, 10))
     assert c.windows == nwin
     assert st["fused_chunks"] == 1 and st["fused_msd_chunks"] == 1 and st["segment_retries"] == 0, st
     assert st["rem32_chunks"] == (1 if fits else 0), st
@@ -112,7 +115,7 @@ def test_rem32_tables_overflow_in_turn():
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
     for e, want in (({"GOSS_GPU_NO_REM32": 1}, (0, None)), ({}, (1, 0)), ({"GOSS_GPU_EST_SCALE": 0.5}, (1, 1))):
-        with env(**e):
+        with env(GOSS_GPU_CANON_L1=0, **e):          # (strand representatives whatever the estimate says: the 9-bit form and its two tables)
             ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
         if not res:
             ctx.synth_reads(buf.data_ptr(), n, L, G, seed=55)
@@ -165,3 +168,78 @@ def test_rem32_skewed_low_bits(oracle):
         assert c.windows == nwin == 1_100_000
         assert st["rem32_chunks"] == 1 and st["segment_retries"] == 0, st
         assert got == exp
+
+
+@pytest.mark.parametrize("bits,split", [(10, 0), (9, 1), (9, 3), (10, 2), (9, 4), (10, 4)])
+def test_rem32_wider_second_level_and_third_level(oracle, bits, split):
+    """Ten bits at the second level, and a third level inside the segments (1 .. 4 bits: what reads with many distinct
+    k-mers get by themselves), forced on the same reads: k = 25 (squeezed at 9 bits, 32-bit remainders at 10), k = 21,
+    graph k = 24 (needs 10), graph k = 20; both tables.  Files against the oracle."""
+    for k, mode in ((25, 0), (21, 0), (24, 1), (20, 1)):
+        if bits == 9 and (k, mode) == (24, 1):
+            continue
+        reads = g.synth_reads_host(300_000, 150, 1_500_000, seed=300 + k + mode)
+        build_o = oracle.build_graph if mode else oracle.build_kmer_set
+        exp, nwin = build_o([(oracle.LINE, "reads", reads)], k, out="o")
+        exp = {n[1:]: d for n, d in exp.items()}
+        for slots in (2048, 4096):
+            with env(GOSS_GPU_REM32_BITS=bits, GOSS_GPU_REM32_SPLIT=split, GOSS_GPU_REM32_SLOTS=slots):
+                with g.Context(k, mode, hbm_budget=8 << 30) as ctx:
+                    ctx.push_host(reads)
+                    c = ctx.finish()
+                    got = ctx.emit()
+                    st = {n: ctx.stat(n) for n in STATS + ("rem32_bits", "rem32_split")}
+            assert c.windows == nwin
+            assert st["rem32_chunks"] == 1 and st["rem32_bits"] == bits and st["rem32_split"] == split and st["segment_retries"] == 0, st
+            assert got == exp, (k, mode, slots)
+
+
+def test_rem32_takes_a_third_level_when_the_tables_overflow():
+    """2.2e8 distinct 25-mers with the estimate at a quarter and the small table forced: 420 per 17-bit segment expected,
+    1 680 there -- the 2048-slot tables overflow and the chunk is redone with every segment split in two (840 each).  With
+    the right estimate and free choice: the 4096-slot tables at once; at 0.6 of the estimate ... the same.  Same keys
+    and counts as the 8-byte form."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 6_000_000, 150, 230_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for e, split in (({"GOSS_GPU_NO_REM32": 1}, 0), ({"GOSS_GPU_EST_SCALE": 0.25, "GOSS_GPU_REM32_SLOTS": 2048}, 1), ({"GOSS_GPU_REM32_SPLIT": 2}, 2)):
+        with env(GOSS_GPU_CANON_L1=0, **e):
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=55)
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        assert ctx.stat("fused_chunks") == 1 and ctx.stat("rem32_split") == split, (e, ctx.stat("rem32_split"), ctx.stat("segment_retries"))
+        assert ctx.stat("rem32_chunks") == (1 if split else 0)
+        kp, cp, m = ctx.result_ptrs()
+        res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    for other in res[1:]:
+        assert res[0][2] == other[2]
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+
+
+@pytest.mark.parametrize("k", [25, 22, 17, 31, 27])
+def test_first_level_computes_the_canonical_form_itself(oracle, k):
+    """GOSS_GPU_CANON_L1=2: the fused first level stores gossamer's canonical form (the strand with the smaller FNV-1a
+    hash, RankSelect.hh:126-140) instead of the strand representative -- what chunks with more than 10 % distinct keys
+    get by themselves, whose re-ordering after counting would cost more than hashing every window.  The run needs no
+    canonical re-ordering (rep_chunks == 0); k = 25 then takes ten second-level bits (no bit to squeeze out).  Files
+    against the oracle; k = 31 and 27: the 8-byte forms behind the same first level."""
+    reads = g.synth_reads_host(300_000, 150, 1_500_000, seed=500 + k)
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    with env(GOSS_GPU_CANON_L1=2):
+        with g.Context(k, 0, hbm_budget=8 << 30) as ctx:
+            ctx.push_host(reads)
+            c = ctx.finish()
+            got = ctx.emit()
+            st = {n: ctx.stat(n) for n in STATS + ("rem32_bits", "canon_chunks", "rep_chunks")}
+    assert c.windows == nwin
+    assert st["fused_chunks"] == 1 and st["canon_chunks"] == 1 and st["rep_chunks"] == 0, st
+    if k == 25:
+        assert st["rem32_chunks"] == 1 and st["rem32_bits"] == 10, st
+    assert got == exp

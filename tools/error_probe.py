@@ -49,7 +49,7 @@ def main():
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         tim = {kk: round(v["ms"], 1) for kk, v in ctx.timing().as_dict().items()}
-        stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "runs", "seg_merges")}
+        stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "rem32_chunks", "rem32_bits", "rem32_split", "big_table_chunks", "segment_retries", "runs", "seg_merges")}
         print(json.dumps({"error_rate": rate, "ms": round(min(times) * 1e3, 1), "windows": c.windows, "distinct": c.distinct,
                           "G_kmers_per_s": round(c.windows / min(times) / 1e9, 1), "device_ms": tim, "stats": stats}))
         sys.stdout.flush()
