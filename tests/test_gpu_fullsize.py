@@ -68,6 +68,67 @@ def test_c2_full_size_properties():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_c2_with_one_percent_errors_full_size_properties():
+    """C2's reads with 1 % of the bases substituted at random (what sequencers produce: every error makes up to k new
+    k-mers, 2.0e9 distinct 25-mers instead of 1.0e8).  The default pipeline then takes forms the clean reads never see --
+    the first level computes gossamer's canonical form itself, ten bits at the second level, a third level inside the
+    segments, 4096-slot tables of 32-bit remainders -- and must give, key for key and count for count, what the 8-byte
+    forms behind a first level of strand representatives give (three partition digits, the canonical re-ordering of
+    2e9 pairs): no kernel in common between the counting stages.  Counts add up to the windows, keys increase."""
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 250 * (1 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    n, L, G = 100_000_000, 150, 100_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    budget = int((free_b - buf.numel() - (60 << 30)) * 0.94)          # (the two results, 24 GB each, live beside the arena)
+    res = []
+    for env in ({}, {"GOSS_GPU_NO_REM32": "1", "GOSS_GPU_CANON_L1": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=budget)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=1)
+            torch.cuda.synchronize()
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(7)
+            lut = torch.tensor([ord(ch) for ch in "ACGT"], dtype=torch.uint8, device="cuda")
+            step = 1 << 28
+            for at in range(0, buf.numel(), step):
+                v = buf[at:at + step]
+                hit = (torch.rand(v.numel(), device="cuda", generator=gen) < 0.01) & (v != 10)
+                sub = lut[torch.randint(0, 4, (v.numel(),), device="cuda", generator=gen)]
+                v[hit] = sub[hit]
+                del hit, sub
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        if not env:
+            assert ctx.stat("rem32_chunks") >= 1 and ctx.stat("canon_chunks") >= 1 and ctx.stat("rem32_split") >= 1, \
+                {s: ctx.stat(s) for s in ("rem32_chunks", "canon_chunks", "rem32_split", "rem32_bits", "fused_chunks")}
+        else:
+            assert ctx.stat("rem32_chunks") == 0 and ctx.stat("canon_chunks") == 0
+        kp, cp, m = ctx.result_ptrs()
+        keys = gd.device_view(kp, m, torch.int64, "cuda").clone()
+        counts = gd.device_view(cp, m, torch.int32, "cuda").clone()
+        assert m == c.distinct and c.keys == c.windows and 1.8e9 < m < 2.3e9
+        if not res:
+            assert bool((keys[1:] > keys[:-1]).all().item())
+            assert int(counts.to(torch.int64).sum().item()) == c.windows
+        res.append((keys, counts, c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_c4_full_size_properties():
     """BASELINE config C4 at full size: build-graph k = 55 on 200 M x 150 bp reads (19 G windows,
     38 G 112-bit keys, several chunks + merge).  The edge set of a graph built from reads is
