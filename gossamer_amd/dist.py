@@ -363,7 +363,13 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         del keep
 
     last_recs = None
+    # (fault injection for the tests: this rank dies while piece GOSS_DIST_FAIL_PIECE is on its way -- its peers then
+    # wait in a collective for ever, and whoever started the ranks must end the job: bench.py's launcher does)
+    fail_rank = int(os.environ.get("GOSS_DIST_FAIL_RANK", "-1"))
+    fail_piece = int(os.environ.get("GOSS_DIST_FAIL_PIECE", "0"))
     for i in range(pieces):
+        if rank == fail_rank and i == min(fail_piece, pieces - 1):
+            os._exit(7)
         if i >= depth:
             landed(i - depth)
         ptr = bases_ptr + cuts[i]

@@ -1091,8 +1091,30 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         std::fill(stagedBytes.begin(), stagedBytes.end(), 0);
     };
     // hand a batch to the next device; `done` runs when the device has taken the bytes (wait = until then)
-    auto feed = [&](const char* p, size_t n, std::function<void()> done, bool wait) {
+    std::function<void(const char*, size_t, std::function<void()>, bool)> feed;
+    feed = [&](const char* p, size_t n, std::function<void()> done, bool wait) {
         if (feedFailed.load()) { if (done) done(); feedError(); }
+        if (useRecords && stageCap[nextDev] && n + 1 > stageCap[nextDev])
+        {
+            // a batch larger than a staging buffer (tiny buffers only: a buffer is 1/24 of the arena): handed over in
+            // pieces cut behind read separators, each taken before the next is offered, the batch released at the end
+            size_t at = 0;
+            while (at < n)
+            {
+                size_t len = std::min(n - at, (size_t)stageCap[nextDev] - 1);
+                if (at + len < n)
+                {
+                    size_t cut = len;
+                    while (cut > 0 && p[at + cut - 1] != '\n') --cut;
+                    if (cut == 0) { if (done) done(); throw Error::General("a read longer than a device's staging buffer (--hbm-budget too small for --devices)\n"); }
+                    len = cut;
+                }
+                feed(p + at, len, nullptr, true);
+                at += len;
+            }
+            if (done) done();
+            return;
+        }
         if (useRecords)
         {
             // (what a device has staged is tracked here: the feeders run behind, and a push that does not fit is refused)
@@ -1103,7 +1125,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
                 gs[d]->check(goss_gpu_stage_room(gs[d]->h, &room, &cap), "sizing the staging buffer");
                 stageCap[d] = cap > 4096 ? cap - 4096 : cap;
             }
-            if (n + 1 > stageCap[d]) { if (done) done(); throw Error::General("a batch of reads larger than a device's staging buffer (--hbm-budget too small for --devices)\n"); }
+            if (n + 1 > stageCap[d]) { feed(p, n, std::move(done), wait); return; }          // (now that the size is known: in pieces)
             if (stagedBytes[d] + n + 1 > stageCap[d]) exchangeRound();
             stagedBytes[d] += n + 1;
         }

@@ -75,6 +75,17 @@ def main():
             env["GOSS_GPU_EST_SCALE"] = rng.choice(["0.3", "3.0"])
         if rng.random() < 0.2:
             env["GOSS_GPU_ORDER_BITS"] = rng.choice(["16", "17", "20"])
+        # the 32-bit-remainder forms (second-level bits, third level, table) and the first level's key space
+        if rng.random() < 0.15:
+            env["GOSS_GPU_NO_REM32"] = "1"
+        if rng.random() < 0.25:
+            env["GOSS_GPU_REM32_BITS"] = "10"
+        if rng.random() < 0.3:
+            env["GOSS_GPU_REM32_SPLIT"] = rng.choice(["1", "2", "3", "4"])
+        if rng.random() < 0.2:
+            env["GOSS_GPU_REM32_SLOTS"] = rng.choice(["2048", "4096"])
+        if rng.random() < 0.25:
+            env["GOSS_GPU_CANON_L1"] = rng.choice(["0", "2"])
         budget = rng.choice([512 << 20, 2 << 30, 8 << 30]) if LARGE else rng.choice([96 << 20, 256 << 20, 1 << 30, 4 << 30])
         t0 = time.time()
         build = oracle.build_graph if graph else oracle.build_kmer_set
@@ -87,8 +98,35 @@ def main():
             try:
                 # one-word keys, some cases: the reads go through the routing kernel (super-k-mer records for 1 .. 8
                 # parts) and the context counts the records of all parts -- the exchange before counting, on one GPU
-                via_records = parts == 1 and 2 * (k + (1 if graph else 0)) <= 62 and rng.random() < 0.4
-                if via_records:
+                via_records = parts == 1 and rng.random() < 0.4
+                rb = g.binding.record_bytes(k, 1 if graph else 0)          # (12-byte records for one-word keys, 20-byte for two-word keys)
+                devices = GROUPS and parts > 1 and rng.random() < 0.25
+                if devices:
+                    # the command line on several "devices" (this GPU several times): from four on the exchange before counting
+                    import subprocess
+                    import tempfile
+                    d = tempfile.mkdtemp(prefix="goss_fuzz_")
+                    try:
+                        with open(os.path.join(d, "r.txt"), "wb") as f:
+                            f.write(reads)
+                        ndev = rng.choice([2, 4, 5])
+                        e2 = dict(os.environ, GOSS_GPU_STAGE_CAP=str(rng.choice([1 << 20, 8 << 20, 1 << 30])), GOSS_PARSE_CHUNK="262144")
+                        p = subprocess.run([os.path.join(ROOT, "gossamer_amd", "goss"), "build-graph" if graph else "build-kmer-set", "-k", str(k),
+                                            "--line-in", os.path.join(d, "r.txt"), "-O", os.path.join(d, "o"), "--hbm-budget", "1", "-T", "4", "-v",
+                                            "--devices", ",".join(["0"] * ndev)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=e2)
+                        if p.returncode != 0:
+                            raise RuntimeError("goss --devices failed: " + p.stderr.decode(errors="replace")[-400:])
+                        got = {n[1:]: open(os.path.join(d, n), "rb").read() for n in os.listdir(d) if n.startswith("o.") or n.startswith("o-")}
+                        import re
+                        m = re.search(rb"k-mer windows: (\d+),", p.stderr)
+                        windows = int(m.group(1)) if m else -1
+                        stats = {"devices": ndev, "records": b"records routed by minimizer" in p.stderr}
+                        if ndev >= 4 and not stats["records"]:
+                            raise RuntimeError("four devices and no exchange before counting")
+                    finally:
+                        import shutil
+                        shutil.rmtree(d, ignore_errors=True)
+                elif via_records:
                     import torch
                     nparts = rng.choice([1, 2, 3, 5, 8])
                     dev = torch.device("cuda", 0)
@@ -97,7 +135,7 @@ def main():
                         need = [1] * nparts
                         for attempt in range(2):
                             first = [sum(need[:p]) for p in range(nparts)]
-                            buf = torch.empty(sum(need) * 12, dtype=torch.uint8, device=dev)
+                            buf = torch.empty(sum(need) * rb, dtype=torch.uint8, device=dev)
                             recs, wins, okr = ctx.route_records(bases.data_ptr(), bases.numel(), nparts, buf.data_ptr(), first, need)
                             need = recs
                         assert okr
@@ -106,7 +144,7 @@ def main():
                         else:
                             for p in range(nparts):
                                 if recs[p]:
-                                    ctx.push_records(buf.data_ptr() + first[p] * 12, recs[p], wins[p])
+                                    ctx.push_records(buf.data_ptr() + first[p] * rb, recs[p], wins[p])
                         c = ctx.finish()
                         got = ctx.emit()
                         windows = c.windows
@@ -119,22 +157,36 @@ def main():
                         windows = c.windows
                         stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "runs")}
                 else:
-                    # several contexts of this process, each counting a share of the reads (goss_gpu_group_exchange / _emit)
+                    # several contexts of this process, each counting a share of the reads (goss_gpu_group_exchange / _emit);
+                    # half of these cases exchange BEFORE counting: deferred contexts, the shards pushed in 1 .. 3 portions
+                    # with a goss_gpu_group_route_exchange behind each
                     from gossamer_amd import dist as gd
                     lines = reads.split(b"\n")[:-1]
                     per = (len(lines) + parts - 1) // parts
                     shards = [b"".join(x + b"\n" for x in lines[i * per:(i + 1) * per]) for i in range(parts)]
                     ctxs = [g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=max(budget, 256 << 20)) for _ in shards]
+                    before = rng.random() < 0.5
                     try:
                         windows = 0
+                        if before:
+                            rounds = rng.choice([1, 2, 3])
+                            for cx in ctxs:
+                                cx.set_deferred(True)
+                            for r in range(rounds):
+                                for cx, sh in zip(ctxs, shards):
+                                    piece = b"".join(x + b"\n" for x in sh.split(b"\n")[:-1][r::rounds])
+                                    if piece:
+                                        cx.push_host(piece)
+                                if r + 1 < rounds or rng.random() < 0.7:          # (what is still staged at finish is counted locally)
+                                    g.group_route_exchange(ctxs)
                         for cx, sh in zip(ctxs, shards):
-                            if sh:
+                            if sh and not before:
                                 cx.push_host(sh)
                             windows += cx.finish().windows
                         g.group_exchange(ctxs, sample_per_context=rng.choice([0, 64, 1000]))
                         g.group_emit(ctxs)
                         got = gd.assemble_files([cx.files() for cx in ctxs])
-                        stats = {"contexts": parts}
+                        stats = {"contexts": parts, "exchange": "before counting" if before else "counted"}
                     finally:
                         for cx in ctxs:
                             cx.close()

@@ -97,3 +97,45 @@ def test_keys_and_bases_mix_and_wide_keys_are_refused(oracle):
         ks, cs = ctx.result()
         assert c.windows == nwin
         assert ks == ek and [int(x) for x in cs] == ec
+
+
+@pytest.mark.parametrize("k,mode", [(25, 0), (45, 0), (27, 1)])
+def test_raw_keys_records_and_bases_in_one_build(oracle, k, mode):
+    """The three entries of the boundary mixed in one context: a third of the reads as raw un-normalised k-mers
+    (goss_gpu_push_keys_host: the templated operator()(cxt, KmerSrc&), GossCmdBuildKmerSet.tcc:246-256), a third as
+    super-k-mer records routed for three parts and pushed part by part (goss_gpu_push_records_device), a third as bases.
+    The result is the oracle's build of all reads (graph mode: the raw keys are the (k+1)-mers and their reverse
+    complements, as ReverseComplementAdapter.hh:34-55 yields them)."""
+    import torch
+    rng = random.Random(777 + k)
+    reads = make_reads(rng, 900, (max(8, k - 3), 170 if k < 40 else 220), 6000, lower=True)
+    length = k + 1 if mode else k
+    text = lambda rs: ("\n".join(rs) + "\n").encode()          # noqa: E731
+    build = oracle.build_graph if mode else oracle.build_kmer_set
+    exp, nwin = build([(oracle.LINE, "r", text(reads))], k, out="ks")
+    exp = {n[2:]: d for n, d in exp.items()}
+    a, b, c3 = reads[:300], reads[300:600], reads[600:]
+    raw = raw_kmers(oracle, a, length)
+    if mode:
+        raw = raw + [oracle.revcomp(x, length) for x in raw]
+    rng.shuffle(raw)
+    rb = g.binding.record_bytes(k, mode)
+    with g.Context(k, mode, hbm_budget=256 * MB) as ctx:
+        ctx.push_keys_host(as_words(raw, ctx.key_words))
+        tb = text(b)
+        bases = torch.frombuffer(bytearray(tb), dtype=torch.uint8).cuda()
+        need = [1, 1, 1]
+        for attempt in range(2):
+            first = [sum(need[:p]) for p in range(3)]
+            buf = torch.empty(sum(need) * rb, dtype=torch.uint8, device="cuda")
+            recs, wins, ok = ctx.route_records(bases.data_ptr(), bases.numel(), 3, buf.data_ptr(), first, need)
+            need = recs
+        assert ok
+        for p in range(3):
+            if recs[p]:
+                ctx.push_records(buf.data_ptr() + first[p] * rb, recs[p], wins[p])
+        ctx.push_host(text(c3))
+        cts = ctx.finish()
+        got = ctx.emit()
+    assert cts.windows == nwin, (cts.windows, nwin)
+    assert got == exp
