@@ -115,6 +115,7 @@ struct goss_gpu_ctx {
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_rep = false;           // the next one-word k-mer extraction stores strand representatives (fused path's sample)
     uint32_t rep_chunks = 0;            // chunks counted in strand-representative space and mapped to canonical order afterwards
+    bool graph_rep = true;              // GOSS_GPU_NO_GRAPH_REP=1: the fused path of a graph build counts both strands of every window (round 3's form)
     int canon_l1 = 1;                   // GOSS_GPU_CANON_L1=0|1|2: the fused first level computes gossamer's canonical form itself never / from 10 % distinct keys on / always
     uint32_t canon_chunks = 0;          // chunks counted that way
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
@@ -617,7 +618,7 @@ void launch_extract_records(goss_gpu_ctx* c, const SkRec* recs, uint64_t nrecs, 
                             uint64_t slice_stride, bool rep)
 {
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ngroups, 1), 256 * 16);
-    if (c->mode == GOSS_MODE_GRAPH)
+    if (c->mode == GOSS_MODE_GRAPH && !rep)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records_kernel<1, false>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out,
                            c->d_ctr, ngroups, slice_groups, slice_stride);
     else if (rep)
@@ -644,7 +645,8 @@ void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
         else launch_extract<Key1, 1, 8>(c, aligned, mis, nstarts, navail, out);
         return;
     }
-    if (c->mode == GOSS_MODE_KMER_SET) launch_extract1<0, 16, 8>(c, aligned, mis, nstarts, navail, out);
+    // (extract_rep in graph mode: one strand representative per window -- the fused path's key space for graphs)
+    if (c->mode == GOSS_MODE_KMER_SET || c->extract_rep) launch_extract1<0, 16, 8>(c, aligned, mis, nstarts, navail, out);
     else launch_extract1<1, 8, 8>(c, aligned, mis, nstarts, navail, out);
 }
 // significant bytes of a two-word key's high word, rounded up to the instantiated classes 2/4/6/8
@@ -652,7 +654,7 @@ inline int key2_nbh(const goss_gpu_ctx* c) { const int nb = (int)(2 * c->len + 7
 
 template <int MODE, int P, int G>
 void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key2* out,
-                     uint64_t slice_tiles = 0, uint64_t slice_stride = 0, uint64_t nsuper_override = 0)
+                     uint64_t slice_tiles = 0, uint64_t slice_stride = 0, uint64_t nsuper_override = 0, bool rep = false)
 {
     constexpr int T = kTB * P * G;
     const uint64_t nsuper = nsuper_override ? nsuper_override : (nstarts + T - 1) / T;
@@ -661,6 +663,7 @@ void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G, NBH>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
                        navail, c->len, out, c->d_ctr, nsuper, slice_tiles, slice_stride)
     if (MODE == 1) { GOSS_LAUNCH_E2(8); return; }             // graph mode does not hash
+    if (rep) { GOSS_LAUNCH_E2(0); return; }                   // strand representatives (NBH 0): no hash either
     switch (key2_nbh(c))
     {
         case 2: GOSS_LAUNCH_E2(2); break;
@@ -691,7 +694,7 @@ void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
         else launch_extract<Key2, 1, 4>(c, aligned, mis, nstarts, navail, out);
         return;
     }
-    if (c->mode == GOSS_MODE_KMER_SET) launch_extract2<0, 8, 8>(c, aligned, mis, nstarts, navail, out);
+    if (c->mode == GOSS_MODE_KMER_SET || c->extract_rep) launch_extract2<0, 8, 8>(c, aligned, mis, nstarts, navail, out, 0, 0, 0, c->extract_rep);
     else launch_extract2<1, 4, 8>(c, aligned, mis, nstarts, navail, out);
 }
 
@@ -1159,6 +1162,71 @@ void canonicalize_run(goss_gpu_ctx* c, Run& r)
     c->arena.release(mark);
 }
 
+// A run of a graph build counted in strand-pair space (one representative per window, process_chunk_fused) -> both
+// strands: run `ri` keeps its keys (palindromic edges get their count doubled: the adapter yields them twice per
+// window), and a second run holds the reverse complements with the same counts, sorted; both are in the full key space
+// and disjoint, the caller merges them.  Exact counts beyond 32 bits are mirrored in the runs' maps.
+template <class K>
+void expand_graph_run(goss_gpu_ctx* c, size_t ri)
+{
+    const uint64_t m = c->runs[ri].m;
+    c->runs[ri].rep = false;
+    if (m == 0) return;
+    PhaseTimer t(c, GOSS_T_ORDER, m);
+    {
+        const uint64_t need = 3 * m * (sizeof(K) + 4) + (256ULL << 20);
+        if (c->arena.avail() < need) grow_arena(c, need);          // (rebases the runs: fetched by index below)
+    }
+    uint64_t mark = c->arena.mark();
+    K* bk = (K*)c->arena.temp(m * sizeof(K));
+    uint32_t* bc = (uint32_t*)c->arena.temp(m * 4);
+    K* tk = (K*)c->arena.temp(m * sizeof(K));
+    uint32_t* tc = (uint32_t*)c->arena.temp(m * 4);
+    unsigned long long* dbig = (unsigned long long*)c->arena.temp((2 + 3 * kMaxBig) * 8);
+    unsigned long long* npal = dbig + 1 + 3 * kMaxBig;
+    HIP_TRY(hipMemsetAsync(dbig, 0, (2 + 3 * kMaxBig) * 8, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(graph_expand_kernel<K>), dim3(grid_for(m, kTB)), dim3(kTB), 0, c->stream, (const K*)c->runs[ri].keys,
+                       c->runs[ri].counts, m, c->len, bk, bc, dbig, kMaxBig, npal);
+    const bool mute = c->mute_timing;
+    c->mute_timing = true;                  // the sort's passes belong to this phase
+    const bool in_b = radix_sort<K, true>(c, bk, tk, bc, tc, m, key_digits(c));
+    c->mute_timing = mute;
+    std::vector<unsigned long long> hb(2 + 3 * kMaxBig);
+    HIP_TRY(hipMemcpyAsync(hb.data(), dbig, hb.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t npads = hb[1 + 3 * kMaxBig];
+    if (hb[0] > kMaxBig) throw StatusError{GOSS_ERR_COUNT_OVERFLOW, "more than 256 keys occurred 2^32 times or more"};
+    const uint64_t mb = m - npads;
+    // exact counts: the representative's entry stays (doubled for a palindrome), its reverse complement gets the same
+    BigMap ma, mbm;
+    if (c->runs[ri].big >= 0)
+        for (const auto& kv : c->big_maps[c->runs[ri].big])
+        {
+            K k;
+            if constexpr (sizeof(K) == 8) k = K{kv.first.second}; else k = K{kv.first.second, kv.first.first};
+            const K r = revcomp(k, c->len);
+            if (r == k) ma[kv.first] = 2 * kv.second;
+            else { ma[kv.first] = kv.second; mbm[std::make_pair((uint64_t)key_hi_word(r), (uint64_t)key_lo_word(r))] = kv.second; }
+        }
+    for (uint64_t i = 0; i < hb[0]; ++i) ma[std::make_pair((uint64_t)hb[2 + 3 * i], (uint64_t)hb[1 + 3 * i])] = hb[3 + 3 * i];
+    c->runs[ri].big = -1;
+    if (!ma.empty()) { c->big_maps.push_back(std::move(ma)); c->runs[ri].big = (int)c->big_maps.size() - 1; }
+    if (mb)
+    {
+        Run b{nullptr, nullptr, mb};
+        b.keys = c->arena.perm(mb * sizeof(K));
+        b.counts = (uint32_t*)c->arena.perm(mb * 4);
+        HIP_TRY(hipMemcpyAsync(b.keys, in_b ? tk : bk, mb * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(b.counts, in_b ? tc : bc, mb * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (!mbm.empty()) { c->big_maps.push_back(std::move(mbm)); b.big = (int)c->big_maps.size() - 1; }
+        c->runs.push_back(b);
+    }
+    t.stop();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->arena.release(mark);
+    if (c->debug) std::fprintf(stderr, "libgossgpu: %llu strand pairs expanded (%llu palindromes)\n", (unsigned long long)m, (unsigned long long)npads);
+}
+
 // Returns kFusedDone, kFusedDeclined (the caller runs the unfused sequence) or kFusedNeedFull (the
 // key buffers were sized for fewer valid windows than the sample shows: the caller retries with
 // buffers of one key per window start).
@@ -1181,6 +1249,13 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     constexpr bool kOne = std::is_same<K, Key1>::value;          // one-word keys
     const uint32_t keybits = 2 * c->len;
     if (c->rec_mode && !kOne) return kFusedDeclined;             // (two-word records: the plain record kernel + the unfused sequence)
+    // Graph mode wants both strands of every window (ReverseComplementAdapter.hh:34-55), and both always come together:
+    // the fused path counts ONE strand representative per window -- half the keys through the partition and the tables
+    // -- and the run is expanded into both strands after counting (expand_graph_run).  Inside this function such a chunk
+    // is a k-mer-set chunk of (k+1)-mers in representative space.
+    const bool rep_graph = c->mode == GOSS_MODE_GRAPH && c->graph_rep;
+    const bool rep_kmer = c->mode != GOSS_MODE_GRAPH && kOne;    // (one-word k-mer sets: representatives, canonical forms after counting)
+    const bool use_rep = rep_graph || rep_kmer;
     if (!c->fused || c->path != 0 || !c->lookback || c->ordered_tiles ||
         c->extract_v1 || nstarts < c->fused_min || keybits < (uint32_t)kSegBits + 8)
         return kFusedDeclined;
@@ -1209,7 +1284,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
-    const bool graph_mode = c->mode == GOSS_MODE_GRAPH;
+    const bool graph_mode = c->mode == GOSS_MODE_GRAPH && !rep_graph;
     // window starts per super-tile of the plain kernels: extract1_kernel<0,16,8> / <1,8,8>, extract2_kernel<0,8,8> / <1,4,8>
     const uint64_t kPlainSuper = 8ULL * kTB * (kOne ? (graph_mode ? 8 : 16) : (graph_mode ? 4 : 8));
     // a slice is ONE super-tile (~217 reads of 150 bp): thousands of slices follow a drifting
@@ -1219,7 +1294,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (nslices > 1 && nstarts < 4 * nslices * slice_starts) return decline("chunk smaller than the sample");
     // key buffers sized from the estimated share of valid windows (process_chunk): they must hold
     // the sample whatever it contains
-    const uint64_t kps = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
+    const uint64_t kps = graph_mode ? 2 : 1;
     const bool reduced = ka_slots < nstarts * kps || kb_slots < nstarts * kps;
     if (reduced && (nslices == 1 || nslices * slice_starts * kps > std::min(ka_slots, kb_slots))) return (int)kFusedNeedFull;
     const uint64_t slice_stride = nslices > 1 ? ((nstarts - slice_starts) / (nslices - 1)) & ~15ULL : 0;
@@ -1232,7 +1307,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         const uint32_t mis0 = c->rec_mode ? 0u : (uint32_t)(addr0 & 15u);          // (records are taken where they lie)
         if (nslices == 1)
         {
-            c->extract_rep = kOne && !graph_mode && rep;
+            c->extract_rep = use_rep && rep;
             extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
             c->extract_rep = false;
         }
@@ -1242,7 +1317,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
             (void)grid;
             if (graph_mode) launch_extract2<1, 4, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
-            else launch_extract2<0, 8, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
+            else launch_extract2<0, 8, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper, rep_graph && rep);
         }
         else if (c->rec_mode)
         {
@@ -1250,7 +1325,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             const uint64_t P = rec_slots(c);
             const uint64_t slice_groups = slice_starts / P / kRecGroup;
             launch_extract_records(c, (const SkRec*)d_bases, nstarts / P, (Key1*)ka, slice_groups * nslices, slice_groups, slice_stride / P,
-                                   !graph_mode && rep);
+                                   use_rep && rep);
         }
         else
         {
@@ -1292,7 +1367,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // (+ ~2.4 ms per 10^9 windows) while distinct keys are few.  Reads with many errors turn that round (2e9 distinct
     // 25-mers of 12.6e9 windows: 116 ms of re-ordering against ~30 ms of hashing): from 10 % distinct keys on the first
     // level computes the canonical form itself and the run needs no re-ordering.
-    const bool canon_l1 = kOne && !graph_mode && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > 0.10 * (double)n_exp));
+    const bool canon_l1 = rep_kmer && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > 0.10 * (double)n_exp));
     if (canon_l1)
     {
         // (the regions are sized from the sample: it must be in the key space the first level writes)
@@ -1538,7 +1613,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 #ifndef GOSS_FUSED_G
 #define GOSS_FUSED_G 1
 #endif
-        const bool graph = c->mode == GOSS_MODE_GRAPH;
+        const bool graph = graph_mode;
         const uint64_t kSuper = kOne ? (uint64_t)kTB * (graph ? GOSS_E1_NK / 2 : GOSS_E1_NK)
                                      : (uint64_t)kTB * (graph ? GOSS_FUSED_NKEYS2 / 2 : GOSS_FUSED_NKEYS2);
         const uint64_t nsuper = (nstarts + kSuper - 1) / kSuper;
@@ -1595,6 +1670,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 #define GOSS_LAUNCH_E2N(MODE, NBH)                                                                                    \
     do { if (nh == 0) GOSS_LAUNCH_E2P(MODE, 0, NBH); else if (nh == 1) GOSS_LAUNCH_E2P(MODE, 1, NBH); else GOSS_LAUNCH_E2P(MODE, 2, NBH); } while (0)
             if (graph) GOSS_LAUNCH_E2N(1, 8);
+            else if (rep_graph) GOSS_LAUNCH_E2N(0, 0);          // (NBH 0: strand representatives)
             else
                 switch (key2_nbh(c))
                 {
@@ -1817,7 +1893,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     }
     lap("segments counted");
     if (canon_l1) c->canon_chunks++;
-    if (kOne && !graph_mode && !canon_l1)
+    if (use_rep && !canon_l1)
     {
         // the run stays in representative space: it is mapped to gossamer's canonical forms when it meets a run
         // that is not, or at finish -- a build of several chunks pays for the re-ordering once, on the merged run
@@ -1826,7 +1902,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     }
     c->runs.push_back(r);
     c->windows += hp->windows;
-    c->keys_total += n;
+    c->keys_total += rep_graph ? 2 * n : n;          // (the adapter's key stream: two keys per window of a graph)
     c->fused_chunks++;
     if (c->rec_mode) c->rec_chunks++;
     return kFusedDone;
@@ -1914,12 +1990,16 @@ void merge_runs(goss_gpu_ctx* c)
     bool all_rep = true, any_rep = false;
     for (auto& r : c->runs) { all_rep = all_rep && r.rep; any_rep = any_rep || r.rep; }
     if (any_rep && !all_rep)
-        for (auto& r : c->runs)
-            if (r.rep)
+    {
+        const size_t nr = c->runs.size();
+        for (size_t i = 0; i < nr; ++i)
+            if (c->runs[i].rep)
             {
-                if constexpr (std::is_same<K, Key1>::value) canonicalize_run<K>(c, r);
+                if (c->mode == GOSS_MODE_GRAPH) expand_graph_run<K>(c, i);          // (appends the reverse complements as a run of their own)
+                else if constexpr (std::is_same<K, Key1>::value) canonicalize_run<K>(c, c->runs[i]);
                 else throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
             }
+    }
     const bool rep_out = all_rep;
     uint64_t total = 0;
     for (auto& r : c->runs) total += r.m;
@@ -2865,6 +2945,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_NO_GRAPH_REP"); if (e && *e && *e != '0') c->graph_rep = false; }
     { const char* e = std::getenv("GOSS_GPU_CANON_L1"); if (e && *e >= '0' && *e <= '2') c->canon_l1 = *e - '0'; }
     { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
     { const char* e = std::getenv("GOSS_GPU_REM32_BITS"); if (e && std::atoi(e) >= 9 && std::atoi(e) <= 10) c->rem32_bits_min = (uint32_t)std::atoi(e); }
@@ -3277,8 +3358,17 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
         if (c->words == 1) merge_runs<Key1>(c); else merge_runs<Key2>(c);
         if (!c->runs.empty() && c->runs[0].rep)
         {
-            if (c->words != 1) throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
-            canonicalize_run<Key1>(c, c->runs[0]);
+            if (c->mode == GOSS_MODE_GRAPH)
+            {
+                // strand pairs -> both strands: the reverse complements as a second run, merged with the first
+                if (c->words == 1) { expand_graph_run<Key1>(c, 0); merge_runs<Key1>(c); }
+                else { expand_graph_run<Key2>(c, 0); merge_runs<Key2>(c); }
+            }
+            else
+            {
+                if (c->words != 1) throw StatusError{GOSS_ERR_STATE, "a two-word run in representative space"};
+                canonicalize_run<Key1>(c, c->runs[0]);
+            }
         }
         if (!c->runs.empty()) { c->res_keys = c->runs[0].keys; c->res_counts = c->runs[0].counts; c->M = c->runs[0].m; }
         else { c->res_keys = c->arena.perm(16); c->res_counts = (uint32_t*)c->arena.perm(16); c->M = 0; }

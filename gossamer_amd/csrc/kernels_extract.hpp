@@ -118,6 +118,23 @@ __device__ __forceinline__ Key1 strand_rep(const Key1& f, const Key1& rc, uint32
 }
 
 struct Rem96 { uint32_t r0, r1, r2; };           // the low 96 bits of a two-word key, packed (12-byte records)
+// The same for two-word keys (32 <= len <= 63), used where BOTH strands of every window are wanted in the end (graph
+// mode): the windows are counted as one representative per strand pair and the pairs are expanded after counting
+// (graph_expand_kernel).  Odd len: the strand whose middle base has a clear low bit (bit len - 1).  Even len: the
+// strand whose halves (len bits each), swapped, give the smaller value -- low half first, then high half.
+__device__ __forceinline__ Key2 strand_rep2(const Key2& f, const Key2& rc, uint32_t len, uint64_t lmask)
+{
+    if (len & 1u)
+    {
+        const uint32_t b = len - 1;              // 32 .. 62
+        return ((f.lo >> b) & 1ULL) ? rc : f;
+    }
+    const uint64_t lf = f.lo & lmask, lr = rc.lo & lmask;
+    const uint64_t hf = ((f.lo >> len) | (f.hi << (64 - len))) & lmask, hr = ((rc.lo >> len) | (rc.hi << (64 - len))) & lmask;
+    const bool take_rc = lr < lf || (lr == lf && hr < hf);
+    return take_rc ? rc : f;
+}
+
 __device__ __forceinline__ bool is_pad_key(const Key1& k) { return k.lo == ~0ULL; }
 __device__ __forceinline__ bool is_pad_key(const Key2& k) { return (k.lo & k.hi) == ~0ULL; }
 
@@ -581,7 +598,7 @@ __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict
                     if ((vm >> i) & 1u)
                     {
                         const Key2 rk{~e.lo, (~e.hi) & mask_hi};
-                        if (MODE == 0) stage[s++] = canonical_tail<NBH>(f, rk);
+                        if (MODE == 0) { if constexpr (NBH == 0) stage[s++] = strand_rep2(f, rk, len, lmask); else stage[s++] = canonical_tail<NBH>(f, rk); }
                         else { stage[s++] = f; stage[s++] = rk; }
                     }
                 }
@@ -1313,7 +1330,8 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                 const Key2 rck = r;
                 if (MODE == 0)
                 {
-                    const Key2 k = canonical_tail<NBH>(f, rck);
+                    Key2 k;
+                    if constexpr (NBH == 0) k = strand_rep2(f, rck, len, lmask); else k = canonical_tail<NBH>(f, rck);          // (NBH 0: the strand representative)
                     kreg[i] = k;
                     bin[i] = ok ? key_digit(k, shift) : spare;
                 }

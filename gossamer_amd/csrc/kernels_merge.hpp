@@ -280,4 +280,45 @@ __global__ __launch_bounds__(kTB) void seg_gather_kernel(const K* __restrict__ s
     }
 }
 
+// Graph mode counts ONE representative per strand pair (the windows' strand_rep: half the keys through the partition
+// and the tables) although ReverseComplementAdapter (ReverseComplementAdapter.hh:34-55) yields both strands of every
+// window.  Both strands of a window always come together, so the edge e and its reverse complement have the same
+// multiplicity: count(e) = count(rc e) = windows(e) + windows(rc e) = the representative's count -- except a
+// palindromic edge (e == rc e), which the adapter yields TWICE per window: twice the count.  This kernel makes the
+// other half of the run: out[i] = (rc keys[i], counts[i]); a palindrome gets a pad there (all ones: sorts behind every
+// key) and its own count doubled in place.  A doubled count that no longer fits 32 bits is kept exactly in `big`
+// ({key lo, key hi, count} triples behind a counter) and the marker 0xFFFFFFFF stored; counts that ARE the marker
+// already (exact value in the run's map) are left to the host, which mirrors / doubles the map's entries.
+template <class K>
+__global__ __launch_bounds__(kTB) void graph_expand_kernel(const K* __restrict__ keys, uint32_t* __restrict__ counts, uint64_t m, uint32_t len,
+                                                          K* __restrict__ out_keys, uint32_t* __restrict__ out_counts,
+                                                          unsigned long long* __restrict__ big, uint32_t big_cap, unsigned long long* __restrict__ npal)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= m) return;
+    const K k = keys[i];
+    const uint32_t c = counts[i];
+    const K r = revcomp(k, len);
+    if (r == k)
+    {
+        K pad;
+        if constexpr (sizeof(K) == 8) pad = K{~0ULL}; else pad = K{~0ULL, ~0ULL};
+        out_keys[i] = pad;
+        out_counts[i] = 0;
+        atomicAdd(npal, 1ULL);
+        if (c != 0xFFFFFFFFu)
+        {
+            const unsigned long long d = 2ULL * c;
+            if (d >= 0xFFFFFFFFULL)
+            {
+                const unsigned long long at = atomicAdd(&big[0], 1ULL);
+                if (at < big_cap) { big[1 + 3 * at] = key_lo_word(k); big[2 + 3 * at] = key_hi_word(k); big[3 + 3 * at] = d; }
+                counts[i] = 0xFFFFFFFFu;
+            }
+            else counts[i] = (uint32_t)d;
+        }
+    }
+    else { out_keys[i] = r; out_counts[i] = c; }
+}
+
 }  // namespace goss

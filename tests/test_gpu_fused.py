@@ -70,9 +70,10 @@ def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
     exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
     exp = _suffix_map(exp, "ks")
     for bits in ("16", "20"):
-        old = {n: os.environ.get(n) for n in ("GOSS_GPU_FUSED_MIN", "GOSS_GPU_ORDER_BITS")}
+        old = {n: os.environ.get(n) for n in ("GOSS_GPU_FUSED_MIN", "GOSS_GPU_ORDER_BITS", "GOSS_GPU_CANON_L1")}
         os.environ["GOSS_GPU_FUSED_MIN"] = "0"
         os.environ["GOSS_GPU_ORDER_BITS"] = bits
+        os.environ["GOSS_GPU_CANON_L1"] = "0"          # (small chunks: more than 10 % of a chunk's keys are distinct, which would make the first level hash)
         try:
             with g.Context(25, g.MODE_KMER_SET, hbm_budget=400 << 20) as ctx:
                 ctx.push_host(reads)
