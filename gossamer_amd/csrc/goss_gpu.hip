@@ -115,6 +115,7 @@ struct goss_gpu_ctx {
     uint32_t extract_hist_shift = 0xFFFFFFFFu;   // digits histogrammed by the last extraction (or none)
     bool extract_rep = false;           // the next one-word k-mer extraction stores strand representatives (fused path's sample)
     uint32_t rep_chunks = 0;            // chunks counted in strand-representative space and mapped to canonical order afterwards
+    bool ef_by_words = false;           // GOSS_GPU_EF_BY_WORDS=1: the high-bits bitmap by a binary search per word (round 1's kernel)
     bool graph_rep = true;              // GOSS_GPU_NO_GRAPH_REP=1: the fused path of a graph build counts both strands of every window (round 3's form)
     int canon_l1 = 1;                   // GOSS_GPU_CANON_L1=0|1|2: the fused first level computes gossamer's canonical form itself never / from 10 % distinct keys on / always
     uint32_t canon_chunks = 0;          // chunks counted that way
@@ -1282,6 +1283,20 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const bool want_msd = c->fused_msd;
     uint64_t sample_starts = nstarts <= (16u << 20) ? nstarts : (4u << 20);
     if (want_msd) sample_starts = nstarts <= (640u << 20) ? nstarts : std::max<uint64_t>(160u << 20, nstarts / 64);
+    // keys that the 32-bit-remainder forms take (by their width): half the sample -- their sub-regions are 4-byte slots,
+    // which have the room for the wider six-sigma margins of a smaller sample (22 % instead of 15 % on C2), and the
+    // sample's extraction, spectrum and joint histogram are 3 ms of a 97 ms step
+    {
+        bool width_ok = false;
+        if (kOne && c->rem32 && keybits >= 8 + 9 + 8)
+            for (uint32_t b2 = kSub32BitsMin; b2 <= (uint32_t)kSub32BitsMax; ++b2)
+            {
+                const uint32_t rb = keybits - 8 - b2;
+                const bool sq = (rep_kmer || rep_graph) && (c->len & 1u) && rb == 33;
+                width_ok = width_ok || rb - (sq ? 1u : 0u) <= 32;
+            }
+        if (want_msd && width_ok && nstarts > (640u << 20)) sample_starts = std::max<uint64_t>(80u << 20, nstarts / 128);
+    }
     // slices are whole super-tiles of the plain kernel (32 768 window starts) and lie a multiple
     // of 16 bytes apart, so that ONE strided launch extracts them all
     const bool graph_mode = c->mode == GOSS_MODE_GRAPH && !rep_graph;
@@ -2489,8 +2504,16 @@ void emit_sparse_index(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, u
 {
     const uint64_t nwords = (nd + m + 3) / 64 + 1;
     uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
-                       keys, m, D, nwords, words);
+    if (m >= (1u << 16) && !c->ef_by_words)
+    {
+        // from the keys' side: one coalesced pass over the keys (GOSS_GPU_EF_BY_WORDS=1: the per-word binary search)
+        HIP_TRY(hipMemsetAsync(words, 0, nwords * 8, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_keys_kernel<K>), dim3(grid_for(m, kEfChunk)), dim3(kTB), 0, c->stream,
+                           keys, m, D, (uint64_t)0, nwords, (unsigned long long*)words);
+    }
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
+                           keys, m, D, nwords, words);
     OutFile f; f.suffix = base + ".high-bits"; f.size = nwords * 8; f.dev = (const uint8_t*)words;
     c->files.push_back(std::move(f));
     emit_dense_select<K>(c, keys, m, D, 1, nd + 2, base + "-d0");
@@ -2945,6 +2968,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_FUSED_GRID"); if (e && *e) c->fused_grid = (uint32_t)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_NO_SEG_MERGE"); if (e && *e == '1') c->seg_merge = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_MSD"); if (e && *e == '1') c->fused_msd = false; }
+    { const char* e = std::getenv("GOSS_GPU_EF_BY_WORDS"); if (e && *e && *e != '0') c->ef_by_words = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_GRAPH_REP"); if (e && *e && *e != '0') c->graph_rep = false; }
     { const char* e = std::getenv("GOSS_GPU_CANON_L1"); if (e && *e >= '0' && *e <= '2') c->canon_l1 = *e - '0'; }
     { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
