@@ -630,6 +630,22 @@ void launch_extract_records(goss_gpu_ctx* c, const SkRec* recs, uint64_t nrecs, 
                            c->d_ctr, ngroups, slice_groups, slice_stride);
 }
 
+// the same for two-word records (rep: graph builds counted as strand pairs)
+void launch_extract_records2(goss_gpu_ctx* c, const SkRec2* recs, uint64_t nrecs, Key2* out, uint64_t ngroups, uint64_t slice_groups,
+                             uint64_t slice_stride, bool rep)
+{
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ngroups, 1), 256 * 16);
+    if (c->mode == GOSS_MODE_GRAPH && !rep)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<1, false>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out, c->d_ctr, ngroups,
+                           slice_groups, slice_stride);
+    else if (rep)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<0, true>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out, c->d_ctr, ngroups,
+                           slice_groups, slice_stride);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<0, false>), dim3(grid), dim3(kTB), 0, c->stream, recs, nrecs, c->len, out, c->d_ctr, ngroups,
+                           slice_groups, slice_stride);
+}
+
 template <>
 void extract_dispatch<Key1>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, Key1* out)
 {
@@ -681,12 +697,7 @@ void extract_dispatch<Key2>(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mi
     {
         // two-word records -> keys with the plain kernel (their counting goes through the unfused sequence)
         const uint64_t nrecs = nstarts / rec_slots(c);
-        const uint64_t ngroups = (nrecs + kRecGroup - 1) / kRecGroup;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ngroups, 1), 256 * 16);
-        if (c->mode == GOSS_MODE_GRAPH)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<1>), dim3(grid), dim3(kTB), 0, c->stream, (const SkRec2*)aligned, nrecs, c->len, out, c->d_ctr, ngroups);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract_records2_kernel<0>), dim3(grid), dim3(kTB), 0, c->stream, (const SkRec2*)aligned, nrecs, c->len, out, c->d_ctr, ngroups);
+        launch_extract_records2(c, (const SkRec2*)aligned, nrecs, out, (nrecs + kRecGroup - 1) / kRecGroup, 0, 0, c->extract_rep);
         return;
     }
     if (c->extract_v1)
@@ -1249,7 +1260,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
 {
     constexpr bool kOne = std::is_same<K, Key1>::value;          // one-word keys
     const uint32_t keybits = 2 * c->len;
-    if (c->rec_mode && !kOne) return kFusedDeclined;             // (two-word records: the plain record kernel + the unfused sequence)
+    if (c->rec_mode && !kOne && c->mode == GOSS_MODE_GRAPH && !c->graph_rep) return kFusedDeclined;          // (the record form extracts one key per window)
     // Graph mode wants both strands of every window (ReverseComplementAdapter.hh:34-55), and both always come together:
     // the fused path counts ONE strand representative per window -- half the keys through the partition and the tables
     // -- and the run is expanded into both strands after counting (expand_graph_run).  Inside this function such a chunk
@@ -1325,6 +1336,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             c->extract_rep = use_rep && rep;
             extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
             c->extract_rep = false;
+        }
+        else if (!kOne && c->rec_mode)
+        {
+            // slices of kPlainSuper window slots of two-word records
+            const uint64_t P = rec_slots(c);
+            const uint64_t slice_groups = std::max<uint64_t>(1, slice_starts / P / kRecGroup);
+            launch_extract_records2(c, (const SkRec2*)d_bases, nstarts / P, (Key2*)ka, slice_groups * nslices, slice_groups, slice_stride / P,
+                                    rep_graph && rep);
         }
         else if constexpr (!kOne)
         {
@@ -1680,8 +1699,19 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         else
         {
 #define GOSS_LAUNCH_E2P(MODE, NH, NBH)                                                                                \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
-                       aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2)
+    do {                                                                                                              \
+        if constexpr (MODE == 0)                                                                                      \
+        {                                                                                                             \
+            if (c->rec_mode)                                                                                          \
+            {                                                                                                         \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<0, NH, GOSS_FUSED_NKEYS2, NBH, true>), dim3(grid), dim3(kTB), 0, c->stream, \
+                                   d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+                break;                                                                                                \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
+                           aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+    } while (0)
 #define GOSS_LAUNCH_E2N(MODE, NBH)                                                                                    \
     do { if (nh == 0) GOSS_LAUNCH_E2P(MODE, 0, NBH); else if (nh == 1) GOSS_LAUNCH_E2P(MODE, 1, NBH); else GOSS_LAUNCH_E2P(MODE, 2, NBH); } while (0)
             if (graph) GOSS_LAUNCH_E2N(1, 8);

@@ -1175,7 +1175,12 @@ __global__ __launch_bounds__(kTB) void normalize_keys_kernel(const K* __restrict
 // bucket (<= 3 keys) carried in the registers of the thread that owns it, kPadKey pairs behind the last
 // keys of every last block, the next tile's bytes fetched one tile ahead.  MODE 0 still computes gossamer's
 // canonical form in the kernel (two FNV chains over 16 bytes).
-template <int MODE, int NH, int NKEYS, int NBH = 8>
+// REC: the input is not bases but two-word super-k-mer records (kernels_route.hpp: SkRec2, 20 bytes = 1..16 windows of
+// 32..63 bases); bases_aligned = the records, navail = their number -- the record form of extract1_part_kernel: a
+// workgroup walks its own share of the records, stages up to 512 per tile in LDS, takes as many whole records as hold at
+// most T windows, and thread t extracts windows P t .. P t + P - 1 of the tile's window sequence wherever the record
+// boundaries fall (MODE 0 only: k-mer sets, and graphs counted as strand pairs).
+template <int MODE, int NH, int NKEYS, int NBH = 8, bool REC = false>
 __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                uint64_t nstarts, uint64_t navail, uint32_t len,
                                                                Key2* __restrict__ out, PartCounters* __restrict__ pc,
@@ -1187,6 +1192,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     constexpr int T = kTB * P;
     constexpr int NVEC = T / 16 + 6;
     constexpr int NK = P * S;
+    static_assert(!REC || MODE == 0, "the record form extracts one key per window");
     constexpr int kCarry = 3;                    // keys of a bucket below a granule of 4
     constexpr uint32_t kSpare = T * S + 256 * kCarry;
     __shared__ __attribute__((aligned(64))) Key2 sorted[T * S + 256 * kCarry + 64];
@@ -1247,7 +1253,38 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     constexpr uint32_t NV0 = T / 16;             // thread tid < NV0 encodes vector tid, threads 0..5 also vector NV0 + tid
     static_assert(NVEC == NV0 + 6 && NV0 <= kTB, "one vector per thread and six more");
     uint32_t c0 = 0, b0 = 0, c1 = 0, b1 = 0;
-    if (blockIdx.x < nsuper)
+    // REC: this workgroup's records [rc_next, rc_end), two per thread and tile staged (five words each)
+    const uint32_t* recw = reinterpret_cast<const uint32_t*>(bases_aligned);
+    const uint64_t nrec = navail;
+    uint64_t rc_next = 0, rc_end = 0;
+    uint32_t ra[5] = {0, 0, 0, 0, 0}, rb[5] = {0, 0, 0, 0, 0}, rna = 0, rnb = 0;
+    uint32_t* rbuf = pk;                                     // [512][5] record words, then [520] prefix sums, then the threads' marks: phase A's share of `sorted`
+    uint32_t* rpre = pk + 512 * 5;
+    uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
+    auto fetch_recs = [&](uint64_t base) {
+        const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
+        rna = rnb = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { ra[j] = 0; rb[j] = 0; }
+        if (ia < rc_end) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ra[j] = recw[5 * ia + j];
+            rna = (ra[4] >> 27) == 1u ? 0u : (ra[4] >> 28) + 1u;
+        }
+        if (ib < rc_end) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) rb[j] = recw[5 * ib + j];
+            rnb = (rb[4] >> 27) == 1u ? 0u : (rb[4] >> 28) + 1u;
+        }
+    };
+    if constexpr (REC)
+    {
+        const uint64_t per = ((nrec + gridDim.x - 1) / gridDim.x + 1) & ~1ULL;
+        rc_next = (uint64_t)blockIdx.x * per;
+        rc_end = rc_next + per < nrec ? rc_next + per : nrec;
+        if (rc_next < rc_end) fetch_recs(rc_next);
+    }
+    else if (blockIdx.x < nsuper)
     {
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
         const uint64_t tb = (uint64_t)blockIdx.x * T;
@@ -1257,25 +1294,126 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         if (tid < 6) encode(q1, c1, b1);
     }
 
-    for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x)
+    for (uint64_t st = blockIdx.x;; st += gridDim.x)
     {
+        if constexpr (REC) { if (rc_next >= rc_end) break; }
+        else { if (st >= nsuper) break; }
         const uint64_t tile_base = st * (uint64_t)T;
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
+        bool more;
+        uint32_t wt = 0;                          // (REC) windows of this tile
+        if constexpr (REC)
+        {
+            // the records that hold windows staged back to back (pads and what lies beyond the share hold none), with
+            // the running sum of their windows: one scan carries both sums
+            if (tid == 0) { rmark[kTB] = 512; rmark[kTB + 1] = 0xFFFFFFFFu; }
+            const uint32_t pa = rna ? 1u : 0u, pb = rnb ? 1u : 0u;
+            uint32_t tot2;
+            const uint32_t sc = block_excl_scan<uint32_t>((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
+            const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
+            const uint32_t ea = ex + rna, eb = ea + rnb;
+            if (pa) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) rbuf[5 * ca + j] = ra[j];
+                rpre[ca] = ex;
+            }
+            if (pb) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) rbuf[5 * cb + j] = rb[j];
+                rpre[cb] = ea;
+            }
+            if (ex <= (uint32_t)T && eb > (uint32_t)T)
+            {
+                const uint32_t one = ea <= (uint32_t)T ? 1u : 0u;
+                rmark[kTB] = 2 * tid + one;
+                rmark[kTB + 1] = one ? ea : ex;
+            }
+            // thread g starts at window P g: a record of at most 16 windows holds at most two such windows
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)((16 + P - 1) / P); ++j)
+            {
+                const uint32_t ga = (ex + P - 1) / P + j, gb = (ea + P - 1) / P + j;
+                if (ga * P < ea && ga < (uint32_t)kTB) rmark[ga] = ca;
+                if (gb * P < eb && gb < (uint32_t)kTB) rmark[gb] = cb;
+            }
+            __syncthreads();
+            const uint32_t nfit = rmark[kTB];
+            wt = rmark[kTB + 1] == 0xFFFFFFFFu ? (tot2 & 0xFFFFu) : rmark[kTB + 1];
+            rc_next += nfit;
+            more = rc_next < rc_end;
+            if (more) fetch_recs(rc_next);
+        }
+        else
+        {
         if (tid < NV0) { pk[tid] = c0; iv[tid] = b0; }
         if (tid < 6) { pk[NV0 + tid] = c1; iv[NV0 + tid] = b1; }
         __syncthreads();
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
-        const bool more = st + gridDim.x < nsuper;
+        more = st + gridDim.x < nsuper;
         if (more)
         {
             const uint64_t tb = (st + gridDim.x) * (uint64_t)T;
             if (tid < NV0) fetch(tb + (uint64_t)tid * 16, q0);
             if (tid < 6) fetch(tb + (uint64_t)(NV0 + tid) * 16, q1);
         }
+        }
 
         // ---- windows out of registers, keys, rank inside their digit (no branch around the LDS atomics) ----
         Key2 kreg[NK];
         uint32_t rk[NK];
         uint32_t vm = 0;
+        if constexpr (REC)
+        {
+            // windows P tid .. P tid + P - 1 of the tile's sequence, starting in record rmark[tid]: every window is cut out
+            // of its record's bases (field of 2 len bits at twice its offset), its forward key the base-4 reversal of the
+            // field, its reverse complement the complemented field
+            const uint32_t j0 = tid * P;
+            const uint32_t left = wt > j0 ? wt - j0 : 0;
+            vm = left >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << left) - 1u);
+            nvalid += __popc(vm);
+            uint32_t r_at = left ? rmark[tid] : 0u;
+            uint32_t r_off = j0 - rpre[r_at];
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            uint32_t r_nw = 0;
+            auto load_rec = [&]() {
+                w0 = (uint64_t)rbuf[5 * r_at] | ((uint64_t)rbuf[5 * r_at + 1] << 32);
+                w1 = (uint64_t)rbuf[5 * r_at + 2] | ((uint64_t)rbuf[5 * r_at + 3] << 32);
+                const uint32_t x4 = rbuf[5 * r_at + 4];
+                w2 = x4 & 0x0FFFFFFFu;
+                r_nw = (x4 >> 28) + 1;                             // (no pad is staged)
+            };
+            load_rec();
+            const uint32_t spare = 256u + (tid & 31u);
+            uint32_t bin[NK];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+            {
+                const uint32_t s2 = 2 * r_off;                     // <= 30
+                Key2 e;
+                e.lo = s2 ? ((w0 >> s2) | (w1 << (64 - s2))) : w0;
+                e.hi = (s2 ? ((w1 >> s2) | (w2 << (64 - s2))) : w1) & mask_hi;
+                Key2 f;
+                {
+                    const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
+                    const uint32_t sft = 128 - bits;
+                    if (sft == 64) { f.lo = rhi; f.hi = 0; }
+                    else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
+                }
+                const Key2 rck{~e.lo, (~e.hi) & mask_hi};
+                if (i + 1 < P)
+                {
+                    ++r_off;
+                    if (r_off >= r_nw && r_at < 511) { ++r_at; r_off = 0; load_rec(); }
+                }
+                const bool ok = (vm >> i) & 1u;
+                Key2 k;
+                if constexpr (NBH == 0) k = strand_rep2(f, rck, len, lmask); else k = canonical_tail<NBH>(f, rck);
+                kreg[i] = k;
+                bin[i] = ok ? key_digit(k, shift) : spare;
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
+        }
+        else
         {
             const uint32_t q0i = tid * P + mis;
             const uint32_t v0 = q0i >> 4, sh = q0i & 15u;
@@ -1398,11 +1536,13 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                 if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], ok ? 1u : 0u);
             }
         }
-        if (more)
+        if (more && !REC)
         {
             encode(q0, c0, b0);
             if (tid < 6) encode(q1, c1, b1);
         }
+        // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one in-order counter)
+        if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // ---- whole granules to the bucket blocks; every 4 aligned lanes store one ----

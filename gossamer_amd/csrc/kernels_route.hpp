@@ -695,10 +695,13 @@ __global__ __launch_bounds__(kTB, 4) void route_records2_kernel(const uint8_t* _
 // two-word records -> keys, densely: one thread per record (the plain kernel of a two-word record source).  MODE 0:
 // gossamer's canonical form of every window (position_type::normalize, RankSelect.hh:126-140); MODE 1: every window's
 // key and its reverse complement (ReverseComplementAdapter.hh:34-55).
-template <int MODE>
+template <int MODE, bool REP = false>
 __global__ __launch_bounds__(kTB) void extract_records2_kernel(const SkRec2* __restrict__ recs, uint64_t nrecs, uint32_t len,
-                                                               Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t ngroups)
+                                                               Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t ngroups,
+                                                               uint64_t slice_groups = 0, uint64_t slice_stride = 0)
 {
+    // (REP, MODE 0: the strand representative of the fused pipeline's key space instead of the canonical form; sampling
+    // mode as extract_records_kernel's: group g of slice s = g / slice_groups starts at record s * slice_stride + ...)
     constexpr int S = MODE == 1 ? 2 : 1;
     __shared__ uint32_t sh_scan[kWaves + 1];
     __shared__ unsigned long long sh_base;
@@ -708,7 +711,9 @@ __global__ __launch_bounds__(kTB) void extract_records2_kernel(const SkRec2* __r
     const uint32_t top = bits - 2;
     for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
-        const uint64_t ri = g * (uint64_t)kRecGroup + tid;
+        uint64_t r0 = g * (uint64_t)kRecGroup;
+        if (slice_groups) r0 = (g / slice_groups) * slice_stride + (g % slice_groups) * (uint64_t)kRecGroup;
+        const uint64_t ri = r0 + tid;
         uint32_t nw = 0;
         SkRec2 rec;
         rec.w[0] = rec.w[1] = rec.w[2] = rec.w[3] = rec.w[4] = 0;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(kTB) void extract_records2_kernel(const SkRec2* __r
                 r.hi = (r.hi >> 2) | (top >= 64 ? cb << (top - 64) : 0ULL);
                 if (top < 64) r.lo |= cb << top;
             }
-            if (MODE == 0) out[ob + i] = canonical(f, r);
+            if (MODE == 0) out[ob + i] = REP ? strand_rep2(f, r, len, (1ULL << len) - 1) : canonical(f, r);
             else { out[ob + 2 * i] = f; out[ob + 2 * i + 1] = r; }
         }
         if (tid == 0 && tot) atomicAdd(&ctr->windows, (unsigned long long)(tot / S));

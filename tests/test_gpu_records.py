@@ -180,7 +180,10 @@ def test_many_parts_small_blocks(oracle, nparts):
 
 
 @pytest.mark.parametrize("k,mode,env", [(27, 1, {}), (24, 1, {}), (30, 1, {}), (22, 0, {}), (16, 0, {}), (25, 0, {"GOSS_GPU_NO_MSD": "1"}),
-                                        (27, 1, {"GOSS_GPU_NO_MSD": "1"}), (31, 0, {}), (21, 0, {"GOSS_GPU_NO_REM32": "1"})])
+                                        (27, 1, {"GOSS_GPU_NO_MSD": "1"}), (31, 0, {}), (21, 0, {"GOSS_GPU_NO_REM32": "1"}),
+                                        # two-word keys: the record form of extract2_part_kernel (20-byte records; graphs as strand pairs)
+                                        (45, 0, {}), (55, 1, {}), (31, 1, {}), (63, 0, {}), (32, 0, {}), (62, 1, {}), (45, 0, {"GOSS_GPU_NO_MSD": "1"}),
+                                        (27, 1, {"GOSS_GPU_NO_GRAPH_REP": "1"})])
 def test_fused_record_kernel_variants_at_its_own_size(oracle, k, mode, env):
     """The record form of the fused extraction in every variant it is compiled in: graph mode (a thread takes 8
     windows, so a record of up to 16 holds the first window of TWO threads), even k (strand_rep instead of the middle
@@ -197,7 +200,8 @@ def test_fused_record_kernel_variants_at_its_own_size(oracle, k, mode, env):
     old = {n: os.environ.get(n) for n in env}
     os.environ.update(env)
     try:
-        ks, cs, c, files, stats = count_parts(k, mode, buf, [0], [sum(recs)], [sum(wins)], [0], budget=6 << 30)
+        # (two-word graph keys: room for the whole input as ONE chunk -- a chunk below the fused path's minimum is counted unfused)
+        ks, cs, c, files, stats = count_parts(k, mode, buf, [0], [sum(recs)], [sum(wins)], [0], budget=(16 if k > 30 and mode else 6) << 30)
     finally:
         for n, v in old.items():
             if v is None:
