@@ -151,6 +151,7 @@ struct goss_gpu_ctx {
     bool debug = false;                 // GOSS_GPU_DEBUG=1: say on stderr why a fast path was not taken
     double fused_capscale = 1.0;        // GOSS_GPU_FUSED_CAPSCALE: multiplies the bucket regions (tests force overflows)
     uint32_t blk_log2_max = 0;          // GOSS_GPU_BLK_LOG2=<b>: blocks of the fused extraction of at most 2^b slots (experiments)
+    bool no_fast32 = false;             // GOSS_GPU_NO_FAST32=1: the fused extraction of one-word keys in its 64-bit form (tests of both forms)
     bool table96 = true;                // GOSS_GPU_NO_TABLE96=1: never count two-word keys as 96-bit remainders in 16-byte slots
     uint32_t table96_chunks = 0;
     bool wide_table = true;             // GOSS_GPU_NO_WIDE_TABLE=1: never count two-word keys in the 6144-slot table
@@ -1610,7 +1611,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
     if (c->blk_log2_max) blk_log2 = std::min(blk_log2, std::max(c->blk_log2_max, kOne ? 3u : 2u));
     const uint64_t B = 1ULL << blk_log2;
-    const double blk_extra = (double)fgrid * (double)B;
+    // (one-word keys: a workgroup also holds a reserved block per bucket that it may never open)
+    const double blk_extra = (double)fgrid * (double)B * (kOne ? 2.0 : 1.0);
     GapTable gt{};
     double base[256], base_sum = 0;
     for (int d = 0; d < 256; ++d)
@@ -1658,14 +1660,21 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
         if constexpr (kOne)
         {
-#define GOSS_LAUNCH_EP3(MODE, NH, ODD)                                                                                \
+            // the 32-bit forms of the kernel: the partition digit is the key's top eight bits (msd) and lies at bit 34 or above
+            const bool fastk = nh == 0 && 2 * c->len >= 32 && part_shift >= 34 && !c->no_fast32;
+#define GOSS_LAUNCH_EP4(MODE, NH, ODD, FAST)                                                                          \
     do {                                                                                                              \
         if (c->rec_mode)                                                                                              \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true>), dim3(grid), dim3(kTB), 0, c->stream, \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true, FAST>), dim3(grid), dim3(kTB), 0, c->stream, \
                                d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
         else                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD>), dim3(grid), dim3(kTB), 0, c->stream, \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, false, FAST>), dim3(grid), dim3(kTB), 0, c->stream, \
                                aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+    } while (0)
+#define GOSS_LAUNCH_EP3(MODE, NH, ODD)                                                                                \
+    do {                                                                                                              \
+        if (fastk) GOSS_LAUNCH_EP4(MODE, NH, ODD, (NH == 0));                                                         \
+        else GOSS_LAUNCH_EP4(MODE, NH, ODD, false);                                                                   \
     } while (0)
             if (graph)
             {
@@ -1695,6 +1704,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
                 else GOSS_LAUNCH_EP3(0, 2, 0);
             }
 #undef GOSS_LAUNCH_EP3
+#undef GOSS_LAUNCH_EP4
         }
         else
         {
@@ -1749,7 +1759,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         sum += gt.cnt[d];
     }
     gt.tile_first[256] = tiles;
-    if (sum < n || sum > n + (uint64_t)fgrid * 256 * (B + 8))
+    if (sum < n || sum > n + (uint64_t)fgrid * 256 * (2 * B + 8))
         throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
     HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
 
@@ -3008,6 +3018,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_NO_FAST32"); if (e && *e == '1') c->no_fast32 = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_TABLE96"); if (e && *e && *e != '0') c->table96 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_WIDE_TABLE"); if (e && *e && *e != '0') c->wide_table = false; }
     { const char* e = std::getenv("GOSS_GPU_BIG_ROUNDS"); if (e && *e) c->big_rounds_max = std::min(3, std::max(0, std::atoi(e))); }

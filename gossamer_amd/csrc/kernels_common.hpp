@@ -80,6 +80,36 @@ __device__ __forceinline__ T block_excl_scan_open(T v, T* sh, T* total)
     return base + inc - v;
 }
 
+// Inclusive scan of one 32-bit value per lane with data-parallel-primitive moves: four shifts inside every row of 16
+// lanes, then the last lane of a row broadcast to the next row, then lane 31 to the upper half -- six vector
+// instructions and no trip through the LDS crossbar (__shfl_up is a ds_bpermute: six dependent round trips).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);       // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t block_excl_scan_open_u32(uint32_t v, uint32_t* sh, uint32_t* total)
+{
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane_id() == 63) sh[wave_id()] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+    {
+        const uint32_t s = sh[w];
+        if ((int)wave_id() > w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // The same for a workgroup of NW waves.
 template <class T, int NW>
 __device__ __forceinline__ T block_excl_scan_n(T v, T* sh, T* total)

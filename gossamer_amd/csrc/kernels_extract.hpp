@@ -656,7 +656,7 @@ struct SubTable {
 
 constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at most 62 bits
 
-// Extraction fused with the first partition level, third form.  What bounded the second form
+// Extraction fused with the first partition level, fourth form.  What bounded the second form
 // (one returning atomic per tile and bucket on 256 cursor words, bucket runs of ~128 bytes landing
 // on partial 64-byte granules of HBM, two FNV chains per window) is designed out:
 //   * a workgroup owns a private BLOCK of B key slots in every bucket region and appends to it;
@@ -664,10 +664,19 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 //   * stores reach HBM as they are issued (nothing merges two partial writes of a 64-byte granule
 //     on the way: 1.4-1.5 x the bytes when runs start anywhere), so a tile stores only whole
 //     granules: per bucket the keys beyond a multiple of 8 wait in the registers of the thread that
-//     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket; in LDS the
-//     stored parts of all buckets lie back to back, each a multiple of 8 keys, so that 4 aligned
-//     lanes of ONE store instruction cover one aligned granule;
+//     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket;
 //   * MODE 0 stores the strand representative (strand_rep) instead of the canonical form.
+// The fourth form (round 4) takes the arithmetic out of the three places that handled every key:
+//   * in LDS every bucket's STREAM of the tile (keys carried in, then the new keys by rank) lies in one piece that
+//     starts on a granule: a key's place is tab[digit] + rank -- one 4-byte table read and one add where the third
+//     form split every stream into a stored and a carried part (an 8-byte table read, a compare and two selects per
+//     key); the last, partial granule of a stream is what the bucket carries out;
+//   * the thread that owns a bucket writes the HBM address of every granule of its stream into `gaddr` (or `skip`
+//     for the partial one), so the store loop is: 16 bytes of keys, one 4-byte address, one store -- no digit, no
+//     table of block positions, no 64-bit selects (17 instructions per key before, 3 now);
+//   * windows come out of the register buffer by constant funnel shifts (the reverse complement is a bit field of
+//     the complemented bases; the bases rolled into the forward strand and the strand-deciding middle bits are
+//     pre-shifted once per thread), in 32-bit halves: 27 -> 16 instructions per window.
 // The unused tail of every workgroup's last block is filled with kPadKey, which the next pass
 // skips; pc->cursors[d] = slots handed out in bucket d (whole blocks), pc->keys_out = keys.
 // The pk/iv arrays of phase A live in the memory of `sorted` (dead until the scatter).
@@ -680,9 +689,9 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 // below bit 64, so no record of windows has that bit without bits 28..31) holds none
 constexpr uint32_t kSkPadWord2 = 1u << 27;
 __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27) == 1u ? 0u : (w2 >> 28) + 1u; }
-// keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads: 16 / 3 (52 KB of LDS, 168 VGPRs)
+// keys per thread / workgroups per CU of extract1_part_kernel.  Measured per 40 M reads (third form): 16 / 3 (52 KB of LDS, 168 VGPRs)
 // 18.5 ms (17.0 since the stores take two keys per lane); 12 / 3 20.0; 8 / 4 (36 KB, 128 VGPRs) 20.9; 8 / 3 23.0 -- what a tile costs beside its keys (carried keys,
-// scans, seven barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
+// scans, barriers) weighs more than the fourth workgroup brings; and 16 / 3 with 928 bytes more LDS runs two
 // workgroups per CU: 22.5; 512 threads of 8 keys (the same tile, two workgroups per CU, four waves per SIMD): 27.7.  The
 // record form needs 16.
 #ifndef GOSS_E1_NK
@@ -694,7 +703,17 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 // REPK (MODE 0): which strand of a k-mer is stored -- 0: strand_rep (even k), 1: the strand whose middle base has a clear
 // low bit (odd k), 2: gossamer's canonical form (the smaller FNV-1a hash: two hash chains per window; chunks with many
 // distinct keys, whose re-ordering after counting would cost more)
-template <int MODE, int NH, int REPK, bool REC = false>
+// (v_bfi_b32 written out: the compiler turns the and-or form of a select by an all-ones / all-zeros mask into
+// compares and conditional moves -- three or four instructions where this is one)
+__device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t ones, uint32_t zeros)
+{
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(ones), "v"(zeros));
+    return d;
+}
+// FAST: the 32-bit forms of the window arithmetic and of the digit -- keys of 32 bits or more whose digit lies at bit 34
+// or above (the headline's: len >= 21, digit = the key's top eight bits); the host picks the instantiation.
+template <int MODE, int NH, int REPK, bool REC = false, bool FAST = false>
 __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
@@ -710,21 +729,25 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     constexpr int NVEC = T / 16 + 4;
     constexpr int NK = P * S;                    // keys per thread
     constexpr int kCarry = 7;
-    // the tile's keys and the keys carried in: first the parts stored now, bucket after bucket
-    // (each a multiple of 8), then the parts carried out
-    // (+ 64 slots nobody reads: LDS writes that do not apply go there instead of under a branch, whose
-    // exec-mask bookkeeping costs scalar issue slots; reads past the live part land there too)
-    constexpr uint32_t kSpare = T * S + 256 * kCarry;
-    __shared__ __attribute__((aligned(64))) Key1 sorted[T * S + 256 * kCarry + 64];
-    __shared__ uint32_t dh[256 + 32];            // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
-    // per bucket: x = first slot in `sorted` of the stored part | its length << 16,
-    //             y = first slot of the part carried out | keys carried in << 13 | stored keys that fit the current block << 16
-    __shared__ uint2 t_lay[256];
-    // per bucket: slot / 8 of the current block's write position (x) and of the new block(s) (y)
-    __shared__ uint2 t_base[256];
-    __shared__ uint32_t sh_ovf;
-    __shared__ uint32_t lh[NH ? 256 * NH : 1];   // histograms of the next NH digits
-    __shared__ uint32_t sh_scan[kWaves + 1];
+    // the NEW keys of the 256 buckets, each bucket's rounded up to whole granules: at most T * S keys and 7 slots per bucket
+    constexpr uint32_t kSlots = T * S + 256 * kCarry;
+    // + 128 slots nobody reads: the keys of windows that are not valid go there (they rank themselves in one of 32
+    // spare counters, 8 threads each: at most 128 per counter and tile) instead of under a branch, whose exec-mask
+    // bookkeeping costs scalar issue slots; reads past the live part land there too
+    constexpr uint32_t kGarb = kSlots;
+    constexpr int kPairs = 5;                                        // pairs of keys per lane and round of the store loop
+    constexpr uint32_t kStep = 2 * kPairs * kTB;                     // slots per round: two rounds cover the 4 096 + 3.5 x 256 slots an average tile takes
+    constexpr uint32_t kNG = kSlots / 8 + 4;                         // granules of the layout; entry kSlots / 8 is always kSkip
+    constexpr uint32_t kSkip = 0xFFFFFFFFu;
+    constexpr uint32_t kSortedBytes = (kSlots + 128) * 8;
+    __shared__ __attribute__((aligned(64))) unsigned char lds_all[kSortedBytes + (288 + 288 + kNG + 8 + (NH ? 256 * NH : 0)) * 4];
+    Key1* const sorted = reinterpret_cast<Key1*>(lds_all);
+    uint32_t* const dh = reinterpret_cast<uint32_t*>(lds_all + kSortedBytes);       // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
+    uint32_t* const tab = dh + 288;              // per bucket: the byte offset in `sorted` of its first NEW key (stream start + keys carried in); spare ones: kGarb
+    uint32_t* const gaddr = tab + 288;           // [kNG] per granule of `sorted`: slot / 8 in `out` it is stored to, or kSkip
+    uint32_t* const sh_scan = gaddr + kNG;       // [kWaves + 1]
+    uint32_t& sh_ovf = sh_scan[6];
+    uint32_t* const lh = sh_scan + 8;            // [256 NH] histograms of the next NH digits
     uint32_t* pk = reinterpret_cast<uint32_t*>(sorted);
     uint32_t* iv = pk + NVEC;
 
@@ -732,7 +755,8 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     if (NH > 0) lh[tid] = 0;
     if (NH > 1) lh[tid + 256] = 0;
     dh[tid] = 0;
-    if (tid == 0) sh_ovf = 0;
+    if (tid < 32) { dh[256 + tid] = 0; tab[256 + tid] = kGarb << 3; }
+    if (tid == 0) { sh_ovf = 0; gaddr[kSlots / 8] = kSkip; }
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
     const uint32_t B = 1u << blk_log2;
     const uint32_t bits = 2 * len;
@@ -811,6 +835,12 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         if (tid < 4) encode(q1, c1, b1);
     }
 
+    // A bucket's next block is reserved AHEAD of the tile that opens it (phase A, when the open block has less than
+    // kAhead slots left -- more than a tile ever asked for in 10^4 tiles): a returning atomic on a cursor takes 1-3 us
+    // under load, a third of a tile, and in phase C every wave has a lane that waits for one.
+    constexpr uint32_t kAhead = 40;
+    unsigned long long resv = 0;
+    bool has_resv = false;
 #if defined(GOSS_E1_STAGGER)
     // (timing experiment: the workgroups that share a CU start a third of a tile apart)
     for (uint32_t z = 0; z < (blockIdx.x >> 8) * GOSS_E1_STAGGER; ++z) __builtin_amdgcn_s_sleep(100);
@@ -877,12 +907,21 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
         }
 
+#if !defined(GOSS_E1_SYNC_BLOCKS)
+        if (!has_resv && ((B - ((uint32_t)wpos & (B - 1))) & (B - 1)) < kAhead)
+        {
+            resv = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+            has_resv = true;
+        }
+#endif
+
         // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
         // Written without branches around the LDS operations: a window that is not valid still gets a
         // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
         // of a thread are issued back to back and waited for once, not one round trip after the other.
         Key1 kreg[NK];
         uint32_t rk[NK];
+        uint32_t bin4[NK];                        // byte offset of the key's counter in dh (and of its entry in tab)
         uint32_t vm;
         {
             uint32_t m;
@@ -936,110 +975,178 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
             vm = m;
             nvalid += __popc(m);
-            // forward key f and reverse complement r of window 0, then one base rolled in per window
-            uint64_t f = rev64(blo & kmask) >> (64 - bits);
-            uint64_t r = (~blo) & kmask;
-            const uint32_t top = bits - 2;
-            const uint32_t spare = 256u + (tid & 31u);          // counters nobody reads
-            uint32_t bin[NK];
-#pragma unroll
-            for (int i = 0; i < P; ++i)
+            // the key(s) of window i from its forward form f and its reverse complement r
+            auto emit = [&](int i, uint64_t f, uint64_t r) {
+                const Key1 fk{f}, rck{r};
+                if (MODE == 0)
+                    // odd length: the central base decides (its low bit differs between the strands)
+                    kreg[i] = REPK == 2 ? canonical(fk, rck) : REPK == 1 ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
+                else { kreg[i * 2] = fk; kreg[i * 2 + 1] = rck; }
+            };
+            // The bases lie in (bhi:blo) lowest first, two bits each: the reverse complement of window i is the field
+            // [2 i, 2 i + bits) of the complemented buffer, its forward form the base-4 reverse of the same field.
+            if constexpr (REC)
             {
-                if constexpr (REC)
+#pragma unroll
+                for (int i = 0; i < P; ++i)
                 {
                     // window r_off of record r_at, cut out of the record's bases; then on to the next window, which
                     // may be the first of the next record
                     const uint32_t s2 = 2 * r_off;
                     const uint64_t x = (s2 ? ((blo >> s2) | (bhi << (64 - s2))) : blo) & kmask;
-                    f = rev64(x) >> (64 - bits);
-                    r = (~x) & kmask;
+                    emit(i, rev64(x) >> (64 - bits), (~x) & kmask);
                     if (i + 1 < P)
                     {
                         ++r_off;
                         if (r_off >= r_nw && r_at < 511) { ++r_at; r_off = 0; load_rec(); }
                     }
                 }
-                else if (i)
+            }
+            else if constexpr (FAST)
+            {
+                // 32-bit halves, constant shifts: the forward form rolled (the bases it takes in, pre-shifted once:
+                // base i + len - 1 at bits 2 i of nx), the reverse complement by funnel shifts of the complemented words
+                const uint32_t kmhi = (uint32_t)(kmask >> 32);
+                const uint32_t cw0 = ~(uint32_t)blo, cw1 = ~(uint32_t)(blo >> 32), cw2 = ~(uint32_t)bhi;
+                const uint32_t pn = bits - 2;                                  // 30 .. 60
+                const uint32_t nx = (uint32_t)((blo >> pn) | (bhi << (64 - pn)));
+                const uint32_t mid = (uint32_t)(blo >> (len - 1));              // bit 2 i: the low bit of window i's central base (odd len)
+                const uint64_t f0 = rev64(blo & kmask) >> (64 - bits);
+                uint32_t flo = (uint32_t)f0, fhi = (uint32_t)(f0 >> 32);
+#pragma unroll
+                for (int i = 0; i < P; ++i)
                 {
-                    const uint32_t pos = 2 * (i + len - 1);
-                    const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
-                    f = ((f << 2) | nb) & kmask;
-                    r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
-                }
-                const bool ok = (m >> i) & 1u;
-                const Key1 fk{f}, rck{r};
-                if (MODE == 0)
-                {
-                    // odd length: the central base decides (its low bit differs between the strands)
-                    const Key1 k = REPK == 2 ? canonical(fk, rck) : REPK == 1 ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
-                    kreg[i] = k;
-                    bin[i] = ok ? ((uint32_t)(k.lo >> shift) & 0xFFu) : spare;
-                }
-                else
-                {
-                    kreg[i * 2] = fk;
-                    bin[i * 2] = ok ? ((uint32_t)(fk.lo >> shift) & 0xFFu) : spare;
-                    kreg[i * 2 + 1] = rck;
-                    bin[i * 2 + 1] = ok ? ((uint32_t)(rck.lo >> shift) & 0xFFu) : spare;
+                    if (i)
+                    {
+                        const uint32_t nb = (nx >> (2 * i)) & 3u;
+                        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30) & kmhi;
+                        flo = (flo << 2) | nb;
+                    }
+                    const uint32_t rlo = i ? __builtin_amdgcn_alignbit(cw1, cw0, 2 * i) : cw0;
+                    const uint32_t rhi = (i ? __builtin_amdgcn_alignbit(cw2, cw1, 2 * i) : cw1) & kmhi;
+                    if (MODE == 0 && REPK == 1)
+                    {
+                        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mid, 2 * i, 1);        // all ones: the reverse complement
+                        kreg[i].lo = ((uint64_t)bit_select(sel, rhi, fhi) << 32) | bit_select(sel, rlo, flo);
+                    }
+                    else emit(i, ((uint64_t)fhi << 32) | flo, ((uint64_t)rhi << 32) | rlo);
                 }
             }
+            else
+            {
+                // forward key f and reverse complement r of window 0, then one base rolled in per window
+                uint64_t f = rev64(blo & kmask) >> (64 - bits);
+                uint64_t r = (~blo) & kmask;
+                const uint32_t top = bits - 2;
 #pragma unroll
-            for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
+                for (int i = 0; i < P; ++i)
+                {
+                    if (i)
+                    {
+                        const uint32_t pos = 2 * (i + len - 1);
+                        const uint32_t nb = (uint32_t)(pos < 64 ? (blo >> pos) : (bhi >> (pos - 64))) & 3u;
+                        f = ((f << 2) | nb) & kmask;
+                        r = (r >> 2) | ((uint64_t)(nb ^ 3u) << top);
+                    }
+                    emit(i, f, r);
+                }
+            }
+            // the counters: the key's digit, or a spare one (window not valid)
+            const uint32_t badm = ~m;
+            const uint32_t spare4 = (256u + (tid & 31u)) << 2;
+#pragma unroll
+            for (int j = 0; j < NK; ++j)
+            {
+                const uint32_t nok = (uint32_t)__builtin_amdgcn_sbfe((int32_t)badm, j / S, 1);
+                const uint32_t d4 = FAST ? ((uint32_t)(kreg[j].lo >> 32) >> (shift - 34)) & 0x3FCu
+                                         : ((uint32_t)(kreg[j].lo >> shift) & 0xFFu) << 2;
+                bin4[j] = bit_select(nok, spare4, d4);
+            }
+#pragma unroll
+            for (int j = 0; j < NK; ++j) rk[j] = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(dh) + bin4[j]), 1u);
         }
         __syncthreads();
 
-        // ---- phase C: bookkeeping of bucket tid: what is stored now, where, what is carried out ----
-        uint32_t total_store;
+        // ---- phase C: bookkeeping of bucket tid: its new keys' place in LDS, where its granules go, what is carried ----
+        // A bucket's new keys lie in one piece that starts on a granule, by rank.  Order inside a bucket does not
+        // matter, so the carried keys do not go in front: the bucket's last, partial granule (b new keys) is TOPPED UP
+        // with carried keys when there are enough of them (b + carried >= 8: the rest stay in the registers where
+        // they are); otherwise it is not stored and its b keys join the carried ones after the scatter.
+        uint32_t total_slots, part_at, absorb;
         {
             const uint32_t cnt = dh[tid];
-            const uint32_t tot = ccnt + cnt;           // the bucket's stream: carried keys, then the new ones by rank
-            const uint32_t fl = tot & ~7u, rem = tot & 7u;
-            uint32_t sums;
-            const uint32_t pre = block_excl_scan_open<uint32_t>(fl | (rem << 16), sh_scan, &sums);          // (the barrier behind phase C closes it)
-            total_store = sums & 0xFFFFu;
-            const uint32_t f_at = pre & 0xFFFFu, l_at = total_store + (pre >> 16);
+            const uint32_t a8 = cnt & ~7u, b = cnt & 7u;
+            const uint32_t s_at = block_excl_scan_open_u32((cnt + 7u) & ~7u, sh_scan, &total_slots);               // (the barrier behind phase C closes it)
             dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
+            if (tid < 32) dh[256 + tid] = 0;
+            const bool top = b + ccnt >= 8u;
+            const uint32_t take = top ? 8u - b : 0u;
+            const uint32_t fl = a8 + (top ? 8u : 0u);  // keys stored now
+            absorb = top ? 0u : b;
+            part_at = s_at + a8;
             const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
             uint32_t thr = fl;
-            uint2 tb = make_uint2((uint32_t)(wpos >> 3), 0u);
+            const uint32_t tbx = (uint32_t)(wpos >> 3);
+            uint32_t tby = 0;
             if (fl > room)
             {
                 thr = room;
                 const uint32_t need = fl - room;
-                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
-                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                unsigned long long at, want;
+                if (has_resv && need <= B) { at = resv; want = B; has_resv = false; }          // (reserved in phase A)
+                else
+                {
+                    want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                    at = atomicAdd(&pc->cursors[tid * kCursorStride], want);
+                }
                 // a region that is too small: nothing of this tile is stored, the host redoes the chunk
                 if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
-                tb.y = (uint32_t)((my_start + at) >> 3);
+                tby = (uint32_t)((my_start + at) >> 3);
                 wpos = my_start + at + need;
             }
             else wpos += fl;
-            t_base[tid] = tb;
-            t_lay[tid] = make_uint2(f_at | (fl << 16), l_at | (ccnt << 13) | (thr << 16));
-            // the keys carried in go first (phase A's arrays in `sorted` are dead: every thread is past phase B)
+            tab[tid] = s_at << 3;
+            // where the bucket's granules go: the rest of the open block, then the new block(s); a partial one stays
+            {
+                const uint32_t g0 = s_at >> 3, ng = fl >> 3, t8 = thr >> 3;
+                const uint32_t yb = tby - t8;
+                // (four whole granules or more are rare: 16 new keys per bucket and tile on average)
 #pragma unroll
-            for (int j = 0; j < kCarry; ++j)
-                sorted[(uint32_t)j < ccnt ? ((uint32_t)j < fl ? f_at + j : l_at + j) : kSpare + (tid & 63u)] = kc[j];
-            ccnt = rem;
+                for (uint32_t g = 0; g < 4; ++g)
+                    if (g < ng) gaddr[g0 + g] = (g < t8 ? tbx : yb) + g;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (uint32_t g = 4; g < ng; ++g) gaddr[g0 + g] = (g < t8 ? tbx : yb) + g;
+                if (absorb) gaddr[g0 + ng] = kSkip;
+            }
+            // topping up: the last `take` carried keys behind the b new ones (phase A's arrays in `sorted` are dead:
+            // every thread is past phase B)
+            if (top)
+            {
+                const uint32_t from = ccnt - take;
+#pragma unroll
+                for (int j = 0; j < kCarry; ++j)
+                    sorted[((uint32_t)j >= from && (uint32_t)j < ccnt ? part_at + b - from : kGarb + (tid & 63u)) + j] = kc[j];
+                ccnt = from;
+            }
         }
         __syncthreads();
-        // new keys to their place: position ccnt_in + rank of the bucket's stream (the table reads of
+        // new keys to their place: the stream's first new slot + rank (the table reads of
         // all sixteen keys first, then the writes: no round trip per key)
         {
-            uint2 tl[NK];
+            uint32_t tb[NK];
 #pragma unroll
-            for (int i = 0; i < NK; ++i) tl[i] = t_lay[(uint32_t)(kreg[i].lo >> shift) & 0xFFu];
+            for (int i = 0; i < NK; ++i) tb[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + bin4[i]);
 #pragma unroll
             for (int i = 0; i < NK; ++i)
             {
-                const bool ok = (vm >> (i / S)) & 1u;
-                const Key1 k = kreg[i];
-                const uint32_t p = ((tl[i].y >> 13) & 7u) + rk[i];
-                const uint32_t fl = tl[i].x >> 16;
-                const uint32_t at = p < fl ? (tl[i].x & 0xFFFFu) + p : (tl[i].y & 0x1FFFu) + (p - fl);
-                sorted[ok ? at : kSpare + (tid & 63u)] = k;
-                if (NH > 0) atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], ok ? 1u : 0u);
-                if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], ok ? 1u : 0u);
+                *reinterpret_cast<Key1*>(reinterpret_cast<char*>(sorted) + (tb[i] + (rk[i] << 3))) = kreg[i];
+                if (NH > 0)
+                {
+                    const bool ok = (vm >> (i / S)) & 1u;
+                    const Key1 k = kreg[i];
+                    atomicAdd(&lh[(uint32_t)(k.lo >> (shift + 8)) & 0xFFu], ok ? 1u : 0u);
+                    if (NH > 1) atomicAdd(&lh[256u + ((uint32_t)(key_shr64(k, shift + 16)) & 0xFFu)], ok ? 1u : 0u);
+                }
             }
         }
         if (more && !REC)
@@ -1056,60 +1163,64 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // (two keys per lane and store: the store path takes 16 bytes per lane as quickly as 8 --
         // experiments/storegran: 4.5 against 4.1 TB/s for this pattern alone -- and the loop has half the instructions)
         if (sh_ovf == 0)
-            for (uint32_t q0 = tid; 2 * q0 < total_store; q0 += 4 * kTB)
+        {
+            Key1* const lane_out = out + ((2 * tid) & 7u);
+            for (uint32_t base = 0; base < total_slots; base += kStep)
             {
-                // four pairs at a time: their LDS reads, then their table reads, then their stores
-                uint4 kk[4];
-                uint2 tl[4], tb[4];
+                // five pairs at a time: their LDS reads, then their stores
+                uint4 kk[kPairs];
+                uint32_t ga[kPairs];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kk[u] = *reinterpret_cast<const uint4*>(&sorted[min(2 * (q0 + u * kTB), kSpare)]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kPairs; ++u)
                 {
-                    const uint64_t lo = (uint64_t)kk[u].x | ((uint64_t)kk[u].y << 32);
-                    const uint32_t d = (uint32_t)(lo >> shift) & 0xFFu;
-                    tl[u] = t_lay[d]; tb[u] = t_base[d];
+                    const uint32_t i = min(base + 2 * (tid + u * kTB), kSlots);        // (beyond the layout: the entry that is always kSkip)
+                    kk[u] = *reinterpret_cast<const uint4*>(&sorted[i]);
+                    ga[u] = gaddr[i >> 3];
                 }
+                // (all ten reads are issued here, not each under the test of its store)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kPairs; ++u) asm volatile("" : "+v"(kk[u].x), "+v"(kk[u].y), "+v"(kk[u].z), "+v"(kk[u].w), "+v"(ga[u]));
+#pragma unroll
+                for (int u = 0; u < kPairs; ++u)
                 {
-                    const uint32_t i = 2 * (q0 + u * kTB);
-                    if (i < total_store)
-                    {
-                        const uint32_t p = i - (tl[u].x & 0xFFFFu);
-                        const uint32_t thr = tl[u].y >> 16;
-                        uint64_t o = p < thr ? ((uint64_t)tb[u].x << 3) + p : ((uint64_t)tb[u].y << 3) + (p - thr);
 #if defined(GOSS_E1_EXP) && GOSS_E1_EXP == 1
-                        // (timing experiment: everything but the stores themselves)
-                        asm volatile("" ::"v"(kk[u].x), "v"(kk[u].y), "v"(kk[u].z), "v"(kk[u].w), "v"((uint32_t)o), "v"((uint32_t)(o >> 32)));
+                    // (timing experiment: everything but the stores themselves)
+                    asm volatile("" ::"v"(kk[u].x), "v"(kk[u].y), "v"(kk[u].z), "v"(kk[u].w), "v"(ga[u]));
 #else
-#if defined(GOSS_E1_EXP) && GOSS_E1_EXP == 2
-                        o &= (1ULL << 21) - 2ULL;          // (timing experiment: the same stores into a 16 MB window)
+                    // (entries between this tile's layout and kSlots / 8 are stale)
+                    if (ga[u] != kSkip && base + 2 * (tid + u * kTB) < total_slots) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = kk[u];
 #endif
-                        *reinterpret_cast<uint4*>(&out[o]) = kk[u];
-#endif
-                    }
                 }
             }
-        // what bucket tid carries out, back into registers
+        }
+        // a partial granule that was not topped up: its keys join the carried ones
+        if (absorb)
         {
-            const uint32_t l_at = t_lay[tid].y & 0x1FFFu;
 #pragma unroll
-            for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];       // (those beyond ccnt are never used)
+            for (int j = 0; j < kCarry; ++j)
+            {
+                const bool in = (uint32_t)j >= ccnt && (uint32_t)j < ccnt + absorb;
+                const Key1 x = sorted[in ? part_at + j - ccnt : kGarb];
+                kc[j] = in ? x : kc[j];
+            }
+            ccnt += absorb;
         }
         __syncthreads();
     }
 
-    // ---- the end: carried keys and the unused tail of every open block ---------------------------
+    // ---- the end: carried keys, the unused tail of every open block, the block reserved and not opened ----------
     if (sh_ovf == 0)
     {
+        bool spare_blk = has_resv;
         if (ccnt)
         {
             // one more granule: the carried keys, padding behind them
             const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
             if (room == 0)
             {
-                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                unsigned long long at;
+                if (has_resv) { at = resv; spare_blk = false; }
+                else at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
                 if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
                 else wpos = my_start + at;
             }
@@ -1119,16 +1230,26 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             wpos += ccnt;
         }
         const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
-        // pad [wpos, end of block) of every bucket: all threads share the work through LDS
+        // a reserved block nobody opened counts as handed out: pads, or (beyond the region) the chunk is redone
+        uint32_t blk_n = 0;
+        if (spare_blk)
+        {
+            if (resv + B > my_cap) atomicOr(&pc->overflow, 1ULL);
+            else blk_n = B;
+        }
+        // pad [wpos, end of block) and the spare block of every bucket: all threads share the work through LDS
         __syncthreads();
-        t_base[tid].x = tail;
+        tab[tid] = tail;
+        dh[tid] = blk_n;
         reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        reinterpret_cast<uint64_t*>(sorted)[256 + tid] = my_start + resv;
         __syncthreads();
         for (uint32_t d = 0; d < 256; ++d)
         {
-            const uint32_t n = t_base[d].x;
-            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            const uint32_t n = tab[d], n2 = dh[d];
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d], from2 = reinterpret_cast<const uint64_t*>(sorted)[256 + d];
             for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{kPadKey};
+            for (uint32_t j = tid; j < n2; j += kTB) out[from2 + j] = Key1{kPadKey};
         }
     }
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }
