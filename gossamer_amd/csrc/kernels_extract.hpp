@@ -724,7 +724,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
     constexpr int S = MODE == 1 ? 2 : 1;
     constexpr int P = GOSS_E1_NK / S;
+#if !defined(GOSS_E1_EXPERIMENT)
     static_assert(!REC || GOSS_E1_NK == 16, "a record of 16 windows holds at most one thread's first window");
+#endif
     constexpr int T = kTB * P;                   // window starts per tile
     constexpr int NVEC = T / 16 + 4;
     constexpr int NK = P * S;                    // keys per thread
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     // spare counters, 8 threads each: at most 128 per counter and tile) instead of under a branch, whose exec-mask
     // bookkeeping costs scalar issue slots; reads past the live part land there too
     constexpr uint32_t kGarb = kSlots;
-    constexpr int kPairs = 5;                                        // pairs of keys per lane and round of the store loop
+    constexpr int kPairs = GOSS_E1_NK >= 16 ? 5 : 3;                 // pairs of keys per lane and round of the store loop
     constexpr uint32_t kStep = 2 * kPairs * kTB;                     // slots per round: two rounds cover the 4 096 + 3.5 x 256 slots an average tile takes
     constexpr uint32_t kNG = kSlots / 8 + 4;                         // granules of the layout; entry kSlots / 8 is always kSkip
     constexpr uint32_t kSkip = 0xFFFFFFFFu;
