@@ -479,13 +479,14 @@ class Context:
         self._L.goss_gpu_emit_part.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         self._check(self._L.goss_gpu_emit_part(self._h, first_index, total, estimate))
 
-    def emit_assemble(self, high_ptr, high_bytes, total, estimate=0, big=b"", hist=b""):
-        """Distributed emission, the files that need all ranges (goss_gpu_emit_assemble): high_ptr =
-        device address of the concatenated high parts, big / hist = the concatenated records (bytes)."""
-        self._L.goss_gpu_emit_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64,
+    def emit_assemble(self, spans_ptr, span_bytes, total, estimate=0, big=b"", hist=b""):
+        """Distributed emission, the files that need all ranges (goss_gpu_emit_assemble): spans_ptr =
+        device address of the ranges' ".part.span" files back to back (span_bytes in all), big / hist = the
+        concatenated records (bytes)."""
+        self._L.goss_gpu_emit_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                    C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
         _torch_ready()
-        self._check(self._L.goss_gpu_emit_assemble(self._h, C.c_void_p(high_ptr), high_bytes, total, estimate,
+        self._check(self._L.goss_gpu_emit_assemble(self._h, C.c_void_p(spans_ptr), span_bytes, total, estimate,
                                                    big, len(big) // 16, hist, len(hist) // 16))
 
     def file_list(self):

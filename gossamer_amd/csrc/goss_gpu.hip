@@ -1611,8 +1611,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     while (blk_log2 < 8 && (double)fgrid * 256.0 * (double)(2u << blk_log2) <= pad_budget) ++blk_log2;
     if (c->blk_log2_max) blk_log2 = std::min(blk_log2, std::max(c->blk_log2_max, kOne ? 3u : 2u));
     const uint64_t B = 1ULL << blk_log2;
-    // (one-word keys: a workgroup also holds a reserved block per bucket that it may never open)
-    const double blk_extra = (double)fgrid * (double)B * (kOne ? 2.0 : 1.0);
+    // (a workgroup also holds a reserved block per bucket that it may never open)
+    const double blk_extra = (double)fgrid * (double)B * 2.0;
     GapTable gt{};
     double base[256], base_sum = 0;
     for (int d = 0; d < 256; ++d)
@@ -2540,16 +2540,17 @@ void emit_sparse_header(goss_gpu_ctx* c, uint32_t D, uint64_t Nend_lo, uint64_t 
 // The index part of a SparseArray: high-bits bitmap, -d0 (zeros), -d1 (ones), from keys whose high part
 // is key >> D -- or from the high parts themselves with D = 0 (distributed emission).
 template <class K>
-void emit_sparse_index(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, uint64_t nd, const std::string& base)
+void emit_sparse_index(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, uint64_t nd, const std::string& base, uint64_t* built = nullptr)
 {
     const uint64_t nwords = (nd + m + 3) / 64 + 1;
-    uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
-    if (m >= (1u << 16) && !c->ef_by_words)
+    uint64_t* words = built ? built : (uint64_t*)c->arena.perm(nwords * 8);
+    if (built) {}                                // (assembled from the ranges' spans: emit_assemble)
+    else if (m >= (1u << 16) && !c->ef_by_words)
     {
         // from the keys' side: one coalesced pass over the keys (GOSS_GPU_EF_BY_WORDS=1: the per-word binary search)
         HIP_TRY(hipMemsetAsync(words, 0, nwords * 8, c->stream));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_keys_kernel<K>), dim3(grid_for(m, kEfChunk)), dim3(kTB), 0, c->stream,
-                           keys, m, D, (uint64_t)0, nwords, (unsigned long long*)words);
+                           keys, m, D, (uint64_t)0, nwords, (unsigned long long*)words, (uint64_t)0);
     }
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_kernel<K>), dim3(grid_for(nwords, 256)), dim3(256), 0, c->stream,
@@ -2758,17 +2759,32 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
     HIP_TRY(hipMemsetAsync(c->d_flags + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_check_kernel<K>), dim3(1), dim3(64), 0, c->stream, keys, m, D, c->d_flags + 1);
     emit_sparse_low_bits<K>(c, keys, m, D, base);
-    // high parts for the assembling rank: u32 when every one of them fits (nd = N >> D bounds them)
-    const bool narrow = nd < (1ULL << 32);
+    // This range's SPAN of the high-bits bitmap for the assembling rank: the words its ones fall into (one i of the
+    // whole array sits at bit (key_i >> D) + i), built from the range's own keys -- about 2.4 bits per key on the wire
+    // where the first form of this path sent key >> D of every key (4 or 8 bytes).  Layout: {first word, words}, the words.
     {
-        const uint64_t bytes = m * (narrow ? 4 : 8);
-        uint8_t* hv = (uint8_t*)c->arena.perm(std::max<uint64_t>(bytes, 8));
+        const uint64_t nwords = (nd + total + 3) / 64 + 1;
+        uint64_t w0 = 0, nspan = 0;
         if (m)
         {
-            if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_part_kernel<K, uint32_t>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream, keys, m, D, (uint32_t*)hv);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_part_kernel<K, uint64_t>), dim3(grid_for(m, 256)), dim3(256), 0, c->stream, keys, m, D, (uint64_t*)hv);
+            K ends[2];
+            HIP_TRY(hipMemcpyAsync(&ends[0], keys, sizeof(K), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(&ends[1], keys + (m - 1), sizeof(K), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint64_t h0 = (D >= 128 ? 0 : key_shr64(ends[0], D)) + first_index;
+            const uint64_t h1 = (D >= 128 ? 0 : key_shr64(ends[1], D)) + first_index + (m - 1);
+            w0 = h0 >> 6;
+            nspan = std::min((h1 >> 6) + 1, nwords) - w0;
         }
-        OutFile f; f.suffix = narrow ? ".part.high32" : ".part.high64"; f.size = bytes; f.dev = hv;
+        uint64_t* span = (uint64_t*)c->arena.perm((2 + nspan) * 8);
+        const uint64_t hdr[2] = {w0, nspan};
+        HIP_TRY(hipMemsetAsync(span + 2, 0, nspan * 8, c->stream));
+        HIP_TRY(hipMemcpyAsync(span, hdr, 16, hipMemcpyHostToDevice, c->stream));
+        if (m)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_keys_kernel<K>), dim3(grid_for(m, kEfChunk)), dim3(kTB), 0, c->stream,
+                               keys, m, D, first_index, nwords, (unsigned long long*)(span + 2), w0);
+        HIP_TRY(hipStreamSynchronize(c->stream));            // (hdr goes out of scope)
+        OutFile f; f.suffix = ".part.span"; f.size = (2 + nspan) * 8; f.dev = (const uint8_t*)span;
         c->files.push_back(std::move(f));
     }
     if (c->mode == GOSS_MODE_GRAPH)
@@ -2843,7 +2859,7 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
 }
 
 // Distributed emission, the assembling side (goss_gpu_emit_assemble): everything that needs all ranges.
-void emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uint64_t total, uint64_t estimate,
+void emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_bytes, uint64_t total, uint64_t estimate,
                    const BigCount* big, uint64_t nbig, const uint64_t* hist, uint64_t nhist)
 {
     PhaseTimer t(c, GOSS_T_EMIT, total);
@@ -2851,19 +2867,38 @@ void emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uin
     object_universe(c, &nlo, &nhi, &base);
     const uint32_t D = (uint32_t)sparse_d(nlo, nhi, estimate);
     const uint64_t nd = sparse_nd(D, nlo, nhi);
-    // the high parts as one-word keys with D = 0: position of one i is (key_i >> 0) + i, as in a whole build
-    uint64_t mark = c->arena.mark();
-    const Key1* hk = (const Key1*)d_high;
-    if (high_bytes == 4 && total)
+    // the bitmap: the ranges' spans ORed together (neighbours share their boundary words)
+    const uint64_t nwords = (nd + total + 3) / 64 + 1;
+    uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
+    HIP_TRY(hipMemsetAsync(words, 0, nwords * 8, c->stream));
+    for (uint64_t at = 0; at + 16 <= span_bytes;)
     {
-        Key1* wide = (Key1*)c->arena.temp(total * 8);
-        hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, (const uint32_t*)d_high, total, wide);
-        hk = wide;
+        uint64_t hdr[2];
+        HIP_TRY(hipMemcpyAsync(hdr, (const uint8_t*)d_spans + at, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hdr[0] + hdr[1] > nwords || at + 16 + hdr[1] * 8 > span_bytes)
+            throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a span does not fit the bitmap"};
+        if (hdr[1])
+            hipLaunchKernelGGL(ef_or_span_kernel, dim3(grid_for(hdr[1], kTB)), dim3(kTB), 0, c->stream, (unsigned long long*)words + hdr[0],
+                               (const unsigned long long*)((const uint8_t*)d_spans + at + 16), hdr[1]);
+        at += 16 + hdr[1] * 8;
     }
+    // the high parts read back from the bitmap, as one-word keys with D = 0 (position of one i is (key_i >> 0) + i, as
+    // in a whole build): what the DenseSelect builders work from
+    uint64_t mark = c->arena.mark();
+    Key1* hkw = (Key1*)c->arena.temp(std::max<uint64_t>(total, 1) * 8);
+    {
+        uint64_t* ones = (uint64_t*)c->arena.temp(nwords * 8);
+        hipLaunchKernelGGL(ef_word_ones_kernel, dim3(grid_for(nwords, kTB)), dim3(kTB), 0, c->stream, (const unsigned long long*)words, nwords, ones);
+        exclusive_scan_u64(c, ones, nwords);
+        hipLaunchKernelGGL(ef_high_from_bits_kernel, dim3(grid_for(nwords, kTB)), dim3(kTB), 0, c->stream, (const unsigned long long*)words, nwords,
+                           (const uint64_t*)ones, hkw, total);
+    }
+    const Key1* hk = hkw;
     if (c->mode == GOSS_MODE_KMER_SET)
     {
         emit_sparse_header(c, D, nlo, nhi, total, base);
-        emit_sparse_index<Key1>(c, hk, total, 0, nd, base);
+        emit_sparse_index<Key1>(c, hk, total, 0, nd, base, words);
         uint64_t hdr[3] = {2011101701ULL, c->k, total};
         add_host_file(c, ".header", hdr, sizeof hdr);
     }
@@ -2872,7 +2907,7 @@ void emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uin
         uint64_t hdr[3] = {2011101014ULL, c->k, 0};
         add_host_file(c, ".header", hdr, sizeof hdr);
         emit_sparse_header(c, D, nlo, nhi, total, base);
-        emit_sparse_index<Key1>(c, hk, total, 0, nd, base);
+        emit_sparse_index<Key1>(c, hk, total, 0, nd, base, words);
         // VariableByteArray continuation arrays from the entries with count > 255 (VariableByteArray.hh:76-118):
         // ord1p marks their global positions, ord1 holds bits 8..15; ord2p marks, among those, the ones with
         // count > 65535 by their index in ord1, ord2 holds bits 16..31
@@ -3565,10 +3600,10 @@ int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, ui
     return rc;
 }
 
-int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_bytes, uint64_t total, uint64_t estimate,
+int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_bytes, uint64_t total, uint64_t estimate,
                            const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist)
 {
-    if (!c || (high_bytes != 4 && high_bytes != 8) || (total && !d_high) || (nbig && !h_big) || (nhist && !h_hist))
+    if (!c || (span_bytes & 7u) || (span_bytes && !d_spans) || (total && !span_bytes) || (nbig && !h_big) || (nhist && !h_hist))
         return GOSS_ERR_INVALID_ARG;
     if (!c->finished && (!c->runs.empty() || c->stage_fill))
     {
@@ -3581,7 +3616,7 @@ int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_high, uint32_t high_by
             const uint64_t need = total * 12 + (256ULL << 20);
             if (c->arena.avail() < need) grow_arena(c, need);
         }
-        emit_assemble(c, d_high, high_bytes, total, estimate ? estimate : total, (const BigCount*)h_big, nbig, h_hist, nhist);
+        emit_assemble(c, d_spans, span_bytes, total, estimate ? estimate : total, (const BigCount*)h_big, nbig, h_hist, nhist);
         HIP_TRY(hipStreamSynchronize(c->stream));
     });
 }
@@ -3774,7 +3809,6 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
     int rc = guarded(c0, [&]() {
         std::vector<uint8_t> big;
         std::vector<uint64_t> hist;
-        uint32_t high_bytes = 0;
         std::vector<std::pair<const OutFile*, goss_gpu_ctx*>> highs;
         uint64_t high_total = 0;
         for (uint32_t i = 0; i < n; ++i)
@@ -3783,11 +3817,8 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
             HIP_TRY(hipSetDevice(c->device));
             for (const OutFile& f : c->files)
             {
-                if (f.suffix == ".part.high32" || f.suffix == ".part.high64")
+                if (f.suffix == ".part.span")
                 {
-                    const uint32_t hb = f.suffix == ".part.high32" ? 4u : 8u;
-                    if (high_bytes && hb != high_bytes) throw StatusError{GOSS_ERR_STATE, "group emit: parts of different width"};
-                    high_bytes = hb;
                     highs.push_back({&f, c});
                     high_total += f.size;
                 }
@@ -3808,7 +3839,7 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
                 }
             }
         }
-        if (highs.size() != n) throw StatusError{GOSS_ERR_STATE, "group emit: a context without its high part"};
+        if (highs.size() != n) throw StatusError{GOSS_ERR_STATE, "group emit: a context without its span of the bitmap"};
         HIP_TRY(hipSetDevice(c0->device));
         if (high_total)
         {
@@ -3822,7 +3853,7 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
             }
             HIP_TRY(hipStreamSynchronize(c0->stream));
         }
-        const int arc = goss_gpu_emit_assemble(c0, d_high, high_bytes ? high_bytes : 4u, total, estimate, big.empty() ? nullptr : big.data(),
+        const int arc = goss_gpu_emit_assemble(c0, d_high, high_total, total, estimate, big.empty() ? nullptr : big.data(),
                                                big.size() / 16, hist.empty() ? nullptr : hist.data(), hist.size() / 2);
         if (arc != GOSS_OK) throw StatusError{arc, c0->last_error};
     });

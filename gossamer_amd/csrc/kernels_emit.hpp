@@ -101,8 +101,10 @@ __global__ void ef_high_bits_kernel(const K* __restrict__ keys, uint64_t m, uint
 constexpr int kEfChunk = 2048, kEfWords = 1024;          // keys per workgroup; words of its LDS window (64 K bit positions)
 template <class K>
 __global__ __launch_bounds__(kTB) void ef_high_bits_keys_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, uint64_t first_index,
-                                                                 uint64_t nwords, unsigned long long* __restrict__ words)
+                                                                 uint64_t nwords, unsigned long long* __restrict__ words_at, uint64_t wbase)
 {
+    // (a range's span of the bitmap: words_at[0] is word `wbase` of the whole; nwords bounds the whole's word numbers)
+    unsigned long long* const words = words_at - wbase;
     __shared__ unsigned long long win[kEfWords];
     const uint64_t i0 = (uint64_t)blockIdx.x * kEfChunk;
     if (i0 >= m) return;
@@ -131,6 +133,36 @@ __global__ __launch_bounds__(kTB) void ef_high_bits_keys_kernel(const K* __restr
         if (w0 + j >= nwords) continue;
         if (j == 0 || j == last) { if (v) atomicOr(&words[w0 + j], v); }
         else words[w0 + j] = v;
+    }
+}
+
+// Distributed emission: a range's span of the bitmap ORed into the whole (spans of neighbouring ranges share at most
+// their boundary words; the launches follow one another on one stream).
+__global__ __launch_bounds__(kTB) void ef_or_span_kernel(unsigned long long* __restrict__ words, const unsigned long long* __restrict__ span, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) { const unsigned long long v = span[i]; if (v) words[i] |= v; }
+}
+// ... ones per word of the assembled bitmap (scanned by the host's exclusive scan), and the high parts read back from
+// it: one i sits at position p, so key_i >> D = p - i -- what the DenseSelect builders take as their keys (D = 0).
+__global__ __launch_bounds__(kTB) void ef_word_ones_kernel(const unsigned long long* __restrict__ words, uint64_t nwords, uint64_t* __restrict__ ones)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (w < nwords) ones[w] = (uint64_t)__popcll(words[w]);
+}
+__global__ __launch_bounds__(kTB) void ef_high_from_bits_kernel(const unsigned long long* __restrict__ words, uint64_t nwords,
+                                                                 const uint64_t* __restrict__ before, Key1* __restrict__ hk, uint64_t total)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (w >= nwords) return;
+    unsigned long long v = words[w];
+    uint64_t i = before[w];
+    while (v && i < total)
+    {
+        const uint32_t b = (uint32_t)__builtin_ctzll(v);
+        hk[i].lo = w * 64 + b - i;
+        v &= v - 1;
+        ++i;
     }
 }
 

@@ -1337,6 +1337,10 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
     const uint32_t B = 1u << blk_log2;
     const uint32_t bits = 2 * len;                                       // 64..126
+    // a bucket's next block is reserved ahead of the tile that opens it (extract1_part_kernel)
+    constexpr uint32_t kAhead = 40;
+    unsigned long long resv = 0;
+    bool has_resv = false;
     const uint64_t mask_hi = bits == 128 ? ~0ULL : ((1ULL << (bits - 64)) - 1);
     const uint64_t lmask = (1ULL << len) - 1;
     unsigned long long nvalid = 0;
@@ -1481,6 +1485,13 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         }
 
         // ---- windows out of registers, keys, rank inside their digit (no branch around the LDS atomics) ----
+#if !defined(GOSS_E1_SYNC_BLOCKS)
+        if (!has_resv && ((B - ((uint32_t)wpos & (B - 1))) & (B - 1)) < kAhead)
+        {
+            resv = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+            has_resv = true;
+        }
+#endif
         Key2 kreg[NK];
         uint32_t rk[NK];
         uint32_t vm = 0;
@@ -1627,8 +1638,13 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             {
                 thr = room;
                 const uint32_t need = fl - room;
-                const uint64_t want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
-                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)want);
+                unsigned long long at, want;
+                if (has_resv && need <= B) { at = resv; want = B; has_resv = false; }          // (reserved before the ranking)
+                else
+                {
+                    want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                    at = atomicAdd(&pc->cursors[tid * kCursorStride], want);
+                }
                 if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
                 tb.y = (uint32_t)((my_start + at) >> 2);
                 wpos = my_start + at + need;
@@ -1706,12 +1722,15 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     // ---- the end: carried keys and the unused tail of every open block ----
     if (sh_ovf == 0)
     {
+        bool spare_blk = has_resv;
         if (ccnt)
         {
             const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
             if (room == 0)
             {
-                const unsigned long long at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
+                unsigned long long at;
+                if (has_resv) { at = resv; spare_blk = false; }
+                else at = atomicAdd(&pc->cursors[tid * kCursorStride], (unsigned long long)B);
                 if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
                 else wpos = my_start + at;
             }
@@ -1721,15 +1740,24 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             wpos += ccnt;
         }
         const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+        // a reserved block nobody opened counts as handed out: pads, or (beyond the region) the chunk is redone
+        uint32_t blk_n = 0;
+        if (spare_blk)
+        {
+            if (resv + B > my_cap) atomicOr(&pc->overflow, 1ULL);
+            else blk_n = B;
+        }
         __syncthreads();
-        t_base[tid].x = tail;
+        t_base[tid] = make_uint2(tail, blk_n);
         reinterpret_cast<uint64_t*>(sorted)[tid] = wpos;
+        reinterpret_cast<uint64_t*>(sorted)[256 + tid] = my_start + resv;
         __syncthreads();
         for (uint32_t d = 0; d < 256; ++d)
         {
-            const uint32_t n = t_base[d].x;
-            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d];
+            const uint32_t n = t_base[d].x, n2 = t_base[d].y;
+            const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d], from2 = reinterpret_cast<const uint64_t*>(sorted)[256 + d];
             for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key2{~0ULL, ~0ULL};
+            for (uint32_t j = tid; j < n2; j += kTB) out[from2 + j] = Key2{~0ULL, ~0ULL};
         }
     }
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }

@@ -558,17 +558,16 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
 
     On every rank (goss_gpu_emit_part): its slice of the low-bits column files (and, for graphs, of the
     ord0 byte file) -- they belong at element offset `first_index` of the whole file and stay in the
-    rank's HBM for its own writer.  Only key >> D of every key (4 bytes per key when N >> D < 2^32) and the
-    few records of counts > 255 / the count histogram travel to rank 0, which builds the header, the
-    high-bits bitmap, -d0 / -d1 and, for graphs, ord1 / ord2 with their presence arrays and the histogram
-    text (goss_gpu_emit_assemble).  Returns {suffix: (size, device address)} of this rank's files."""
+    rank's HBM for its own writer -- and its SPAN of the high-bits bitmap, built from its own keys (".part.span":
+    about 2.4 bits per key).  Only the spans and the few records of counts > 255 / the count histogram travel to
+    rank 0, which ORs the spans together (neighbours share their boundary words) and builds the header, -d0 / -d1
+    from the assembled bitmap and, for graphs, ord1 / ord2 with their presence arrays and the histogram text
+    (goss_gpu_emit_assemble).  Returns {suffix: (size, device address)} of this rank's files."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ctx.emit_part(first_index, total, estimate)
     files = {name: (size, ptr) for name, size, ptr in ctx.file_list()}
-    high = [n for n in files if n.startswith(".part.high")][0]
-    high_bytes = 4 if high.endswith("32") else 8
-    size, ptr = files[high]
+    size, ptr = files[".part.span"]
     xdev = _exchange_device(device, group)
     mine = device_view(ptr, size, torch.uint8, device).to(xdev) if size else torch.empty(0, dtype=torch.uint8, device=xdev)
     # sizes of every rank's parts: one small all-gather
@@ -608,7 +607,7 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
             hst += raw[at + int(r[1]):at + int(r[1]) + int(r[2])]
             at += int(r[1]) + int(r[2])
         hp = allhigh.to(device) if allhigh.device.type != "cuda" else allhigh
-        ctx.emit_assemble(hp.data_ptr(), high_bytes, total, estimate, big, hst)
+        ctx.emit_assemble(hp.data_ptr(), sum(recv), total, estimate, big, hst)
         del hp
     return {name: (size, ptr) for name, size, ptr in ctx.file_list()}
 

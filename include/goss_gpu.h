@@ -337,7 +337,9 @@ int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, 
  * goss_gpu_emit_part, after finish, on every range's owner: builds what the range alone determines --
  *   "<base>.low-bits*"   this range's slice of every low-bits column file (base ".kmers" / "-edges"),
  *   "-counts.ord0"        (graph) this range's slice of the ord0 byte file,
- *   ".part.high32|64"     key >> D of every key (u32 when N >> D < 2^32, else u64), for the assembler,
+ *   ".part.span"          this range's span of the high-bits bitmap (SparseArray.hh:87-118: one i of the whole array is
+ *                         bit (key_i >> D) + i), built from its own keys: {u64 first word, u64 words}, then the words --
+ *                         about 2.4 bits per key for the assembler (round 3 sent key >> D of every key: 4 or 8 bytes),
  *   ".part.big"           (graph) the entries with count > 255: {u64 global index, u32 count, u32 0},
  *   ".part.hist"          (graph) {u64 count, u64 frequency} pairs of this range, ascending.
  * first_index = number of result items in the ranges below this one, total = items in all ranges,
@@ -345,13 +347,15 @@ int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, 
  * element offset first_index of the whole file.
  *
  * goss_gpu_emit_assemble, on one context of the same (k, mode): from the concatenation (in range order)
- * of every ".part.high*" on the device and of the ".part.big" / ".part.hist" records in host memory, builds
- * the files that need all ranges: ".header", "<base>.header", "<base>.high-bits", "<base>-d0", "<base>-d1"
+ * of every ".part.span" on the device (span_bytes in all) and of the ".part.big" / ".part.hist" records in host
+ * memory, builds the files that need all ranges: ".header", "<base>.header", "<base>.high-bits" (the spans ORed
+ * together: neighbours share their boundary words), "<base>-d0", "<base>-d1" (DenseArray.cc:446-675, from the
+ * positions of the assembled bitmap's ones)
  * and for graphs "-counts.ord1p.*", "-counts.ord1", "-counts.ord2p.*", "-counts.ord2", "-counts-hist.txt".
  * The files are appended to the context's list (a context may hold its own part and the assembly).
  */
 int goss_gpu_emit_part(goss_gpu_ctx* ctx, uint64_t first_index, uint64_t total, uint64_t estimate);
-int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_high, uint32_t high_bytes, uint64_t total,
+int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_spans, uint64_t span_bytes, uint64_t total,
                            uint64_t estimate, const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist);
 
 /*
