@@ -217,14 +217,23 @@ def multi_gpu_probe(ranks=8):
         # first half of the records is counted while the second half travels: the wire runs beside device work unless
         # it is longer than half of the step; while it is busy RCCL's copy kernels hold about a tenth of the CUs
         exposed = max(0.0, wire_ms - 0.5 * rec["ms_per_step"]) + 0.1 * wire_ms + 10.0          # + the second exchange and merge
-        step = rec["ms_per_step"] + exposed
+        # emission: every rank builds its own slices and its span of the high-bits bitmap (inside the measured step: "emit");
+        # rank 0 then takes the spans (2.44 bits per distinct key of the whole build, ranks - 1 links at once), ORs them and
+        # builds -d0 / -d1 for ALL keys alone -- three quarters of a whole emit per rank's worth of keys, one after the other
+        emit_1 = rec["device_ms_per_step"].get("emit", 0.0)
+        distinct_all = ranks * 125e6
+        span_ms = distinct_all * 2.44 / 8 / 1e9 / ((ranks - 1) * 50.0) * 1e3
+        emission = span_ms + 0.75 * emit_1 * ranks
+        step = rec["ms_per_step"] + exposed + emission
         out["projection"] = {"per_rank_step_ms": step, "ratio_to_one_rank": step / one["ms_per_step"],
+                             "emission_ms": emission,
                              "value_M_kmers_per_s": ranks * rec["windows_per_step"] / (step * 1e-3) / 1e6,
                              "assumed": "records on the wire %.1f GB per rank over %d links at 50 GB/s = %.0f ms, beside the routing of "
                                         "the later pieces and the counting of the first half of the records (exposed: what exceeds "
                                         "half of the step, here %.0f ms; a tenth of the wire time for RCCL's kernels on the CUs); "
-                                        "second exchange and merge 10 ms"
-                                        % (wire_gb, ranks - 1, wire_ms, max(0.0, wire_ms - 0.5 * rec["ms_per_step"]))}
+                                        "second exchange and merge 10 ms; emission on rank 0: spans of the bitmap in %.1f ms, "
+                                        "-d0 / -d1 of all %.0f M keys at 0.75 of this rank's emit per rank's worth of keys"
+                                        % (wire_gb, ranks - 1, wire_ms, max(0.0, wire_ms - 0.5 * rec["ms_per_step"]), span_ms, distinct_all / 1e6)}
     except KeyError:
         pass
     return out
