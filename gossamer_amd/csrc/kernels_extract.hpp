@@ -700,6 +700,18 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 #ifndef GOSS_E1_OCC
 #define GOSS_E1_OCC 3
 #endif
+// Wave priorities by phase (s_setprio; the SIMD's issue arbiter takes priority before age).  The three workgroups of a
+// CU are in different phases; a wave in the store phase issues few instructions, each of which starts a long-latency
+// operation (LDS read, global store) that the tile's end waits for, a wave in the ranking phase issues hundreds of
+// vector instructions nothing waits for yet.  Stores first, ranking (and the next tile's byte encoder) last:
+// 36.9 -> 33.7 ms on C2.  Measured (bookkeeping, scatter, encoder, stores): (0,0,0,0) 36.3, (3,3,3,3) 35.5, (3,3,0,3) 34.9,
+// (0,3,0,3) 34.3, (0,0,0,3) 33.9, (1,2,0,3) 33.7, (3,0,0,0) 36.7.
+#ifndef GOSS_E1_PRIO_C
+#define GOSS_E1_PRIO_C 1
+#define GOSS_E1_PRIO_S 2
+#define GOSS_E1_PRIO_E 0
+#define GOSS_E1_PRIO_D 3
+#endif
 // REPK (MODE 0): which strand of a k-mer is stored -- 0: strand_rep (even k), 1: the strand whose middle base has a clear
 // low bit (odd k), 2: gossamer's canonical form (the smaller FNV-1a hash: two hash chains per window; chunks with many
 // distinct keys, whose re-ordering after counting would cost more)
@@ -921,6 +933,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // Written without branches around the LDS operations: a window that is not valid still gets a
         // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
         // of a thread are issued back to back and waited for once, not one round trip after the other.
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         Key1 kreg[NK];
         uint32_t rk[NK];
         uint32_t bin4[NK];                        // byte offset of the key's counter in dh (and of its entry in tab)
@@ -985,6 +1000,16 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                     kreg[i] = REPK == 2 ? canonical(fk, rck) : REPK == 1 ? (((f >> (len - 1)) & 1ULL) ? rck : fk) : strand_rep(fk, rck, len, lmask);
                 else { kreg[i * 2] = fk; kreg[i * 2 + 1] = rck; }
             };
+            // the counter of key j: its digit, or a spare one (window not valid); ranked at once
+            const uint32_t badm = ~m;
+            const uint32_t spare4 = (256u + (tid & 31u)) << 2;
+            auto rank_key = [&](int j) {
+                const uint32_t nok = (uint32_t)__builtin_amdgcn_sbfe((int32_t)badm, j / S, 1);
+                const uint32_t d4 = FAST ? ((uint32_t)(kreg[j].lo >> 32) >> (shift - 34)) & 0x3FCu
+                                         : ((uint32_t)(kreg[j].lo >> shift) & 0xFFu) << 2;
+                bin4[j] = bit_select(nok, spare4, d4);
+                rk[j] = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(dh) + bin4[j]), 1u);
+            };
             // The bases lie in (bhi:blo) lowest first, two bits each: the reverse complement of window i is the field
             // [2 i, 2 i + bits) of the complemented buffer, its forward form the base-4 reverse of the same field.
             if constexpr (REC)
@@ -1032,6 +1057,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                         kreg[i].lo = ((uint64_t)bit_select(sel, rhi, fhi) << 32) | bit_select(sel, rlo, flo);
                     }
                     else emit(i, ((uint64_t)fhi << 32) | flo, ((uint64_t)rhi << 32) | rlo);
+                    // (ranked at once: the LDS atomics of the first windows run beside the arithmetic of the later ones)
+#pragma unroll
+                    for (int u = 0; u < S; ++u) rank_key(i * S + u);
                 }
             }
             else
@@ -1053,21 +1081,16 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                     emit(i, f, r);
                 }
             }
-            // the counters: the key's digit, or a spare one (window not valid)
-            const uint32_t badm = ~m;
-            const uint32_t spare4 = (256u + (tid & 31u)) << 2;
-#pragma unroll
-            for (int j = 0; j < NK; ++j)
+            if constexpr (REC || !FAST)
             {
-                const uint32_t nok = (uint32_t)__builtin_amdgcn_sbfe((int32_t)badm, j / S, 1);
-                const uint32_t d4 = FAST ? ((uint32_t)(kreg[j].lo >> 32) >> (shift - 34)) & 0x3FCu
-                                         : ((uint32_t)(kreg[j].lo >> shift) & 0xFFu) << 2;
-                bin4[j] = bit_select(nok, spare4, d4);
-            }
 #pragma unroll
-            for (int j = 0; j < NK; ++j) rk[j] = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(dh) + bin4[j]), 1u);
+                for (int j = 0; j < NK; ++j) rank_key(j);
+            }
         }
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_C);
+#endif
 
         // ---- phase C: bookkeeping of bucket tid: its new keys' place in LDS, where its granules go, what is carried ----
         // A bucket's new keys lie in one piece that starts on a granule, by rank.  Order inside a bucket does not
@@ -1132,6 +1155,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
         }
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_S);
+#endif
         // new keys to their place: the stream's first new slot + rank (the table reads of
         // all sixteen keys first, then the writes: no round trip per key)
         {
@@ -1151,6 +1177,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 }
             }
         }
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_E);
+#endif
         if (more && !REC)
         {
             encode(q0, c0, b0);
@@ -1160,6 +1189,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // in-order counter, and a wait at its first use in the next tile would wait for those stores as well)
         if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_D);
+#endif
 
         // ---- phase D: whole granules to the bucket blocks; every 4 aligned lanes store one (two keys each) -------
         // (two keys per lane and store: the store path takes 16 bytes per lane as quickly as 8 --
@@ -1492,6 +1524,9 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             has_resv = true;
         }
 #endif
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(0);              // (priorities by phase as in extract1_part_kernel)
+#endif
         Key2 kreg[NK];
         uint32_t rk[NK];
         uint32_t vm = 0;
@@ -1619,6 +1654,9 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
         }
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_C);
+#endif
 
         // ---- bookkeeping of bucket tid: what is stored now, where, what is carried out ----
         uint32_t total_store;
@@ -1658,6 +1696,9 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             ccnt = rem;
         }
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_S);
+#endif
         {
             uint2 tl[NK];
 #pragma unroll
@@ -1675,6 +1716,9 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                 if (NH > 1) atomicAdd(&lh[256u + key_digit(k, shift + 16)], ok ? 1u : 0u);
             }
         }
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_E);
+#endif
         if (more && !REC)
         {
             encode(q0, c0, b0);
@@ -1683,6 +1727,9 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one in-order counter)
         if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if !defined(GOSS_E1_NOPRIO)
+        __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_D);
+#endif
 
         // ---- whole granules to the bucket blocks; every 4 aligned lanes store one ----
         if (sh_ovf == 0)
