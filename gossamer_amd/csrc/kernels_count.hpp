@@ -582,9 +582,6 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
                                                                 Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
                                                                 uint32_t rbits, uint32_t sqbit, uint32_t split_bits)
 {
-#if defined(GOSS_R32_PRIO_L)
-    __builtin_amdgcn_s_setprio(GOSS_R32_PRIO_L);
-#endif
     // split_bits: the segments are the sub-segments of subsplit32_kernel -- 2^split_bits per second-level segment, told
     // apart by the top split_bits bits of the remainder (which they keep) and starting anywhere, not on a 16-byte boundary
     constexpr int NT = kTB;
@@ -646,9 +643,6 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
         const uint32_t i = (uint32_t)u * NT + tid;
         nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
     }
-#if defined(GOSS_R32_PRIO_L)
-    __builtin_amdgcn_s_setprio(0);
-#endif
     for (uint32_t i0 = 0; i0 < nvec; i0 += (uint32_t)NT * kVec)
     {
         u32x4 cur[kVec];
@@ -794,9 +788,6 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
         if (*vovf) break;
     }
     __syncthreads();
-#if defined(GOSS_R32_PRIO_O)
-    __builtin_amdgcn_s_setprio(GOSS_R32_PRIO_O);
-#endif
     if (ovf)
     {
         if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
