@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
         const uint64_t tb = tile * (uint64_t)T;
+        __builtin_amdgcn_s_setprio(3);              // (priorities by phase, as in extract1_part_kernel: loads first, stores next, the minimizers last)
         // ---- phase A: bytes of the tile -> codes + non-base flags ------------------------------------------
         for (uint32_t v = tid; v < (uint32_t)NVEC; v += kTB)
         {
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             pk[v] = codes; iv[v] = bads;
         }
         if (tid < nparts) { cnt[tid] = 0; win[tid] = 0; }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
 
         // ---- phase B: this thread's 16 windows: validity, minimizers, destinations, runs --------------------
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
         // ---- phase D: room in every part's buffer, then the records leave ------------------------------------------
         // A workgroup takes room in blocks: what the tile needs beyond the rest of its block, and `block` slots for the
         // tiles to come (none after its last tile), with ONE atomic -- one returning atomic per part and tile on 2 nparts
