@@ -1745,6 +1745,18 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const PartCounters* hp = (const PartCounters*)hpc.data();
     if (hp->overflow) { c->fused_overflows++; return decline("a bucket region overflowed"); }
     lap("extraction + first level");
+#if defined(GOSS_STAMPS)
+    // (timing build: wave 0's cycles per phase and tile, averaged over the workgroups)
+    if (hp->hist[505])
+        std::fprintf(stderr, "libgossgpu: stamps per tile (cycles): A %.0f  B %.0f  C %.0f  scatter %.0f  D %.0f   (%llu tiles)\n",
+                     (double)hp->hist[500] / hp->hist[505], (double)hp->hist[501] / hp->hist[505], (double)hp->hist[502] / hp->hist[505],
+                     (double)hp->hist[503] / hp->hist[505], (double)hp->hist[504] / hp->hist[505], (unsigned long long)hp->hist[505]);
+    if (hp->hist[505] && hp->hist[506])
+        std::fprintf(stderr, "libgossgpu: stamps, finer: C = scan %.0f + bookkeeping %.0f + barrier; scatter = LDS %.0f + encoder %.0f + barrier; D = stores %.0f + absorb %.0f + barrier %.0f\n",
+                     (double)hp->hist[506] / hp->hist[505], (double)hp->hist[507] / hp->hist[505], (double)hp->hist[510] / hp->hist[505],
+                     (double)hp->hist[511] / hp->hist[505], (double)hp->hist[508] / hp->hist[505], (double)hp->hist[509] / hp->hist[505],
+                     (double)hp->hist[504] / hp->hist[505]);
+#endif
     const uint64_t n = hp->keys_out;
     if (n == 0) return kFusedDeclined;
     if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");

@@ -124,15 +124,27 @@ struct Rem96 { uint32_t r0, r1, r2; };           // the low 96 bits of a two-wor
 // strand whose halves (len bits each), swapped, give the smaller value -- low half first, then high half.
 __device__ __forceinline__ Key2 strand_rep2(const Key2& f, const Key2& rc, uint32_t len, uint64_t lmask)
 {
+    // The strand is picked WORD BY WORD from values pinned in registers: `cond ? rc : f` on the two references -- and
+    // equally two selects between their fields, which the compiler folds back into one -- selects an ADDRESS, which puts
+    // both keys into scratch memory and every window through a store, a dependent load and a wait for the memory
+    // counter: what two-word extraction spent most of its time on until round 4.
+    uint64_t flo = f.lo, fhi = f.hi, rlo = rc.lo, rhi = rc.hi;
+    asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi));
     if (len & 1u)
     {
         const uint32_t b = len - 1;              // 32 .. 62
-        return ((f.lo >> b) & 1ULL) ? rc : f;
+        const bool take = (flo >> b) & 1ULL;
+        return Key2{take ? rlo : flo, take ? rhi : fhi};
     }
-    const uint64_t lf = f.lo & lmask, lr = rc.lo & lmask;
-    const uint64_t hf = ((f.lo >> len) | (f.hi << (64 - len))) & lmask, hr = ((rc.lo >> len) | (rc.hi << (64 - len))) & lmask;
-    const bool take_rc = lr < lf || (lr == lf && hr < hf);
-    return take_rc ? rc : f;
+    const uint64_t lf = flo & lmask, lr = rlo & lmask;
+    bool take_rc = lr < lf;
+    // (the high halves decide a tie of the low ones -- one window in 2^len: looked at only when a lane of the wave has one)
+    if (__builtin_amdgcn_ballot_w64(lr == lf))
+    {
+        const uint64_t hf = ((flo >> len) | (fhi << (64 - len))) & lmask, hr = ((rlo >> len) | (rhi << (64 - len))) & lmask;
+        if (lr == lf) take_rc = hr < hf;
+    }
+    return Key2{take_rc ? rlo : flo, take_rc ? rhi : fhi};
 }
 
 __device__ __forceinline__ bool is_pad_key(const Key1& k) { return k.lo == ~0ULL; }
@@ -852,6 +864,11 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     // A bucket's next block is reserved AHEAD of the tile that opens it (phase A, when the open block has less than
     // kAhead slots left -- more than a tile ever asked for in 10^4 tiles): a returning atomic on a cursor takes 1-3 us
     // under load, a third of a tile, and in phase C every wave has a lane that waits for one.
+    // (The read of the reservation in phase C carries an `s_waitcnt vmcnt(0)`, which also waits for the previous tile's
+    // stores.  A form that hides the atomic from the compiler -- inline assembly, issued a tile earlier still, covered by
+    // the wait for the next tile's bytes -- took that wait out of phase C (wave 0's bookkeeping 2 676 -> 1 597 cycles per
+    // tile, GOSS_STAMPS build) and left the kernel's time where it was, 33.6 ms: the waiting moved into the store
+    // phase.  Not kept.)
     constexpr uint32_t kAhead = 40;
     unsigned long long resv = 0;
     bool has_resv = false;
@@ -859,11 +876,25 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     // (timing experiment: the workgroups that share a CU start a third of a tile apart)
     for (uint32_t z = 0; z < (blockIdx.x >> 8) * GOSS_E1_STAGGER; ++z) __builtin_amdgcn_s_sleep(100);
 #endif
+    // (the bucket's region, loaded at the top, is looked at here once: the compiler's wait for it would otherwise sit at
+    // its first use inside the loop -- `s_waitcnt vmcnt(0)` in phase C of every tile, i.e. a wait for the previous
+    // tile's stores)
+    asm volatile("" ::"v"(my_start), "v"(my_cap));
+#if defined(GOSS_STAMPS)
+    // (timing build: cycles of wave 0 per phase, summed over its tiles, into the unused histogram words)
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define GOSS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define GOSS_STAMP(i)
+#endif
     for (uint64_t st = blockIdx.x;; st += gridDim.x)
     {
         if constexpr (REC) { if (rc_next >= rc_end) break; }
         else { if (st >= nsuper) break; }
         const uint64_t tile_base = st * (uint64_t)T;
+#if defined(GOSS_STAMPS)
+        st_acc[5] += 1;
+#endif
 
         // ---- phase A: this tile's codes from registers to LDS, the next tile's bytes on their way ----
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
@@ -921,6 +952,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
         }
 
+        // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
+        // Written without branches around the LDS operations: a window that is not valid still gets a
+        // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
+        // of a thread are issued back to back and waited for once, not one round trip after the other.
 #if !defined(GOSS_E1_SYNC_BLOCKS)
         if (!has_resv && ((B - ((uint32_t)wpos & (B - 1))) & (B - 1)) < kAhead)
         {
@@ -928,11 +963,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             has_resv = true;
         }
 #endif
-
-        // ---- phase B: windows out of registers, keys, rank inside their digit --------------------
-        // Written without branches around the LDS operations: a window that is not valid still gets a
-        // (meaningless) key and ranks itself in a spare counter, so that the sixteen returning atomics
-        // of a thread are issued back to back and waited for once, not one round trip after the other.
+        GOSS_STAMP(0);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1088,6 +1119,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
         }
         __syncthreads();
+        GOSS_STAMP(1);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_C);
 #endif
@@ -1102,6 +1134,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             const uint32_t cnt = dh[tid];
             const uint32_t a8 = cnt & ~7u, b = cnt & 7u;
             const uint32_t s_at = block_excl_scan_open_u32((cnt + 7u) & ~7u, sh_scan, &total_slots);               // (the barrier behind phase C closes it)
+            GOSS_STAMP(6);
             dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
             if (tid < 32) dh[256 + tid] = 0;
             const bool top = b + ccnt >= 8u;
@@ -1154,7 +1187,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 ccnt = from;
             }
         }
+        GOSS_STAMP(7);
         __syncthreads();
+        GOSS_STAMP(2);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_S);
 #endif
@@ -1177,6 +1212,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 }
             }
         }
+        GOSS_STAMP(10);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_E);
 #endif
@@ -1185,10 +1221,12 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             encode(q0, c0, b0);
             if (tid < 4) encode(q1, c1, b1);
         }
+        GOSS_STAMP(11);
         // (REC: the next record must have arrived before this tile's stores are issued -- loads and stores share one
         // in-order counter, and a wait at its first use in the next tile would wait for those stores as well)
         if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        GOSS_STAMP(3);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_D);
 #endif
@@ -1196,6 +1234,14 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // ---- phase D: whole granules to the bucket blocks; every 4 aligned lanes store one (two keys each) -------
         // (two keys per lane and store: the store path takes 16 bytes per lane as quickly as 8 --
         // experiments/storegran: 4.5 against 4.1 TB/s for this pattern alone -- and the loop has half the instructions)
+        // (the reads of a partial granule that joins the carried keys go ahead of the stores)
+        Key1 ab[kCarry];
+#pragma unroll
+        for (int j = 0; j < kCarry; ++j)
+        {
+            const bool in = (uint32_t)j >= ccnt && (uint32_t)j < ccnt + absorb;
+            ab[j] = sorted[in ? part_at + j - ccnt : kGarb];
+        }
         if (sh_ovf == 0)
         {
             Key1* const lane_out = out + ((2 * tid) & 7u);
@@ -1227,20 +1273,26 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 }
             }
         }
+        GOSS_STAMP(8);
         // a partial granule that was not topped up: its keys join the carried ones
-        if (absorb)
         {
 #pragma unroll
             for (int j = 0; j < kCarry; ++j)
             {
                 const bool in = (uint32_t)j >= ccnt && (uint32_t)j < ccnt + absorb;
-                const Key1 x = sorted[in ? part_at + j - ccnt : kGarb];
-                kc[j] = in ? x : kc[j];
+                kc[j] = in ? ab[j] : kc[j];
             }
             ccnt += absorb;
         }
+        GOSS_STAMP(9);
         __syncthreads();
+        GOSS_STAMP(4);
     }
+#if defined(GOSS_STAMPS)
+    if (tid == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&pc->hist[500 + i], st_acc[i]);
+#endif
+#undef GOSS_STAMP
 
     // ---- the end: carried keys, the unused tail of every open block, the block reserved and not opened ----------
     if (sh_ovf == 0)
@@ -1453,11 +1505,21 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         if (tid < 6) encode(q1, c1, b1);
     }
 
+#if defined(GOSS_STAMPS)
+    // (timing build: cycles of wave 0 per phase, summed over its tiles, into the unused histogram words)
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define GOSS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define GOSS_STAMP(i)
+#endif
     for (uint64_t st = blockIdx.x;; st += gridDim.x)
     {
         if constexpr (REC) { if (rc_next >= rc_end) break; }
         else { if (st >= nsuper) break; }
         const uint64_t tile_base = st * (uint64_t)T;
+#if defined(GOSS_STAMPS)
+        st_acc[5] += 1;
+#endif
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = make_uint4(0, 0, 0, 0);
         bool more;
         uint32_t wt = 0;                          // (REC) windows of this tile
@@ -1527,6 +1589,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(0);              // (priorities by phase as in extract1_part_kernel)
 #endif
+        GOSS_STAMP(0);
         Key2 kreg[NK];
         uint32_t rk[NK];
         uint32_t vm = 0;
@@ -1584,57 +1647,91 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         }
         else
         {
+            // The bytes' form, round 4: windows out of the register buffer in 32-bit words by CONSTANT funnel shifts, as in
+            // the one-word kernel -- the buffer shifted to the thread's first base once, the reverse complement of window i
+            // the field [2 i, 2 i + bits) of the complemented words, the forward strand rolled (the bases it takes in are
+            // pre-shifted once: base i + len - 1 at bits 2 i of nx), validity of all P windows at once by run doubling.
+            // (Before: every window cut its next base out of three 64-bit words by variable shifts and rolled two 128-bit
+            // values, and tested its own len flags: phase B was 27 500 of the 39 600 cycles of a tile.)
             const uint32_t q0i = tid * P + mis;
             const uint32_t v0 = q0i >> 4, sh = q0i & 15u;
             const uint64_t p0 = tile_base + (uint64_t)tid * P;
-            const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
-            const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
-            const uint64_t w0 = (uint64_t)pk[v0] | ((uint64_t)pk[v0 + 1] << 32);
-            const uint64_t w1 = (uint64_t)pk[v0 + 2] | ((uint64_t)pk[v0 + 3] << 32);
-            const uint64_t w2 = (uint64_t)pk[v0 + 4] | ((uint64_t)pk[v0 + 5] << 32);
-#pragma unroll
-            for (int i = 0; i < P; ++i)
+            // ---- validity: window i is valid iff flags [i, i + len) are clear (96 flags from the thread's first base)
             {
-                const uint32_t t = sh + i;
-                const uint64_t win = t ? ((inv_lo >> t) | (inv_hi << (64 - t))) : inv_lo;
-                bool ok = (win & lmask) == 0 && (p0 + i < nstarts);
-                vm |= ok ? (1u << i) : 0u;
+                const uint64_t inv_lo = (uint64_t)iv[v0] | ((uint64_t)iv[v0 + 1] << 16) | ((uint64_t)iv[v0 + 2] << 32) | ((uint64_t)iv[v0 + 3] << 48);
+                const uint64_t inv_hi = (uint64_t)iv[v0 + 4] | ((uint64_t)iv[v0 + 5] << 16);
+                // (bits above the 96 that were read count as good: they belong to windows beyond P)
+                uint64_t rl = ~(sh ? ((inv_lo >> sh) | (inv_hi << (64 - sh))) : inv_lo), rh = ~(inv_hi >> sh);
+                uint64_t al = ~0ULL;
+                uint32_t covered = 0;
+                auto shr_lo = [](uint64_t lo, uint64_t hi, uint32_t s) -> uint64_t {          // low word of (hi:lo) >> s, s < 128 (uniform)
+                    return s == 0 ? lo : s < 64 ? ((lo >> s) | (hi << (64 - s))) : (hi >> (s - 64));
+                };
+#pragma unroll
+                for (int j = 0; j < 6; ++j)               // len <= 63
+                {
+                    if ((len >> j) & 1u) { al &= shr_lo(rl, rh, covered); covered += 1u << j; }
+                    const uint32_t s = 1u << j;           // run &= run >> s (constant s < 64)
+                    const uint64_t nl = (rl >> s) | (rh << (64 - s)), nh = rh >> s;
+                    // (the bits shifted in at the top are zero = "not good": only windows near bit 128 - len see them, none of ours)
+                    rl &= nl; rh &= nh;
+                }
+                const uint64_t left = nstarts > p0 ? nstarts - p0 : 0;
+                const uint32_t lim = left >= (uint64_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << (uint32_t)left) - 1u);
+                vm = (uint32_t)al & lim;
             }
             nvalid += __popc(vm);
             const uint32_t spare = 256u + (tid & 31u);
             uint32_t bin[NK];
-            // forward key f and reverse complement r of window 0 from the register buffer, then one base
-            // rolled into both per window
-            Key2 f{0, 0}, r{0, 0};
-            const uint32_t top = bits - 2;                  // position of a key's first base (>= 62)
+            // ---- the buffer from the thread's first base on: five words (P + len - 1 <= 76 bases)
+            uint32_t x[5], cx[5];
+            {
+                const uint32_t s2 = 2 * sh;
+                uint32_t w[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) w[j] = pk[v0 + j];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { x[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], s2); cx[j] = ~x[j]; }
+            }
+            // the bases rolled in: base len - 1 + i at bits 2 i (2 (len - 1) = 62 .. 124: words 1 .. 3 of x)
+            uint32_t nx;
+            {
+                const uint32_t pn = 2 * (len - 1), wi = pn >> 5, bo = pn & 31u;
+                const uint32_t lo = wi == 1 ? x[1] : wi == 2 ? x[2] : x[3];
+                const uint32_t hi = wi == 1 ? x[2] : wi == 2 ? x[3] : x[4];
+                nx = __builtin_amdgcn_alignbit(hi, lo, bo);
+            }
+            const uint32_t mh2 = (uint32_t)mask_hi, mh3 = (uint32_t)(mask_hi >> 32);
+            // forward key of window 0 (base-4 reversal of its field)
+            uint32_t f0, f1, f2, f3;
+            {
+                const uint64_t elo = (uint64_t)x[0] | ((uint64_t)x[1] << 32);
+                const uint64_t ehi = ((uint64_t)x[2] | ((uint64_t)x[3] << 32)) & mask_hi;
+                const uint64_t rlo = rev64(ehi), rhi = rev64(elo);
+                const uint32_t sft = 128 - bits;
+                uint64_t flo, fhi;
+                if (sft == 64) { flo = rhi; fhi = 0; }
+                else { flo = (rlo >> sft) | (rhi << (64 - sft)); fhi = rhi >> sft; }
+                f0 = (uint32_t)flo; f1 = (uint32_t)(flo >> 32); f2 = (uint32_t)fhi; f3 = (uint32_t)(fhi >> 32);
+            }
 #pragma unroll
             for (int i = 0; i < P; ++i)
             {
-                if (i == 0)
+                if (i)
                 {
-                    const uint32_t t2 = 2 * sh;
-                    Key2 e;
-                    e.lo = t2 ? ((w0 >> t2) | (w1 << (64 - t2))) : w0;
-                    e.hi = (t2 ? ((w1 >> t2) | (w2 << (64 - t2))) : w1) & mask_hi;
-                    const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
-                    const uint32_t sft = 128 - bits;
-                    if (sft == 64) { f.lo = rhi; f.hi = 0; }
-                    else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
-                    r.lo = ~e.lo; r.hi = (~e.hi) & mask_hi;
+                    const uint32_t nb = (nx >> (2 * i)) & 3u;
+                    f3 = __builtin_amdgcn_alignbit(f3, f2, 30) & mh3;
+                    f2 = __builtin_amdgcn_alignbit(f2, f1, 30) & mh2;
+                    f1 = __builtin_amdgcn_alignbit(f1, f0, 30);
+                    f0 = (f0 << 2) | nb;
                 }
-                else
-                {
-                    const uint32_t pos = 2 * (sh + i + len - 1);
-                    const uint64_t nb = (pos < 64 ? (w0 >> pos) : pos < 128 ? (w1 >> (pos - 64)) : (w2 >> (pos - 128))) & 3u;
-                    f.hi = ((f.hi << 2) | (f.lo >> 62)) & mask_hi;
-                    f.lo = (f.lo << 2) | nb;
-                    const uint64_t cb = nb ^ 3u;
-                    r.lo = (r.lo >> 2) | (r.hi << 62);
-                    r.hi = (r.hi >> 2) | (top >= 64 ? cb << (top - 64) : 0ULL);
-                    if (top < 64) r.lo |= cb << top;
-                }
+                const uint32_t r0 = i ? __builtin_amdgcn_alignbit(cx[1], cx[0], 2 * i) : cx[0];
+                const uint32_t r1 = i ? __builtin_amdgcn_alignbit(cx[2], cx[1], 2 * i) : cx[1];
+                const uint32_t r2 = (i ? __builtin_amdgcn_alignbit(cx[3], cx[2], 2 * i) : cx[2]) & mh2;
+                const uint32_t r3 = (i ? __builtin_amdgcn_alignbit(cx[4], cx[3], 2 * i) : cx[3]) & mh3;
+                const Key2 f{(uint64_t)f0 | ((uint64_t)f1 << 32), (uint64_t)f2 | ((uint64_t)f3 << 32)};
+                const Key2 rck{(uint64_t)r0 | ((uint64_t)r1 << 32), (uint64_t)r2 | ((uint64_t)r3 << 32)};
                 const bool ok = (vm >> i) & 1u;
-                const Key2 rck = r;
                 if (MODE == 0)
                 {
                     Key2 k;
@@ -1654,6 +1751,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             for (int i = 0; i < NK; ++i) rk[i] = atomicAdd(&dh[bin[i]], 1u);
         }
         __syncthreads();
+        GOSS_STAMP(1);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_C);
 #endif
@@ -1696,6 +1794,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             ccnt = rem;
         }
         __syncthreads();
+        GOSS_STAMP(2);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_S);
 #endif
@@ -1727,6 +1826,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one in-order counter)
         if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        GOSS_STAMP(3);
 #if !defined(GOSS_E1_NOPRIO)
         __builtin_amdgcn_s_setprio(GOSS_E1_PRIO_D);
 #endif
@@ -1764,7 +1864,13 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             for (int j = 0; j < kCarry; ++j) kc[j] = sorted[l_at + j];
         }
         __syncthreads();
+        GOSS_STAMP(4);
     }
+#if defined(GOSS_STAMPS)
+    if (tid == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&pc->hist[500 + i], st_acc[i]);
+#endif
+#undef GOSS_STAMP
 
     // ---- the end: carried keys and the unused tail of every open block ----
     if (sh_ovf == 0)

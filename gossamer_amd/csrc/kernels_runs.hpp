@@ -282,6 +282,8 @@ __global__ __launch_bounds__(kTB) void select_write_kernel(const K* __restrict__
     {
         uint64_t i = base + (uint64_t)j * kTB + threadIdx.x;
         bool keep = false;
+        key[j] = K{};                  // (every element set on every path: a conditionally filled array of two-word keys lives in scratch memory)
+        val[j] = 0;
         if (i < n)
         {
             key[j] = keys[i];
