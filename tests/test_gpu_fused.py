@@ -58,6 +58,11 @@ def test_fused_path_runs_and_matches_oracle(oracle):
     c, got, st = _build(reads, 25, env={"GOSS_GPU_NO_FUSED": "1"})
     assert st["fused_chunks"] == 0 and st["fused_overflows"] == 0
     _same(got, exp)
+    # the 64-bit form of the window arithmetic (the 32-bit form is what the other runs took: k = 25, msd)
+    c, got, st = _build(reads, 25, env={"GOSS_GPU_NO_FAST32": "1"})
+    assert st["fused_chunks"] == 1 and st["fused_overflows"] == 0
+    assert c.windows == nwin
+    _same(got, exp)
 
 
 def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
