@@ -110,6 +110,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_open_u32(uint32_t v, uint32_
     return base + inc - v;
 }
 
+// ... and with the closing barrier (`sh` may be written again right behind it).
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sh, uint32_t* total)
+{
+    const uint32_t r = block_excl_scan_open_u32(v, sh, total);
+    __syncthreads();
+    return r;
+}
+
 // The same for a workgroup of NW waves.
 template <class T, int NW>
 __device__ __forceinline__ T block_excl_scan_n(T v, T* sh, T* total)

@@ -834,15 +834,17 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     const uint32_t* recw = reinterpret_cast<const uint32_t*>(bases_aligned);
     const uint64_t nrec = navail;                            // (REC: the number of records travels in `navail`)
     uint64_t rc_next = 0, rc_end = 0;
-    uint32_t ra0 = 0, ra1 = 0, ra2 = 0, rb0 = 0, rb1 = 0, rb2 = 0, rna = 0, rnb = 0;      // the records the thread stages next
+    uint32_t ra0 = 0, ra1 = 0, ra2 = kSkPadWord2, rb0 = 0, rb1 = 0, rb2 = kSkPadWord2;      // the records the thread stages next (a pad: none)
     uint32_t* rbuf = pk;                                     // [512][3] record words, then [513] prefix sums: phase A's share of `sorted`
     uint32_t* rpre = pk + 512 * 3;
     uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
     auto fetch_recs = [&](uint64_t base) {
         const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
-        ra0 = ra1 = ra2 = rb0 = rb1 = rb2 = rna = rnb = 0;
-        if (ia < rc_end) { ra0 = recw[3 * ia]; ra1 = recw[3 * ia + 1]; ra2 = recw[3 * ia + 2]; rna = rec_windows(ra2); }
-        if (ib < rc_end) { rb0 = recw[3 * ib]; rb1 = recw[3 * ib + 1]; rb2 = recw[3 * ib + 2]; rnb = rec_windows(rb2); }
+        // (loads only: nothing here looks at what they return -- the window counts are taken where the records are
+        // staged, a tile later; taken here they put a wait for memory behind each load)
+        ra0 = ra1 = rb0 = rb1 = 0; ra2 = rb2 = kSkPadWord2;
+        if (ia < rc_end) { ra0 = recw[3 * ia]; ra1 = recw[3 * ia + 1]; ra2 = recw[3 * ia + 2]; }
+        if (ib < rc_end) { rb0 = recw[3 * ib]; rb1 = recw[3 * ib + 1]; rb2 = recw[3 * ib + 2]; }
     };
     if constexpr (REC)
     {
@@ -906,9 +908,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             // blocks -- and what lies beyond the share's end hold none and take no place), with the running sum of
             // their windows: one scan carries both sums (windows <= 8 192 in the low half, staged records above).
             if (tid == 0) { rmark[kTB] = 512; rmark[kTB + 1] = 0xFFFFFFFFu; }     // (records that fit: all, unless a thread finds the one that does not)
+            const uint32_t rna = rec_windows(ra2), rnb = rec_windows(rb2);
             const uint32_t pa = rna ? 1u : 0u, pb = rnb ? 1u : 0u;
             uint32_t tot2;
-            const uint32_t sc = block_excl_scan<uint32_t>((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
+            const uint32_t sc = block_excl_scan_u32((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
             const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
             const uint32_t ea = ex + rna, eb = ea + rnb;          // ends of the thread's two records in the window sequence
             if (pa) { rbuf[3 * ca] = ra0; rbuf[3 * ca + 1] = ra1; rbuf[3 * ca + 2] = ra2; rpre[ca] = ex; }
@@ -981,6 +984,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 bhi = w2 & 0x0FFFFFFFu;
                 r_nw = (w2 >> 28) + 1;                             // (no pad is staged)
             };
+            // (a look-ahead -- the record behind the current one kept in registers, its LDS reads issued a record early --
+            // changed nothing: 85.4 against 84.6 ms)
+            auto next_rec = [&]() { ++r_at; r_off = 0; load_rec(); };
             if constexpr (REC)
             {
                 // windows P tid .. P tid + P - 1 of the tile's sequence, starting in record rmark[tid]
@@ -1045,6 +1051,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             // [2 i, 2 i + bits) of the complemented buffer, its forward form the base-4 reverse of the same field.
             if constexpr (REC)
             {
+                // (a form that complements and base-4 reverses a record ONCE when it becomes the current one and cuts every window
+                // out of both by two funnel shifts -- 8 instructions per window where the reversal per window takes 14 and the
+                // cut by 64-bit shifts 9 -- needs six more live registers in this loop: 33 spilled to scratch, 137.8 against
+                // 85 ms.  Not kept; staging the reversed words in LDS beside the record would be the way.)
 #pragma unroll
                 for (int i = 0; i < P; ++i)
                 {
@@ -1056,7 +1066,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                     if (i + 1 < P)
                     {
                         ++r_off;
-                        if (r_off >= r_nw && r_at < 511) { ++r_at; r_off = 0; load_rec(); }
+                        if (r_off >= r_nw && r_at < 511) next_rec();
                     }
                 }
             }
@@ -1222,9 +1232,12 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             if (tid < 4) encode(q1, c1, b1);
         }
         GOSS_STAMP(11);
-        // (REC: the next record must have arrived before this tile's stores are issued -- loads and stores share one
-        // in-order counter, and a wait at its first use in the next tile would wait for those stores as well)
-        if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one
+        // in-order counter, and a wait at their first use in the next tile would wait for those stores as well.  They are
+        // LOOKED AT here, so that the wait is the compiler's own: behind a wait it does not see -- inline assembly -- it
+        // still put `s_waitcnt vmcnt(0)` in front of the next tile's staging, i.e. waited for the stores all the same:
+        // phase A of the record form took 7 700 of a tile's 22 400 cycles)
+        if constexpr (REC) asm volatile("" ::"v"(ra0), "v"(ra1), "v"(ra2), "v"(rb0), "v"(rb1), "v"(rb2));
         __syncthreads();
         GOSS_STAMP(3);
 #if !defined(GOSS_E1_NOPRIO)
@@ -1468,24 +1481,23 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     const uint32_t* recw = reinterpret_cast<const uint32_t*>(bases_aligned);
     const uint64_t nrec = navail;
     uint64_t rc_next = 0, rc_end = 0;
-    uint32_t ra[5] = {0, 0, 0, 0, 0}, rb[5] = {0, 0, 0, 0, 0}, rna = 0, rnb = 0;
+    uint32_t ra[5] = {0, 0, 0, 0, kSkPadWord2}, rb[5] = {0, 0, 0, 0, kSkPadWord2};      // (a pad: no window)
     uint32_t* rbuf = pk;                                     // [512][5] record words, then [520] prefix sums, then the threads' marks: phase A's share of `sorted`
     uint32_t* rpre = pk + 512 * 5;
     uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
     auto fetch_recs = [&](uint64_t base) {
         const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
-        rna = rnb = 0;
+        // (loads only: the window counts are taken where the records are staged -- extract1_part_kernel)
 #pragma unroll
         for (int j = 0; j < 5; ++j) { ra[j] = 0; rb[j] = 0; }
+        ra[4] = rb[4] = kSkPadWord2;
         if (ia < rc_end) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) ra[j] = recw[5 * ia + j];
-            rna = (ra[4] >> 27) == 1u ? 0u : (ra[4] >> 28) + 1u;
         }
         if (ib < rc_end) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) rb[j] = recw[5 * ib + j];
-            rnb = (rb[4] >> 27) == 1u ? 0u : (rb[4] >> 28) + 1u;
         }
     };
     if constexpr (REC)
@@ -1528,9 +1540,10 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             // the records that hold windows staged back to back (pads and what lies beyond the share hold none), with
             // the running sum of their windows: one scan carries both sums
             if (tid == 0) { rmark[kTB] = 512; rmark[kTB + 1] = 0xFFFFFFFFu; }
+            const uint32_t rna = rec_windows(ra[4]), rnb = rec_windows(rb[4]);
             const uint32_t pa = rna ? 1u : 0u, pb = rnb ? 1u : 0u;
             uint32_t tot2;
-            const uint32_t sc = block_excl_scan<uint32_t>((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
+            const uint32_t sc = block_excl_scan_u32((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
             const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
             const uint32_t ea = ex + rna, eb = ea + rnb;
             if (pa) {
@@ -1613,6 +1626,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                 w2 = x4 & 0x0FFFFFFFu;
                 r_nw = (x4 >> 28) + 1;                             // (no pad is staged)
             };
+            auto next_rec = [&]() { ++r_at; r_off = 0; load_rec(); };
             load_rec();
             const uint32_t spare = 256u + (tid & 31u);
             uint32_t bin[NK];
@@ -1634,7 +1648,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
                 if (i + 1 < P)
                 {
                     ++r_off;
-                    if (r_off >= r_nw && r_at < 511) { ++r_at; r_off = 0; load_rec(); }
+                    if (r_off >= r_nw && r_at < 511) next_rec();
                 }
                 const bool ok = (vm >> i) & 1u;
                 Key2 k;
@@ -1823,8 +1837,10 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             encode(q0, c0, b0);
             if (tid < 6) encode(q1, c1, b1);
         }
-        // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one in-order counter)
-        if constexpr (REC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (REC: the next records must have arrived before this tile's stores are issued -- loads and stores share one in-order
+        // counter; they are looked at here so that the wait is the compiler's own: extract1_part_kernel)
+        if constexpr (REC)
+            asm volatile("" ::"v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]), "v"(rb[4]));
         __syncthreads();
         GOSS_STAMP(3);
 #if !defined(GOSS_E1_NOPRIO)
