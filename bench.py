@@ -70,6 +70,36 @@ def cpu_model():
     return "unknown"
 
 
+def note(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout): were a side record ever to hang, the last note says which."""
+    sys.stderr.write("bench.py [%s] %s\n" % (time.strftime("%H:%M:%S"), msg))
+    sys.stderr.flush()
+
+
+def run_bounded(cmd, seconds, **kw):
+    """subprocess.run with a time limit: a child that does not end is killed and reported, never waited for -- the headline
+    line must not be lost to a side record (the end-to-end CLI, the probes, the CPU baseline all run as children)."""
+    import subprocess
+    try:
+        return subprocess.run(cmd, timeout=seconds, **kw), None
+    except subprocess.TimeoutExpired:
+        return None, "timed out after %d s: %s" % (seconds, " ".join(str(c) for c in cmd[:4]))
+
+
+def cpu_baseline_child(k, read_len, genome_len, seed, sample_reads):
+    """cpu_baseline() in a child process with a time limit (the oracle's threaded driver runs 64 threads of C)."""
+    import subprocess
+    p, err = run_bounded([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "-k", str(k), "--read-len", str(read_len),
+                          "--genome", str(genome_len), "--seed", str(seed), "--cpu-sample-reads", str(sample_reads)], 420,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if err:
+        return {"failed": err}
+    try:
+        return json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return {"failed": p.stderr.decode(errors="replace")[-300:]}
+
+
 def cpu_baseline(k, read_len, genome_len, seed, sample_reads):
     """The CPU oracle (oracle/, a restatement of the reference algorithm: kind "port") timed on
     bounded samples of the same synthetic workload: on one core, and with T = min(cores, 64) worker
@@ -146,7 +176,9 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
     try:
         fq = os.path.join(d, "reads.fq")
         t0 = time.perf_counter()
-        p = subprocess.run([goss, "synth-reads", str(want), str(read_len), str(genome_len), str(seed), fq], stderr=subprocess.PIPE)
+        p, err = run_bounded([goss, "synth-reads", str(want), str(read_len), str(genome_len), str(seed), fq], 300, stderr=subprocess.PIPE)
+        if err:
+            return {"failed": err}
         if p.returncode != 0:
             return {"failed": "synth-reads: " + p.stderr.decode(errors="replace")[-300:]}
         gen_s = time.perf_counter() - t0
@@ -157,8 +189,10 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
                 if f.startswith("ks"):
                     os.unlink(os.path.join(d, f))
             t0 = time.perf_counter()
-            p = subprocess.run([goss, "build-kmer-set", "-k", str(k), "-T", str(threads), "-i", fq, "-O", os.path.join(d, "ks"), "-v"],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            p, err = run_bounded([goss, "build-kmer-set", "-k", str(k), "-T", str(threads), "-i", fq, "-O", os.path.join(d, "ks"), "-v"], 150,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if err:
+                return {"failed": err}
             runs.append(time.perf_counter() - t0)
             logs.append(p.stderr.decode(errors="replace"))
             if p.returncode != 0:
@@ -171,9 +205,11 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
         for _ in range(2):
             t0 = time.perf_counter()
             with open(os.devnull, "wb") as null:
-                subprocess.run([goss, "dump-bases", "-T", str(threads), "-i", fq], stdout=null, stderr=subprocess.PIPE)
+                _, err = run_bounded([goss, "dump-bases", "-T", str(threads), "-i", fq], 90, stdout=null, stderr=subprocess.PIPE)
+            if err:
+                break
             parse.append(time.perf_counter() - t0)
-        parse_s = min(parse)
+        parse_s = min(parse) if parse else float("nan")
         m = re.search(r"HBM arena: (\d+) GB mapped in ([0-9.]+)s", log)
         w = re.search(r"k-mer windows: (\d+)", log)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("ks"))
@@ -201,7 +237,10 @@ def multi_gpu_probe(ranks=8):
               "--no-cpu-baseline", "--e2e-reads", "0"]
     out = {"what": "one rank's share of a %d-GPU build (125 M reads per GPU) measured on one GPU; projection by arithmetic" % ranks}
     for name, extra in (("counted_1", ["--exchange", "counted"]), ("records_%d" % ranks, ["--exchange", "records", "--route-parts", str(ranks)])):
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        p, err = run_bounded([sys.executable, os.path.abspath(__file__)] + common + extra, 300, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if err:
+            out[name] = {"failed": err}
+            continue
         try:
             d = json.loads(p.stdout.decode().strip().splitlines()[-1])
             out[name] = {"ms_per_step": d["ms_per_step"], "windows_per_step": d["value"] * 1e6 * d["ms_per_step"] * 1e-3,
@@ -340,6 +379,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and print its record: the child "
+                    "process of the default run's cpu_baseline")
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end CLI record: C2's 100 M by default, "
                     "fewer when the scratch file system has no room (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed-by-the-headline C4 record (build-graph k=55, 200 M reads)")
@@ -356,6 +397,9 @@ def main():
                     "two keys per window); not the headline metric")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.k, args.read_len, args.genome, args.seed, args.cpu_sample_reads)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -551,11 +595,13 @@ def main():
                             "frac": o["achieved"] / HBM_PEAK_GBS}
         out["roofline"]["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k, L, genome_len, args.seed, args.cpu_sample_reads)
+            note("headline done: %.1f ms per step; CPU baseline (child process, <= 420 s)" % (dt / args.steps * 1e3))
+            out["cpu_baseline"] = cpu_baseline_child(k, L, genome_len, args.seed, args.cpu_sample_reads)
             # BASELINE.md holds no published figure for this metric: the ratio is against the CPU port timed on
             # this box's host cores just above (same synthetic workload, bounded sample)
-            out["vs_baseline"] = value / out["cpu_baseline"]["value"]
-            out["vs_baseline_of"] = "cpu_baseline.value (oracle port, %d threads, this box)" % out["cpu_baseline"]["cores"]
+            if "value" in out["cpu_baseline"]:
+                out["vs_baseline"] = value / out["cpu_baseline"]["value"]
+                out["vs_baseline_of"] = "cpu_baseline.value (oracle port, %d threads, this box)" % out["cpu_baseline"]["cores"]
         # beside the headline, never part of `value`: the end-to-end CLI on a bounded FASTQ sample, and
         # BASELINE config C4 (build-graph k = 55, 200 M x 150 bp reads) through the same library
         if world == 1 and not use_dist and not args.graph:
@@ -565,6 +611,7 @@ def main():
                 del bases
                 torch.cuda.empty_cache()
                 bases = None
+                note("end-to-end CLI record (children, each with a time limit)")
                 out["e2e"] = e2e_record(n_e2e, L, genome_len, args.seed, k, max(1, min(os.cpu_count() or 1, 64)))
                 # SURVEY.md section 8(d)'s own metric (first input byte -> last file closed), copied where a reader of
                 # the roofline block sees it: never `value`
@@ -576,9 +623,12 @@ def main():
             if not args.no_extra and not (args.reads or args.genome):
                 bases = None
                 torch.cuda.empty_cache()
+                note("C4 record")
                 out["extra"] = c4_record(g, torch, device, dev_index)
                 torch.cuda.empty_cache()
+                note("multi-GPU probe (two children, <= 300 s each)")
                 out["multi_gpu_probe"] = multi_gpu_probe(8)
+                note("side records done")
         # RCCL writes a version banner through C stdio; flush it so that the JSON line is last
         import ctypes
         ctypes.CDLL(None).fflush(None)

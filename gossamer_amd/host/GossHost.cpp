@@ -869,7 +869,20 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         {
             const auto a = now();
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return res[i].done || allocFailed.load(); });
+            // Buffers lent to the library (packed pushes) come back only from inside a library call of THIS thread.  When
+            // all of them are lent -- a burst of parsed chunks pushed back to back, their copies still queued -- the
+            // workers wait for a buffer, chunk i is nobody's yet, and waiting here without calling the library would
+            // wait for ever (one build in four hung that way once the device side had got faster): while buffers are
+            // out and none is free, the wait is bounded and the library is asked to hand them back.
+            while (!cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return res[i].done || allocFailed.load(); }))
+            {
+                if (lent > 0 && freeBufs.empty() && pushPacked && pushPacked->drain)
+                {
+                    lk.unlock();
+                    pushPacked->drain();
+                    lk.lock();
+                }
+            }
             // no buffer could be had: the workers have left and nobody will parse this chunk
             if (!res[i].done) throw Error::General("cannot allocate parser buffers\n");
             r = res[i];
