@@ -676,16 +676,19 @@ constexpr uint64_t kPadKey = ~0ULL;              // no key: one-word keys use at
 //   * stores reach HBM as they are issued (nothing merges two partial writes of a 64-byte granule
 //     on the way: 1.4-1.5 x the bytes when runs start anywhere), so a tile stores only whole
 //     granules: per bucket the keys beyond a multiple of 8 wait in the registers of the thread that
-//     owns the bucket (<= 7 keys) and go in front of the next tile's keys of that bucket;
+//     owns the bucket (<= 7 keys) for the next tile's keys of that bucket;
 //   * MODE 0 stores the strand representative (strand_rep) instead of the canonical form.
 // The fourth form (round 4) takes the arithmetic out of the three places that handled every key:
-//   * in LDS every bucket's STREAM of the tile (keys carried in, then the new keys by rank) lies in one piece that
-//     starts on a granule: a key's place is tab[digit] + rank -- one 4-byte table read and one add where the third
-//     form split every stream into a stored and a carried part (an 8-byte table read, a compare and two selects per
-//     key); the last, partial granule of a stream is what the bucket carries out;
-//   * the thread that owns a bucket writes the HBM address of every granule of its stream into `gaddr` (or `skip`
-//     for the partial one), so the store loop is: 16 bytes of keys, one 4-byte address, one store -- no digit, no
+//   * in LDS every bucket's NEW keys of the tile lie in one piece, by rank, that starts on a granule: a key's place
+//     is tab[digit] + rank -- one 4-byte table read and one add where the third form laid a stored and a carried
+//     part of every bucket apart (an 8-byte table read, a compare and two selects per key).  Order inside a bucket
+//     does not matter, so the carried keys need not go in front: the bucket's last, partial granule is TOPPED UP from
+//     them when together they fill it (the rest stay in their registers), else its keys join them after the scatter;
+//   * the thread that owns a bucket writes the HBM address of every whole granule of its keys into `gaddr` (`skip`
+//     for a partial one), so the store loop is: 16 bytes of keys, one 4-byte address, one store -- no digit, no
 //     table of block positions, no 64-bit selects (17 instructions per key before, 3 now);
+//   * a bucket's next block is reserved a tile AHEAD of the one that opens it: the returning atomic on the bucket's
+//     cursor (1-3 us under load) is off the critical path of phase C;
 //   * windows come out of the register buffer by constant funnel shifts (the reverse complement is a bit field of
 //     the complemented bases; the bases rolled into the forward strand and the strand-deciding middle bits are
 //     pre-shifted once per thread), in 32-bit halves: 27 -> 16 instructions per window.
