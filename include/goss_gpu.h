@@ -124,7 +124,10 @@ int goss_gpu_push_bases_host_async(goss_gpu_ctx* ctx, const char* bases, uint64_
  * (north_star: "2-bit read encoding"; the per-base encoder it stands for is GossReadBaseString.hh:133-188); on the
  * device the groups are unpacked into the byte form the extraction kernels read (one more byte written and read per
  * base in HBM, 1/8 of what a key costs).  Windows never span two pushes.  _async: as goss_gpu_push_bases_host_async,
- * both arrays belong to the library until release(user).
+ * both arrays belong to the library until release(user).  A caller that recycles a bounded pool of such buffers must not
+ * wait for a free one (or for the thread that would fill it) without calling the library: release only ever runs inside a
+ * call on this context -- goss_gpu_flush is the one that makes every outstanding release happen (the `goss` parser's
+ * consumer does so while buffers are out and none is free; waiting without it hung one build in four).
  */
 int goss_gpu_push_packed_host(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases);
 int goss_gpu_push_packed_host_async(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases,

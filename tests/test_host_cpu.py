@@ -333,3 +333,18 @@ def test_parser_threads_pack_bases_to_two_bits(tmp_path):
     b = (bad[idx // 16] >> (idx % 16).astype(np.uint16)) & 1
     got = np.where(b == 1, 10, np.frombuffer(b"ACGT", dtype=np.uint8)[c]).astype(np.uint8).tobytes()
     assert got == want
+
+
+def test_bench_children_have_time_limits():
+    """bench.py's side records run as child processes with a time limit: a child that does not end is killed and
+    reported, the headline line is not lost to it (a hung CLI build once took the whole bench with it)."""
+    import importlib
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    t0 = time.time()
+    p, err = bench.run_bounded(["sleep", "30"], 1)
+    assert p is None and "timed out" in err and time.time() - t0 < 10
+    p, err = bench.run_bounded(["true"], 5)
+    assert err is None and p.returncode == 0
