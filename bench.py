@@ -343,14 +343,22 @@ def launch_ranks(n, argv):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     codes = [None] * n
+    # (a rank that never ends -- a collective nobody answers -- must not hold the launcher for ever: after
+    # GOSS_BENCH_RANK_TIMEOUT seconds, 1 800 by default, the ranks are ended and the launcher fails)
+    deadline = time.time() + float(os.environ.get("GOSS_BENCH_RANK_TIMEOUT", "1800"))
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
                 codes[r] = p.poll()
-        if any(c not in (None, 0) for c in codes):
+        if any(c not in (None, 0) for c in codes) or time.time() > deadline:
             for r, p in enumerate(procs):          # a rank failed: its peers would wait in a collective for ever
                 if codes[r] is None:
                     p.terminate()
+            if time.time() > deadline + 10:
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.kill()
+                        codes[r] = -9
         time.sleep(0.05)
     reader.join(10)
     out0 = b"".join(chunks)
