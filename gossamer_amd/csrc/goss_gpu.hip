@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -142,6 +143,8 @@ struct goss_gpu_ctx {
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
     int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
+    int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
+    uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
     uint32_t rem32_bits_min = 0;        // GOSS_GPU_REM32_BITS=<9..12>: at least that many second-level bits (tests)
     uint32_t rem32_bits_last = 0;       // second-level bits of the last chunk counted in that form
@@ -182,6 +185,9 @@ struct goss_gpu_ctx {
     BigMap res_big;                     // ... of the result (its u32 counts hold the value modulo 2^32, as the reference stores it)
     uint64_t windows = 0, keys_total = 0;
     bool finished = false, emitted = false;
+    // a group's route-and-exchange round failed half way: what this context had staged may be in records that were
+    // lost with the round -- every later push, exchange and finish is refused (GOSS_ERR_STATE) until goss_gpu_reset
+    bool broken = false;
     void* res_keys = nullptr;
     uint32_t* res_counts = nullptr;
     uint64_t M = 0;
@@ -1012,11 +1018,20 @@ int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_
     SegOut hso{};
     hso.stage_cap = cap;
     HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
-#define GOSS_LAUNCH_R32(SLOTS, SQ)                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(seg_hash_reduce32_kernel<SLOTS, SQ>), unit_grid(nseg), dim3(kTB), 0, c->stream, rems, seg_beg, \
+#define GOSS_LAUNCH_R32(KERNEL, SLOTS, SQ)                                                                               \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<SLOTS, SQ>), unit_grid(nseg), dim3(kTB), 0, c->stream, rems, seg_beg, \
                        seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rbits, sqbit, split_bits)
-    if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(2048, true); else GOSS_LAUNCH_R32(2048, false); }
-    else { if (squeeze) GOSS_LAUNCH_R32(4096, true); else GOSS_LAUNCH_R32(4096, false); }
+    // (round 5: buckets of four remainders, home bucket only in the fast path; GOSS_GPU_R32_FORM=0: the pair layout)
+    if (c->r32_form)
+    {
+        if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 2048, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 2048, false); }
+        else { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 4096, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 4096, false); }
+    }
+    else
+    {
+        if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32_kernel, 2048, true); else GOSS_LAUNCH_R32(seg_hash_reduce32_kernel, 2048, false); }
+        else { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32_kernel, 4096, true); else GOSS_LAUNCH_R32(seg_hash_reduce32_kernel, 4096, false); }
+    }
 #undef GOSS_LAUNCH_R32
     check_launch("32-bit segment counting kernel");
     SegOut* h = (SegOut*)c->h_pinned;
@@ -1469,7 +1484,9 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             const uint64_t per = m_est >> (8 + b2 + b3);
             int slots = 0;
             if (c->rem32_slots) slots = per <= (uint64_t)(c->rem32_slots / 4 * 3) || (b2 == 10 && b3 == (uint32_t)kSub32SplitMax) ? c->rem32_slots : 0;
-            else if (per <= 2048 / 4 * 3 * 3 / 4 && b3 == 0 && b2 == (uint32_t)kSub32BitsMin) slots = 2048;
+            // (buckets of four: what is not at home costs a second look, and at a load of 0.37 that is 1.5 % of the keys, at
+            // 0.19 a per-mille -- the small table only where it stays that empty)
+            else if (per <= (c->r32_small_max ? c->r32_small_max : c->r32_form ? 400u : 2048u / 4 * 3 * 3 / 4) && b3 == 0 && b2 == (uint32_t)kSub32BitsMin) slots = 2048;
             else if (per <= 4096 / 4 * 3 * 3 / 4) slots = 4096;
             if (!slots) continue;
             r32_slots = slots; r32_bits = b2; rbits32 = rb; squeeze = sq; r32_split = b3;
@@ -2994,6 +3011,17 @@ int guarded(goss_gpu_ctx* c, F&& f, bool wait_bg = true)
         if (c) c->last_error = "host allocation failed";
         return GOSS_ERR_OOM;
     }
+    catch (const std::system_error& e)
+    {
+        // (a thread that could not be started: nothing may cross the C boundary)
+        if (c) c->last_error = std::string("a host resource is exhausted: ") + e.what();
+        return GOSS_ERR_OOM;
+    }
+    catch (const std::exception& e)
+    {
+        if (c) c->last_error = std::string("unexpected failure: ") + e.what();
+        return GOSS_ERR_STATE;
+    }
 }
 
 }  // namespace
@@ -3001,6 +3029,7 @@ int guarded(goss_gpu_ctx* c, F&& f, bool wait_bg = true)
 // ============================================================================================
 // C ABI
 // ============================================================================================
+static const char* const kBrokenMsg = "an exchange round of this context's group failed half way: reads staged before it may be lost (goss_gpu_reset starts over)";
 
 extern "C" {
 
@@ -3062,6 +3091,8 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_REM32_BITS"); if (e && std::atoi(e) >= 9 && std::atoi(e) <= 10) c->rem32_bits_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SPLIT"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 4) c->rem32_split_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_R32_FORM"); if (e) c->r32_form = std::atoi(e) ? 1 : 0; }
+    { const char* e = std::getenv("GOSS_GPU_R32_SMALL_MAX"); if (e) c->r32_small_max = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }
@@ -3221,6 +3252,7 @@ int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nb
 {
     if (!c || (!d_bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     return guarded(c, [&]() {
         flush_staging(c);
         if (c->words == 1) push_device<Key1>(c, (const uint8_t*)d_bases, nbytes);
@@ -3368,6 +3400,17 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
     // them -- so a push costs one copy (two when the caller's arrays do not lie back to back) and one launch)
     uint64_t pos = 0, kill = 0;
     bool cont = false;
+    if (c->deferred)
+    {
+        // (goss_gpu.h: a deferred push that does not fit is refused with NOTHING of it taken -- the caller runs the
+        // group's exchange round and pushes the same batch again, so a piece staged before the refusal would be
+        // counted twice.  The whole push must fit behind what is staged, or the state is not touched.)
+        const uint64_t at0 = (c->stage_fill + 15) & ~15ULL;
+        const uint64_t need = ((nbases + 15) / 16 + 1) * 16;
+        if (at0 + need + 32 > c->stage_cap)
+            throw StatusError{GOSS_ERR_BUFFER, c->stage_fill ? "the staging buffer is full and counting is deferred: goss_gpu_group_route_exchange first (goss_gpu_stage_room says how much fits)"
+                                                             : "a push larger than the staging buffer while counting is deferred"};
+    }
     if (c->stage_fill & 15ULL)          // (bytes staged by the byte form: pad to a boundary)
     {
         const uint64_t at = (c->stage_fill + 15) & ~15ULL;
@@ -3421,6 +3464,7 @@ int goss_gpu_push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     return guarded(c, [&]() { push_bases_host(c, bases, nbytes, false, nullptr, nullptr); }, false);
 }
 
@@ -3428,6 +3472,7 @@ int goss_gpu_push_bases_host_async(goss_gpu_ctx* c, const char* bases, uint64_t 
 {
     if (!c || (!bases && nbytes)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     return guarded(c, [&]() {
         // (a failed push hands the buffer back to the caller on return: what was queued from it must have run)
         try { push_bases_host(c, bases, nbytes, true, release, user); }
@@ -3439,6 +3484,7 @@ int goss_gpu_push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint
 {
     if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     return guarded(c, [&]() { push_packed_host(c, codes, nonbase, nbases, false, nullptr, nullptr); }, false);
 }
 
@@ -3447,6 +3493,7 @@ int goss_gpu_push_packed_host_async(goss_gpu_ctx* c, const uint32_t* codes, cons
 {
     if (!c || (nbases && (!codes || !nonbase))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     return guarded(c, [&]() {
         try { push_packed_host(c, codes, nonbase, nbases, true, release, user); }
         catch (...) { if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); throw; }
@@ -3463,6 +3510,7 @@ int goss_gpu_finish(goss_gpu_ctx* c, goss_gpu_counts* out)
 {
     if (!c) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "finish called twice"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     int rc = guarded(c, [&]() {
         ensure_arena(c);
         flush_staging(c);
@@ -3956,9 +4004,18 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
     std::vector<std::vector<uint64_t>> recs(n, std::vector<uint64_t>(n, 0)), wins(n, std::vector<uint64_t>(n, 0)), first(n, std::vector<uint64_t>(n, 0));
     std::vector<int> status(n, GOSS_OK);
     {
+        // (a thread that cannot be started must not take the process down with the ones that were: join what runs,
+        // then report; and once one member has failed, the others' staged reads are in records nobody will count --
+        // the whole group is marked and refuses further work)
         std::vector<std::thread> pool;
+        auto join_all = [&]() { for (auto& t : pool) if (t.joinable()) t.join(); };
+        auto mark_broken = [&]() { for (uint32_t i = 0; i < n; ++i) ctxs[i]->broken = true; };
+        auto start = [&](std::function<void()> f) {
+            try { pool.emplace_back(std::move(f)); }
+            catch (const std::system_error& e) { join_all(); mark_broken(); throw StatusError{GOSS_ERR_OOM, std::string("no thread for a member of the group: ") + e.what()}; }
+        };
         for (uint32_t i = 0; i < n; ++i)
-            pool.emplace_back([&, i]() {
+            start([&, i]() {
                 goss_gpu_ctx* c = ctxs[i];
                 status[i] = guarded(c, [&]() {
                     if (!c->stage || c->stage_fill == 0) return;
@@ -3986,9 +4043,9 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
                     c->stage_fill = 0;          // (the windows of these bases now live in the records)
                 });
             });
-        for (auto& t : pool) t.join();
+        join_all();
         for (uint32_t i = 0; i < n; ++i)
-            if (status[i] != GOSS_OK) throw StatusError{status[i], "member " + std::to_string(i) + ": " + ctxs[i]->last_error};
+            if (status[i] != GOSS_OK) { mark_broken(); throw StatusError{status[i], "member " + std::to_string(i) + ": " + ctxs[i]->last_error}; }
     }
     const double route_ms = ms_since(t0);
     // 2. part p of every member -> member p's inbox
@@ -4063,15 +4120,24 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
     const auto t2 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> pool;
+        auto join_all = [&]() { for (auto& t : pool) if (t.joinable()) t.join(); };
         for (uint32_t p = 0; p < n; ++p)
-            pool.emplace_back([&, p]() {
+        {
+            auto work = [&, p]() {
                 uint64_t w = 0;
                 for (uint32_t i = 0; i < n; ++i) w += wins[i][p];
                 status[p] = in_off[p][n] ? goss_gpu_push_records_device(ctxs[p], ctxs[p]->grp_inbox, in_off[p][n], w) : GOSS_OK;
-            });
-        for (auto& t : pool) t.join();
+            };
+            try { pool.emplace_back(work); }
+            catch (const std::system_error&) { work(); }          // (no thread to be had: this member's share on the caller's)
+        }
+        join_all();
         for (uint32_t p = 0; p < n; ++p)
-            if (status[p] != GOSS_OK) throw StatusError{status[p], "member " + std::to_string(p) + " counting its records: " + ctxs[p]->last_error};
+            if (status[p] != GOSS_OK)
+            {
+                for (uint32_t i = 0; i < n; ++i) ctxs[i]->broken = true;
+                throw StatusError{status[p], "member " + std::to_string(p) + " counting its records: " + ctxs[p]->last_error};
+            }
     }
     if (st)
     {
@@ -4114,6 +4180,7 @@ int goss_gpu_group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int tra
         goss_gpu_ctx* c = ctxs[i];
         if (c->k != c0->k || c->mode != c0->mode) { c0->last_error = "group: contexts of different k or mode"; return GOSS_ERR_INVALID_ARG; }
         if (c->finished) { c0->last_error = "group route exchange after finish"; return GOSS_ERR_STATE; }
+        if (c->broken) { c0->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
         if (c->len > 63) { c0->last_error = "records carry windows of at most 63 bases"; return GOSS_ERR_INVALID_ARG; }
         for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == c) { c0->last_error = "group: the same context twice"; return GOSS_ERR_INVALID_ARG; }
     }
@@ -4236,6 +4303,7 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         c->files.clear();
         c->windows = c->keys_total = 0;
         c->finished = c->emitted = false;
+        c->broken = false;
         c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;
         c->arena.lo = 0; c->arena.hi = c->arena.size;
         if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
@@ -4249,6 +4317,7 @@ int goss_gpu_push_run_device(goss_gpu_ctx* c, const void* d_keys, const uint32_t
 {
     if (!c || (m && (!d_keys || !d_counts))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     if (m == 0) return GOSS_OK;
     return guarded(c, [&]() {
         ensure_arena(c);
@@ -4271,6 +4340,7 @@ int goss_gpu_push_run_host(goss_gpu_ctx* c, const uint64_t* keys, const uint32_t
 {
     if (!c || (m && (!keys || !counts))) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     if (m == 0) return GOSS_OK;
     return guarded(c, [&]() {
         ensure_arena(c);
@@ -4347,6 +4417,7 @@ static int push_keys_entry(goss_gpu_ctx* c, const void* keys, uint64_t n, bool o
 {
     if (!c || (n && !keys)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     if (n == 0) return GOSS_OK;
     return guarded(c, [&]() {
         if (c->words == 1) push_keys<Key1>(c, keys, n, on_host); else push_keys<Key2>(c, keys, n, on_host);
@@ -4416,6 +4487,7 @@ int goss_gpu_push_records_device(goss_gpu_ctx* c, const void* d_records, uint64_
 {
     if (!c || (nrecords && !d_records)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     if (c->len > 63) { c->last_error = "records carry windows of at most 63 bases"; return GOSS_ERR_INVALID_ARG; }
     return guarded(c, [&]() {
         flush_staging(c);
@@ -4464,6 +4536,7 @@ int goss_gpu_push_run_sparse(goss_gpu_ctx* c, const goss_gpu_sparse_run* s)
 {
     if (!c || !sparse_run_ok(s)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     if (s->count == 0) return GOSS_OK;
     return guarded(c, [&]() {
         ensure_arena(c);
@@ -4490,6 +4563,7 @@ int goss_gpu_push_run_graph(goss_gpu_ctx* c, const goss_gpu_sparse_run* edges, c
 {
     if (!c || !sparse_run_ok(edges) || !v || !sparse_run_ok(&v->ord1p) || !sparse_run_ok(&v->ord2p)) return GOSS_ERR_INVALID_ARG;
     if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
     const uint64_t m = edges->count, n1 = v->ord1p.count, n2 = v->ord2p.count;
     if (m == 0) return GOSS_OK;
     if (v->ord0_bytes < m || v->ord1_bytes < n1 || v->ord2_bytes < 2 * n2 || (m && !v->ord0) || (n1 && !v->ord1) || (n2 && !v->ord2))

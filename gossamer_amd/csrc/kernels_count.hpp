@@ -1,6 +1,7 @@
 // kernels_count.hpp -- per-segment counting in LDS hash tables, ordering of (key,count) groups.
 // Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp, in this order.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -806,6 +807,340 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
     unsigned long long ck[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) ck[j] = tab[tid * kPer + j];
+    for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
+    if (tid == 0) big = 0;
+    __syncthreads();
+    const uint32_t rem_bits = rbits - (SQ ? 1u : 0u);
+    // (the top split_bits bits are the same for the whole sub-segment: the bins are cut below them)
+    const uint32_t bsh = rem_bits > (uint32_t)kBinBits + split_bits ? rem_bits - split_bits - kBinBits : 0;
+    uint32_t rnk[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if ((ck[j] >> 32) != 0) rnk[j] = atomicAdd(&bins[((uint32_t)ck[j] >> bsh) & (kBins - 1)], 1u);
+    __syncthreads();
+    uint32_t bn[kBinsPer], bs[kBinsPer], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q) { bn[q] = bins[tid * kBinsPer + q]; mine += bn[q]; }
+    uint32_t tot_occ;
+    uint32_t at = block_excl_scan_n<uint32_t, NT / 64>(mine, sh_scan2, &tot_occ);
+    lds_vu32 vbig = (lds_vu32)&big;
+#pragma unroll
+    for (int q = 0; q < kBinsPer; ++q)
+    {
+        bs[q] = at; bins[tid * kBinsPer + q] = at; at += bn[q];
+        if (bn[q] > 24) *vbig = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if ((ck[j] >> 32) != 0)
+            tab[bins[((uint32_t)ck[j] >> bsh) & (kBins - 1)] + rnk[j]] = (ck[j] << 32) | (ck[j] >> 32);
+    __syncthreads();
+    if (!big)
+    {
+#pragma unroll
+        for (int q = 0; q < kBinsPer; ++q)
+            for (uint32_t i = 1; i < bn[q]; ++i)
+            {
+                const unsigned long long kk = tab[bs[q] + i];
+                uint32_t j = i;
+                while (j > 0 && tab[bs[q] + j - 1] > kk) { tab[bs[q] + j] = tab[bs[q] + j - 1]; --j; }
+                tab[bs[q] + j] = kk;
+            }
+        __syncthreads();
+    }
+    else
+    {
+        uint32_t nsort = 512;
+        while (nsort < tot_occ) nsort <<= 1;
+        for (uint32_t i = tot_occ + tid; i < nsort; i += NT) tab[i] = ~0ULL;
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= nsort; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
+            {
+                for (uint32_t t = tid; t < nsort / 2; t += NT)
+                {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t p = i + j;
+                    const bool up = (i & k2) == 0;
+                    const unsigned long long a = tab[i], c2 = tab[p];
+                    if ((a > c2) == up) { tab[i] = c2; tab[p] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    const uint32_t d = ndist;
+    if (tid == 0)
+    {
+        sh_base = atomicAdd(&so->cursor, (unsigned long long)d);
+        if (sh_base + d > so->stage_cap) { atomicOr(&so->overflow, 2u); sh_base = ~0ULL; }
+        seg_pos[s] = sh_base;
+        seg_cnt[s] = d;
+    }
+    __syncthreads();
+    const uint64_t ob = sh_base;
+    if (ob == ~0ULL) return;
+    const uint64_t prefix = (uint64_t)(s >> split_bits) << rbits;
+    for (uint32_t i = tid; i < d; i += NT)
+    {
+        const unsigned long long v = tab[i];
+        stage_keys[ob + i].lo = prefix | rem32_unpack<SQ>((uint32_t)(v >> 32), sqbit);
+        stage_counts[ob + i] = (uint32_t)v;
+    }
+}
+
+// Which of a bucket's four slots holds the key: the byte offset of the slot (0, 4, 8, 12), or 16 for none.  Four compares
+// into four scalar masks, then four selects: written out because the compiler runs every compare and its select through
+// vcc back to back, with an `s_nop 1` between them for the two wait states a mask needs before a vector instruction may
+// read it -- 16 issue slots where these 8 instructions hide each other's.
+__device__ __forceinline__ uint32_t r32b_slot_offset(const uint32_t __attribute__((ext_vector_type(4)))& q, uint32_t k)
+{
+    uint32_t off;
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_eq_u32_e64 %1, %5, %9\n\t"
+        "v_cmp_eq_u32_e64 %2, %6, %9\n\t"
+        "v_cmp_eq_u32_e64 %3, %7, %9\n\t"
+        "v_cmp_eq_u32_e64 %4, %8, %9\n\t"
+        "v_cndmask_b32_e64 %0, 16, 12, %1\n\t"
+        "v_cndmask_b32_e64 %0, %0, 8, %2\n\t"
+        "v_cndmask_b32_e64 %0, %0, 4, %3\n\t"
+        "v_cndmask_b32_e64 %0, %0, 0, %4"
+        : "=&v"(off), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(q.w), "v"(q.z), "v"(q.y), "v"(q.x), "v"(k));
+    return off;
+}
+
+// The same counting with what round 5's look at the instruction stream took out (profiles/r05/SUMMARY.md): the kernel
+// above issues 51 vector instructions and three LDS operations per key -- two 16-byte bucket reads and the add -- for a
+// table whose LDS pipe is 70-85 % busy.  Here a bucket is FOUR remainders = 16 bytes of a key array, with the four
+// counts at the same offset of a count array: one 16-byte read shows a key four candidates where the pair layout
+// shows two, so at the same table size far fewer keys live outside their home bucket (load 0.19: 0.13 % of them
+// against 1.8 %) and the fast path looks at the home bucket ONLY: mix, one read, four compare-selects for the offset of
+// the count word, one add.  A key that is not at home (that per-mille, and every first occurrence) looks at its second
+// bucket under a wave-level branch and otherwise waits for the slow path, which walks home, second, second + 1, ...
+// Empty slots of bucket b hold a key that never looks at b in either of those two places (home b ^ 1, second b ^ 2), so
+// neither needs a look at the counts; the slow path's chain can reach b with that very key, and skips the bucket.
+// A slot is claimed by a 32-bit CAS on its key word (marker -> key); counts are only ever added to.
+template <int SLOTS, bool SQ>
+__global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
+                                                                const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
+                                                                uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
+                                                                Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
+                                                                uint32_t rbits, uint32_t sqbit, uint32_t split_bits)
+{
+    constexpr int NT = kTB;
+    constexpr int kLimit = SLOTS / 4 * 3;
+    constexpr int BB = SLOTS == 4096 ? 10 : SLOTS == 2048 ? 9 : -1;       // log2(buckets of four slots)
+    constexpr uint32_t NB = SLOTS / 4;
+    constexpr uint32_t kCnt = 4u * SLOTS;                                 // byte offset of the count array
+    static_assert(BB > 0, "table size");
+    // keys, counts, then a word per lane (64) for the adds of keys that missed; the ordering below reuses all of it as pairs
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[SLOTS + 32];
+    __shared__ uint32_t ndist, ovf;
+    __shared__ unsigned long long sh_base;
+    const uint32_t s = unit_block(), tid = threadIdx.x;
+    const uint64_t b = seg_off[s], e = seg_end[s];
+    if (b == e)
+    {
+        if (tid == 0) { seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    if (e - b > 0xFFFFFFF0ULL)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 2u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
+    typedef const __attribute__((address_space(3))) u32x4* lds_bucket_plain;
+    typedef const volatile __attribute__((address_space(3))) u32x4* lds_bucket_ptr;
+    typedef __attribute__((address_space(3))) uint32_t* lds_word;
+    const lds_bytes tb = (lds_bytes)tab;
+    uint32_t* const tkey = reinterpret_cast<uint32_t*>(tab);
+    uint32_t* const tcnt = tkey + SLOTS;
+    // (f of the marker: home b ^ 1, odd field 3 -> second bucket b ^ 2)
+    auto marker = [](uint32_t bkt) -> uint32_t { return r32_unmix(((bkt ^ 1u) << (32 - BB)) | (3u << (32 - 2 * BB))); };
+    for (uint32_t i = tid; i < NB; i += NT)
+    {
+        const uint32_t m = marker(i);
+        *(__attribute__((address_space(3))) u32x4*)(tb + 16 * i) = u32x4{m, m, m, m};
+        *(__attribute__((address_space(3))) u32x4*)(tb + kCnt + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (tid < 32) tab[SLOTS + tid] = 0;
+    if (tid == 0) { ndist = 0; ovf = 0; }
+    __syncthreads();
+
+    lds_vu32 vovf = (lds_vu32)&ovf;
+    const uint32_t dummy = 8u * (uint32_t)SLOTS + 4u * (tid & 63u);          // the lane's own word behind the table
+    auto home_of = [](uint32_t f) -> uint32_t { return f >> (32 - BB); };
+    auto second_of = [](uint32_t f, uint32_t h) -> uint32_t { return h ^ (((f >> (32 - 2 * BB)) & (NB - 1u)) | 1u); };
+
+    constexpr int kVec = 4;                                  // 16-byte loads in flight per lane
+    const uint32_t head = (uint32_t)(b & 3ULL);
+    const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + (b - head));
+    const uint32_t n = (uint32_t)(e - b) + head;
+    const uint32_t nvec = (n + 3u) >> 2, nfull = n >> 2;      // vectors, and vectors of four live remainders
+    u32x4 nxt[kVec];
+#pragma unroll
+    for (int u = 0; u < kVec; ++u)
+    {
+        const uint32_t i = (uint32_t)u * NT + tid;
+        nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
+    }
+    for (uint32_t i0 = 0; i0 < nvec; i0 += (uint32_t)NT * kVec)
+    {
+        u32x4 cur[kVec];
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) cur[u] = nxt[u];
+        // software pipeline: the next batch's loads are in flight while this one is inserted
+#pragma unroll
+        for (int u = 0; u < kVec; ++u)
+        {
+            const uint32_t i = i0 + (uint32_t)(kVec + u) * NT + tid;
+            nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
+        }
+        uint32_t pend = 0;                                   // bit 4 u + j: remainder j of vector u is left to the slow path
+        // four keys at a time: their home buckets read together and looked at; a key that is not at home looks at its
+        // second bucket under a wave-level branch of its own (a per-mille of the keys once the table is filled: the branch
+        // is scalar work unless some lane needs it); not there either -> pend.  `live`: which of the four are the segment's
+        auto four_keys = [&](const u32x4& v, uint32_t bit0, uint32_t live, auto whole_tag) {
+            constexpr bool kWhole = decltype(whole_tag)::value;
+            const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
+            uint32_t f[4], a1[4], off[4];
+            u32x4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                f[j] = r32_mix(kk[j]);
+                a1[j] = home_of(f[j]) << 4;
+                q[j] = *(lds_bucket_plain)(tb + a1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[j] = r32b_slot_offset(q[j], kk[j]);
+            uint32_t t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                t[j] = kCnt + a1[j] + off[j];
+                bool miss = off[j] == 16u;
+                if (!kWhole) miss = miss && ((live >> j) & 1u);
+                if (__builtin_expect(__ballot(miss) != 0, 0))
+                {
+                    if (miss)
+                    {
+                        const uint32_t a2 = second_of(f[j], a1[j] >> 4) << 4;
+                        const u32x4 q2 = *(lds_bucket_plain)(tb + a2);
+                        off[j] = r32b_slot_offset(q2, kk[j]);
+                        t[j] = kCnt + a2 + off[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                // (off = 16: not found -- the add goes to the lane's own word and the key waits in pend)
+                uint32_t o = off[j];
+                if (!kWhole) o = ((live >> j) & 1u) ? o : 32u;          // (not the segment's: no add, no wait either)
+                __hip_atomic_fetch_add((lds_word)(tb + (o >= 16u ? dummy : t[j])), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pend |= (o & 16u) << (bit0 + j);          // (bits 4 .. 19)
+            }
+        };
+        // every vector of the batch whole?  (all but a segment's last batch: no validity arithmetic in that form)
+        const bool whole = i0 + (uint32_t)NT * kVec <= nfull && (i0 != 0 || head == 0);
+        if (whole)
+        {
+#pragma unroll
+            for (int u = 0; u < kVec; ++u) four_keys(cur[u], 4 * u, 0xFu, std::true_type{});
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < kVec; ++u)
+            {
+                const uint32_t i = i0 + (uint32_t)u * NT + tid;
+                const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
+                uint32_t live = (1u << have) - 1u;
+                if (i == 0) live &= ~((1u << head) - 1u);
+                four_keys(cur[u], 4 * u, live, std::false_type{});
+            }
+        }
+        // slow path: every lane walks its own queue of leftover keys, one probe per wave iteration
+        if (__ballot(pend != 0))
+        {
+            pend >>= 4;
+            uint32_t key = 0, bk = 0, st = 0;
+            bool busy = false;
+            for (;;)
+            {
+                if (!busy && pend)
+                {
+                    const uint32_t u = __ffs(pend) - 1;
+                    pend &= pend - 1;
+#pragma unroll
+                    for (int uu = 0; uu < kVec; ++uu)
+                        if ((u >> 2) == (uint32_t)uu)
+                        {
+                            const uint32_t j = u & 3u;
+                            key = j == 0 ? cur[uu].x : j == 1 ? cur[uu].y : j == 2 ? cur[uu].z : cur[uu].w;
+                        }
+                    bk = home_of(r32_mix(key));
+                    st = 0;
+                    busy = true;
+                }
+                if (!__ballot(busy)) break;
+                if (busy)
+                {
+                    const u32x4 q = *(lds_bucket_ptr)(tb + 16u * bk);
+                    const uint32_t mk = marker(bk);
+                    uint32_t hit = ~0u;                       // slot that holds the key
+                    bool move = false;
+                    if (key == mk) move = true;               // (this bucket's empty slots look like the key: it lives elsewhere)
+                    else if (q.x == key) hit = 4 * bk;
+                    else if (q.y == key) hit = 4 * bk + 1;
+                    else if (q.z == key) hit = 4 * bk + 2;
+                    else if (q.w == key) hit = 4 * bk + 3;
+                    else if (q.x == mk || q.y == mk || q.z == mk || q.w == mk)
+                    {
+                        const uint32_t slot = 4 * bk + (q.x == mk ? 0u : q.y == mk ? 1u : q.z == mk ? 2u : 3u);
+                        const uint32_t old = atomicCAS(&tkey[slot], mk, key);
+                        if (old == mk)
+                        {
+                            const uint32_t nd = atomicAdd(&ndist, 1u);
+                            if (nd + 1 > (uint32_t)kLimit) *vovf = 1;
+                            hit = slot;
+                        }
+                        else if (old == key) hit = slot;
+                        // else: somebody else took the slot; look at this bucket again
+                    }
+                    else move = true;
+                    if (move)
+                    {
+                        if (st == 0) { bk = second_of(r32_mix(key), bk); st = 1; }
+                        else bk = (bk + 1) & (NB - 1u);
+                    }
+                    if (hit != ~0u) { atomicAdd(&tcnt[hit], 1u); busy = false; }
+                }
+                if (*vovf) break;
+            }
+        }
+        if (*vovf) break;
+    }
+    __syncthreads();
+    if (ovf)
+    {
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        return;
+    }
+
+    // Order the occupied slots on the remainder (as above): bucket sort on the top bits, insertion sort of every bin
+    constexpr int kPer = SLOTS / NT;
+    constexpr int kBins = SLOTS / 4, kBinsPer = kBins / NT, kBinBits = BB;
+    __shared__ uint32_t bins[kBins];
+    __shared__ uint32_t sh_scan2[NT / 64 + 1];
+    __shared__ uint32_t big;
+    unsigned long long ck[kPer];              // count << 32 | remainder
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) ck[j] = ((unsigned long long)tcnt[tid * kPer + j] << 32) | tkey[tid * kPer + j];
     for (uint32_t i = tid; i < kBins; i += NT) bins[i] = 0;
     if (tid == 0) big = 0;
     __syncthreads();

@@ -138,9 +138,12 @@ def test_group_route_exchange_builds_the_oracles_object(oracle, kind, k, parts):
         assert got[name] == exp[name], name
 
 
-def test_deferred_context_reports_a_full_staging_buffer(oracle):
+@pytest.mark.parametrize("packed", [False, True])
+def test_deferred_context_reports_a_full_staging_buffer(oracle, packed):
     """A deferred context refuses the push that does not fit (nothing of it taken) and says how much fits; what is
-    staged when it is finished without an exchange is counted locally -- same result."""
+    staged when it is finished without an exchange is counted locally -- same result.  packed: the 2-bit form of the
+    push, whose first piece would fit into what is left of the buffer (>= 64 KB) while the whole push does not -- a
+    refusal after that piece was staged would count its windows twice when the caller pushes the batch again."""
     import os
     reads = g.synth_reads_host(4000, 150, 50000, seed=5)
     exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="o")
@@ -152,17 +155,21 @@ def test_deferred_context_reports_a_full_staging_buffer(oracle):
             assert cap == 256 << 10 and 0 < room <= cap
             lines = reads.split(b"\n")[:-1]
             chunk = b"".join(l + b"\n" for l in lines[:1000])          # 151 000 bytes
-            ctx.push_host(chunk)
+            push = ctx.push_packed_host if packed else ctx.push_host
+            push(chunk)
             room2, _ = ctx.stage_room()
-            assert room2 == room - len(chunk)          # (the chunk ends with its own separator)
+            if packed:
+                assert room - len(chunk) - 64 <= room2 <= room - len(chunk) and room2 >= 65536          # (whole groups + a group of separators)
+            else:
+                assert room2 == room - len(chunk)          # (the chunk ends with its own separator)
             with pytest.raises(g.GossGpuError) as e:
-                ctx.push_host(chunk)
+                push(chunk)
             assert e.value.status == -9
             assert ctx.stage_room()[0] == room2
             st = g.group_route_exchange([ctx])
             assert 990 * 126 < st["windows"] <= 1000 * 126 and ctx.stage_room()[0] == room          # (a read in 97 holds an N)
             for i in range(1, 4):
-                ctx.push_host(b"".join(l + b"\n" for l in lines[1000 * i:1000 * (i + 1)]))
+                push(b"".join(l + b"\n" for l in lines[1000 * i:1000 * (i + 1)]))
                 if i < 3:
                     g.group_route_exchange([ctx])
             c = ctx.finish()          # (the last thousand reads are still staged: counted here)

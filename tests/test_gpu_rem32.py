@@ -108,13 +108,14 @@ def test_rem32_tables_overflow_in_turn():
     """2.2e8 distinct 25-mers with the estimate halved on purpose: 840 per 17-bit segment expected, 1 680 there -- the
     2048-slot tables (1 536) overflow and the counting alone is redone in the 4096-slot tables (the remainders are still
     in their sub-regions); with the right estimate the 4096-slot tables are taken at once.  Same keys and counts as
-    the 8-byte form every time."""
+    the 8-byte form every time.  (Round 5's tables of four-slot buckets take the small table only up to 400 expected
+    keys per segment -- GOSS_GPU_R32_SMALL_MAX puts the old threshold back so that the ladder is still walked.)"""
     import torch
     from gossamer_amd import dist as gd
     n, L, G = 6_000_000, 150, 230_000_000
     buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
     res = []
-    for e, want in (({"GOSS_GPU_NO_REM32": 1}, (0, None)), ({}, (1, 0)), ({"GOSS_GPU_EST_SCALE": 0.5}, (1, 1))):
+    for e, want in (({"GOSS_GPU_NO_REM32": 1}, (0, None)), ({}, (1, 0)), ({"GOSS_GPU_EST_SCALE": 0.5, "GOSS_GPU_R32_SMALL_MAX": 1152}, (1, 1))):
         with env(GOSS_GPU_CANON_L1=0, **e):          # (strand representatives whatever the estimate says: the 9-bit form and its two tables)
             ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
         if not res:
