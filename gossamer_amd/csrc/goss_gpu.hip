@@ -143,6 +143,8 @@ struct goss_gpu_ctx {
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
     int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
+    uint32_t narrow_capg = 664;         // GOSS_GPU_NARROW_CAPG (tests): granules a tile of the narrow form may lay out before it sends its carried granules off short
+    bool narrow = true;                 // GOSS_GPU_NARROW=0: 8-byte keys between the two levels of the 32-bit-remainder form (rounds 3-4)
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
@@ -1037,6 +1039,12 @@ int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+#if defined(GOSS_STAMPS)
+    if (h->stamps[7])
+        std::fprintf(stderr, "libgossgpu: counting stamps per segment (cycles of wave 0): set-up %.0f  loads+copy %.0f  fast path %.0f  slow path %.0f  closing barrier %.0f  ordering %.0f  write-out %.0f   (%llu segments)\n",
+                     (double)h->stamps[0] / h->stamps[7], (double)h->stamps[1] / h->stamps[7], (double)h->stamps[2] / h->stamps[7], (double)h->stamps[3] / h->stamps[7],
+                     (double)h->stamps[4] / h->stamps[7], (double)h->stamps[5] / h->stamps[7], (double)h->stamps[6] / h->stamps[7], (unsigned long long)h->stamps[7]);
+#endif
     if (h->overflow)
     {
         const int why = (h->overflow & 1u) ? 1 : 2;
@@ -1607,6 +1615,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         }
     }
     const uint32_t part_shift = msd ? keybits - 8 : shift;           // the fused kernel's digit
+    const bool narrow = kOne && msd && r32_slots && c->narrow;       // remainder + digit between the two levels, 5.33 bytes a key
     lap("sample histograms");
 
     // bucket regions of the first buffer: expected size of every bucket plus five standard
@@ -1679,14 +1688,25 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         {
             // the 32-bit forms of the kernel: the partition digit is the key's top eight bits (msd) and lies at bit 34 or above
             const bool fastk = nh == 0 && 2 * c->len >= 32 && part_shift >= 34 && !c->no_fast32;
-#define GOSS_LAUNCH_EP4(MODE, NH, ODD, FAST)                                                                          \
+            // (round 5: ahead of the 32-bit-remainder form of the second level the keys leave as remainder + digit, twelve
+            // to a granule -- kernels_extract.hpp, NARROW)
+            const uint32_t nr_rbits = rbits32, nr_sqbit = squeeze ? sqbit32 : 0u, nr_dmask = (1u << r32_bits) - 1u;
+            const uint32_t nr_capg = std::min(664u, std::max(576u, c->narrow_capg));          // (granules of the kernel's LDS layout: kernels_extract.hpp, kSlots)
+#define GOSS_LAUNCH_EP5(MODE, NH, ODD, FAST, NRW)                                                                     \
     do {                                                                                                              \
         if (c->rec_mode)                                                                                              \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true, FAST>), dim3(grid), dim3(kTB), 0, c->stream, \
-                               d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true, FAST, NRW>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, \
+                               nr_rbits, nr_sqbit, nr_dmask, nr_capg);                                                \
         else                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, false, FAST>), dim3(grid), dim3(kTB), 0, c->stream, \
-                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, false, FAST, NRW>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, \
+                               nr_rbits, nr_sqbit, nr_dmask, nr_capg);                                                \
+    } while (0)
+#define GOSS_LAUNCH_EP4(MODE, NH, ODD, FAST)                                                                          \
+    do {                                                                                                              \
+        if (narrow) GOSS_LAUNCH_EP5(MODE, NH, ODD, FAST, (NH == 0));                                                  \
+        else GOSS_LAUNCH_EP5(MODE, NH, ODD, FAST, false);                                                             \
     } while (0)
 #define GOSS_LAUNCH_EP3(MODE, NH, ODD)                                                                                \
     do {                                                                                                              \
@@ -1722,6 +1742,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             }
 #undef GOSS_LAUNCH_EP3
 #undef GOSS_LAUNCH_EP4
+#undef GOSS_LAUNCH_EP5
         }
         else
         {
@@ -1778,7 +1799,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (n == 0) return kFusedDeclined;
     if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");
     uint64_t tiles = 0, sum = 0;
-    const uint64_t tile_keys = (msd && r32_slots) ? (uint64_t)kSub32Tile : msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
+    const uint64_t tile_keys = narrow ? (uint64_t)kSub32TileSlotsN : (msd && r32_slots) ? (uint64_t)kSub32Tile : msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
     for (int d = 0; d < 256; ++d)
     {
         // one-word keys: slots handed out in whole blocks, padding included (the next pass skips it)
@@ -1788,7 +1809,9 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         sum += gt.cnt[d];
     }
     gt.tile_first[256] = tiles;
-    if (sum < n || sum > n + (uint64_t)fgrid * 256 * (2 * B + 8))
+    // (the 8-byte slots handed out hold the keys: one each, or -- narrow form -- twelve to a granule of eight)
+    const uint64_t n_slots = narrow ? n / 3 * 2 : n;
+    if (sum < n_slots || sum > n_slots + 8 + (uint64_t)fgrid * 256 * (2 * B + 8))
         throw StatusError{GOSS_ERR_HIP, "fused extraction: bucket counts do not add up"};
     HIP_TRY(hipMemcpyAsync(dgt, &gt, sizeof(GapTable), hipMemcpyHostToDevice, c->stream));
 
@@ -1808,18 +1831,24 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         HIP_TRY(hipMemcpyAsync(dsub->start, hsub32_start.data(), (uint64_t)r32_regions * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(dsub->cap, hsub32_cap.data(), (uint64_t)r32_regions * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)r32_regions * 4, c->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32Tile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
-                           (const GapTable*)dgt, tdesc, (uint32_t)tiles);
+        if (narrow)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32TileSlotsN>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+                               (const GapTable*)dgt, tdesc, (uint32_t)tiles);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32Tile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+                               (const GapTable*)dgt, tdesc, (uint32_t)tiles);
         {
             PhaseTimer t(c, GOSS_T_SCATTER, n);
             const dim3 g2((uint32_t)((tiles + 7) / 8 * 8));
-#define GOSS_LAUNCH_S32(SQ, B2)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<SQ, B2>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32, \
+#define GOSS_LAUNCH_S32N(SQ, B2, NRW)                                                                                    \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(subpart32_kernel<SQ, B2, NRW>), g2, dim3(kTB), 0, c->stream, (const Key1*)ka, (uint32_t*)kb, rbits32, \
                        sqbit32, cur2, (const Tile32*)tdesc, (uint32_t)tiles, (const SubTable32*)dsub, ctl)
+#define GOSS_LAUNCH_S32(SQ, B2) do { if (narrow) GOSS_LAUNCH_S32N(SQ, B2, true); else GOSS_LAUNCH_S32N(SQ, B2, false); } while (0)
             if (squeeze) GOSS_LAUNCH_S32(true, 9);          // (only the 9-bit form of an odd k-mer set needs the squeeze)
             else if (r32_bits == 9) GOSS_LAUNCH_S32(false, 9);
             else GOSS_LAUNCH_S32(false, 10);
 #undef GOSS_LAUNCH_S32
+#undef GOSS_LAUNCH_S32N
             t.stop();
         }
         hipLaunchKernelGGL(sub_bounds32_kernel, dim3(r32_regions / 256), dim3(256), 0, c->stream, (const SubTable32*)dsub,
@@ -3092,6 +3121,8 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_REM32_SPLIT"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 4) c->rem32_split_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_FORM"); if (e) c->r32_form = std::atoi(e) ? 1 : 0; }
+    { const char* e = std::getenv("GOSS_GPU_NARROW"); if (e) c->narrow = std::atoi(e) != 0; }
+    { const char* e = std::getenv("GOSS_GPU_NARROW_CAPG"); if (e && std::atoi(e) > 0) c->narrow_capg = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_SMALL_MAX"); if (e) c->r32_small_max = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }

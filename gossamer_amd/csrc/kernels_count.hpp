@@ -52,6 +52,9 @@ struct SegOut {
                                    // or the staging area is full
     uint32_t count_overflow;
     unsigned long long stage_cap;  // entries the staging area can take
+#if defined(GOSS_STAMPS)
+    unsigned long long stamps[8];  // (timing build) wave 0's cycles per phase of the counting kernel, summed over the segments; [7] = segments
+#endif
 };
 
 // NT threads per workgroup, a table of SLOTS slots (a power of two) taking SLOTS * 3 / 4 distinct keys.
@@ -910,6 +913,22 @@ __device__ __forceinline__ uint32_t r32b_slot_offset(const uint32_t __attribute_
     return off;
 }
 
+// t[j] = off[j] >= 16 ? dummy : t[j] for four keys: the compares first, then the selects (see above)
+__device__ __forceinline__ void r32b_pick4(uint32_t (&t)[4], const uint32_t (&off)[4], uint32_t dummy)
+{
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_lt_u32_e64 %4, 15, %8\n\t"
+        "v_cmp_lt_u32_e64 %5, 15, %9\n\t"
+        "v_cmp_lt_u32_e64 %6, 15, %10\n\t"
+        "v_cmp_lt_u32_e64 %7, 15, %11\n\t"
+        "v_cndmask_b32_e64 %0, %0, %12, %4\n\t"
+        "v_cndmask_b32_e64 %1, %1, %12, %5\n\t"
+        "v_cndmask_b32_e64 %2, %2, %12, %6\n\t"
+        "v_cndmask_b32_e64 %3, %3, %12, %7"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(dummy));
+}
+
 // The same counting with what round 5's look at the instruction stream took out (profiles/r05/SUMMARY.md): the kernel
 // above issues 51 vector instructions and three LDS operations per key -- two 16-byte bucket reads and the add -- for a
 // table whose LDS pipe is 70-85 % busy.  Here a bucket is FOUR remainders = 16 bytes of a key array, with the four
@@ -939,6 +958,12 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
     __shared__ uint32_t ndist, ovf;
     __shared__ unsigned long long sh_base;
     const uint32_t s = unit_block(), tid = threadIdx.x;
+#if defined(GOSS_STAMPS)
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define GOSS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define GOSS_STAMP(i)
+#endif
     const uint64_t b = seg_off[s], e = seg_end[s];
     if (b == e)
     {
@@ -969,6 +994,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
     if (tid < 32) tab[SLOTS + tid] = 0;
     if (tid == 0) { ndist = 0; ovf = 0; }
     __syncthreads();
+    GOSS_STAMP(0);
 
     lds_vu32 vovf = (lds_vu32)&ovf;
     const uint32_t dummy = 8u * (uint32_t)SLOTS + 4u * (tid & 63u);          // the lane's own word behind the table
@@ -999,11 +1025,18 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
             const uint32_t i = i0 + (uint32_t)(kVec + u) * NT + tid;
             nxt[u] = __builtin_nontemporal_load(&v4[i < nvec ? i : nvec - 1]);
         }
-        uint32_t pend = 0;                                   // bit 4 u + j: remainder j of vector u is left to the slow path
+#if defined(GOSS_R32_EXP) && GOSS_R32_EXP == 1
+        // (timing experiment: the loads alone)
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) asm volatile("" ::"v"(cur[u].x), "v"(cur[u].y), "v"(cur[u].z), "v"(cur[u].w));
+        continue;
+#endif
+        GOSS_STAMP(1);
         // four keys at a time: their home buckets read together and looked at; a key that is not at home looks at its
         // second bucket under a wave-level branch of its own (a per-mille of the keys once the table is filled: the branch
-        // is scalar work unless some lane needs it); not there either -> pend.  `live`: which of the four are the segment's
-        auto four_keys = [&](const u32x4& v, uint32_t bit0, uint32_t live, auto whole_tag) {
+        // is scalar work unless some lane needs it); not there either -> a bit of the result.  `live`: which of the four are
+        // the segment's
+        auto four_keys = [&](const u32x4& v, uint32_t live, auto whole_tag) -> uint32_t {
             constexpr bool kWhole = decltype(whole_tag)::value;
             const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
             uint32_t f[4], a1[4], off[4];
@@ -1035,14 +1068,70 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
                     }
                 }
             }
+            // (off = 16: not found -- the add goes to the lane's own word and the key is left to the slow path)
+            if (!kWhole)
+            {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) off[j] = ((live >> j) & 1u) ? off[j] : 32u;          // (not the segment's: no add, no wait either)
+            }
+            r32b_pick4(t, off, dummy);
+            uint32_t left = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
             {
-                // (off = 16: not found -- the add goes to the lane's own word and the key waits in pend)
-                uint32_t o = off[j];
-                if (!kWhole) o = ((live >> j) & 1u) ? o : 32u;          // (not the segment's: no add, no wait either)
-                __hip_atomic_fetch_add((lds_word)(tb + (o >= 16u ? dummy : t[j])), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pend |= (o & 16u) << (bit0 + j);          // (bits 4 .. 19)
+                __hip_atomic_fetch_add((lds_word)(tb + t[j]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                left |= (off[j] & 16u) << j;          // (bits 4 .. 7)
+            }
+            return left >> 4;
+        };
+        // Slow path, per vector (what it inserts is there for the next vector's fast path: of a key's copies in a batch only
+        // those of one vector walk through here): every lane takes its leftover keys in turn, one probe per wave iteration
+        // -- home, second, then the buckets behind the second.  A bucket is looked at with the same two compare chains as
+        // in the fast path (the key, and the bucket's marker = an empty slot); a slot is claimed by a CAS on its key word.
+        // Nothing in an iteration waits for more than that read and that CAS: the number of distinct keys is only added
+        // to (and looked at once per batch), and a walk that has passed every bucket ends the segment (table full).
+        auto slow_keys = [&](const u32x4& v, uint32_t pd) {
+            uint32_t key = 0, bk = 0, f = 0, st = 0, moves = 0;
+            bool busy = false;
+            for (;;)
+            {
+                if (!busy && pd)
+                {
+                    const uint32_t j = __ffs(pd) - 1;
+                    pd &= pd - 1;
+                    key = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+                    f = r32_mix(key);
+                    bk = home_of(f);
+                    st = 0;
+                    busy = true;
+                }
+                if (!__ballot(busy)) break;
+                if (busy)
+                {
+                    const u32x4 q = *(lds_bucket_ptr)(tb + 16u * bk);
+                    const uint32_t mk = marker(bk);
+                    const u32x4 qq = u32x4{q.x, q.y, q.z, q.w};
+                    const uint32_t ho = r32b_slot_offset(qq, key);           // where the key is
+                    const uint32_t eo = r32b_slot_offset(qq, mk);            // the first empty slot
+                    uint32_t hit = ~0u;                                      // slot that holds the key
+                    // (key == mk: this bucket's empty slots look like the key -- it lives elsewhere)
+                    if (key != mk && ho < 16u) hit = 4 * bk + (ho >> 2);
+                    else if (key != mk && eo < 16u)
+                    {
+                        const uint32_t slot = 4 * bk + (eo >> 2);
+                        const uint32_t old = atomicCAS(&tkey[slot], mk, key);
+                        if (old == mk) { atomicAdd(&ndist, 1u); hit = slot; }
+                        else if (old == key) hit = slot;
+                        // else: somebody else took the slot; look at this bucket again
+                    }
+                    else
+                    {
+                        if (st == 0) { bk = second_of(f, bk); st = 1; }
+                        else bk = (bk + 1) & (NB - 1u);
+                        if (++moves > NB) { *vovf = 1; busy = false; pd = 0; }
+                    }
+                    if (hit != ~0u) { atomicAdd(&tcnt[hit], 1u); busy = false; }
+                }
             }
         };
         // every vector of the batch whole?  (all but a segment's last batch: no validity arithmetic in that form)
@@ -1050,7 +1139,11 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
         if (whole)
         {
 #pragma unroll
-            for (int u = 0; u < kVec; ++u) four_keys(cur[u], 4 * u, 0xFu, std::true_type{});
+            for (int u = 0; u < kVec; ++u)
+            {
+                const uint32_t left = four_keys(cur[u], 0xFu, std::true_type{});
+                if (__builtin_expect(__ballot(left != 0) != 0, 0)) slow_keys(cur[u], left);
+            }
         }
         else
         {
@@ -1061,71 +1154,18 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
                 const uint32_t have = i < nvec ? (n - 4u * i >= 4u ? 4u : n - 4u * i) : 0u;
                 uint32_t live = (1u << have) - 1u;
                 if (i == 0) live &= ~((1u << head) - 1u);
-                four_keys(cur[u], 4 * u, live, std::false_type{});
+                const uint32_t left = four_keys(cur[u], live, std::false_type{});
+                if (__ballot(left != 0)) slow_keys(cur[u], left);
             }
         }
-        // slow path: every lane walks its own queue of leftover keys, one probe per wave iteration
-        if (__ballot(pend != 0))
-        {
-            pend >>= 4;
-            uint32_t key = 0, bk = 0, st = 0;
-            bool busy = false;
-            for (;;)
-            {
-                if (!busy && pend)
-                {
-                    const uint32_t u = __ffs(pend) - 1;
-                    pend &= pend - 1;
-#pragma unroll
-                    for (int uu = 0; uu < kVec; ++uu)
-                        if ((u >> 2) == (uint32_t)uu)
-                        {
-                            const uint32_t j = u & 3u;
-                            key = j == 0 ? cur[uu].x : j == 1 ? cur[uu].y : j == 2 ? cur[uu].z : cur[uu].w;
-                        }
-                    bk = home_of(r32_mix(key));
-                    st = 0;
-                    busy = true;
-                }
-                if (!__ballot(busy)) break;
-                if (busy)
-                {
-                    const u32x4 q = *(lds_bucket_ptr)(tb + 16u * bk);
-                    const uint32_t mk = marker(bk);
-                    uint32_t hit = ~0u;                       // slot that holds the key
-                    bool move = false;
-                    if (key == mk) move = true;               // (this bucket's empty slots look like the key: it lives elsewhere)
-                    else if (q.x == key) hit = 4 * bk;
-                    else if (q.y == key) hit = 4 * bk + 1;
-                    else if (q.z == key) hit = 4 * bk + 2;
-                    else if (q.w == key) hit = 4 * bk + 3;
-                    else if (q.x == mk || q.y == mk || q.z == mk || q.w == mk)
-                    {
-                        const uint32_t slot = 4 * bk + (q.x == mk ? 0u : q.y == mk ? 1u : q.z == mk ? 2u : 3u);
-                        const uint32_t old = atomicCAS(&tkey[slot], mk, key);
-                        if (old == mk)
-                        {
-                            const uint32_t nd = atomicAdd(&ndist, 1u);
-                            if (nd + 1 > (uint32_t)kLimit) *vovf = 1;
-                            hit = slot;
-                        }
-                        else if (old == key) hit = slot;
-                        // else: somebody else took the slot; look at this bucket again
-                    }
-                    else move = true;
-                    if (move)
-                    {
-                        if (st == 0) { bk = second_of(r32_mix(key), bk); st = 1; }
-                        else bk = (bk + 1) & (NB - 1u);
-                    }
-                    if (hit != ~0u) { atomicAdd(&tcnt[hit], 1u); busy = false; }
-                }
-                if (*vovf) break;
-            }
-        }
+        GOSS_STAMP(2);
+        // (once per batch: more distinct keys than the table is meant to hold, or a walk that found it full)
+        if (*(lds_vu32)&ndist > (uint32_t)kLimit) *vovf = 1;
         if (*vovf) break;
+        GOSS_STAMP(3);
     }
     __syncthreads();
+    GOSS_STAMP(4);
     if (ovf)
     {
         if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
@@ -1203,6 +1243,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
                 __syncthreads();
             }
     }
+    GOSS_STAMP(5);
     const uint32_t d = ndist;
     if (tid == 0)
     {
@@ -1221,6 +1262,15 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
         stage_keys[ob + i].lo = prefix | rem32_unpack<SQ>((uint32_t)(v >> 32), sqbit);
         stage_counts[ob + i] = (uint32_t)v;
     }
+    GOSS_STAMP(6);
+#if defined(GOSS_STAMPS)
+    if (tid == 0)
+    {
+        for (int i = 0; i < 7; ++i) atomicAdd(&so->stamps[i], st_acc[i]);
+        atomicAdd(&so->stamps[7], 1ULL);
+    }
+#endif
+#undef GOSS_STAMP
 }
 
 // Two-word keys.  LDS has no 128-bit compare-and-swap, so a slot is claimed through its state

@@ -715,6 +715,9 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 #ifndef GOSS_E1_OCC
 #define GOSS_E1_OCC 3
 #endif
+#ifndef GOSS_E1_NCH
+#define GOSS_E1_NCH 4          // (NARROW) chunks of three keys per lane and round of the store loop
+#endif
 // Wave priorities by phase (s_setprio; the SIMD's issue arbiter takes priority before age).  The three workgroups of a
 // CU are in different phases; a wave in the store phase issues few instructions, each of which starts a long-latency
 // operation (LDS read, global store) that the tile's end waits for, a wave in the ranking phase issues hundreds of
@@ -740,13 +743,27 @@ __device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t ones, uin
 }
 // FAST: the 32-bit forms of the window arithmetic and of the digit -- keys of 32 bits or more whose digit lies at bit 34
 // or above (the headline's: len >= 21, digit = the key's top eight bits); the host picks the instantiation.
-template <int MODE, int NH, int REPK, bool REC = false, bool FAST = false>
+// NARROW (round 5): what leaves is not the 8-byte key but what the second level of the 32-bit-remainder form needs of
+// it -- the 32-bit remainder (rem32_pack, kernels_partition.hpp) and the second-level digit (<= 10 bits) -- TWELVE keys
+// to a 64-byte granule instead of eight: a granule is four 16-byte chunks {rem, rem, rem, D}, D = the three digits
+// at bits 0, 10, 20 and, at bits 30-31, how many of the chunk's three keys are keys (pads: an all-zero chunk holds
+// none); slot s = 4 m + c of a granule is field m of chunk c.  5.33 bytes per key written here and read by
+// subpart32_kernel<.., NARROW> instead of 8 (profiles/r05: with two granules of three stored the first level takes
+// 28.3 ms instead of 33.3, the second level is bound by the bytes it moves).  In LDS the remainders and the digits are
+// staged in two arrays by slot; a bucket's piece starts on a granule and begins with the <= 11 keys it carries, which
+// the bucket's thread holds in registers AS A GRANULE (48 + 24 bytes) between tiles and copies to the head of the
+// next piece with six wide LDS writes -- no key is moved one by one and the new keys simply follow (rank + carried).
+// Cursors, blocks and regions keep counting 8-byte slots: a granule is eight of them whatever it holds.
+template <int MODE, int NH, int REPK, bool REC = false, bool FAST = false, bool NARROW = false>
 __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
                                                             const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
-                                                            uint32_t blk_log2)
+                                                            uint32_t blk_log2, uint32_t nr_rbits = 0, uint32_t nr_sqbit = 0, uint32_t nr_dmask = 0, uint32_t nr_capg = 0)
 {
+    // (nr_capg: granules of the LDS layout a tile may take before its carried granules are sent off short -- the layout's
+    // 664, or down to the 576 a tile without carried keys needs at most: tests make the rare path common with it)
+    static_assert(!NARROW || NH == 0, "the narrow form is the two-level form's");
     // MODE 0: one key per window, 16 windows per thread.  MODE 1 (graph): forward key and
     // reverse complement of every window, 8 windows per thread -- 16 keys per thread either way.
     constexpr int S = MODE == 1 ? 2 : 1;
@@ -757,18 +774,27 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     constexpr int T = kTB * P;                   // window starts per tile
     constexpr int NVEC = T / 16 + 4;
     constexpr int NK = P * S;                    // keys per thread
-    constexpr int kCarry = 7;
-    // the NEW keys of the 256 buckets, each bucket's rounded up to whole granules: at most T * S keys and 7 slots per bucket
-    constexpr uint32_t kSlots = T * S + 256 * kCarry;
+    constexpr int kCarry = NARROW ? 11 : 7;
+    constexpr uint32_t kGran = NARROW ? 12 : 8;                      // keys per 64-byte granule
+    // the NEW keys of the 256 buckets, each bucket's rounded up to whole granules: at most T * S keys and 7 (11) slots per bucket
+    // NARROW: a bucket's piece holds its carried keys as well -- at most T * S + 2 * 256 * 11 slots, but 27 per bucket on
+    // average (16 new, 5.5 carried, 5.5 of rounding) with a deviation of ~80 for the whole tile: 664 granules are what
+    // three workgroups per CU leave room for and 13 deviations above the mean; a tile that needs more (keys dealt out
+    // on purpose) first sends every carried granule to its bucket as it is, short, and then holds T * S + 256 * 11 at most
+    constexpr uint32_t kSlots = NARROW ? 664 * 12 : T * S + 256 * kCarry;
+    static_assert(kSlots % kGran == 0 && kSlots >= T * S + 256 * kCarry, "whole granules, and room for a tile without carried keys");
     // + 128 slots nobody reads: the keys of windows that are not valid go there (they rank themselves in one of 32
     // spare counters, 8 threads each: at most 128 per counter and tile) instead of under a branch, whose exec-mask
     // bookkeeping costs scalar issue slots; reads past the live part land there too
     constexpr uint32_t kGarb = kSlots;
     constexpr int kPairs = GOSS_E1_NK >= 16 ? 5 : 3;                 // pairs of keys per lane and round of the store loop
     constexpr uint32_t kStep = 2 * kPairs * kTB;                     // slots per round: two rounds cover the 4 096 + 3.5 x 256 slots an average tile takes
-    constexpr uint32_t kNG = kSlots / 8 + 4;                         // granules of the layout; entry kSlots / 8 is always kSkip
+    constexpr uint32_t kNG = kSlots / kGran + 4;                     // granules of the layout; entry kSlots / kGran is always kSkip
     constexpr uint32_t kSkip = 0xFFFFFFFFu;
-    constexpr uint32_t kSortedBytes = (kSlots + 128) * 8;
+    // NARROW: remainders (4 bytes a slot), then digits (2 bytes a slot)
+    constexpr uint32_t kSortedBytes = NARROW ? (kSlots + 128) * 6 : (kSlots + 128) * 8;
+    constexpr uint32_t kDigBase = (kSlots + 128) * 4;
+    static_assert(kDigBase % 16 == 0, "the digit array starts on a 16-byte boundary");
     __shared__ __attribute__((aligned(64))) unsigned char lds_all[kSortedBytes + (288 + 288 + kNG + 8 + (NH ? 256 * NH : 0)) * 4];
     Key1* const sorted = reinterpret_cast<Key1*>(lds_all);
     uint32_t* const dh = reinterpret_cast<uint32_t*>(lds_all + kSortedBytes);       // new keys of this tile per digit (rank counter); 32 spare ones for windows that are not valid
@@ -784,8 +810,8 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     if (NH > 0) lh[tid] = 0;
     if (NH > 1) lh[tid + 256] = 0;
     dh[tid] = 0;
-    if (tid < 32) { dh[256 + tid] = 0; tab[256 + tid] = kGarb << 3; }
-    if (tid == 0) { sh_ovf = 0; gaddr[kSlots / 8] = kSkip; }
+    if (tid < 32) { dh[256 + tid] = 0; tab[256 + tid] = kGarb << (NARROW ? 2 : 3); }
+    if (tid == 0) { sh_ovf = 0; gaddr[kSlots / kGran] = kSkip; }
     const uint64_t my_start = gt->reg_start[tid], my_cap = gt->reg_cap[tid];
     const uint32_t B = 1u << blk_log2;
     const uint32_t bits = 2 * len;
@@ -794,9 +820,27 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     unsigned long long nvalid = 0;
     uint64_t wpos = 0;                           // next slot of bucket tid's open block (a block boundary = none open)
     uint32_t ccnt = 0;                           // keys of bucket tid carried over from the previous tile
-    Key1 kc[kCarry];                             // ... and the keys themselves
+    Key1 kc[NARROW ? 1 : kCarry];                // ... and the keys themselves
 #pragma unroll
-    for (int j = 0; j < kCarry; ++j) kc[j].lo = 0;
+    for (int j = 0; j < (NARROW ? 1 : kCarry); ++j) kc[j].lo = 0;
+    // NARROW: the carried keys as the granule they are part of -- twelve remainders, twelve 16-bit digits
+    uint4 clo0 = make_uint4(0, 0, 0, 0), clo1 = clo0, clo2 = clo0;
+    uint64_t cdig0 = 0, cdig1 = 0, cdig2 = 0;
+    // the carried granule as it stands to `at`, every chunk saying how many of its slots c, c + 4, c + 8 hold a key
+    [[maybe_unused]] auto store_short_granule = [&](Key1* at) {
+        const uint32_t lw[12] = {clo0.x, clo0.y, clo0.z, clo0.w, clo1.x, clo1.y, clo1.z, clo1.w, clo2.x, clo2.y, clo2.z, clo2.w};
+        const uint64_t dw[3] = {cdig0, cdig1, cdig2};
+        uint4* const g = reinterpret_cast<uint4*>(at);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            const uint32_t nv = ccnt > (uint32_t)c + 8 ? 3u : ccnt > (uint32_t)c + 4 ? 2u : ccnt > (uint32_t)c ? 1u : 0u;
+            const uint32_t da = (uint32_t)(dw[c / 4] >> (16 * (c % 4))) & 0x3FFu;
+            const uint32_t db = (uint32_t)(dw[(c + 4) / 4] >> (16 * ((c + 4) % 4))) & 0x3FFu;
+            const uint32_t dc = (uint32_t)(dw[(c + 8) / 4] >> (16 * ((c + 8) % 4))) & 0x3FFu;
+            g[c] = make_uint4(lw[c], lw[c + 4], lw[c + 8], da | (db << 10) | (dc << 20) | (nv << 30));
+        }
+    };
 
     // 16 bytes of the input at `byte0` -> 32 bits of 2-bit codes + 16 non-base flags
     auto fetch = [&](uint64_t byte0, uint4& q) -> bool {
@@ -1142,7 +1186,87 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // matter, so the carried keys do not go in front: the bucket's last, partial granule (b new keys) is TOPPED UP
         // with carried keys when there are enough of them (b + carried >= 8: the rest stay in the registers where
         // they are); otherwise it is not stored and its b keys join the carried ones after the scatter.
-        uint32_t total_slots, part_at, absorb;
+        uint32_t total_slots = 0, part_at = 0, absorb = 0;
+        if constexpr (NARROW)
+        {
+            // carried + new keys of the bucket: whole granules leave, the rest is the granule carried on
+            const uint32_t cnt = dh[tid];
+            uint32_t tot = ccnt + cnt;
+            uint32_t fg = (tot * 0xAAABu) >> 19;                       // tot / 12 (tot < 2^13)
+            uint32_t rest = tot - 12u * fg;
+            uint32_t g_at = block_excl_scan_open_u32(fg + (rest ? 1u : 0u), sh_scan, &total_slots);      // (granules; the barrier behind phase C closes it)
+            GOSS_STAMP(6);
+            dh[tid] = 0;                               // ready for the next tile (its ranking starts behind two barriers)
+            if (tid < 32) dh[256 + tid] = 0;
+            // room for `fl` 8-byte slots of bucket tid: the rest of the open block (thr of them, from granule tbx on), then
+            // new block(s) from granule tby on
+            uint32_t thr, tbx, tby;
+            auto take_room = [&](uint32_t fl) {
+                const uint32_t room = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
+                thr = fl;
+                tbx = (uint32_t)(wpos >> 3);
+                tby = 0;
+                if (fl > room)
+                {
+                    thr = room;
+                    const uint32_t need = fl - room;
+                    unsigned long long at, want;
+                    if (has_resv && need <= B) { at = resv; want = B; has_resv = false; }          // (reserved in phase A)
+                    else
+                    {
+                        want = ((uint64_t)(need + B - 1) >> blk_log2) << blk_log2;
+                        at = atomicAdd(&pc->cursors[tid * kCursorStride], want);
+                    }
+                    // a region that is too small: nothing of this tile is stored, the host redoes the chunk
+                    if (at + want > my_cap) { atomicOr(&pc->overflow, 1ULL); sh_ovf = 1; }
+                    tby = (uint32_t)((my_start + at) >> 3);
+                    wpos = my_start + at + need;
+                }
+                else wpos += fl;
+            };
+            if (total_slots > nr_capg)
+            {
+                // (more granules than the layout holds -- never with keys that spread: see kSlots.  Every carried granule
+                // goes to its bucket short, its chunks saying how many keys they hold, and the tile is laid out without)
+                if (ccnt)
+                {
+                    take_room(8u);
+                    if (sh_ovf == 0) store_short_granule(out + ((uint64_t)(thr ? tbx : tby) << 3));
+                    ccnt = 0;
+                }
+                __syncthreads();                       // (everybody has read the first scan's sums)
+                tot = cnt;
+                fg = (tot * 0xAAABu) >> 19;
+                rest = tot - 12u * fg;
+                g_at = block_excl_scan_open_u32(fg + (rest ? 1u : 0u), sh_scan, &total_slots);
+            }
+            const uint32_t fl = fg << 3;               // 8-byte slots stored now
+            part_at = 12u * (g_at + fg);               // the granule carried on, if any
+            take_room(fl);
+            tab[tid] = (12u * g_at + ccnt) << 2;       // byte offset of the first NEW key's remainder
+            {
+                const uint32_t t8 = thr >> 3;
+                const uint32_t yb = tby - t8;
+#pragma unroll
+                for (uint32_t g = 0; g < 3; ++g)
+                    if (g < fg) gaddr[g_at + g] = (g < t8 ? tbx : yb) + g;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (uint32_t g = 3; g < fg; ++g) gaddr[g_at + g] = (g < t8 ? tbx : yb) + g;
+                if (rest) gaddr[g_at + fg] = kSkip;
+            }
+            // the carried granule to the head of the piece (phase A's arrays in `sorted` are dead: every thread is past
+            // phase B); whole, the new keys follow behind the `ccnt` that count.  (Not without carried keys: a bucket that
+            // holds nothing has no piece, and the granule at g_at is the next bucket's.)
+            if (ccnt)
+            {
+                unsigned char* const lp = lds_all + 48u * g_at;
+                unsigned char* const dp = lds_all + kDigBase + 24u * g_at;
+                reinterpret_cast<uint4*>(lp)[0] = clo0; reinterpret_cast<uint4*>(lp)[1] = clo1; reinterpret_cast<uint4*>(lp)[2] = clo2;
+                reinterpret_cast<uint64_t*>(dp)[0] = cdig0; reinterpret_cast<uint64_t*>(dp)[1] = cdig1; reinterpret_cast<uint64_t*>(dp)[2] = cdig2;
+            }
+            ccnt = rest;
+        }
+        else
         {
             const uint32_t cnt = dh[tid];
             const uint32_t a8 = cnt & ~7u, b = cnt & 7u;
@@ -1212,6 +1336,26 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             uint32_t tb[NK];
 #pragma unroll
             for (int i = 0; i < NK; ++i) tb[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tab) + bin4[i]);
+            if constexpr (NARROW)
+            {
+                // remainder and digit of every key to their slot: the low nr_rbits bits with the always-clear bit nr_sqbit
+                // taken out (none: nr_sqbit = 0 and no bits above it are moved), the nr_dmask bits above them
+                const uint32_t sq1 = nr_sqbit ? nr_sqbit + 1u : 0u;
+                const uint32_t lomask = nr_sqbit ? (1u << nr_sqbit) - 1u : (nr_rbits >= 32 ? 0xFFFFFFFFu : (1u << nr_rbits) - 1u);
+                const uint32_t himask = nr_sqbit ? ~lomask : 0u;
+#pragma unroll
+                for (int i = 0; i < NK; ++i)
+                {
+                    const uint32_t klo = (uint32_t)kreg[i].lo, khi = (uint32_t)(kreg[i].lo >> 32);
+                    const uint32_t up = __builtin_amdgcn_alignbit(khi, klo, sq1) << nr_sqbit;          // bits above the squeezed one, moved down by one
+                    const uint32_t rem = (up & himask) | (klo & lomask);
+                    const uint32_t dg = (uint32_t)(kreg[i].lo >> nr_rbits) & nr_dmask;
+                    const uint32_t la = tb[i] + (rk[i] << 2);
+                    *reinterpret_cast<uint32_t*>(lds_all + la) = rem;
+                    *reinterpret_cast<uint16_t*>(lds_all + kDigBase + (la >> 1)) = (uint16_t)dg;
+                }
+            }
+            else
 #pragma unroll
             for (int i = 0; i < NK; ++i)
             {
@@ -1251,6 +1395,51 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         // (two keys per lane and store: the store path takes 16 bytes per lane as quickly as 8 --
         // experiments/storegran: 4.5 against 4.1 TB/s for this pattern alone -- and the loop has half the instructions)
         // (the reads of a partial granule that joins the carried keys go ahead of the stores)
+        if constexpr (NARROW)
+        {
+            // the granule that is carried on (whatever lies there when there is none): read ahead of the stores
+            {
+                const unsigned char* const lp = lds_all + 4u * part_at;
+                const unsigned char* const dp = lds_all + kDigBase + 2u * part_at;
+                clo0 = reinterpret_cast<const uint4*>(lp)[0]; clo1 = reinterpret_cast<const uint4*>(lp)[1]; clo2 = reinterpret_cast<const uint4*>(lp)[2];
+                cdig0 = reinterpret_cast<const uint64_t*>(dp)[0]; cdig1 = reinterpret_cast<const uint64_t*>(dp)[1]; cdig2 = reinterpret_cast<const uint64_t*>(dp)[2];
+            }
+            if (sh_ovf == 0)
+            {
+                // a lane stores chunk c = tid & 3 of a granule: slots c, c + 4, c + 8 -- three remainders and their digits
+                constexpr int kCh = GOSS_E1_NCH;                             // chunks per lane and round
+                const uint32_t nchunk = total_slots << 2;                    // (total_slots: granules of the layout)
+                const uint32_t c = tid & 3u;
+                const uint32_t* const lo_lds = reinterpret_cast<const uint32_t*>(lds_all);
+                const uint16_t* const dg_lds = reinterpret_cast<const uint16_t*>(lds_all + kDigBase);
+                Key1* const lane_out = out + 2u * c;
+                for (uint32_t base = 0; base < nchunk; base += kCh * kTB)
+                {
+                    uint32_t r0[kCh], r1[kCh], r2[kCh], d0[kCh], d1[kCh], d2[kCh], ga[kCh];
+#pragma unroll
+                    for (int u = 0; u < kCh; ++u)
+                    {
+                        const uint32_t i = min(base + tid + u * kTB, (kSlots / 12u) * 4u + c);      // (beyond the layout: the granule that is always kSkip)
+                        const uint32_t s0 = 3u * (i - c) + c;                      // slot c of granule i / 4
+                        r0[u] = lo_lds[s0]; r1[u] = lo_lds[s0 + 4]; r2[u] = lo_lds[s0 + 8];
+                        d0[u] = dg_lds[s0]; d1[u] = dg_lds[s0 + 4]; d2[u] = dg_lds[s0 + 8];
+                        ga[u] = gaddr[i >> 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kCh; ++u) asm volatile("" : "+v"(r0[u]), "+v"(r1[u]), "+v"(r2[u]), "+v"(d0[u]), "+v"(d1[u]), "+v"(d2[u]), "+v"(ga[u]));
+#pragma unroll
+                    for (int u = 0; u < kCh; ++u)
+                    {
+                        const uint4 ch = make_uint4(r0[u], r1[u], r2[u], d0[u] | (d1[u] << 10) | (d2[u] << 20) | (3u << 30));
+                        if (ga[u] != kSkip && base + tid + u * kTB < nchunk) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = ch;
+                    }
+                }
+            }
+            GOSS_STAMP(8);
+            GOSS_STAMP(9);
+        }
+        else
+        {
         Key1 ab[kCarry];
 #pragma unroll
         for (int j = 0; j < kCarry; ++j)
@@ -1282,6 +1471,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
 #if defined(GOSS_E1_EXP) && GOSS_E1_EXP == 1
                     // (timing experiment: everything but the stores themselves)
                     asm volatile("" ::"v"(kk[u].x), "v"(kk[u].y), "v"(kk[u].z), "v"(kk[u].w), "v"(ga[u]));
+#elif defined(GOSS_E1_EXP) && GOSS_E1_EXP == 2
+                    // (timing experiment: two granules of three stored -- what a tile would write with 5.33-byte keys; results wrong)
+                    if (ga[u] != kSkip && (ga[u] % 3u) != 0u && base + 2 * (tid + u * kTB) < total_slots) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = kk[u];
 #else
                     // (entries between this tile's layout and kSlots / 8 are stale)
                     if (ga[u] != kSkip && base + 2 * (tid + u * kTB) < total_slots) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = kk[u];
@@ -1301,6 +1493,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             ccnt += absorb;
         }
         GOSS_STAMP(9);
+        }
         __syncthreads();
         GOSS_STAMP(4);
     }
@@ -1326,10 +1519,21 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 if (at + B > my_cap) { atomicOr(&pc->overflow, 1ULL); ccnt = 0; wpos = 0; }
                 else wpos = my_start + at;
             }
+            if constexpr (NARROW)
+            {
+                if (ccnt)          // (0: the region overflowed)
+                {
+                    store_short_granule(out + wpos);
+                    wpos += 8;
+                }
+            }
+            else
+            {
 #pragma unroll
             for (int j = 0; j < kCarry; ++j)
                 if ((uint32_t)j < ccnt) out[wpos + j] = kc[j];
             wpos += ccnt;
+            }
         }
         const uint32_t tail = (B - ((uint32_t)wpos & (B - 1))) & (B - 1);
         // a reserved block nobody opened counts as handed out: pads, or (beyond the region) the chunk is redone
@@ -1350,8 +1554,9 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         {
             const uint32_t n = tab[d], n2 = dh[d];
             const uint64_t from = reinterpret_cast<const uint64_t*>(sorted)[d], from2 = reinterpret_cast<const uint64_t*>(sorted)[256 + d];
-            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{kPadKey};
-            for (uint32_t j = tid; j < n2; j += kTB) out[from2 + j] = Key1{kPadKey};
+            // (NARROW: a chunk of zeros holds no key)
+            for (uint32_t j = tid; j < n; j += kTB) out[from + j] = Key1{NARROW ? 0ULL : kPadKey};
+            for (uint32_t j = tid; j < n2; j += kTB) out[from2 + j] = Key1{NARROW ? 0ULL : kPadKey};
         }
     }
     if (NH > 0) { if (lh[tid]) atomicAdd(&pc->hist[tid], (unsigned long long)lh[tid]); }

@@ -626,14 +626,20 @@ __global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restri
 #ifndef GOSS_S32_OCC
 #define GOSS_S32_OCC 4
 #endif
-template <bool SQ, int B2>
+// NARROW (round 5): the regions hold what extract1_part_kernel<.., NARROW> wrote -- 16-byte chunks {remainder, remainder,
+// remainder, D} with the three second-level digits at bits 0, 10, 20 of D and the number of keys the chunk holds at
+// bits 30-31: a lane takes a chunk with one 16-byte load, three keys, and has nothing to pack (5.33 bytes read per
+// key instead of 8).  A tile is 7 chunks per thread = 3 584 8-byte slots of the region.
+constexpr int kSub32ChunksN = 7;                         // chunks per thread of the narrow form
+constexpr int kSub32TileSlotsN = kTB * kSub32ChunksN * 2;   // ... in 8-byte slots of a region
+template <bool SQ, int B2, bool NARROW = false>
 __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
                                                            uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
                                                            const Tile32* __restrict__ desc, uint32_t total_tiles,
                                                            const SubTable32* __restrict__ sub, LookbackCtl* __restrict__ ctl)
 {
-    constexpr int kItems = kSub32Items;
-    constexpr int kTile = kSub32Tile;
+    constexpr int kItems = NARROW ? 3 * kSub32ChunksN : kSub32Items;
+    constexpr int kTile = kTB * kItems;
     constexpr uint32_t ND = 1u << B2;                        // second-level digits
     constexpr int DPT = ND / kTB;                            // digits a thread owns: 2, 4, 8 or 16 neighbours
     static_assert(DPT >= 2 && DPT % 2 == 0, "a thread owns pairs of digits");
@@ -657,16 +663,69 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
 
     // (a workgroup that has just started issues its key loads ahead of the others' ranking and staging: 30.85 -> 30.05 ms)
     __builtin_amdgcn_s_setprio(3);
-    Key1 key[kItems];
+    Key1 key[NARROW ? 1 : kItems];
+    [[maybe_unused]] uint32_t rem[NARROW ? kItems : 1], dw[NARROW ? kSub32ChunksN : 1];
     uint16_t rank[kItems];
     uint32_t have = 0;
     const uint32_t wbase = w * 64 * kItems;
+    if constexpr (NARROW)
+    {
+        const uint32_t nchunk = tile_n >> 1;                     // (the tile's 8-byte slots, two to a chunk)
+        const uint4* const cin = reinterpret_cast<const uint4*>(keys_in + tile_base);
+        const uint32_t cbase = w * 64 * kSub32ChunksN;
+#pragma unroll
+        for (int r = 0; r < kSub32ChunksN; ++r)
+        {
+            const uint32_t ci = cbase + r * 64 + lane;
+            dw[r] = 0;
+            rem[3 * r] = rem[3 * r + 1] = rem[3 * r + 2] = 0;
+            if (ci < nchunk)
+            {
+                const uint4 v = cin[ci];
+                rem[3 * r] = v.x; rem[3 * r + 1] = v.y; rem[3 * r + 2] = v.z; dw[r] = v.w;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        // (a second loop: looking at a chunk inside the load loop would wait for every load in turn)
+#pragma unroll
+        for (int r = 0; r < kSub32ChunksN; ++r) have |= ((1u << (dw[r] >> 30)) - 1u) << (3 * r);
+#pragma unroll
+        for (int r = 0; r < kItems; ++r)
+            if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(dw[r / 3] >> (10 * (r % 3))) & (ND - 1u)], 1u);
+    }
+    else
+    {
+#if !defined(GOSS_S32_LOAD8)
+    // (16 bytes per lane and load: two neighbouring keys -- a tile starts on a granule of the first level and holds an
+    // even number of slots; which keys a thread takes does not matter, they rank themselves by atomics)
+    static_assert(kItems % 2 == 0, "pairs of keys per load");
+#pragma unroll
+    for (int r = 0; r < kItems / 2; ++r)
+    {
+        const uint32_t li = wbase + r * 128 + 2 * lane;
+        if (li < tile_n)
+        {
+#if defined(GOSS_S32_NT)
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ vv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(keys_in + tile_base + li));
+            const uint4 v = make_uint4(vv.x, vv.y, vv.z, vv.w);
+#else
+            const uint4 v = *reinterpret_cast<const uint4*>(keys_in + tile_base + li);
+#endif
+            key[2 * r].lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            key[2 * r + 1].lo = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            have |= 3u << (2 * r);
+        }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
     {
         const uint32_t li = wbase + r * 64 + lane;
         if (li < tile_n) { key[r] = keys_in[tile_base + li]; have |= 1u << r; }
     }
+#endif
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     // (a second loop: looking at a key inside the load loop would wait for every load in turn)
@@ -676,6 +735,7 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
         if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(uint32_t)(key[r].lo >> rbits) & (ND - 1u)], 1u);
+    }
     __syncthreads();
     const uint64_t region_first = sub->start[b * ND];       // (uniform)
     {
@@ -712,10 +772,20 @@ __global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1
     for (int r = 0; r < kItems; ++r)
         if ((have >> r) & 1u)
         {
+            if constexpr (NARROW)
+            {
+                const uint32_t d = (dw[r / 3] >> (10 * (r % 3))) & (ND - 1u);
+                const uint32_t at = hist[d] + rank[r];
+                stage[at] = rem[r];
+                sdig[at] = (uint16_t)d;
+            }
+            else
+            {
             const uint32_t d = (uint32_t)(key[r].lo >> rbits) & (ND - 1u);
             const uint32_t at = hist[d] + rank[r];
             stage[at] = rem32_pack<SQ>(key[r].lo, rbits, sqbit);
             sdig[at] = (uint16_t)d;
+            }
         }
     __syncthreads();
     if (sh_skip) return;

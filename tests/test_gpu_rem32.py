@@ -64,6 +64,14 @@ def test_rem32_form_matches_the_oracle(oracle, k, mode):
         with env(GOSS_GPU_NO_REM32=1):
             c2, got2, st2 = build(reads, k, mode)
         assert st2["rem32_chunks"] == 0 and st2["fused_msd_chunks"] == 1 and got2 == exp
+        # between the two levels: remainder + digit, twelve keys to a granule (round 5) -- with the LDS layout capped at
+        # what a tile without carried keys needs, so that every other tile sends its carried granules off short (the
+        # path keys that spread never take); and the 8-byte keys of rounds 3-4
+        for e in ({"GOSS_GPU_NARROW_CAPG": 576}, {"GOSS_GPU_NARROW": 0}):
+            with env(**e):
+                c3, got3, st3 = build(reads, k, mode)
+            assert c3.windows == nwin and st3["rem32_chunks"] == 1 and st3["segment_retries"] == 0, (e, st3)
+            assert got3 == exp, e
 
 
 def test_rem32_small_inputs_every_k(oracle):
