@@ -143,7 +143,7 @@ struct goss_gpu_ctx {
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
     int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
-    uint32_t narrow_capg = 664;         // GOSS_GPU_NARROW_CAPG (tests): granules a tile of the narrow form may lay out before it sends its carried granules off short
+    uint32_t narrow_capg = 656;         // GOSS_GPU_NARROW_CAPG (tests): granules a tile of the narrow form may lay out before it sends its carried granules off short
     bool narrow = true;                 // GOSS_GPU_NARROW=0: 8-byte keys between the two levels of the 32-bit-remainder form (rounds 3-4)
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
@@ -1691,7 +1691,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             // (round 5: ahead of the 32-bit-remainder form of the second level the keys leave as remainder + digit, twelve
             // to a granule -- kernels_extract.hpp, NARROW)
             const uint32_t nr_rbits = rbits32, nr_sqbit = squeeze ? sqbit32 : 0u, nr_dmask = (1u << r32_bits) - 1u;
-            const uint32_t nr_capg = std::min(664u, std::max(576u, c->narrow_capg));          // (granules of the kernel's LDS layout: kernels_extract.hpp, kSlots)
+            const uint32_t nr_capg = std::min(656u, std::max(576u, c->narrow_capg));          // (granules of the kernel's LDS layout: kernels_extract.hpp, kSlots)
 #define GOSS_LAUNCH_EP5(MODE, NH, ODD, FAST, NRW)                                                                     \
     do {                                                                                                              \
         if (c->rec_mode)                                                                                              \

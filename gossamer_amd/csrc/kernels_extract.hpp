@@ -1,6 +1,7 @@
 // kernels_extract.hpp -- k-mer extraction: plain kernels and the extraction fused with the first partition level.
 // Part of the kernel set of libgossgpu.so (gfx950); included through goss_kernels.hpp, in this order.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -778,10 +779,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     constexpr uint32_t kGran = NARROW ? 12 : 8;                      // keys per 64-byte granule
     // the NEW keys of the 256 buckets, each bucket's rounded up to whole granules: at most T * S keys and 7 (11) slots per bucket
     // NARROW: a bucket's piece holds its carried keys as well -- at most T * S + 2 * 256 * 11 slots, but 27 per bucket on
-    // average (16 new, 5.5 carried, 5.5 of rounding) with a deviation of ~80 for the whole tile: 664 granules are what
-    // three workgroups per CU leave room for and 13 deviations above the mean; a tile that needs more (keys dealt out
+    // average (16 new, 5.5 carried, 5.5 of rounding) with a deviation of ~80 for the whole tile: 656 granules are what
+    // three workgroups per CU leave room for and 12 deviations above the mean; a tile that needs more (keys dealt out
     // on purpose) first sends every carried granule to its bucket as it is, short, and then holds T * S + 256 * 11 at most
-    constexpr uint32_t kSlots = NARROW ? 664 * 12 : T * S + 256 * kCarry;
+    constexpr uint32_t kSlots = NARROW ? 656 * 12 : T * S + 256 * kCarry;
     static_assert(kSlots % kGran == 0 && kSlots >= T * S + 256 * kCarry, "whole granules, and room for a tile without carried keys");
     // + 128 slots nobody reads: the keys of windows that are not valid go there (they rank themselves in one of 32
     // spare counters, 8 threads each: at most 128 per counter and tile) instead of under a branch, whose exec-mask
@@ -789,7 +790,10 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     constexpr uint32_t kGarb = kSlots;
     constexpr int kPairs = GOSS_E1_NK >= 16 ? 5 : 3;                 // pairs of keys per lane and round of the store loop
     constexpr uint32_t kStep = 2 * kPairs * kTB;                     // slots per round: two rounds cover the 4 096 + 3.5 x 256 slots an average tile takes
-    constexpr uint32_t kNG = kSlots / kGran + 4;                     // granules of the layout; entry kSlots / kGran is always kSkip
+    // granules of the layout; entry kSlots / kGran is always kSkip.  (NARROW: the store loop reads its table entries, remainders
+    // and digits at fixed strides from the lane's first chunk, past the layout's end in its last round -- up to chunk
+    // 3 071 = granule 767, slot 9 220: all inside this allocation, and nothing of it is stored)
+    constexpr uint32_t kNG = NARROW ? 772 : kSlots / kGran + 4;
     constexpr uint32_t kSkip = 0xFFFFFFFFu;
     // NARROW: remainders (4 bytes a slot), then digits (2 bytes a slot)
     constexpr uint32_t kSortedBytes = NARROW ? (kSlots + 128) * 6 : (kSlots + 128) * 8;
@@ -1339,21 +1343,28 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             if constexpr (NARROW)
             {
                 // remainder and digit of every key to their slot: the low nr_rbits bits with the always-clear bit nr_sqbit
-                // taken out (none: nr_sqbit = 0 and no bits above it are moved), the nr_dmask bits above them
-                const uint32_t sq1 = nr_sqbit ? nr_sqbit + 1u : 0u;
-                const uint32_t lomask = nr_sqbit ? (1u << nr_sqbit) - 1u : (nr_rbits >= 32 ? 0xFFFFFFFFu : (1u << nr_rbits) - 1u);
-                const uint32_t himask = nr_sqbit ? ~lomask : 0u;
+                // taken out (if any), the nr_dmask bits above them.  Four forms of the loop, picked by the (uniform)
+                // parameters: the 64-bit shifts and selects of one form for all cost 9 instructions per key, these 4-6
+                auto put = [&](auto sq_tag, auto hi_tag) {
+                    constexpr bool kSq = decltype(sq_tag)::value, kHi = decltype(hi_tag)::value;
+                    const uint32_t lomask = kSq ? (1u << nr_sqbit) - 1u : (nr_rbits >= 32 ? 0xFFFFFFFFu : (1u << nr_rbits) - 1u);
+                    const uint32_t dbits = (uint32_t)__popc(nr_dmask);
 #pragma unroll
-                for (int i = 0; i < NK; ++i)
-                {
-                    const uint32_t klo = (uint32_t)kreg[i].lo, khi = (uint32_t)(kreg[i].lo >> 32);
-                    const uint32_t up = __builtin_amdgcn_alignbit(khi, klo, sq1) << nr_sqbit;          // bits above the squeezed one, moved down by one
-                    const uint32_t rem = (up & himask) | (klo & lomask);
-                    const uint32_t dg = (uint32_t)(kreg[i].lo >> nr_rbits) & nr_dmask;
-                    const uint32_t la = tb[i] + (rk[i] << 2);
-                    *reinterpret_cast<uint32_t*>(lds_all + la) = rem;
-                    *reinterpret_cast<uint16_t*>(lds_all + kDigBase + (la >> 1)) = (uint16_t)dg;
-                }
+                    for (int i = 0; i < NK; ++i)
+                    {
+                        const uint32_t klo = (uint32_t)kreg[i].lo, khi = (uint32_t)(kreg[i].lo >> 32);
+                        uint32_t rem = klo & lomask;
+                        // (the bits above the squeezed one, moved down by one; what leaves the word at the top is the digit's)
+                        if (kSq) rem |= __builtin_amdgcn_alignbit(khi, klo, nr_sqbit + 1u) << nr_sqbit;
+                        const uint32_t dg = kHi ? __builtin_amdgcn_ubfe(khi, nr_rbits - 32u, dbits)
+                                                : (__builtin_amdgcn_alignbit(khi, klo, nr_rbits) & nr_dmask);
+                        const uint32_t la = tb[i] + (rk[i] << 2);
+                        *reinterpret_cast<uint32_t*>(lds_all + la) = rem;
+                        *reinterpret_cast<uint16_t*>(lds_all + kDigBase + (la >> 1)) = (uint16_t)dg;
+                    }
+                };
+                if (nr_sqbit) { if (nr_rbits >= 32) put(std::true_type{}, std::true_type{}); else put(std::true_type{}, std::false_type{}); }
+                else { if (nr_rbits >= 32) put(std::false_type{}, std::true_type{}); else put(std::false_type{}, std::false_type{}); }
             }
             else
 #pragma unroll
@@ -1406,32 +1417,39 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             }
             if (sh_ovf == 0)
             {
-                // a lane stores chunk c = tid & 3 of a granule: slots c, c + 4, c + 8 -- three remainders and their digits
+                // a lane stores chunk c = tid & 3 of a granule: slots c, c + 4, c + 8 -- three remainders and their digits.
+                // Chunk i = tid + 256 u of a round lies 3 072 u bytes (remainders) / 1 536 u bytes (digits) / 256 u bytes
+                // (granule table) behind chunk tid: every LDS read of a round is one address register + a constant
                 constexpr int kCh = GOSS_E1_NCH;                             // chunks per lane and round
+                static_assert(kSlots / 12u * 4u <= 2624u + 64u && kCh == 4, "the reads past the layout stay inside the allocation (kNG)");
                 const uint32_t nchunk = total_slots << 2;                    // (total_slots: granules of the layout)
                 const uint32_t c = tid & 3u;
-                const uint32_t* const lo_lds = reinterpret_cast<const uint32_t*>(lds_all);
-                const uint16_t* const dg_lds = reinterpret_cast<const uint16_t*>(lds_all + kDigBase);
                 Key1* const lane_out = out + 2u * c;
-                for (uint32_t base = 0; base < nchunk; base += kCh * kTB)
+                const unsigned char* lp = lds_all + (12u * tid - 8u * c);                  // remainder of slot c of granule tid / 4
+                const unsigned char* dp = lds_all + kDigBase + (6u * tid - 4u * c);
+                const unsigned char* gp = reinterpret_cast<const unsigned char*>(gaddr) + (tid & ~3u);
+                for (uint32_t base = 0; base < nchunk; base += kCh * kTB, lp += 12u * kCh * kTB, dp += 6u * kCh * kTB, gp += kCh * kTB)
                 {
                     uint32_t r0[kCh], r1[kCh], r2[kCh], d0[kCh], d1[kCh], d2[kCh], ga[kCh];
 #pragma unroll
                     for (int u = 0; u < kCh; ++u)
                     {
-                        const uint32_t i = min(base + tid + u * kTB, (kSlots / 12u) * 4u + c);      // (beyond the layout: the granule that is always kSkip)
-                        const uint32_t s0 = 3u * (i - c) + c;                      // slot c of granule i / 4
-                        r0[u] = lo_lds[s0]; r1[u] = lo_lds[s0 + 4]; r2[u] = lo_lds[s0 + 8];
-                        d0[u] = dg_lds[s0]; d1[u] = dg_lds[s0 + 4]; d2[u] = dg_lds[s0 + 8];
-                        ga[u] = gaddr[i >> 2];
+                        r0[u] = *reinterpret_cast<const uint32_t*>(lp + 3072 * u);
+                        r1[u] = *reinterpret_cast<const uint32_t*>(lp + 3072 * u + 16);
+                        r2[u] = *reinterpret_cast<const uint32_t*>(lp + 3072 * u + 32);
+                        d0[u] = *reinterpret_cast<const uint16_t*>(dp + 1536 * u);
+                        d1[u] = *reinterpret_cast<const uint16_t*>(dp + 1536 * u + 8);
+                        d2[u] = *reinterpret_cast<const uint16_t*>(dp + 1536 * u + 16);
+                        ga[u] = *reinterpret_cast<const uint32_t*>(gp + 256 * u);
                     }
 #pragma unroll
                     for (int u = 0; u < kCh; ++u) asm volatile("" : "+v"(r0[u]), "+v"(r1[u]), "+v"(r2[u]), "+v"(d0[u]), "+v"(d1[u]), "+v"(d2[u]), "+v"(ga[u]));
+                    const uint32_t left = nchunk - base;                     // chunks of this round and behind it
 #pragma unroll
                     for (int u = 0; u < kCh; ++u)
                     {
                         const uint4 ch = make_uint4(r0[u], r1[u], r2[u], d0[u] | (d1[u] << 10) | (d2[u] << 20) | (3u << 30));
-                        if (ga[u] != kSkip && base + tid + u * kTB < nchunk) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = ch;
+                        if (ga[u] != kSkip && tid + u * kTB < left) *reinterpret_cast<uint4*>(lane_out + ((uint64_t)ga[u] << 3)) = ch;
                     }
                 }
             }
