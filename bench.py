@@ -199,6 +199,20 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
                 return {"failed": logs[-1][-400:]}
         secs = min(runs)
         log = logs[runs.index(secs)]
+
+        def phases(wall, text):
+            """where a run's wall clock went, from goss -v's own time stamps (seconds since the command object started)"""
+            def at(pat):
+                mm = re.search(pat, text)
+                return float(mm.group(1)) if mm else None
+            ready, parsed, merged = at(r"contexts ready at ([0-9.eE+-]+)s"), at(r"reads at ([0-9.eE+-]+)s"), at(r"merged at ([0-9.eE+-]+)s")
+            written, total = at(r"written at ([0-9.eE+-]+)s"), at(r"total build time: ([0-9.eE+-]+)s")
+            arena = at(r"GB mapped in ([0-9.eE+-]+)s")
+            if None in (ready, parsed, merged, written, total):
+                return None
+            return {"process_start_and_exit": round(wall - total, 3), "context": round(ready, 3), "parse_and_push": round(parsed - ready, 3),
+                    "finish": round(merged - parsed, 3), "emit_and_write": round(written - merged, 3),
+                    "arena_mapping_beside_the_parser": arena}
         # the parser alone: the parallel FASTQ framer the build uses, bases written to /dev/null (after the builds: the
         # first pass over a freshly written file maps cold pages; the faster of two)
         parse = []
@@ -209,7 +223,7 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
             if err:
                 break
             parse.append(time.perf_counter() - t0)
-        parse_s = min(parse) if parse else float("nan")
+        parse_s = min(parse) if parse else None
         m = re.search(r"HBM arena: (\d+) GB mapped in ([0-9.]+)s", log)
         w = re.search(r"k-mer windows: (\d+)", log)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("ks"))
@@ -217,7 +231,12 @@ def e2e_record(nreads, read_len, genome_len, seed, k, threads):
         return {"what": "goss build-kmer-set -k %d -T %d on a %d-read 4-line FASTQ file in %s (the bench's read set): process start -> "
                         "KmerSet files closed; the faster of two runs" % (k, threads, want, base),
                 "reads": want, "fastq_bytes": nbytes, "seconds": secs, "runs_seconds": runs, "value": windows / secs / 1e6,
-                "unit": "M k-mers/s", "parse_only_seconds": parse_s, "parser_GB_per_s": nbytes / parse_s / 1e9,
+                "first_run_seconds": runs[0],
+                "phases": phases(secs, log), "first_run_phases": phases(runs[0], logs[0]),
+                "phases_what": "seconds by goss -v's stamps: process start + runtime load + exit (wall - total build time), GPU context(s) "
+                               "created, parse + pack + push loop, finish (last chunks counted, runs merged, canonical order), "
+                               "emit + file writes; the arena is mapped by a thread of its own beside the parser",
+                "unit": "M k-mers/s", "parse_only_seconds": parse_s, "parser_GB_per_s": (nbytes / parse_s / 1e9) if parse_s else None,
                 "parse_only_what": "goss dump-bases -T %d (the build's parallel FASTQ framer, bases to /dev/null)" % threads,
                 "generate_seconds": gen_s, "arena_GB": int(m.group(1)) if m else None,
                 "arena_map_ms": float(m.group(2)) * 1e3 if m else None, "output_bytes": out_bytes}
@@ -626,6 +645,8 @@ def main():
                 e = out["e2e"]
                 if "seconds" in e:
                     out["roofline"]["e2e"] = {"seconds": e["seconds"], "reads": e["reads"], "runs_seconds": e["runs_seconds"],
+                                              "first_run_seconds": e.get("first_run_seconds"), "phases": e.get("phases"),
+                                              "first_run_phases": e.get("first_run_phases"),
                                               "parse_only_seconds": e["parse_only_seconds"], "M_kmers_per_s": e["value"],
                                               "what": "goss build-kmer-set on the bench's reads as a FASTQ file, process start -> files closed"}
             if not args.no_extra and not (args.reads or args.genome):

@@ -856,12 +856,13 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     size_t expected = 0;
     bool serialRest = false;
     double waitSeconds = 0, pushSeconds = 0;         // GOSS_PARSE_STATS=1: where the in-order consumer spends its time
+    uint64_t drains = 0;                             // ... and how often it had to ask the library for its buffers (all lent, none free)
     const bool stats = std::getenv("GOSS_PARSE_STATS") != nullptr;
-    struct Report { bool on; double& w; double& p; const std::string& n; std::chrono::steady_clock::time_point t0;
-                    ~Report() { if (on) std::fprintf(stderr, "goss: %s: consumer waited %.3f s for parsed chunks, %.3f s in pushes; loop started %.3f s after entry, ended at %.3f s\n",
-                                                     n.c_str(), w, p, start, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    struct Report { bool on; double& w; double& p; uint64_t& d; const std::string& n; std::chrono::steady_clock::time_point t0;
+                    ~Report() { if (on) std::fprintf(stderr, "goss: %s: consumer waited %.3f s for parsed chunks, %.3f s in pushes; loop started %.3f s after entry, ended at %.3f s; every buffer lent and none free: %llu times\n",
+                                                     n.c_str(), w, p, start, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)d); }
                     double start; }
-        report{stats, waitSeconds, pushSeconds, name, tEnter, std::chrono::duration<double>(std::chrono::steady_clock::now() - tEnter).count()};
+        report{stats, waitSeconds, pushSeconds, drains, name, tEnter, std::chrono::duration<double>(std::chrono::steady_clock::now() - tEnter).count()};
     auto now = [] { return std::chrono::steady_clock::now(); };
     for (size_t i = 0; i < nchunks && !serialRest; ++i)
     {
@@ -880,6 +881,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 {
                     lk.unlock();
                     pushPacked->drain();
+                    ++drains;
                     lk.lock();
                 }
             }

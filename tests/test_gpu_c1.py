@@ -50,3 +50,30 @@ def test_c1_files_equal_oracle_and_committed_digests(oracle, c1, cmd):
     assert ("k-mer windows: %d" % nwin).encode() in p.stderr or str(nwin).encode() in p.stderr
     for name, data in exp.items():
         assert got[name[len(base):]] == data, name
+
+
+def test_every_parser_buffer_lent_and_none_free_does_not_hang(c1):
+    """The parallel parser's consumer waits for parsed chunks in file order while the buffers of packed pushes come back
+    only from inside library calls of that same thread (GossHost.cpp: "every buffer lent and none free").  Once the
+    device side had got faster, one build in four hung there: all buffers out with their copies queued, the workers
+    waiting for a buffer, the consumer waiting for a chunk nobody could parse.  With ONE buffer beyond the workers' and
+    256 KB chunks that state is reached hundreds of times per build: twenty builds of C1's 1 M reads, each under a
+    60 s limit, each with the committed digests -- and the state was met (GOSS_PARSE_STATS says how often)."""
+    import re
+    d, fq, golden = c1
+    want = golden["build-kmer-set"]["files"]
+    env = dict(os.environ, GOSS_PARSE_POOL="1", GOSS_PARSE_CHUNK=str(256 << 10), GOSS_PARSE_STATS="1")
+    met = 0
+    for it in range(20):
+        base = "hang%d" % it
+        p = subprocess.run([GOSS, "build-kmer-set", "-k", str(c1_input.K), "-T", "6", "-i", str(d / "c1.fq"), "-O", str(d / base)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+        assert p.returncode == 0, (it, p.stderr.decode()[-2000:])
+        m = re.search(r"every buffer lent and none free: (\d+) times", p.stderr.decode())
+        assert m, p.stderr.decode()[-2000:]
+        met += int(m.group(1))
+        for name, rec in want.items():
+            data = (d / (base + name)).read_bytes()
+            assert len(data) == rec["bytes"] and hashlib.md5(data).hexdigest() == rec["md5"], (it, name)
+            os.unlink(d / (base + name))
+    assert met > 0          # (else the pool and chunk settings no longer force the state: the test would prove nothing)
