@@ -101,6 +101,14 @@ struct goss_gpu_ctx {
     uint64_t flush_wait_us = 0, flush_count_us = 0, flushes = 0;   // staging buffer counted: waiting for queued copies / counting (host wall)
     // Host pushes are staged in one of TWO buffers (device memory of their own, beside the arena) by copies on a stream of
     // their own; a full buffer is counted by a thread of the library while the caller goes on filling the other
+    // A packed staging buffer (round 5): what goss_gpu_push_packed_host* hands over stays 2-bit codes + flags in HBM --
+    // u32 of codes per sixteen positions from the buffer's start, u16 of flags per sixteen positions behind them -- and the
+    // kernels that read bases take it as it is (load_group16, kernels_common.hpp).  A buffer holds bytes OR packed
+    // groups (stage_pk[i]); `pk` describes the packed string a count is running on: the plumbing between the entry
+    // points and the kernels goes on passing byte addresses -- made-up ones (pk.fake + position) that only the launch
+    // sites turn into the two real pointers (pk_ptrs).
+    struct PackedSrc { bool on = false; const uint32_t* codes = nullptr; const uint16_t* bad = nullptr; } pk;
+    bool stage_pk[2] = {false, false};
     uint8_t* stage_buf[2] = {nullptr, nullptr};
     int stage_cur = 0;
     hipStream_t copy_stream = nullptr;
@@ -148,6 +156,8 @@ struct goss_gpu_ctx {
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
+    uint32_t pk_fused_chunks = 0;       // chunks of a packed string the fused kernels read as they were
+    uint32_t pk_unpacked_chunks = 0;    // ... and chunks (or samples) unpacked to bytes for the plain kernels
     uint32_t rem32_bits_min = 0;        // GOSS_GPU_REM32_BITS=<9..12>: at least that many second-level bits (tests)
     uint32_t rem32_bits_last = 0;       // second-level bits of the last chunk counted in that form
     uint32_t rem32_split_min = 0;       // GOSS_GPU_REM32_SPLIT=<0..4>: at least that many third-level bits (tests; raised when tables overflow)
@@ -575,6 +585,36 @@ Run reduce_runs(goss_gpu_ctx* c, const K* keys, const uint32_t* vals, uint64_t n
     return r;
 }
 
+// ---- packed strings (ctx.pk) ---------------------------------------------------------------------------------------
+constexpr uintptr_t kPkFake = (uintptr_t)1 << 44;          // "address" of position 0 of the packed string being counted (a multiple of 16)
+// groups of a packed staging buffer of `cap` positions, and its two arrays
+static inline uint64_t pk_groups(uint64_t cap) { return cap / 16 + 4; }
+static inline uint32_t* pk_codes_of(uint8_t* buf) { return (uint32_t*)buf; }
+static inline uint16_t* pk_bad_of(uint8_t* buf, uint64_t cap) { return (uint16_t*)(buf + pk_groups(cap) * 4); }
+// a 16-byte aligned made-up address -> the codes and flags of its group
+static inline void pk_ptrs(const goss_gpu_ctx* c, const uint8_t* aligned, const uint8_t** src, const uint16_t** bad)
+{
+    const uint64_t g = ((uintptr_t)aligned - kPkFake) >> 4;
+    *src = (const uint8_t*)(c->pk.codes + g);
+    *bad = c->pk.bad + g;
+}
+// Bytes of `n` positions of the packed string from made-up address `p` on, for the kernels that have no packed form (the
+// plain extraction of small inputs and of the fallback sequence -- never the fused path's): unpacked into a temporary
+// of the arena (the caller releases its mark).  Returns the aligned byte address; *mis as for a byte string.
+static const uint8_t* pk_unpack_temp(goss_gpu_ctx* c, const uint8_t* p, uint64_t n, uint32_t* mis)
+{
+    const uintptr_t addr = (uintptr_t)p;
+    *mis = (uint32_t)(addr & 15u);
+    const uint8_t* src; const uint16_t* bad;
+    pk_ptrs(c, (const uint8_t*)(addr - *mis), &src, &bad);
+    const uint64_t groups = (n + *mis + 15) / 16;
+    c->pk_unpacked_chunks++;
+    uint8_t* out = (uint8_t*)c->arena.temp((groups + 1) * 16 + 64);
+    hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups + 1, kTB)), dim3(kTB), 0, c->stream, (const uint32_t*)src, bad, groups,
+                       n + *mis, out);
+    return out;
+}
+
 template <class K, int MODE, int P>
 void launch_extract(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint64_t nstarts, uint64_t navail, K* out)
 {
@@ -685,9 +725,18 @@ void launch_extract2(goss_gpu_ctx* c, const uint8_t* aligned, uint32_t mis, uint
     constexpr int T = kTB * P * G;
     const uint64_t nsuper = nsuper_override ? nsuper_override : (nstarts + T - 1) / T;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper ? nsuper : 1, 1024 * 2);
+    // (a packed string -- only the fused path's sample comes here with one: the plain extraction of a whole chunk unpacks first)
+    const uint8_t* pk_src = nullptr; const uint16_t* pk_bad = nullptr;
+    if (c->pk.on) pk_ptrs(c, aligned, &pk_src, &pk_bad);
 #define GOSS_LAUNCH_E2(NBH)                                                                                           \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G, NBH>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
-                       navail, c->len, out, c->d_ctr, nsuper, slice_tiles, slice_stride)
+    do {                                                                                                              \
+        if (c->pk.on)                                                                                                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G, NBH, true>), dim3(grid), dim3(kTB), 0, c->stream, pk_src, mis, nstarts,  \
+                               navail, c->len, out, c->d_ctr, nsuper, slice_tiles, slice_stride, pk_bad);             \
+        else                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_kernel<MODE, P, G, NBH>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts,  \
+                               navail, c->len, out, c->d_ctr, nsuper, slice_tiles, slice_stride, (const uint16_t*)nullptr); \
+    } while (0)
     if (MODE == 1) { GOSS_LAUNCH_E2(8); return; }             // graph mode does not hash
     if (rep) { GOSS_LAUNCH_E2(0); return; }                   // strand representatives (NBH 0): no hash either
     switch (key2_nbh(c))
@@ -1355,7 +1404,10 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     {
         const uintptr_t addr0 = (uintptr_t)d_bases;
         const uint32_t mis0 = c->rec_mode ? 0u : (uint32_t)(addr0 & 15u);          // (records are taken where they lie)
-        if (nslices == 1)
+        // (a packed string whose sample is the whole chunk: the slice kernels below, told to take every tile in turn --
+        // they have a packed form, the plain kernels behind extract_dispatch read bytes)
+        const bool whole_pk = nslices == 1 && c->pk.on && !c->rec_mode;
+        if (nslices == 1 && !whole_pk)
         {
             c->extract_rep = use_rep && rep;
             extract_dispatch<K>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka);
@@ -1371,7 +1423,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         }
         else if constexpr (!kOne)
         {
-            const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
+            const uint64_t slice_tiles = whole_pk ? 0 : slice_starts / kPlainSuper, nsuper = whole_pk ? (nstarts + kPlainSuper - 1) / kPlainSuper : slice_tiles * nslices;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
             (void)grid;
             if (graph_mode) launch_extract2<1, 4, 8>(c, (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, ka, slice_tiles, slice_stride, nsuper);
@@ -1387,20 +1439,18 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         }
         else
         {
-            const uint64_t slice_tiles = slice_starts / kPlainSuper, nsuper = slice_tiles * nslices;
+            const uint64_t slice_tiles = whole_pk ? 0 : slice_starts / kPlainSuper, nsuper = whole_pk ? (nstarts + kPlainSuper - 1) / kPlainSuper : slice_tiles * nslices;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsuper, 2048);
-            if (graph_mode)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<1, 8, 8, 8>), dim3(grid), dim3(kTB), 0, c->stream,
-                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
-                                   slice_tiles, slice_stride);
+            const uint8_t* src = (const uint8_t*)(addr0 - mis0); const uint16_t* pbad = nullptr;
+            if (c->pk.on) pk_ptrs(c, src, &src, &pbad);
+#define GOSS_LAUNCH_SAMPLE1(MODE, P, REP, PK)                                                                         \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<MODE, P, 8, 8, REP, PK>), dim3(grid), dim3(kTB), 0, c->stream, src, mis0, nstarts, navail, \
+                       c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper, slice_tiles, slice_stride, pbad)
+            if (graph_mode) { if (c->pk.on) GOSS_LAUNCH_SAMPLE1(1, 8, false, true); else GOSS_LAUNCH_SAMPLE1(1, 8, false, false); }
             else if (rep)      // strand representatives: the key space the fused kernel counts in
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, 8, true>), dim3(grid), dim3(kTB), 0, c->stream,
-                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
-                                   slice_tiles, slice_stride);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_kernel<0, 16, 8, 8, false>), dim3(grid), dim3(kTB), 0, c->stream,
-                                   (const uint8_t*)(addr0 - mis0), mis0, nstarts, navail, c->len, ka, c->d_ctr, 0xFFFFFFFFu, nsuper,
-                                   slice_tiles, slice_stride);
+            { if (c->pk.on) GOSS_LAUNCH_SAMPLE1(0, 16, true, true); else GOSS_LAUNCH_SAMPLE1(0, 16, true, false); }
+            else { if (c->pk.on) GOSS_LAUNCH_SAMPLE1(0, 16, false, true); else GOSS_LAUNCH_SAMPLE1(0, 16, false, false); }
+#undef GOSS_LAUNCH_SAMPLE1
         }
     }
     c->extract_hist_shift = 0xFFFFFFFFu;
@@ -1671,6 +1721,8 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const uintptr_t addr = (uintptr_t)d_bases;
     const uint32_t mis = (uint32_t)(addr & 15u);
     const uint8_t* aligned = (const uint8_t*)(addr - mis);
+    const uint8_t* pk_src = nullptr; const uint16_t* pk_bad = nullptr;          // (a packed string: the group `aligned` stands for)
+    if (c->pk.on && !c->rec_mode) { pk_ptrs(c, aligned, &pk_src, &pk_bad); c->pk_fused_chunks++; }
     {
 #ifndef GOSS_FUSED_G
 #define GOSS_FUSED_G 1
@@ -1698,10 +1750,14 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, true, FAST, NRW>), dim3(grid), dim3(kTB), 0, c->stream, \
                                d_bases, 0u, nstarts, nstarts / rec_slots(c), c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, \
                                nr_rbits, nr_sqbit, nr_dmask, nr_capg);                                                \
+        else if (c->pk.on)                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, false, FAST, NRW, true>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               pk_src, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, \
+                               nr_rbits, nr_sqbit, nr_dmask, nr_capg, pk_bad);                                        \
         else                                                                                                          \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(extract1_part_kernel<MODE, NH, ODD, false, FAST, NRW>), dim3(grid), dim3(kTB), 0, c->stream, \
                                aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, \
-                               nr_rbits, nr_sqbit, nr_dmask, nr_capg);                                                \
+                               nr_rbits, nr_sqbit, nr_dmask, nr_capg, (const uint16_t*)nullptr);                      \
     } while (0)
 #define GOSS_LAUNCH_EP4(MODE, NH, ODD, FAST)                                                                          \
     do {                                                                                                              \
@@ -1757,8 +1813,12 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
                 break;                                                                                                \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
-                           aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2); \
+        if (c->pk.on)                                                                                                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH, false, true>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               pk_src, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, pk_bad); \
+        else                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(extract2_part_kernel<MODE, NH, GOSS_FUSED_NKEYS2, NBH>), dim3(grid), dim3(kTB), 0, c->stream, \
+                               aligned, mis, nstarts, navail, c->len, ka, pc, (const GapTable*)dgt, part_shift, nsuper, blk_log2, (const uint16_t*)nullptr); \
     } while (0)
 #define GOSS_LAUNCH_E2N(MODE, NBH)                                                                                    \
     do { if (nh == 0) GOSS_LAUNCH_E2P(MODE, 0, NBH); else if (nh == 1) GOSS_LAUNCH_E2P(MODE, 1, NBH); else GOSS_LAUNCH_E2P(MODE, 2, NBH); } while (0)
@@ -2077,7 +2137,16 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     const uint8_t* aligned = (const uint8_t*)(addr - mis);
     {
         PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
-        extract_dispatch<K>(c, aligned, mis, nstarts, navail, ka);
+        if (c->pk.on && !c->rec_mode)
+        {
+            // (a packed string outside the fused path -- a small input, or the sequence a chunk falls back to: the plain
+            // kernels read bytes, and this chunk's are made here; released with the chunk's other temporaries)
+            aligned = pk_unpack_temp(c, d_bases, navail, &mis);
+            const auto keep = c->pk; c->pk.on = false;
+            extract_dispatch<K>(c, aligned, mis, nstarts, navail, ka);
+            c->pk = keep;
+        }
+        else extract_dispatch<K>(c, aligned, mis, nstarts, navail, ka);
         t.stop();
     }
     ExtractCounters* h = (ExtractCounters*)c->h_pinned;
@@ -2316,8 +2385,16 @@ double estimate_valid_fraction(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbyte
     const uint64_t stride = ((nbytes - skip - kSlice) / (kSlices - 1)) & ~15ULL;
     c->mute_timing = true;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, 16, c->stream));
-    hipLaunchKernelGGL(nonbase_sample_kernel, dim3(1024), dim3(kTB), 0, c->stream, al, kSlices, stride, kSlice,
-                       (unsigned long long*)c->d_ctr);
+    if (c->pk.on)
+    {
+        const uint8_t* src; const uint16_t* bad;
+        pk_ptrs(c, al, &src, &bad);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(nonbase_sample_kernel<true>), dim3(1024), dim3(kTB), 0, c->stream, (const uint8_t*)bad, kSlices, stride,
+                           kSlice, (unsigned long long*)c->d_ctr);
+    }
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(nonbase_sample_kernel<false>), dim3(1024), dim3(kTB), 0, c->stream, al, kSlices, stride, kSlice,
+                           (unsigned long long*)c->d_ctr);
     c->mute_timing = false;
     unsigned long long* h = (unsigned long long*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, c->d_ctr, 16, hipMemcpyDeviceToHost, c->stream));
@@ -3211,9 +3288,16 @@ static void wait_background(goss_gpu_ctx* c)
     }
 }
 
-static void count_staged(goss_gpu_ctx* c, const uint8_t* buf, uint64_t n)
+static void count_staged(goss_gpu_ctx* c, const uint8_t* buf, uint64_t n, bool packed = false)
 {
     const auto t1 = std::chrono::steady_clock::now();
+    struct PkOff { goss_gpu_ctx* c; ~PkOff() { c->pk.on = false; } } pkOff{c};
+    if (packed)
+    {
+        // (a packed buffer: counted as the string at the made-up address kPkFake, which the launch sites resolve)
+        c->pk.on = true; c->pk.codes = pk_codes_of((uint8_t*)buf); c->pk.bad = pk_bad_of((uint8_t*)buf, c->stage_cap);
+        buf = (const uint8_t*)kPkFake;
+    }
     if (c->words == 1) push_device<Key1>(c, buf, n); else push_device<Key2>(c, buf, n);
     c->flush_count_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
     c->flushes++;
@@ -3229,7 +3313,7 @@ static void flush_staging(goss_gpu_ctx* c)
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(c->copy_stream));      // (the copies queued so far: counted apart from the chunk's own time)
     c->flush_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    count_staged(c, c->stage, n);
+    count_staged(c, c->stage, n, c->stage_pk[c->stage_cur]);
 }
 
 // A staging buffer is full while the caller keeps pushing: a thread of the library counts it -- its kernels wait on
@@ -3251,17 +3335,18 @@ static void flush_staging_background(goss_gpu_ctx* c)
     // (the caller's next copies go to the other buffer: the background run below reads this one.  The buffer being
     // switched to is free: wait_background above returned only after the run that read it had synchronised its stream)
     const int cur0 = c->stage_cur;
+    const bool packed = c->stage_pk[cur0];
     c->stage_cur ^= 1;
     c->stage = c->stage_buf[c->stage_cur];
     c->stage_fill = 0;
     c->bg_status = GOSS_OK;
     try {
-    c->bg = std::thread([c, buf, n]() {
+    c->bg = std::thread([c, buf, n, packed]() {
         try
         {
             HIP_TRY(hipSetDevice(c->device));
             (void)hipGetLastError();
-            count_staged(c, buf, n);
+            count_staged(c, buf, n, packed);
             check_launch("a kernel launch was refused");
         }
         catch (const HipError& e) { c->bg_status = GOSS_ERR_HIP; c->bg_error = std::string(e.what) + ": " + hipGetErrorString(e.e); }
@@ -3341,9 +3426,6 @@ static void note_pending_checked(goss_gpu_ctx* c, void (*fn)(void*), void* user)
     }
 }
 
-// positions unpacked per landing of a packed push (24 MB of packed bytes at most; a small arena lands less at a time)
-static inline uint64_t land_positions(const goss_gpu_ctx* c) { return std::min<uint64_t>(64ULL << 20, (c->stage_cap + 15) & ~15ULL); }
-// (landing: codes of a piece, then its flags)
 static void ensure_stage(goss_gpu_ctx* c)
 {
     if (c->stage) return;
@@ -3357,7 +3439,7 @@ static void ensure_stage(goss_gpu_ctx* c)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const uint64_t room = free_b > (768ULL << 20) ? (free_b - (512ULL << 20)) / 2 : (64ULL << 20);
-        const uint64_t fits = room > (48ULL << 20) ? (room - (32ULL << 20)) * 8 / 11 : (1ULL << 20);      // (buffer + landing = 11/8 of it)
+        const uint64_t fits = room > (48ULL << 20) ? (room - (32ULL << 20)) : (1ULL << 20);
         if (c->stage_cap > fits) c->stage_cap = std::max<uint64_t>(fits, 1u << 20) & ~4095ULL;
     }
     // (tests: a small staging buffer makes a small input take several flushes / exchange rounds)
@@ -3367,15 +3449,14 @@ static void ensure_stage(goss_gpu_ctx* c)
         if (v) c->stage_cap = std::min<uint64_t>(c->stage_cap, std::max<uint64_t>(v, 1u << 16) & ~4095ULL);
     }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    // (one block each: the staging buffer, and behind it the landing area of packed pushes)
-    const uint64_t bytes = c->stage_cap + 16 + 256 + land_positions(c) / 16 * 6 + 64;
+    // (one block each: stage_cap bytes, or -- packed -- 6 bytes per sixteen positions of them: codes, then flags)
+    const uint64_t bytes = c->stage_cap + 16 + 256 + 64;
     for (auto*& b : c->stage_buf)
         if (!b && hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipGetLastError(); b = nullptr; throw StatusError{GOSS_ERR_OOM, "no device memory for the staging buffers"}; }
     c->stage_cur = 0;
     c->stage = c->stage_buf[0];
     c->stage_fill = 0;
 }
-static inline uint8_t* landing(goss_gpu_ctx* c) { return c->stage + ((c->stage_cap + 16 + 255) & ~255ULL); }
 
 static inline bool is_base_byte(char ch) { const char l = (char)(ch | 0x20); return l == 'a' || l == 'c' || l == 'g' || l == 't'; }
 
@@ -3397,6 +3478,7 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
         {
             uint64_t ns = std::min<uint64_t>(c->stage_cap - c->len, nstarts_total - done);
             uint64_t nb = ns + c->len - 1;
+            c->stage_pk[c->stage_cur] = false;
             HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(hipStreamSynchronize(c->copy_stream));
             count_staged(c, c->stage, nb);
@@ -3406,7 +3488,15 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
         if (release) release(user);
         return;
     }
+    // (a buffer holds bytes or packed groups: what is staged in the other form is counted first -- or, when counting is
+    // deferred, is the exchange round's to take)
+    if (c->stage_fill && c->stage_pk[c->stage_cur])
+    {
+        if (c->deferred) throw StatusError{GOSS_ERR_BUFFER, "the staging buffer holds packed bases and counting is deferred: goss_gpu_group_route_exchange first"};
+        flush_staging_background(c);
+    }
     if (c->stage_fill + nbytes + 1 > c->stage_cap) flush_staging_background(c);
+    c->stage_pk[c->stage_cur] = false;
     HIP_TRY(hipMemcpyAsync(c->stage + c->stage_fill, bases, nbytes, hipMemcpyHostToDevice, c->copy_stream));
     // reads of two pushes must not join: a separator unless the caller's bytes end with one already
     const bool sep = is_base_byte(bases[nbytes - 1]);
@@ -3416,19 +3506,19 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
     else { HIP_TRY(hipStreamSynchronize(c->copy_stream)); release_pending(c, false); if (release) release(user); }
 }
 
-// packed bases -> landing area -> unpacked into the staging buffer (unpack_bases_kernel), 16 positions per group
+// packed bases -> the staging buffer, as they are: codes to the buffer's code array, flags to its flag array, sixteen
+// positions per group (round 5: no landing area, no unpacking kernel -- the kernels that read bases take the groups)
 static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases, bool async,
                              void (*release)(void*), void* user)
 {
     if (nbases < c->len) { if (release) release(user); return; }
     ensure_stage(c);
-    const uint64_t kPiece = land_positions(c);
     // The pieces of one push are staged back to back without separators (all but the last are whole groups), so no
     // window is lost where one piece ends.  When the staging buffer must be counted in between, the last len - 1
     // positions are staged again in front of the rest -- their groups from the start, the positions whose windows
-    // have been counted turned into separators.
-    // (the staged string always ends on a 16-byte boundary behind a group of separators -- the unpack kernel writes
-    // them -- so a push costs one copy (two when the caller's arrays do not lie back to back) and one launch)
+    // have been counted flagged as no bases.
+    // (the staged string always ends on a group boundary behind a group of separators: the flag array of a buffer is
+    // all ones when it starts to fill, and a push sets the flags behind its own last group back to that)
     uint64_t pos = 0, kill = 0;
     bool cont = false;
     if (c->deferred)
@@ -3441,15 +3531,20 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         if (at0 + need + 32 > c->stage_cap)
             throw StatusError{GOSS_ERR_BUFFER, c->stage_fill ? "the staging buffer is full and counting is deferred: goss_gpu_group_route_exchange first (goss_gpu_stage_room says how much fits)"
                                                              : "a push larger than the staging buffer while counting is deferred"};
+        if (c->stage_fill && !c->stage_pk[c->stage_cur])
+            throw StatusError{GOSS_ERR_BUFFER, "the staging buffer holds bytes and counting is deferred: goss_gpu_group_route_exchange first"};
     }
-    if (c->stage_fill & 15ULL)          // (bytes staged by the byte form: pad to a boundary)
-    {
-        const uint64_t at = (c->stage_fill + 15) & ~15ULL;
-        if (at + 64 < c->stage_cap) { HIP_TRY(hipMemsetAsync(c->stage + c->stage_fill, '\n', at - c->stage_fill, c->copy_stream)); c->stage_fill = at; }
-        else flush_staging_background(c);
-    }
+    // (bytes staged by the byte form: counted first -- a buffer holds one form)
+    if (c->stage_fill && !c->stage_pk[c->stage_cur]) flush_staging_background(c);
+    const uint16_t ones = 0xFFFFu;
     while (pos < nbases)
     {
+        if (c->stage_fill == 0)
+        {
+            // a buffer that starts to fill: packed from here on, every flag set
+            c->stage_pk[c->stage_cur] = true;
+            HIP_TRY(hipMemsetAsync(pk_bad_of(c->stage, c->stage_cap), 0xFF, pk_groups(c->stage_cap) * 2, c->copy_stream));
+        }
         // continuing a push: over the separator group of the piece before (whole groups but for the last piece)
         uint64_t at = cont ? c->stage_fill - 16 : c->stage_fill;
         uint64_t room = at + 64 < c->stage_cap ? (c->stage_cap - 32 - at) & ~15ULL : 0;
@@ -3457,7 +3552,6 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         {
             c->stage_fill = at;
             flush_staging_background(c);
-            at = 0;
             if (cont)
             {
                 const uint64_t keep = pos >= c->len - 1 ? pos - (c->len - 1) : 0;      // first position whose window is still to be counted
@@ -3465,24 +3559,33 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
                 kill = keep - from;
                 pos = from;
             }
-            room = (c->stage_cap - 32) & ~15ULL;
+            cont = false;
+            continue;          // (the other buffer, from its start)
         }
-        const uint64_t n = std::min<uint64_t>({nbases - pos, kPiece, room});
+        const uint64_t n = std::min<uint64_t>(nbases - pos, room);
         const uint64_t groups = (n + 15) / 16;
-        uint32_t* dcodes = (uint32_t*)landing(c);
-        uint16_t* dbad = (uint16_t*)(dcodes + groups);
+        uint32_t* dcodes = pk_codes_of(c->stage) + at / 16;
+        uint16_t* dbad = pk_bad_of(c->stage, c->stage_cap) + at / 16;
         const uint32_t* hc = codes + pos / 16;
         const uint16_t* hb = nonbase + pos / 16;
-        if ((const void*)hb == (const void*)(hc + groups))
-            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 6, hipMemcpyHostToDevice, c->copy_stream));
-        else
+        HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->copy_stream));
+        // positions behind the piece's last in its last group are no bases (the caller's flags need not say so), and the
+        // positions of a continued push whose windows were counted with the buffer before are none any more: the two
+        // flag words concerned are sent once more, corrected (from pageable memory: staged by the call itself)
+        if ((n & 15ULL) && (uint16_t)(hb[groups - 1] | (ones << (n & 15ULL))) != hb[groups - 1])
         {
-            HIP_TRY(hipMemcpyAsync(dcodes, hc, groups * 4, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->copy_stream));
+            const uint16_t w = (uint16_t)(hb[groups - 1] | (ones << (n & 15ULL)));
+            HIP_TRY(hipMemcpyAsync(dbad + (groups - 1), &w, 2, hipMemcpyHostToDevice, c->copy_stream));
         }
-        hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid_for(groups + 1, kTB)), dim3(kTB), 0, c->copy_stream, (const uint32_t*)dcodes,
-                           (const uint16_t*)dbad, groups, n, c->stage + at);
-        if (kill) { HIP_TRY(hipMemsetAsync(c->stage + at, '\n', kill, c->copy_stream)); kill = 0; }
+        if (kill)
+        {
+            const uint16_t w = (uint16_t)(hb[0] | ((1u << kill) - 1u) | ((groups == 1 && (n & 15ULL)) ? (ones << (n & 15ULL)) : 0u));
+            HIP_TRY(hipMemcpyAsync(dbad, &w, 2, hipMemcpyHostToDevice, c->copy_stream));
+            kill = 0;
+        }
+        // (the group behind the piece is a group of separators as it stands: a buffer fills from its start, nothing has
+        // been written at or behind that group since the flags were set to ones)
         c->stage_fill = at + (groups + 1) * 16;
         pos += n;
         cont = true;
@@ -4066,7 +4169,12 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
                             { (void)hipGetLastError(); throw StatusError{GOSS_ERR_OOM, "no device memory for the routed records"}; }
                             c->grp_send_cap = tot;
                         }
-                        const int rc = goss_gpu_route_records_device(c, c->stage, nb, n, c->grp_send, first[i].data(), cap.data(), recs[i].data(), wins[i].data());
+                        // (a packed staging buffer is routed as it is: ctx.pk for the call's duration)
+                        const bool pk = c->stage_pk[c->stage_cur];
+                        if (pk) { c->pk.on = true; c->pk.codes = pk_codes_of(c->stage); c->pk.bad = pk_bad_of(c->stage, c->stage_cap); }
+                        const int rc = goss_gpu_route_records_device(c, pk ? (const void*)kPkFake : (const void*)c->stage, nb, n, c->grp_send, first[i].data(), cap.data(),
+                                                                     recs[i].data(), wins[i].data());
+                        c->pk.on = false;
                         if (rc == GOSS_OK) break;
                         if (rc != GOSS_ERR_BUFFER || attempt) throw StatusError{rc, "routing the staged reads: " + c->last_error};
                         for (uint32_t p = 0; p < n; ++p) cap[p] = recs[i][p] + 1;
@@ -4485,14 +4593,31 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
         const uint32_t block = std::max<uint32_t>(32, std::min<uint32_t>(GOSS_ROUTE_BLOCK, 8 * GOSS_ROUTE_BLOCK / nparts));
         {
             PhaseTimer t(c, GOSS_T_EXTRACT, nstarts);
+            // (a packed staging buffer -- the group's exchange round sets ctx.pk -- is routed as it is)
+            const uint8_t* src = aligned; const uint16_t* pbad = nullptr;
+            if (c->pk.on) pk_ptrs(c, aligned, &src, &pbad);
 #define GOSS_LAUNCH_ROUTE(W)                                                                                                \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W>), dim3(grid), dim3(kTB), 0, c->stream, aligned, mis, nstarts, nbytes, \
-                       c->len, maxwin, nparts, block, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles)
+    do {                                                                                                                    \
+        if (c->pk.on)                                                                                                       \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W, true>), dim3(grid), dim3(kTB), 0, c->stream, src, mis, nstarts, nbytes, \
+                               c->len, maxwin, nparts, block, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles, pbad); \
+        else                                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records_kernel<W, false>), dim3(grid), dim3(kTB), 0, c->stream, src, mis, nstarts, nbytes, \
+                               c->len, maxwin, nparts, block, (SkRec*)d_records, (const unsigned long long*)dfirst, (const unsigned long long*)dcap, rc, ntiles, pbad); \
+    } while (0)
             if (c->words == 2)
+            {
                 // two-word keys: 20-byte records, the minimizer taken over the central 31 / 30 bases of a window (17 positions)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records2_kernel<17>), dim3((uint32_t)std::min<uint64_t>(ntiles, 256 * 4)), dim3(kTB), 0, c->stream, aligned, mis,
-                                   nstarts, nbytes, c->len, nparts, block, (SkRec2*)d_records, (const unsigned long long*)dfirst,
-                                   (const unsigned long long*)dcap, rc, ntiles);
+                const dim3 g2((uint32_t)std::min<uint64_t>(ntiles, 256 * 4));
+                if (c->pk.on)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records2_kernel<17, true>), g2, dim3(kTB), 0, c->stream, src, mis,
+                                       nstarts, nbytes, c->len, nparts, block, (SkRec2*)d_records, (const unsigned long long*)dfirst,
+                                       (const unsigned long long*)dcap, rc, ntiles, pbad);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(route_records2_kernel<17, false>), g2, dim3(kTB), 0, c->stream, src, mis,
+                                       nstarts, nbytes, c->len, nparts, block, (SkRec2*)d_records, (const unsigned long long*)dfirst,
+                                       (const unsigned long long*)dcap, rc, ntiles, pbad);
+            }
             else
             switch (route_positions(c->len))
             {
@@ -4789,6 +4914,8 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
+    else if (n == "packed_fused_chunks") *value = c->pk_fused_chunks;
+    else if (n == "packed_unpacked_chunks") *value = c->pk_unpacked_chunks;
     else if (n == "rem32_bits") *value = c->rem32_bits_last;
     else if (n == "rem32_split") *value = c->rem32_split_last;
     else if (n == "big_table_chunks") *value = c->big_table_chunks;

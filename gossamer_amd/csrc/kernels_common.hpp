@@ -205,4 +205,54 @@ __device__ __forceinline__ uint32_t base_codes(uint32_t w, uint32_t& bad)
 __device__ __forceinline__ uint32_t pack_codes(uint32_t x) { return (x * 0x01041040u) >> 24; }
 __device__ __forceinline__ uint32_t pack_flags(uint32_t bad) { return ((bad >> 7) * 0x01020408u) >> 24; }
 
+// Sixteen positions of the input at offset `byte0` (a multiple of 16) of a 16-byte aligned string -> 32 bits of 2-bit codes
+// and 16 non-base flags; positions at or beyond `limit` are no bases.  The string is bytes (one letter per position,
+// anything but ACGTacgt a non-base), or -- PACKED, what the host's parser threads hand over (goss_gpu_push_packed_host*)
+// and the staging buffer keeps as it is -- one u32 of codes at src[4 g] and one u16 of flags at pbad[g] per group g of
+// sixteen: the role of GossReadBaseString's encoder (GossReadBaseString.hh:133-188) is the host packer's, the device
+// reads 3 bits per base and encodes nothing.
+template <bool PACKED>
+__device__ __forceinline__ void load_group16(const uint8_t* __restrict__ src, const uint16_t* __restrict__ pbad, uint64_t byte0, uint64_t limit,
+                                             uint32_t& codes, uint32_t& bads)
+{
+    if constexpr (PACKED)
+    {
+        codes = 0; bads = 0xFFFFu;
+        if (byte0 < limit)
+        {
+            const uint64_t g = byte0 >> 4;
+            codes = reinterpret_cast<const uint32_t*>(src)[g];
+            bads = pbad[g];
+            if (byte0 + 16 > limit) bads = (bads | (0xFFFFu << (uint32_t)(limit - byte0))) & 0xFFFFu;
+        }
+    }
+    else
+    {
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        if (byte0 + 16 <= limit)
+        {
+            const uint4 q = *reinterpret_cast<const uint4*>(src + byte0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        else if (byte0 < limit)
+        {
+            for (int j = 0; j < 16; ++j)
+            {
+                const uint64_t b = byte0 + j;
+                const uint32_t c = b < limit ? src[b] : 0x0Au;
+                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+            }
+        }
+        codes = 0; bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            uint32_t bad;
+            const uint32_t x = base_codes(w[i], bad);
+            codes |= pack_codes(x) << (8 * i);
+            bads |= pack_flags(bad) << (4 * i);
+        }
+    }
+}
+
 }  // namespace goss

@@ -35,6 +35,8 @@ struct ExtractCounters {
 // Bytes that are not one of ACGTacgt in `nslices` slices of `slice` bytes (a multiple of 16),
 // `stride` bytes apart, of a 16-byte aligned string: out[0] += such bytes, out[1] += bytes looked
 // at.  The host sizes the key buffers of a chunk from it (a non-base removes at most `len` windows).
+// (PACKED: `aligned` is the string's first group of sixteen positions in the flag array of a packed string -- one u16 a group)
+template <bool PACKED = false>
 __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __restrict__ aligned, uint64_t nslices,
                                                              uint64_t stride, uint32_t slice,
                                                              unsigned long long* __restrict__ out)
@@ -42,6 +44,12 @@ __global__ __launch_bounds__(kTB) void nonbase_sample_kernel(const uint8_t* __re
     unsigned long long bad = 0, seen = 0;
     for (uint64_t s = blockIdx.x; s < nslices; s += gridDim.x)
     {
+        if constexpr (PACKED)
+        {
+            const uint16_t* f = reinterpret_cast<const uint16_t*>(aligned) + (s * stride >> 4);
+            for (uint32_t v = threadIdx.x; v < slice / 16; v += kTB) { bad += __popc((uint32_t)f[v]); seen += 16; }
+            continue;
+        }
         const uint4* p = reinterpret_cast<const uint4*>(aligned + s * stride);
         for (uint32_t v = threadIdx.x; v < slice / 16; v += kTB)
         {
@@ -174,10 +182,11 @@ template <> struct KeyOps<Key2> {
     }
 };
 
-template <class K, int MODE, int P>
+template <class K, int MODE, int P, bool PACKED = false>
 __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                       uint64_t nstarts, uint64_t navail, uint32_t len,
-                                                      K* __restrict__ out, ExtractCounters* __restrict__ ctr)
+                                                      K* __restrict__ out, ExtractCounters* __restrict__ ctr,
+                                                      const uint16_t* __restrict__ pbad = nullptr)
 {
     constexpr int T = kTB * P;
     constexpr int NVEC = T / 16 + 5;
@@ -196,6 +205,23 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
     for (uint32_t v = tid; v < NVEC; v += kTB)
     {
         uint64_t byte0 = tile_base + (uint64_t)v * 16;            // aligned-stream offset
+        if constexpr (PACKED)
+        {
+            // (a packed string: the group's codes and flags spread out to the code bytes this kernel works on)
+            uint32_t cd, bd, o[4];
+            load_group16<true>(bases_aligned, pbad, byte0, navail + mis, cd, bd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                uint32_t x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x |= (((bd >> (4 * i + j)) & 1u) ? 4u : ((cd >> (2 * (4 * i + j))) & 3u)) << (8 * j);
+                o[i] = x;
+            }
+            *reinterpret_cast<uint4*>(&code[v * 16]) = make_uint4(o[0], o[1], o[2], o[3]);
+            continue;
+        }
         uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
         // positions byte0-mis .. byte0-mis+15 ; fully in range?
         if (byte0 + 16 <= navail + mis)
@@ -308,12 +334,13 @@ __global__ __launch_bounds__(kTB) void extract_kernel(const uint8_t* __restrict_
 // them fold into one multiplication (goss_key.hpp, key_hash_short).
 // REP: MODE 0 stores the strand representative (strand_rep) instead of the canonical form -- the
 // key space extract1_part_kernel counts in; its sample must be drawn from the same space.
-template <int MODE, int P, int G, int NB, bool REP = false>
+template <int MODE, int P, int G, int NB, bool REP = false, bool PACKED = false>
 __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key1* __restrict__ out, ExtractCounters* __restrict__ ctr,
                                                        uint32_t hist_shift, uint64_t nsuper,
-                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0,
+                                                       const uint16_t* __restrict__ pbad = nullptr)
 {
     // Persistent grid: a workgroup loops over super-tiles (blockIdx.x, +gridDim.x, ...).
     // A super-tile is G consecutive sub-tiles of T = 256*P window starts and reserves the
@@ -346,31 +373,8 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
     // ---- phase A: ASCII -> packed 2-bit codes + non-base mask, all G sub-tiles -------------
     for (uint32_t v = tid; v < NVEC; v += kTB)
     {
-        uint64_t byte0 = tile_base + (uint64_t)v * 16;
-        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-        if (byte0 + 16 <= navail + mis)
-        {
-            uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-        }
-        else if (byte0 < navail + mis)
-        {
-            for (int j = 0; j < 16; ++j)
-            {
-                uint64_t b = byte0 + j;
-                uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
-            }
-        }
-        uint32_t codes = 0, bads = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-        {
-            uint32_t bad;
-            const uint32_t x = base_codes(w[i], bad);
-            codes |= pack_codes(x) << (8 * i);
-            bads |= pack_flags(bad) << (4 * i);
-        }
+        uint32_t codes, bads;
+        load_group16<PACKED>(bases_aligned, pbad, tile_base + (uint64_t)v * 16, navail + mis, codes, bads);
         pk[v] = codes;
         iv[v] = bads;
     }
@@ -477,11 +481,12 @@ __global__ __launch_bounds__(kTB) void extract1_kernel(const uint8_t* __restrict
 // K2, two-word keys (32 <= len <= 63): the same windows-out-of-registers scheme with a 192-bit
 // buffer of 2-bit codes per thread (96 bases >= 15 + P - 1 + 63)
 // --------------------------------------------------------------------------------------
-template <int MODE, int P, int G, int NBH = 8>
+template <int MODE, int P, int G, int NBH = 8, bool PACKED = false>
 __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                        uint64_t nstarts, uint64_t navail, uint32_t len,
                                                        Key2* __restrict__ out, ExtractCounters* __restrict__ ctr, uint64_t nsuper,
-                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0)
+                                                       uint64_t slice_tiles = 0, uint64_t slice_stride = 0,
+                                                       const uint16_t* __restrict__ pbad = nullptr)
 {
     constexpr int T = kTB * P;
     constexpr int NVEC = G * T / 16 + 6;
@@ -506,31 +511,8 @@ __global__ __launch_bounds__(kTB) void extract2_kernel(const uint8_t* __restrict
         // ---- phase A: ASCII -> packed 2-bit codes + non-base mask (as extract1_kernel) ----------
         for (uint32_t v = tid; v < NVEC; v += kTB)
         {
-            uint64_t byte0 = tile_base + (uint64_t)v * 16;
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-            if (byte0 + 16 <= navail + mis)
-            {
-                uint4 q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            }
-            else if (byte0 < navail + mis)
-            {
-                for (int j = 0; j < 16; ++j)
-                {
-                    uint64_t b = byte0 + j;
-                    uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
-                }
-            }
-            uint32_t codes = 0, bads = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                uint32_t bad;
-                const uint32_t x = base_codes(w[i], bad);
-                codes |= pack_codes(x) << (8 * i);
-                bads |= pack_flags(bad) << (4 * i);
-            }
+            uint32_t codes, bads;
+            load_group16<PACKED>(bases_aligned, pbad, tile_base + (uint64_t)v * 16, navail + mis, codes, bads);
             pk[v] = codes;
             iv[v] = bads;
         }
@@ -755,13 +737,17 @@ __device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t ones, uin
 // the bucket's thread holds in registers AS A GRANULE (48 + 24 bytes) between tiles and copies to the head of the
 // next piece with six wide LDS writes -- no key is moved one by one and the new keys simply follow (rank + carried).
 // Cursors, blocks and regions keep counting 8-byte slots: a granule is eight of them whatever it holds.
-template <int MODE, int NH, int REPK, bool REC = false, bool FAST = false, bool NARROW = false>
+template <int MODE, int NH, int REPK, bool REC = false, bool FAST = false, bool NARROW = false, bool PACKED = false>
 __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                             uint64_t nstarts, uint64_t navail, uint32_t len,
                                                             Key1* __restrict__ out, PartCounters* __restrict__ pc,
                                                             const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
-                                                            uint32_t blk_log2, uint32_t nr_rbits = 0, uint32_t nr_sqbit = 0, uint32_t nr_dmask = 0, uint32_t nr_capg = 0)
+                                                            uint32_t blk_log2, uint32_t nr_rbits = 0, uint32_t nr_sqbit = 0, uint32_t nr_dmask = 0, uint32_t nr_capg = 0,
+                                                            const uint16_t* __restrict__ pbad = nullptr)
 {
+    // PACKED: the input is a packed string (load_group16, kernels_common.hpp) -- bases_aligned its codes, pbad its flags; the
+    // tile's vectors are fetched as they are and nothing is encoded
+    static_assert(!(PACKED && REC), "records are not bases");
     // (nr_capg: granules of the LDS layout a tile may take before its carried granules are sent off short -- the layout's
     // 664, or down to the 576 a tile without carried keys needs at most: tests make the rare path common with it)
     static_assert(!NARROW || NH == 0, "the narrow form is the two-level form's");
@@ -848,6 +834,20 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
 
     // 16 bytes of the input at `byte0` -> 32 bits of 2-bit codes + 16 non-base flags
     auto fetch = [&](uint64_t byte0, uint4& q) -> bool {
+        if constexpr (PACKED)
+        {
+            // (codes and flags as they lie; positions beyond the string are flagged where the vector is "encoded")
+            q = make_uint4(0u, 0xFFFFu, 0u, 0u);
+            if (byte0 < navail + mis)
+            {
+                const uint64_t g = byte0 >> 4;
+                q.x = reinterpret_cast<const uint32_t*>(bases_aligned)[g];
+                q.y = pbad[g];
+                const uint64_t left = navail + mis - byte0;
+                q.z = left < 16 ? (0xFFFFu << (uint32_t)left) & 0xFFFFu : 0u;
+            }
+            return true;
+        }
         if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return true; }
         q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
         if (byte0 < navail + mis)
@@ -864,6 +864,7 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         return true;
     };
     auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        if constexpr (PACKED) { codes = q.x; bads = q.y | q.z; return; }
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
         codes = 0; bads = 0;
 #pragma unroll
@@ -1626,13 +1627,14 @@ __global__ __launch_bounds__(kTB) void normalize_keys_kernel(const K* __restrict
 // workgroup walks its own share of the records, stages up to 512 per tile in LDS, takes as many whole records as hold at
 // most T windows, and thread t extracts windows P t .. P t + P - 1 of the tile's window sequence wherever the record
 // boundaries fall (MODE 0 only: k-mer sets, and graphs counted as strand pairs).
-template <int MODE, int NH, int NKEYS, int NBH = 8, bool REC = false>
+template <int MODE, int NH, int NKEYS, int NBH = 8, bool REC = false, bool PACKED = false>
 __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                uint64_t nstarts, uint64_t navail, uint32_t len,
                                                                Key2* __restrict__ out, PartCounters* __restrict__ pc,
                                                                const GapTable* __restrict__ gt, uint32_t shift, uint64_t nsuper,
-                                                               uint32_t blk_log2)
+                                                               uint32_t blk_log2, const uint16_t* __restrict__ pbad = nullptr)
 {
+    static_assert(!(PACKED && REC), "records are not bases");          // (PACKED: as in extract1_part_kernel)
     constexpr int S = MODE == 1 ? 2 : 1;
     constexpr int P = NKEYS / S;                 // windows per thread; NKEYS keys per thread
     constexpr int T = kTB * P;
@@ -1674,6 +1676,19 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     for (int j = 0; j < kCarry; ++j) kc[j] = Key2{0, 0};
 
     auto fetch = [&](uint64_t byte0, uint4& q) {
+        if constexpr (PACKED)
+        {
+            q = make_uint4(0u, 0xFFFFu, 0u, 0u);
+            if (byte0 < navail + mis)
+            {
+                const uint64_t g = byte0 >> 4;
+                q.x = reinterpret_cast<const uint32_t*>(bases_aligned)[g];
+                q.y = pbad[g];
+                const uint64_t left = navail + mis - byte0;
+                q.z = left < 16 ? (0xFFFFu << (uint32_t)left) & 0xFFFFu : 0u;
+            }
+            return;
+        }
         if (byte0 + 16 <= navail + mis) { q = *reinterpret_cast<const uint4*>(bases_aligned + byte0); return; }
         q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
         if (byte0 < navail + mis)
@@ -1689,6 +1704,7 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
         }
     };
     auto encode = [](const uint4& q, uint32_t& codes, uint32_t& bads) {
+        if constexpr (PACKED) { codes = q.x; bads = q.y | q.z; return; }
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
         codes = 0; bads = 0;
 #pragma unroll

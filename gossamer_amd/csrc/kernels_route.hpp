@@ -81,13 +81,14 @@ __device__ __forceinline__ uint32_t route_scale(uint32_t h16, uint32_t nparts)
 // reads (ASCII, any non-ACGT byte ends a run of windows) -> records appended to `nparts` buffers.
 // out + part_first[p] = first record slot of part p, part_cap[p] its capacity.  Tile = 4096 window starts,
 // 16 per thread; phase A (bytes -> 2-bit codes + non-base flags in LDS) is the extraction kernels'.
-template <int W>
+template <int W, bool PACKED = false>
 __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                uint64_t nstarts, uint64_t navail, uint32_t len, uint32_t maxwin,
                                                                uint32_t nparts, uint32_t block, SkRec* __restrict__ out,
                                                                const unsigned long long* __restrict__ part_first,
                                                                const unsigned long long* __restrict__ part_cap,
-                                                               RouteCounters* __restrict__ rc, uint64_t ntiles)
+                                                               RouteCounters* __restrict__ rc, uint64_t ntiles,
+                                                               const uint16_t* __restrict__ pbad = nullptr)
 {
     constexpr int P = 16;
     constexpr int T = kTB * P;
@@ -118,30 +119,8 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         for (uint32_t v = tid; v < (uint32_t)NVEC; v += kTB)
         {
             const uint64_t byte0 = tb + (uint64_t)v * 16;
-            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-            if (byte0 + 16 <= navail + mis) q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-            else if (byte0 < navail + mis)
-            {
-                uint32_t w[4] = {q.x, q.y, q.z, q.w};
-                for (int j = 0; j < 16; ++j)
-                {
-                    const uint64_t b = byte0 + j;
-                    const uint32_t c = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
-                }
-                q = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            // (bytes in front of the string, when it does not start on a 16-byte boundary, are not bases)
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-            uint32_t codes = 0, bads = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                uint32_t bad;
-                const uint32_t x = base_codes(w[i], bad);
-                codes |= pack_codes(x) << (8 * i);
-                bads |= pack_flags(bad) << (4 * i);
-            }
+            uint32_t codes, bads;
+            load_group16<PACKED>(bases_aligned, pbad, byte0, navail + mis, codes, bads);
             if (byte0 < mis) bads |= (1u << (uint32_t)(mis - byte0 > 16 ? 16 : mis - byte0)) - 1u;
             pk[v] = codes; iv[v] = bads;
         }
@@ -408,13 +387,14 @@ __host__ __device__ inline uint32_t rec2_windows(uint32_t w4) { return (w4 >> 27
 // central bases the minimizer of a long window is taken from, and where they start
 __host__ __device__ inline uint32_t route_central(uint32_t len) { return len <= 31 ? len : ((len & 1u) ? 31u : 30u); }
 
-template <int W>
+template <int W, bool PACKED = false>
 __global__ __launch_bounds__(kTB, 4) void route_records2_kernel(const uint8_t* __restrict__ bases_aligned, uint32_t mis,
                                                                 uint64_t nstarts, uint64_t navail, uint32_t len,
                                                                 uint32_t nparts, uint32_t block, SkRec2* __restrict__ out,
                                                                 const unsigned long long* __restrict__ part_first,
                                                                 const unsigned long long* __restrict__ part_cap,
-                                                                RouteCounters* __restrict__ rc, uint64_t ntiles)
+                                                                RouteCounters* __restrict__ rc, uint64_t ntiles,
+                                                                const uint16_t* __restrict__ pbad = nullptr)
 {
     constexpr int P = 16;
     constexpr int T = kTB * P;
@@ -444,29 +424,8 @@ __global__ __launch_bounds__(kTB, 4) void route_records2_kernel(const uint8_t* _
         for (uint32_t v = tid; v < (uint32_t)NVEC; v += kTB)
         {
             const uint64_t byte0 = tb + (uint64_t)v * 16;
-            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-            if (byte0 + 16 <= navail + mis) q = *reinterpret_cast<const uint4*>(bases_aligned + byte0);
-            else if (byte0 < navail + mis)
-            {
-                uint32_t w[4] = {q.x, q.y, q.z, q.w};
-                for (int j = 0; j < 16; ++j)
-                {
-                    const uint64_t b = byte0 + j;
-                    const uint32_t ch = b < navail + mis ? bases_aligned[b] : 0x0Au;
-                    w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (ch << (8 * (j & 3)));
-                }
-                q = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-            uint32_t codes = 0, bads = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                uint32_t bad;
-                const uint32_t x = base_codes(w[i], bad);
-                codes |= pack_codes(x) << (8 * i);
-                bads |= pack_flags(bad) << (4 * i);
-            }
+            uint32_t codes, bads;
+            load_group16<PACKED>(bases_aligned, pbad, byte0, navail + mis, codes, bads);
             if (byte0 < mis) bads |= (1u << (uint32_t)(mis - byte0 > 16 ? 16 : mis - byte0)) - 1u;
             pk[v] = codes; iv[v] = bads;
         }

@@ -77,3 +77,25 @@ def test_host_pushes_beside_an_arena_that_takes_nearly_all_memory(oracle):
         c = ctx.finish()
         ks, cs = ctx.result()
     assert c.windows == nwin and ks == ek and [int(x) for x in cs] == ec
+
+
+@pytest.mark.parametrize("k,mode", [(25, 0), (27, 1), (55, 1)])
+def test_packed_pushes_are_read_as_they_are_by_the_fused_kernels(oracle, k, mode):
+    """Packed bases stay packed in HBM (round 5): at a size the fused path takes by itself its kernels -- the sample's, the
+    first level's -- read the staged groups of 2-bit codes and flags, nothing is unpacked to bytes
+    (packed_fused_chunks / packed_unpacked_chunks), and the files are the oracle's.  Pushed in pieces that do not end on
+    group boundaries, alternately with and without waiting for the copy."""
+    reads = g.synth_reads_host(300_000, 150, 1_500_000, seed=900 + k)
+    build_o = oracle.build_graph if mode else oracle.build_kmer_set
+    exp, nwin = build_o([(oracle.LINE, "reads", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    lines = reads.split(b"\n")[:-1]
+    with g.Context(k, mode, hbm_budget=24 << 30) as ctx:          # (room for one chunk of two-word keys: the fused path's)
+        for i in range(0, len(lines), 77_777):
+            ctx.push_packed_host(b"".join(l + b"\n" for l in lines[i:i + 77_777]), async_=(i % 2 == 0))
+        c = ctx.finish()
+        got = ctx.emit()
+        st = {n: ctx.stat(n) for n in ("packed_fused_chunks", "packed_unpacked_chunks", "fused_chunks")}
+    assert c.windows == nwin
+    assert st["packed_fused_chunks"] >= 1 and st["packed_unpacked_chunks"] == 0 and st["fused_chunks"] == st["packed_fused_chunks"], st
+    assert got == exp
