@@ -121,9 +121,14 @@ int goss_gpu_push_bases_host_async(goss_gpu_ctx* ctx, const char* bases, uint64_
  * nonbase = one u16 per 16 positions, bit j set where position j is NOT a base (read separators, N, ...: it ends the
  * run of windows like any non-ACGT byte of the byte form).  nbases positions; the upper bits of a partial last
  * group are ignored.  Packed by the host's parser threads this moves 3 bits per base over PCIe instead of 8
- * (north_star: "2-bit read encoding"; the per-base encoder it stands for is GossReadBaseString.hh:133-188); on the
- * device the groups are unpacked into the byte form the extraction kernels read (one more byte written and read per
- * base in HBM, 1/8 of what a key costs).  Windows never span two pushes.  _async: as goss_gpu_push_bases_host_async,
+ * (north_star: "2-bit read encoding", "coalesced HBM loads of packed reads"; the per-base encoder it stands for is
+ * GossReadBaseString.hh:133-188); on the device the groups stay as they are -- the staging buffer keeps codes and flags,
+ * and the kernels that read bases (the fused extraction, its sample, the routing kernels of a group's exchange) load
+ * them straight: 3 bits per base in HBM too, nothing is unpacked (the plain kernels that small inputs and the fallback
+ * sequence go through read bytes: such a chunk is unpacked for them; goss_gpu_stat "packed_fused_chunks" /
+ * "packed_unpacked_chunks" count the two).  A staging buffer holds bytes or packed groups: a push of the other form
+ * counts what is staged first (a deferred context refuses it with GOSS_ERR_BUFFER, like a push that does not fit).
+ * Windows never span two pushes.  _async: as goss_gpu_push_bases_host_async,
  * both arrays belong to the library until release(user).  A caller that recycles a bounded pool of such buffers must not
  * wait for a free one (or for the thread that would fill it) without calling the library: release only ever runs inside a
  * call on this context -- goss_gpu_flush is the one that makes every outstanding release happen (the `goss` parser's
