@@ -172,7 +172,8 @@ def group_exchange(contexts, sample_per_context=0):
 
 class GroupXStats(C.Structure):
     _fields_ = [("transport", C.c_uint32), ("rounds", C.c_uint32), ("records", C.c_uint64), ("windows", C.c_uint64),
-                ("record_bytes", C.c_uint64), ("route_ms", C.c_double), ("wire_ms", C.c_double), ("count_ms", C.c_double)]
+                ("record_bytes", C.c_uint64), ("route_ms", C.c_double), ("wire_ms", C.c_double), ("count_ms", C.c_double),
+                ("count_wait_ms", C.c_double)]
 
 
 def group_route_exchange(contexts, transport=0):

@@ -200,6 +200,7 @@ struct goss_gpu_ctx {
     // a group's route-and-exchange round failed half way: what this context had staged may be in records that were
     // lost with the round -- every later push, exchange and finish is refused (GOSS_ERR_STATE) until goss_gpu_reset
     bool broken = false;
+    double grp_count_ms = 0;            // how long the background thread of the last exchange round took to count this member's records
     void* res_keys = nullptr;
     uint32_t* res_counts = nullptr;
     uint64_t M = 0;
@@ -4132,8 +4133,25 @@ constexpr uint64_t kXferRound = 512ULL << 20;          // bytes per (source, des
 void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, goss_gpu_group_xstats* st)
 {
     const uint64_t kRecBytes = rec_bytes(ctxs[0]);          // (all members have one k and mode)
-    const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    // 0. the round before: its records are counted by a thread of every member while the caller stages this round's reads
+    // (step 3); that counting must have ended before the inboxes are written again -- what is waited for here is the
+    // part of it that the staging did not cover
+    const auto tw = std::chrono::steady_clock::now();
+    double prev_count_ms = 0;
+    {
+        int bad = GOSS_OK; std::string why;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            try { HIP_TRY(hipSetDevice(ctxs[i]->device)); wait_background(ctxs[i]); }
+            catch (const StatusError& e) { if (bad == GOSS_OK) { bad = e.status; why = "member " + std::to_string(i) + " counting the records of the round before: " + e.msg; } }
+            prev_count_ms = std::max(prev_count_ms, ctxs[i]->grp_count_ms);
+            ctxs[i]->grp_count_ms = 0;
+        }
+        if (bad != GOSS_OK) { for (uint32_t i = 0; i < n; ++i) ctxs[i]->broken = true; throw StatusError{bad, why}; }
+    }
+    const double wait_ms = ms_since(tw);
+    const auto t0 = std::chrono::steady_clock::now();
     // 1. every member routes what it has staged into n parts (side by side: one host thread per device)
     std::vector<std::vector<uint64_t>> recs(n, std::vector<uint64_t>(n, 0)), wins(n, std::vector<uint64_t>(n, 0)), first(n, std::vector<uint64_t>(n, 0));
     std::vector<int> status(n, GOSS_OK);
@@ -4255,35 +4273,44 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
         HIP_TRY(hipStreamSynchronize(ctxs[p]->xstream));
     }
     const double wire_ms = ms_since(t1);
-    // 3. every member counts what it received (side by side)
-    const auto t2 = std::chrono::steady_clock::now();
+    // 3. every member counts what it received -- on a thread of its own that this call does NOT wait for (round 5): the
+    // members' staging buffers are free again (the windows of their bases live in the records), so the caller stages the
+    // next round's reads while the devices count this round's.  The thread is the context's background thread: every
+    // entry point that works on the arena or the runs (finish, emit, a device push, the next exchange round) waits for
+    // it and takes over its failure; host pushes, which only stage, go on beside it.
+    for (uint32_t p = 0; p < n; ++p)
     {
-        std::vector<std::thread> pool;
-        auto join_all = [&]() { for (auto& t : pool) if (t.joinable()) t.join(); };
-        for (uint32_t p = 0; p < n; ++p)
-        {
-            auto work = [&, p]() {
-                uint64_t w = 0;
-                for (uint32_t i = 0; i < n; ++i) w += wins[i][p];
-                status[p] = in_off[p][n] ? goss_gpu_push_records_device(ctxs[p], ctxs[p]->grp_inbox, in_off[p][n], w) : GOSS_OK;
-            };
-            try { pool.emplace_back(work); }
-            catch (const std::system_error&) { work(); }          // (no thread to be had: this member's share on the caller's)
-        }
-        join_all();
-        for (uint32_t p = 0; p < n; ++p)
-            if (status[p] != GOSS_OK)
+        goss_gpu_ctx* c = ctxs[p];
+        const uint64_t nrec = in_off[p][n];
+        if (!nrec) continue;
+        uint64_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) w += wins[i][p];
+        auto work = [c, nrec, w]() {
+            const auto tc = std::chrono::steady_clock::now();
+            try
             {
-                for (uint32_t i = 0; i < n; ++i) ctxs[i]->broken = true;
-                throw StatusError{status[p], "member " + std::to_string(p) + " counting its records: " + ctxs[p]->last_error};
+                HIP_TRY(hipSetDevice(c->device));
+                (void)hipGetLastError();
+                if (c->words == 1) push_records<Key1>(c, c->grp_inbox, nrec, w); else push_records<Key2>(c, c->grp_inbox, nrec, w);
+                check_launch("a kernel launch was refused");
             }
+            catch (const HipError& e) { c->bg_status = GOSS_ERR_HIP; c->bg_error = std::string(e.what) + ": " + hipGetErrorString(e.e); }
+            catch (const StatusError& e) { c->bg_status = e.status; c->bg_error = e.msg; }
+            catch (const std::bad_alloc&) { c->bg_status = GOSS_ERR_OOM; c->bg_error = "host allocation failed"; }
+            c->grp_count_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
+        };
+        c->bg_status = GOSS_OK;
+        try { c->bg = std::thread(work); }
+        catch (const std::system_error&) { work(); }          // (no thread to be had: this member's share on the caller's)
     }
     if (st)
     {
         st->transport = comms ? 1u : 2u;
         st->rounds = rounds;
         st->records = total_recs; st->windows = total_wins; st->record_bytes = total_recs * kRecBytes;
-        st->route_ms = route_ms; st->wire_ms = wire_ms; st->count_ms = ms_since(t2);
+        st->route_ms = route_ms; st->wire_ms = wire_ms;
+        st->count_ms = prev_count_ms;          // (of the round BEFORE this one: this round's counting has only been started)
+        st->count_wait_ms = wait_ms;
     }
 }
 

@@ -1090,7 +1090,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     }
     std::vector<uint64_t> stagedBytes(P, 0), stageCap(P, 0);
     uint64_t xRounds = 0, xRecords = 0, xWindows = 0;
-    double xRouteMs = 0, xWireMs = 0, xCountMs = 0;
+    double xRouteMs = 0, xWireMs = 0, xCountMs = 0, xCountWaitMs = 0;
     uint32_t xTransport = 0;
     if (useRecords)
         for (size_t d = 0; d < P; ++d) gs[d]->check(goss_gpu_set_deferred(gs[d]->h, 1), "deferring the count");
@@ -1102,6 +1102,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         goss_gpu_group_xstats st;
         gs[0]->check(goss_gpu_group_route_exchange(hs.data(), (uint32_t)P, 0, &st), "exchanging the reads' records");
         ++xRounds; xRecords += st.records; xWindows += st.windows; xRouteMs += st.route_ms; xWireMs += st.wire_ms; xCountMs += st.count_ms;
+        xCountWaitMs += st.count_wait_ms;
         xTransport = st.transport;
         std::fill(stagedBytes.begin(), stagedBytes.end(), 0);
     };
@@ -1278,7 +1279,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         exchangeRound();          // (what is still staged)
         std::ostringstream o;
         o << "records routed by minimizer: " << xRecords << " records (" << xWindows << " windows) exchanged in " << xRounds << " round(s) over "
-          << (xTransport == 1 ? "RCCL" : "peer copies") << ": routing " << xRouteMs / 1e3 << "s, transfer " << xWireMs / 1e3 << "s, counting " << xCountMs / 1e3 << "s";
+          << (xTransport == 1 ? "RCCL" : "peer copies") << ": routing " << xRouteMs / 1e3 << "s, transfer " << xWireMs / 1e3 << "s, counting (beside the staging of the next round; the last round's is the finish's) "
+          << xCountMs / 1e3 << "s, of which waited for " << xCountWaitMs / 1e3 << "s";
         log(info, o.str());
     }
     { std::ostringstream o; o << "parsed and counted " << reads << " reads at " << secs() << "s (device time in pushes "

@@ -403,15 +403,19 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* contexts, uint32_t n, uint64_t esti
  *
  * goss_gpu_group_route_exchange(contexts, n, transport, stats): every context cuts the windows of its staged bases
  * into super-k-mer records routed by minimizer into n parts (goss_gpu_route_records_device), part p of every context
- * is moved to context p's device, and every context counts what it received (goss_gpu_push_records_device).  All
- * copies of a key -- either strand -- reach ONE context, so the contexts' counted sets are disjoint.  The staging
- * buffers are empty afterwards; call it whenever a buffer is full and once before the finishes, then
- * goss_gpu_group_exchange (range partition of the counted sets) and goss_gpu_group_emit as above.
+ * is moved to context p's device, and every context counts what it received (as goss_gpu_push_records_device does)
+ * -- on a thread of its own that the call does not wait for: when it returns, the records have arrived, the staging
+ * buffers are empty and take the next round's reads WHILE the devices count this round's (every entry point that needs
+ * the counted runs -- the next round, finish, emit, a device push -- waits for that thread and takes over its failure,
+ * as for the thread that counts a full staging buffer of a single context).  All copies of a key -- either strand --
+ * reach ONE context, so the contexts' counted sets are disjoint.  Call it whenever a buffer is full and once before
+ * the finishes, then goss_gpu_group_exchange (range partition of the counted sets) and goss_gpu_group_emit as above.
  *   transport   0 = RCCL when librccl.so can be loaded at run time and communicators for the contexts' devices can
  *               be made (ncclCommInitAll; not with one device twice): ncclSend / ncclRecv of all n x n parts inside
  *               one ncclGroupStart / ncclGroupEnd, at most 512 MiB per pair and round -- else hipMemcpyPeerAsync;
  *               1 = RCCL or fail (GOSS_ERR_STATE); 2 = peer copies.  GOSS_GROUP_TRANSPORT=rccl|peer overrides.
- *   stats       (may be NULL) what the call moved and how long its three steps took on the host's clock.
+ *   stats       (may be NULL) what the call moved, how long routing and transfer took on the host's clock, and what
+ *               the counting of the round before cost beside the caller's staging (count_ms) and beyond it (count_wait_ms).
  * Both key widths: 12-byte records for one-word keys, 20-byte records for two-word keys (below).
  */
 typedef struct goss_gpu_group_xstats {
@@ -419,7 +423,10 @@ typedef struct goss_gpu_group_xstats {
     uint32_t rounds;               /* transfer rounds (<= 512 MiB per pair each) */
     uint64_t records, windows;     /* moved by this call, all members */
     uint64_t record_bytes;
-    double route_ms, wire_ms, count_ms;
+    double route_ms, wire_ms;
+    double count_ms;               /* counting of the round BEFORE this call's (the slowest member): it ran on the members' own
+                                      threads while the caller staged this round's reads */
+    double count_wait_ms;          /* ... and how long this call had to wait for it to end: the part the staging did not cover */
 } goss_gpu_group_xstats;
 int goss_gpu_set_deferred(goss_gpu_ctx* ctx, int on);
 int goss_gpu_stage_room(goss_gpu_ctx* ctx, uint64_t* free_bytes, uint64_t* capacity);
