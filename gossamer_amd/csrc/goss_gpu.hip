@@ -1325,7 +1325,7 @@ constexpr uint32_t kFusedGrid = 256 * GOSS_E1_OCC;                         // wo
 #define GOSS_FUSED_GRID2 512
 #endif
 constexpr uint32_t kFusedGrid2 = GOSS_FUSED_GRID2;                        // ... of extract2_part_kernel: 2 per CU (75 KB)
-constexpr double kValidSlackA = 1.06, kValidSlackB = 1.13;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each)
+constexpr double kValidSlackA = 1.06, kValidSlackB = 1.17;   // key buffer slots per expected key (bucket regions; sub-regions with their six sigma each: 1.149 measured on C4's two-word keys)
 constexpr uint64_t kValidSizingMin = 640u << 20;             // window starts: smaller chunks are sampled whole into a full buffer
 
 template <class K>
@@ -2094,24 +2094,27 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
     // slots in the first buffer when the arena can spare them beyond the two buffers and the
     // partition / segment tables
     uint64_t ka_slots = cap, kb_slots = cap;
-    auto full_slots = [&]() {
-        ka_slots = cap; kb_slots = cap;
-        const uint64_t extra = cap / 8 + 256 * 16;
-        const uint64_t need = (2 * cap + extra) * sizeof(K) + cap / 2 + (uint64_t)(1u << kSegBits) * kSegLimit * 12 + (64u << 20);
-        if (c->arena.avail() >= need) ka_slots = cap + extra;
+    auto full_slots = [&](uint64_t basis) {
+        ka_slots = basis; kb_slots = basis;
+        const uint64_t extra = basis / 8 + 256 * 16;
+        const uint64_t need = (2 * basis + extra) * sizeof(K) + basis / 2 + (uint64_t)(1u << kSegBits) * kSegLimit * 12 + (64u << 20);
+        if (c->arena.avail() >= need) ka_slots = basis + extra;
     };
     bool reduced = false;
     if (c->fused && nstarts >= c->fused_min)
     {
+        // (strand pairs: ONE key per window of a graph on the fused path -- what chunk_capacity cut the chunk for; the
+        // sequence a declined chunk falls back to emits both strands and gets its buffers then, below)
+        const uint64_t capf = c->mode == GOSS_MODE_GRAPH && c->graph_rep ? nstarts : cap;
         // a chunk whose sample is a set of slices (not the whole chunk): buffers for the expected
         // number of keys -- bucket regions with 6 % of slack, sub-regions with 13 %
         if (c->valid_frac < 0.97 && nstarts > kValidSizingMin)
         {
-            ka_slots = std::min<uint64_t>(cap, (uint64_t)((double)cap * c->valid_frac * kValidSlackA) + (1u << 20));
-            kb_slots = std::min<uint64_t>(cap, (uint64_t)((double)cap * c->valid_frac * kValidSlackB) + (8u << 20));
+            ka_slots = std::min<uint64_t>(cap, (uint64_t)((double)capf * c->valid_frac * kValidSlackA) + (1u << 20));
+            kb_slots = std::min<uint64_t>(cap, (uint64_t)((double)capf * c->valid_frac * kValidSlackB) + (8u << 20));
             reduced = ka_slots < cap || kb_slots < cap;
         }
-        if (!reduced) full_slots();
+        if (!reduced) { full_slots(capf); reduced = capf < cap; }
     }
     K* ka = (K*)c->arena.temp(ka_slots * sizeof(K));
     K* kb = (K*)c->arena.temp(kb_slots * sizeof(K));
@@ -2123,7 +2126,7 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
         // the unfused kernels (and a fused retry) want one slot per window start
         c->arena.release(mark);
         c->valid_frac = 1.0;
-        full_slots();
+        full_slots(cap);
         ka = (K*)c->arena.temp(ka_slots * sizeof(K));
         kb = (K*)c->arena.temp(kb_slots * sizeof(K));
         if (frc == kFusedNeedFull && process_chunk_fused<K>(c, d_bases, nstarts, navail, ka, ka_slots, kb, kb_slots) == kFusedDone)
@@ -2349,7 +2352,10 @@ void merge_runs(goss_gpu_ctx* c)
 uint64_t chunk_capacity(goss_gpu_ctx* c, bool optimistic)
 {
     const uint64_t ksz = c->words * 8;
-    const uint32_t S = c->mode == GOSS_MODE_GRAPH ? 2 : 1;
+    // (keys per window: two for a graph -- but ONE where the fused path counts strand pairs (round 4) and makes the other
+    // strand from the counted pairs: sized for two, C4's chunks were half of what the arena holds, seven where four do;
+    // a chunk the fused path declines after all asks for its full buffers and is cut in halves if they are not there)
+    const uint32_t S = c->mode == GOSS_MODE_GRAPH && !(optimistic && c->graph_rep && c->fused) ? 2 : 1;
     uint64_t avail = c->arena.avail();
     double per_key;
     if (optimistic)
@@ -4262,8 +4268,16 @@ void group_route_exchange(goss_gpu_ctx* const* ctxs, uint32_t n, int transport, 
             HIP_TRY(hipSetDevice(d->device));
             for (uint32_t i = 0; i < n; ++i)
                 if (recs[i][p])
-                    HIP_TRY(hipMemcpyPeerAsync(d->grp_inbox + in_off[p][i] * kRecBytes, d->device, ctxs[i]->grp_send + first[i][p] * kRecBytes, ctxs[i]->device,
-                                               recs[i][p] * kRecBytes, d->xstream));
+                {
+                    // (one device listed several times -- how the tests run a group on one GPU: a plain device-to-device copy,
+                    // the peer call takes a slow path between a device and itself)
+                    if (ctxs[i]->device == d->device)
+                        HIP_TRY(hipMemcpyAsync(d->grp_inbox + in_off[p][i] * kRecBytes, ctxs[i]->grp_send + first[i][p] * kRecBytes, recs[i][p] * kRecBytes,
+                                               hipMemcpyDeviceToDevice, d->xstream));
+                    else
+                        HIP_TRY(hipMemcpyPeerAsync(d->grp_inbox + in_off[p][i] * kRecBytes, d->device, ctxs[i]->grp_send + first[i][p] * kRecBytes, ctxs[i]->device,
+                                                   recs[i][p] * kRecBytes, d->xstream));
+                }
         }
         rounds = 1;
     }
