@@ -22,7 +22,7 @@ SYMBOLS = [
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
     "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
-    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble",
+    "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble", "goss_gpu_emit_part_ranges", "goss_gpu_emit_last_high",
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
     "goss_gpu_set_deferred", "goss_gpu_stage_room", "goss_gpu_group_route_exchange",
@@ -475,10 +475,22 @@ class Context:
         self.emit_device()
         return self.files()
 
-    def emit_part(self, first_index, total, estimate=0):
-        """Distributed emission, this range's part (goss_gpu_emit_part)."""
-        self._L.goss_gpu_emit_part.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
-        self._check(self._L.goss_gpu_emit_part(self._h, first_index, total, estimate))
+    def emit_part(self, first_index, total, estimate=0, prev_last_high=None):
+        """Distributed emission, this range's part (goss_gpu_emit_part; with prev_last_high -- the high part of the last
+        key of the ranges below, emit_last_high of their owners -- goss_gpu_emit_part_ranges: "-d0" blocks too)."""
+        if prev_last_high is None:
+            self._L.goss_gpu_emit_part.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+            self._check(self._L.goss_gpu_emit_part(self._h, first_index, total, estimate))
+        else:
+            self._L.goss_gpu_emit_part_ranges.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+            self._check(self._L.goss_gpu_emit_part_ranges(self._h, first_index, total, estimate, prev_last_high))
+
+    def emit_last_high(self, total, estimate=0):
+        """goss_gpu_emit_last_high -> (high part of this range's last key, range is not empty)"""
+        h, ne = C.c_uint64(), C.c_int()
+        self._L.goss_gpu_emit_last_high.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        self._check(self._L.goss_gpu_emit_last_high(self._h, total, estimate, C.byref(h), C.byref(ne)))
+        return h.value, bool(ne.value)
 
     def emit_assemble(self, spans_ptr, span_bytes, total, estimate=0, big=b"", hist=b""):
         """Distributed emission, the files that need all ranges (goss_gpu_emit_assemble): spans_ptr =

@@ -152,10 +152,12 @@ struct goss_gpu_ctx {
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
     int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
     uint32_t narrow_capg = 656;         // GOSS_GPU_NARROW_CAPG (tests): granules a tile of the narrow form may lay out before it sends its carried granules off short
+    bool ds_parts = true;               // GOSS_GPU_DS_PARTS=0: a range builds no DenseSelect blocks of its own (round 4: the assembler builds them all)
     bool narrow = true;                 // GOSS_GPU_NARROW=0: 8-byte keys between the two levels of the 32-bit-remainder form (rounds 3-4)
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
+    uint64_t ds_blocks_ranges = 0, ds_blocks_own = 0;      // DenseSelect blocks of the last assembly: taken from the ranges' records / built here from the bitmap
     uint32_t pk_fused_chunks = 0;       // chunks of a packed string the fused kernels read as they were
     uint32_t pk_unpacked_chunks = 0;    // ... and chunks (or samples) unpacked to bytes for the plain kernels
     uint32_t rem32_bits_min = 0;        // GOSS_GPU_REM32_BITS=<9..12>: at least that many second-level bits (tests)
@@ -2610,7 +2612,7 @@ void emit_dense_select(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, i
         d_brank = (uint64_t*)c->arena.temp(nblocks * 8);
         d_boff = (uint64_t*)c->arena.temp(nblocks * 8);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_classify_kernel<K>), dim3(grid_for(nblocks, 64)), dim3(64), 0, c->stream,
-                           keys, m, D, invert, count, nblocks, d_btype, d_bbytes, d_brank);
+                           DsSrc<K>{keys, m, D, invert, 0, nullptr, 0}, count, (uint64_t)0, nblocks, d_btype, d_bbytes, d_brank);
         HIP_TRY(hipMemcpyAsync(btype.data(), d_btype, nblocks * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(bbytes.data(), d_bbytes, nblocks * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2642,11 +2644,159 @@ void emit_dense_select(goss_gpu_ctx* c, const K* keys, uint64_t m, uint32_t D, i
     {
         HIP_TRY(hipMemcpyAsync(d_boff, boff.data(), nblocks * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_fill_kernel<K>), dim3((uint32_t)nblocks), dim3(128), 0, c->stream,
-                           keys, m, D, invert, count, (const uint32_t*)d_btype, (const uint64_t*)d_boff,
+                           DsSrc<K>{keys, m, D, invert, 0, nullptr, 0}, count, (uint64_t)0, (const uint32_t*)d_btype, (const uint64_t*)d_boff,
                            (const uint64_t*)d_brank, image, (uint64_t*)(image + h.indexArrayOffset));
         HIP_TRY(hipMemcpyAsync(image + h.rankArrayOffset, d_brank, nblocks * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));    // host vectors / header go out of scope
+    c->arena.release(mark);
+    OutFile f; f.suffix = suffix; f.size = size; f.dev = image;
+    c->files.push_back(std::move(f));
+}
+
+// ---- DenseSelect blocks per range (round 5) ---------------------------------------------------------------------------
+// A block of 8192 indexed positions is a function of those positions alone (DenseArray.cc:446-647): type, bytes and body.
+// A range's owner builds the blocks that lie wholly inside its share of the ones (or zeros); the assembler builds the few
+// that straddle two ranges from the bitmap, adds up the sizes, copies the bodies to their offsets and writes the master
+// index and the rank array.  A range's blocks travel as ONE record: {nb, payload bytes, 0, 0}, bytes[nb], rank[nb],
+// type[nb] (u32, padded to 8), the bodies back to back.
+constexpr uint64_t kPartSpan = 1, kPartDs = 2;          // kinds of the records of a ".part.span" file: {kind, a, b, body bytes}, the body
+struct DsPlan { uint64_t b0 = 0, nb = 0, payload = 0; std::vector<uint32_t> type; std::vector<uint64_t> bytes, rank; uint32_t* d_type = nullptr; uint64_t* d_rank = nullptr; };
+static inline uint64_t ds_record_bytes(const DsPlan& p) { return 32 + p.nb * 16 + ((p.nb * 4 + 7) & ~7ULL) + p.payload; }
+
+// types, sizes and first positions of blocks b0 .. b0 + nb - 1 (temporaries of the arena stay for ds_fill_record)
+template <class K>
+DsPlan ds_plan(goss_gpu_ctx* c, const DsSrc<K>& src, uint64_t count, uint64_t b0, uint64_t nb)
+{
+    DsPlan p; p.b0 = b0; p.nb = nb;
+    if (!nb) return p;
+    p.type.resize(nb); p.bytes.resize(nb); p.rank.resize(nb);
+    p.d_type = (uint32_t*)c->arena.temp(nb * 4);
+    uint64_t* d_bytes = (uint64_t*)c->arena.temp(nb * 8);
+    p.d_rank = (uint64_t*)c->arena.temp(nb * 8);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_classify_kernel<K>), dim3(grid_for(nb, 64)), dim3(64), 0, c->stream, src, count, b0, nb, p.d_type, d_bytes, p.d_rank);
+    HIP_TRY(hipMemcpyAsync(p.type.data(), p.d_type, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p.bytes.data(), d_bytes, nb * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(p.rank.data(), p.d_rank, nb * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint64_t b = 0; b < nb; ++b) p.payload += p.bytes[b];
+    return p;
+}
+// the record of a plan at `at` (ds_record_bytes(p) bytes, zeroed by the caller)
+template <class K>
+void ds_fill_record(goss_gpu_ctx* c, const DsSrc<K>& src, uint64_t count, const DsPlan& p, uint8_t* at)
+{
+    const uint64_t head[4] = {p.nb, p.payload, 0, 0};
+    HIP_TRY(hipMemcpyAsync(at, head, 32, hipMemcpyHostToDevice, c->stream));
+    if (p.nb)
+    {
+        uint8_t* a_bytes = at + 32; uint8_t* a_rank = a_bytes + p.nb * 8; uint8_t* a_type = a_rank + p.nb * 8;
+        uint8_t* body = a_type + ((p.nb * 4 + 7) & ~7ULL);
+        std::vector<uint64_t> boff(p.nb);
+        uint64_t pos = 0;
+        for (uint64_t b = 0; b < p.nb; ++b) { boff[b] = pos; pos += p.bytes[b]; }
+        uint64_t* d_boff = (uint64_t*)c->arena.temp(p.nb * 8);
+        HIP_TRY(hipMemcpyAsync(d_boff, boff.data(), p.nb * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(a_bytes, p.bytes.data(), p.nb * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(a_rank, p.d_rank, p.nb * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(a_type, p.d_type, p.nb * 4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ds_fill_kernel<K>), dim3((uint32_t)p.nb), dim3(128), 0, c->stream, src, count, p.b0, (const uint32_t*)p.d_type,
+                           (const uint64_t*)d_boff, (const uint64_t*)p.d_rank, body, (uint64_t*)nullptr);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));          // (host vectors go out of scope)
+}
+
+// A DenseSelect file from the records of the ranges (device addresses on this context's device: `recs` = {first block, the
+// record}) and, for every block none of them holds, from the assembled bitmap (words, nwords, ones before every word).
+void ds_compose(goss_gpu_ctx* c, int invert, uint64_t count, const std::vector<std::pair<uint64_t, const uint8_t*>>& recs,
+                const unsigned long long* words, uint64_t nwords, const uint64_t* before, const std::string& suffix)
+{
+    const uint64_t NB = (count + 8191) >> 13;
+    std::vector<uint32_t> type(NB);
+    std::vector<uint64_t> bytes(NB), rank(NB), boff(NB);
+    std::vector<uint8_t> have(NB, 0);
+    struct Seg { uint64_t b0, nb; const uint8_t* body; uint64_t payload; };
+    std::vector<Seg> segs;
+    uint64_t mark = c->arena.mark();
+    for (auto& r : recs)
+    {
+        uint64_t head[4];
+        HIP_TRY(hipMemcpyAsync(head, r.second, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint64_t b0 = r.first, nb = head[0];
+        if (!nb) continue;
+        if (b0 + nb > NB) throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a range's blocks lie beyond the array"};
+        const uint8_t* a_bytes = r.second + 32; const uint8_t* a_rank = a_bytes + nb * 8; const uint8_t* a_type = a_rank + nb * 8;
+        HIP_TRY(hipMemcpyAsync(bytes.data() + b0, a_bytes, nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(rank.data() + b0, a_rank, nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(type.data() + b0, a_type, nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint64_t b = b0; b < b0 + nb; ++b) { if (have[b]) throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a block built twice"}; have[b] = 1; }
+        c->ds_blocks_ranges += nb;
+        segs.push_back({b0, nb, a_type + ((nb * 4 + 7) & ~7ULL), head[1]});
+    }
+    // the blocks nobody built (they straddle two ranges, or their range gave no record): runs of them, from the bitmap
+    struct Own { DsPlan plan; uint64_t* pos; uint64_t first; uint8_t* rec; };
+    std::vector<Own> own;
+    for (uint64_t b = 0; b < NB;)
+    {
+        if (have[b]) { ++b; continue; }
+        uint64_t e = b;
+        while (e < NB && !have[e] && e - b < 4096) ++e;          // (at most 32 M positions at a time)
+        const uint64_t first = b << 13, n = std::min<uint64_t>(count, e << 13) - first;
+        uint64_t* pos = (uint64_t*)c->arena.temp(n * 8);
+        hipLaunchKernelGGL(ef_select_range_kernel, dim3(grid_for(n, kTB)), dim3(kTB), 0, c->stream, words, nwords, before, first, n, invert, pos);
+        const DsSrc<Key1> src{nullptr, 0, 0, invert, 0, pos, first};
+        Own o; o.pos = pos; o.first = first;
+        o.plan = ds_plan<Key1>(c, src, count, b, e - b);
+        const uint64_t rb = ds_record_bytes(o.plan);
+        o.rec = (uint8_t*)c->arena.temp(rb);
+        HIP_TRY(hipMemsetAsync(o.rec, 0, rb, c->stream));
+        ds_fill_record<Key1>(c, src, count, o.plan, o.rec);
+        for (uint64_t x = b; x < e; ++x) { type[x] = o.plan.type[x - b]; bytes[x] = o.plan.bytes[x - b]; rank[x] = o.plan.rank[x - b]; have[x] = 1; }
+        segs.push_back({b, e - b, o.rec + 32 + (e - b) * 16 + (((e - b) * 4 + 7) & ~7ULL), o.plan.payload});
+        own.push_back(std::move(o));
+        c->ds_blocks_own += e - b;
+        b = e;
+    }
+    DsHeader h{};
+    h.version = 2012092701ULL;
+    h.flags = invert ? 1 : 0;
+    h.logBlockSize = 13; h.blockSize = 8192; h.logSampleRate = 6; h.sampleRate = 64;
+    uint64_t pos = 4096;
+    for (uint64_t b = 0; b < NB; ++b)
+    {
+        boff[b] = pos;
+        const uint64_t cnt = std::min<uint64_t>(8192, count - (b << 13));
+        switch (type[b])
+        {
+            case kDsSmall: h.smallBlocks++; h.smallBlocksSize += 256; break;
+            case kDsIntermediate: h.intermediateBlocks++; h.intermediateBlocksSize += bytes[b]; break;
+            case kDsSpill32: h.largeBlocks++; h.largeBlocksSize += cnt * 4; break;
+            default: h.largeBlocks++; h.largeBlocksSize += cnt * 8; break;
+        }
+        pos += bytes[b];
+    }
+    h.numBlocks = NB;
+    pos = (pos + 15) & ~15ULL;
+    h.indexArrayOffset = pos;
+    h.rankArrayOffset = pos + NB * 8;
+    h.indexSize = NB * 16;
+    const uint64_t size = pos + NB * 16;
+    // (the image is permanent, the temporaries above it are released below: it goes first in the arena's order -- taken
+    // from the permanent end, which grows from the other side)
+    uint8_t* image = (uint8_t*)c->arena.perm(size);
+    HIP_TRY(hipMemsetAsync(image, 0, size, c->stream));
+    HIP_TRY(hipMemcpyAsync(image, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    for (auto& sg : segs)
+        if (sg.payload) HIP_TRY(hipMemcpyAsync(image + boff[sg.b0], sg.body, sg.payload, hipMemcpyDeviceToDevice, c->stream));
+    for (uint64_t b = 0; b < NB; ++b) boff[b] |= type[b];          // the master index entries
+    if (NB)
+    {
+        HIP_TRY(hipMemcpyAsync(image + h.indexArrayOffset, boff.data(), NB * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(image + h.rankArrayOffset, rank.data(), NB * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena.release(mark);
     OutFile f; f.suffix = suffix; f.size = size; f.dev = image;
     c->files.push_back(std::move(f));
@@ -2888,8 +3038,10 @@ void object_universe(const goss_gpu_ctx* c, uint64_t* nlo, uint64_t* nhi, std::s
 }
 
 // Distributed emission, the part a range's owner builds from its own keys (goss_gpu_emit_part).
+// prev_high: the high part (key >> D) of the last key of the ranges below this one (0 when there is none) -- what tells a
+// range which zeros of the bitmap are its own; have_prev: it was given (else the range builds no blocks of "-d0").
 template <class K>
-void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
+void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate, uint64_t prev_high = 0, bool have_prev = false)
 {
     const K* keys = (const K*)c->res_keys;
     const uint64_t m = c->M;
@@ -2903,10 +3055,13 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
     emit_sparse_low_bits<K>(c, keys, m, D, base);
     // This range's SPAN of the high-bits bitmap for the assembling rank: the words its ones fall into (one i of the
     // whole array sits at bit (key_i >> D) + i), built from the range's own keys -- about 2.4 bits per key on the wire
-    // where the first form of this path sent key >> D of every key (4 or 8 bytes).  Layout: {first word, words}, the words.
+    // where the first form of this path sent key >> D of every key (4 or 8 bytes) -- and, behind it, the DenseSelect blocks
+    // that lie wholly inside the range's share of the ones ("-d1") and of the zeros ("-d0": with prev_high).  Records
+    // {kind, a, b, body bytes} + body: the span {kPartSpan, first word, words} + the words; blocks {kPartDs, sense (0 ones,
+    // 1 zeros), first block} + ds_fill_record's record.
     {
         const uint64_t nwords = (nd + total + 3) / 64 + 1;
-        uint64_t w0 = 0, nspan = 0;
+        uint64_t w0 = 0, nspan = 0, last_high = prev_high;
         if (m)
         {
             K ends[2];
@@ -2914,19 +3069,57 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
             HIP_TRY(hipMemcpyAsync(&ends[1], keys + (m - 1), sizeof(K), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const uint64_t h0 = (D >= 128 ? 0 : key_shr64(ends[0], D)) + first_index;
-            const uint64_t h1 = (D >= 128 ? 0 : key_shr64(ends[1], D)) + first_index + (m - 1);
+            last_high = D >= 128 ? 0 : key_shr64(ends[1], D);
+            const uint64_t h1 = last_high + first_index + (m - 1);
             w0 = h0 >> 6;
             nspan = std::min((h1 >> 6) + 1, nwords) - w0;
         }
-        uint64_t* span = (uint64_t*)c->arena.perm((2 + nspan) * 8);
-        const uint64_t hdr[2] = {w0, nspan};
-        HIP_TRY(hipMemsetAsync(span + 2, 0, nspan * 8, c->stream));
-        HIP_TRY(hipMemcpyAsync(span, hdr, 16, hipMemcpyHostToDevice, c->stream));
+        const uint64_t tmark = c->arena.mark();
+        // whole blocks of ones [first_index, first_index + m) -- the array's last, partial block is the last range's --
+        // and of zeros [prev_high, last_high) (the last range: up to the array's nd + 2 zeros)
+        const bool last_range = first_index + m == total;
+        const uint64_t count1 = total, count0 = nd + 2;
+        DsPlan p1, p0;
+        const DsSrc<K> src1{keys, m, D, 0, first_index, nullptr, 0}, src0{keys, m, D, 1, first_index, nullptr, 0};
+        if (m && c->ds_parts)
+        {
+            const uint64_t b0 = (first_index + 8191) >> 13;
+            const uint64_t e = last_range ? (count1 + 8191) >> 13 : (first_index + m) >> 13;
+            if (e > b0) p1 = ds_plan<K>(c, src1, count1, b0, e - b0);
+        }
+        if (have_prev && c->ds_parts && (m || last_range))
+        {
+            const uint64_t z0 = prev_high, z1 = last_range ? count0 : last_high;
+            const uint64_t b0 = (z0 + 8191) >> 13;
+            const uint64_t e = last_range ? (count0 + 8191) >> 13 : z1 >> 13;
+            if (e > b0) p0 = ds_plan<K>(c, src0, count0, b0, e - b0);
+        }
+        const uint64_t r1 = p1.nb ? 32 + ds_record_bytes(p1) : 0, r0 = p0.nb ? 32 + ds_record_bytes(p0) : 0;
+        const uint64_t bytes = 32 + nspan * 8 + r1 + r0;
+        uint8_t* blob = (uint8_t*)c->arena.perm(bytes);
+        HIP_TRY(hipMemsetAsync(blob, 0, bytes, c->stream));
+        const uint64_t hdr[4] = {kPartSpan, w0, nspan, nspan * 8};
+        HIP_TRY(hipMemcpyAsync(blob, hdr, 32, hipMemcpyHostToDevice, c->stream));
         if (m)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(ef_high_bits_keys_kernel<K>), dim3(grid_for(m, kEfChunk)), dim3(kTB), 0, c->stream,
-                               keys, m, D, first_index, nwords, (unsigned long long*)(span + 2), w0);
-        HIP_TRY(hipStreamSynchronize(c->stream));            // (hdr goes out of scope)
-        OutFile f; f.suffix = ".part.span"; f.size = (2 + nspan) * 8; f.dev = (const uint8_t*)span;
+                               keys, m, D, first_index, nwords, (unsigned long long*)(blob + 32), w0);
+        uint8_t* at = blob + 32 + nspan * 8;
+        const uint64_t h1[4] = {kPartDs, 0, p1.b0, ds_record_bytes(p1)}, h0[4] = {kPartDs, 1, p0.b0, ds_record_bytes(p0)};
+        if (p1.nb)
+        {
+            HIP_TRY(hipMemcpyAsync(at, h1, 32, hipMemcpyHostToDevice, c->stream));
+            ds_fill_record<K>(c, src1, count1, p1, at + 32);
+            at += r1;
+        }
+        if (p0.nb)
+        {
+            HIP_TRY(hipMemcpyAsync(at, h0, 32, hipMemcpyHostToDevice, c->stream));
+            ds_fill_record<K>(c, src0, count0, p0, at + 32);
+            at += r0;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));            // (the headers go out of scope)
+        c->arena.release(tmark);
+        OutFile f; f.suffix = ".part.span"; f.size = bytes; f.dev = (const uint8_t*)blob;
         c->files.push_back(std::move(f));
     }
     if (c->mode == GOSS_MODE_GRAPH)
@@ -3009,38 +3202,46 @@ void emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_bytes, ui
     object_universe(c, &nlo, &nhi, &base);
     const uint32_t D = (uint32_t)sparse_d(nlo, nhi, estimate);
     const uint64_t nd = sparse_nd(D, nlo, nhi);
-    // the bitmap: the ranges' spans ORed together (neighbours share their boundary words)
+    c->ds_blocks_ranges = c->ds_blocks_own = 0;
+    // the bitmap: the ranges' spans ORed together (neighbours share their boundary words); the ranges' DenseSelect blocks
+    // noted for the composition below
     const uint64_t nwords = (nd + total + 3) / 64 + 1;
     uint64_t* words = (uint64_t*)c->arena.perm(nwords * 8);
     HIP_TRY(hipMemsetAsync(words, 0, nwords * 8, c->stream));
-    for (uint64_t at = 0; at + 16 <= span_bytes;)
+    std::vector<std::pair<uint64_t, const uint8_t*>> ds_recs[2];          // [sense]: {first block, record}
+    for (uint64_t at = 0; at + 32 <= span_bytes;)
     {
-        uint64_t hdr[2];
-        HIP_TRY(hipMemcpyAsync(hdr, (const uint8_t*)d_spans + at, 16, hipMemcpyDeviceToHost, c->stream));
+        uint64_t hdr[4];
+        HIP_TRY(hipMemcpyAsync(hdr, (const uint8_t*)d_spans + at, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (hdr[0] + hdr[1] > nwords || at + 16 + hdr[1] * 8 > span_bytes)
-            throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a span does not fit the bitmap"};
-        if (hdr[1])
-            hipLaunchKernelGGL(ef_or_span_kernel, dim3(grid_for(hdr[1], kTB)), dim3(kTB), 0, c->stream, (unsigned long long*)words + hdr[0],
-                               (const unsigned long long*)((const uint8_t*)d_spans + at + 16), hdr[1]);
-        at += 16 + hdr[1] * 8;
+        const uint8_t* body = (const uint8_t*)d_spans + at + 32;
+        if (at + 32 + hdr[3] > span_bytes) throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a record runs past the parts"};
+        if (hdr[0] == kPartSpan)
+        {
+            if (hdr[1] + hdr[2] > nwords || hdr[3] != hdr[2] * 8) throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: a span does not fit the bitmap"};
+            if (hdr[2])
+                hipLaunchKernelGGL(ef_or_span_kernel, dim3(grid_for(hdr[2], kTB)), dim3(kTB), 0, c->stream, (unsigned long long*)words + hdr[1],
+                                   (const unsigned long long*)body, hdr[2]);
+        }
+        else if (hdr[0] == kPartDs && hdr[1] < 2) ds_recs[hdr[1]].push_back({hdr[2], body});
+        else throw StatusError{GOSS_ERR_INVALID_ARG, "emit_assemble: not a part's record"};
+        at += 32 + hdr[3];
     }
-    // the high parts read back from the bitmap, as one-word keys with D = 0 (position of one i is (key_i >> 0) + i, as
-    // in a whole build): what the DenseSelect builders work from
+    // ones in the words below every word: what finds the positions of the blocks no range could build alone
     uint64_t mark = c->arena.mark();
-    Key1* hkw = (Key1*)c->arena.temp(std::max<uint64_t>(total, 1) * 8);
-    {
-        uint64_t* ones = (uint64_t*)c->arena.temp(nwords * 8);
-        hipLaunchKernelGGL(ef_word_ones_kernel, dim3(grid_for(nwords, kTB)), dim3(kTB), 0, c->stream, (const unsigned long long*)words, nwords, ones);
-        exclusive_scan_u64(c, ones, nwords);
-        hipLaunchKernelGGL(ef_high_from_bits_kernel, dim3(grid_for(nwords, kTB)), dim3(kTB), 0, c->stream, (const unsigned long long*)words, nwords,
-                           (const uint64_t*)ones, hkw, total);
-    }
-    const Key1* hk = hkw;
+    uint64_t* ones = (uint64_t*)c->arena.temp(nwords * 8);
+    hipLaunchKernelGGL(ef_word_ones_kernel, dim3(grid_for(nwords, kTB)), dim3(kTB), 0, c->stream, (const unsigned long long*)words, nwords, ones);
+    exclusive_scan_u64(c, ones, nwords);
+    auto index_files = [&]() {
+        OutFile f; f.suffix = base + ".high-bits"; f.size = nwords * 8; f.dev = (const uint8_t*)words;
+        c->files.push_back(std::move(f));
+        ds_compose(c, 1, nd + 2, ds_recs[1], (const unsigned long long*)words, nwords, ones, base + "-d0");
+        ds_compose(c, 0, total, ds_recs[0], (const unsigned long long*)words, nwords, ones, base + "-d1");
+    };
     if (c->mode == GOSS_MODE_KMER_SET)
     {
         emit_sparse_header(c, D, nlo, nhi, total, base);
-        emit_sparse_index<Key1>(c, hk, total, 0, nd, base, words);
+        index_files();
         uint64_t hdr[3] = {2011101701ULL, c->k, total};
         add_host_file(c, ".header", hdr, sizeof hdr);
     }
@@ -3049,7 +3250,7 @@ void emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_bytes, ui
         uint64_t hdr[3] = {2011101014ULL, c->k, 0};
         add_host_file(c, ".header", hdr, sizeof hdr);
         emit_sparse_header(c, D, nlo, nhi, total, base);
-        emit_sparse_index<Key1>(c, hk, total, 0, nd, base, words);
+        index_files();
         // VariableByteArray continuation arrays from the entries with count > 255 (VariableByteArray.hh:76-118):
         // ord1p marks their global positions, ord1 holds bits 8..15; ord2p marks, among those, the ones with
         // count > 65535 by their index in ord1, ord2 holds bits 16..31
@@ -3206,6 +3407,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_FORM"); if (e) c->r32_form = std::atoi(e) ? 1 : 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW"); if (e) c->narrow = std::atoi(e) != 0; }
+    { const char* e = std::getenv("GOSS_GPU_DS_PARTS"); if (e) c->ds_parts = std::atoi(e) != 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW_CAPG"); if (e && std::atoi(e) > 0) c->narrow_capg = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_SMALL_MAX"); if (e) c->r32_small_max = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
@@ -3782,7 +3984,7 @@ int goss_gpu_big_counts(goss_gpu_ctx* c, uint64_t* keys, uint64_t* counts, uint3
     return GOSS_OK;
 }
 
-int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
+static int emit_part_entry(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate, uint64_t prev_high, bool have_prev)
 {
     if (!c) return GOSS_ERR_INVALID_ARG;
     if (!c->finished || c->emitted) { c->last_error = "emit_part needs exactly one finish before it"; return GOSS_ERR_STATE; }
@@ -3794,11 +3996,46 @@ int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, ui
             if (c->arena.avail() < need) grow_arena(c, need);
         }
         const uint64_t est = estimate ? estimate : total;
-        if (c->words == 1) emit_part<Key1>(c, first_index, total, est); else emit_part<Key2>(c, first_index, total, est);
+        if (c->words == 1) emit_part<Key1>(c, first_index, total, est, prev_high, have_prev);
+        else emit_part<Key2>(c, first_index, total, est, prev_high, have_prev);
         HIP_TRY(hipStreamSynchronize(c->stream));
     });
     if (rc == GOSS_OK) c->emitted = true;
     return rc;
+}
+int goss_gpu_emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate)
+{
+    return emit_part_entry(c, first_index, total, estimate, 0, false);
+}
+int goss_gpu_emit_part_ranges(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t estimate, uint64_t prev_last_high)
+{
+    return emit_part_entry(c, first_index, total, estimate, prev_last_high, true);
+}
+int goss_gpu_emit_last_high(goss_gpu_ctx* c, uint64_t total, uint64_t estimate, uint64_t* high, int* nonempty)
+{
+    if (!c || !high || !nonempty) return GOSS_ERR_INVALID_ARG;
+    if (!c->finished) { c->last_error = "emit_last_high needs a finished range"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        *high = 0; *nonempty = c->M ? 1 : 0;
+        if (!c->M) return;
+        uint64_t nlo, nhi; std::string base;
+        object_universe(c, &nlo, &nhi, &base);
+        const uint32_t D = (uint32_t)sparse_d(nlo, nhi, estimate ? estimate : total);
+        if (c->words == 1)
+        {
+            Key1 k;
+            HIP_TRY(hipMemcpyAsync(&k, (const Key1*)c->res_keys + (c->M - 1), sizeof k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            *high = D >= 128 ? 0 : key_shr64(k, D);
+        }
+        else
+        {
+            Key2 k;
+            HIP_TRY(hipMemcpyAsync(&k, (const Key2*)c->res_keys + (c->M - 1), sizeof k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            *high = D >= 128 ? 0 : key_shr64(k, D);
+        }
+    });
 }
 
 int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_bytes, uint64_t total, uint64_t estimate,
@@ -3995,12 +4232,25 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
     uint64_t total = 0;
     std::vector<uint64_t> first(n);
     for (uint32_t i = 0; i < n; ++i) { first[i] = total; total += ctxs[i]->M; }
-    // every context's own span, side by side
+    // the high part of the last key of the ranges below every range: which zeros of the bitmap a range owns
+    std::vector<uint64_t> prev(n, 0);
+    {
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            prev[i] = run;
+            uint64_t h = 0; int ne = 0;
+            const int rc = goss_gpu_emit_last_high(ctxs[i], total, estimate, &h, &ne);
+            if (rc != GOSS_OK) { if (i) c0->last_error = ctxs[i]->last_error; return rc; }
+            if (ne) run = h;
+        }
+    }
+    // every context's own span and blocks, side by side
     {
         std::vector<int> status(n, GOSS_OK);
         std::vector<std::thread> pool;
         for (uint32_t i = 0; i < n; ++i)
-            pool.emplace_back([&, i]() { status[i] = goss_gpu_emit_part(ctxs[i], first[i], total, estimate); });
+            pool.emplace_back([&, i]() { status[i] = goss_gpu_emit_part_ranges(ctxs[i], first[i], total, estimate, prev[i]); });
         for (auto& t : pool) t.join();
         for (uint32_t i = 0; i < n; ++i)
             if (status[i] != GOSS_OK) { if (i) c0->last_error = ctxs[i]->last_error; return status[i]; }
@@ -4956,6 +5206,8 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
     else if (n == "packed_fused_chunks") *value = c->pk_fused_chunks;
+    else if (n == "ds_blocks_from_ranges") *value = c->ds_blocks_ranges;
+    else if (n == "ds_blocks_assembled") *value = c->ds_blocks_own;
     else if (n == "packed_unpacked_chunks") *value = c->pk_unpacked_chunks;
     else if (n == "rem32_bits") *value = c->rem32_bits_last;
     else if (n == "rem32_split") *value = c->rem32_split_last;

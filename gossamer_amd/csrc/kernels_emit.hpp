@@ -173,35 +173,49 @@ __global__ __launch_bounds__(kTB) void ef_high_from_bits_kernel(const unsigned l
 // The indexed positions are never materialised: for sense 1 (ones) position i is h_i; for
 // sense 0 (zeros) the j-th zero sits at j + #{i : (key_i >> D) <= j}.
 
+// Where the positions come from (round 5: a range's owner builds the whole blocks inside its share of the ones / zeros,
+// DenseArray.cc:446-647 per block; the assembler the blocks that straddle two ranges, from the bitmap):
+//   keys, m, D       the keys of THIS range (all keys: first = 0), their high parts key >> D;
+//   first            ones of the whole array in the ranges below this one: one i of the whole is key (i - first);
+//                    the j-th zero of the whole sits at j + first + #{local keys with high part <= j} -- as long as j is
+//                    at or above the last high part of the ranges below and below the first of the ranges above (the
+//                    zeros a range owns);
+//   direct           (straddling blocks) the positions themselves, direct[idx - direct_first].
 template <class K>
-__device__ __forceinline__ uint64_t ds_pos(const K* keys, uint64_t m, uint32_t D, int invert, uint64_t idx)
+struct DsSrc {
+    const K* keys; uint64_t m; uint32_t D; int invert; uint64_t first;
+    const uint64_t* direct; uint64_t direct_first;
+};
+template <class K>
+__device__ __forceinline__ uint64_t ds_pos(const DsSrc<K>& s, uint64_t idx)
 {
-    if (!invert) return ef_hi(keys, idx, D) + idx;
-    uint64_t a = 0, b = m;                  // upper_bound of idx among the high parts
+    if (s.direct) return s.direct[idx - s.direct_first];
+    if (!s.invert) return ef_hi(s.keys, idx - s.first, s.D) + idx;
+    uint64_t a = 0, b = s.m;                // upper_bound of idx among the high parts
     while (a < b)
     {
         uint64_t mid = a + ((b - a) >> 1);
-        if (ef_hi(keys, mid, D) <= idx) a = mid + 1; else b = mid;
+        if (ef_hi(s.keys, mid, s.D) <= idx) a = mid + 1; else b = mid;
     }
-    return idx + a;
+    return idx + s.first + a;
 }
 
 enum : uint32_t { kDsSmall = 0, kDsSpill64 = 1, kDsSpill32 = 2, kDsSpill16 = 3, kDsSpill8 = 4, kDsIntermediate = 5 };
 
 // Pass 1: one thread per block of 8192 indexed positions: block type and byte size (already
 // padded to 8).  count = number of indexed positions.
+// (blocks b0 .. b0 + nblocks - 1 of the whole array; the arrays are indexed from b0)
 template <class K>
-__global__ void ds_classify_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, int invert,
-                                   uint64_t count, uint64_t nblocks,
+__global__ void ds_classify_kernel(const DsSrc<K> src, uint64_t count, uint64_t b0, uint64_t nblocks,
                                    uint32_t* __restrict__ btype, uint64_t* __restrict__ bbytes,
                                    uint64_t* __restrict__ brank)
 {
     uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
-    uint64_t first = b << 13;
+    uint64_t first = (b0 + b) << 13;
     uint64_t cnt = count - first < 8192 ? count - first : 8192;
-    uint64_t pp = ds_pos(keys, m, D, invert, first);
-    uint64_t p = ds_pos(keys, m, D, invert, first + cnt - 1);
+    uint64_t pp = ds_pos(src, first);
+    uint64_t p = ds_pos(src, first + cnt - 1);
     uint64_t span = p - pp;
     uint32_t t;
     uint64_t bytes;
@@ -216,7 +230,7 @@ __global__ void ds_classify_kernel(const K* __restrict__ keys, uint64_t m, uint3
         bytes = 128 * 6;
         for (uint32_t s = 0; s < 128; ++s)
         {
-            uint64_t r = ds_pos(keys, m, D, invert, first + s * 64 + 63) - ds_pos(keys, m, D, invert, first + s * 64);
+            uint64_t r = ds_pos(src, first + s * 64 + 63) - ds_pos(src, first + s * 64);
             if (r <= 128) {}
             else if (r < 256) bytes += 64;
             else if (r < 65536) bytes += 128;
@@ -231,42 +245,42 @@ __global__ void ds_classify_kernel(const K* __restrict__ keys, uint64_t m, uint3
 
 // Pass 2: one workgroup of 128 threads per block writes the block body at boff[b] and the
 // master index entry.  The image was zero-filled, so alignment padding is already there.
+// (index: the master index entries of these blocks, or null when the assembler writes them)
 template <class K>
-__global__ __launch_bounds__(128) void ds_fill_kernel(const K* __restrict__ keys, uint64_t m, uint32_t D, int invert,
-                                                      uint64_t count, const uint32_t* __restrict__ btype,
+__global__ __launch_bounds__(128) void ds_fill_kernel(const DsSrc<K> src, uint64_t count, uint64_t b0, const uint32_t* __restrict__ btype,
                                                       const uint64_t* __restrict__ boff, const uint64_t* __restrict__ brank,
                                                       uint8_t* __restrict__ image, uint64_t* __restrict__ index)
 {
     __shared__ uint32_t sh_sub[128];
     const uint64_t b = blockIdx.x;
     const uint32_t s = threadIdx.x;
-    const uint64_t first = b << 13;
+    const uint64_t first = (b0 + b) << 13;
     const uint64_t cnt = count - first < 8192 ? count - first : 8192;
     const uint32_t t = btype[b];
     const uint64_t off = boff[b];
     const uint64_t pp = brank[b];
     uint8_t* blk = image + off;
-    if (s == 0) index[b] = off | t;
+    if (s == 0 && index) index[b] = off | t;
     if (t == kDsSmall)
     {
-        uint16_t v = (uint16_t)(ds_pos(keys, m, D, invert, first + (uint64_t)s * 64) - pp);
+        uint16_t v = (uint16_t)(ds_pos(src, first + (uint64_t)s * 64) - pp);
         reinterpret_cast<uint16_t*>(blk)[s] = v;
     }
     else if (t == kDsSpill32)
     {
         for (uint64_t i = s; i < cnt; i += 128)
-            reinterpret_cast<uint32_t*>(blk)[i] = (uint32_t)(ds_pos(keys, m, D, invert, first + i) - pp);
+            reinterpret_cast<uint32_t*>(blk)[i] = (uint32_t)(ds_pos(src, first + i) - pp);
     }
     else if (t == kDsSpill64)
     {
         for (uint64_t i = s; i < cnt; i += 128)
-            reinterpret_cast<uint64_t*>(blk)[i] = ds_pos(keys, m, D, invert, first + i);
+            reinterpret_cast<uint64_t*>(blk)[i] = ds_pos(src, first + i);
     }
     else
     {
         // intermediate: 128 x u32 sample offsets, 128 x u16 internal pointers, sub-blocks
-        uint64_t p0 = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64);
-        uint64_t p1 = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64 + 63);
+        uint64_t p0 = ds_pos(src, first + (uint64_t)s * 64);
+        uint64_t p1 = ds_pos(src, first + (uint64_t)s * 64 + 63);
         uint64_t r = p1 - p0;
         reinterpret_cast<uint32_t*>(blk)[s] = (uint32_t)(p0 - pp);
         uint32_t sz = r <= 128 ? 0u : r < 256 ? 64u : r < 65536 ? 128u : 256u;
@@ -281,13 +295,36 @@ __global__ __launch_bounds__(128) void ds_fill_kernel(const K* __restrict__ keys
         {
             for (uint32_t j = 0; j < 64; ++j)
             {
-                uint64_t d = ds_pos(keys, m, D, invert, first + (uint64_t)s * 64 + j) - p0;
+                uint64_t d = ds_pos(src, first + (uint64_t)s * 64 + j) - p0;
                 if (ty == kDsSpill8) blk[base + j] = (uint8_t)d;
                 else if (ty == kDsSpill16) reinterpret_cast<uint16_t*>(blk + base)[j] = (uint16_t)d;
                 else reinterpret_cast<uint32_t*>(blk + base)[j] = (uint32_t)d;
             }
         }
     }
+}
+
+// Positions of elements idx0 .. idx0 + n - 1 (ones, or -- invert -- zeros) of an assembled bitmap: `before` = ones in the
+// words below each word (exclusive scan of ef_word_ones_kernel's output).  For the few blocks that straddle two ranges.
+__global__ __launch_bounds__(kTB) void ef_select_range_kernel(const unsigned long long* __restrict__ words, uint64_t nwords,
+                                                              const uint64_t* __restrict__ before, uint64_t idx0, uint64_t n, int invert,
+                                                              uint64_t* __restrict__ out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t idx = idx0 + j;
+    // the last word with at most idx such elements below it
+    uint64_t a = 0, b = nwords;
+    while (b - a > 1)
+    {
+        const uint64_t mid = a + ((b - a) >> 1);
+        const uint64_t below = invert ? mid * 64 - before[mid] : before[mid];
+        if (below <= idx) a = mid; else b = mid;
+    }
+    unsigned long long v = invert ? ~words[a] : words[a];
+    uint64_t r = idx - (invert ? a * 64 - before[a] : before[a]);          // rank inside the word
+    while (r--) v &= v - 1;
+    out[j] = a * 64 + (uint64_t)__builtin_ctzll(v);
 }
 
 // --------------------------------------------------------------------------------------

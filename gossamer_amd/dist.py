@@ -559,13 +559,25 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
     On every rank (goss_gpu_emit_part): its slice of the low-bits column files (and, for graphs, of the
     ord0 byte file) -- they belong at element offset `first_index` of the whole file and stay in the
     rank's HBM for its own writer -- and its SPAN of the high-bits bitmap, built from its own keys (".part.span":
-    about 2.4 bits per key).  Only the spans and the few records of counts > 255 / the count histogram travel to
-    rank 0, which ORs the spans together (neighbours share their boundary words) and builds the header, -d0 / -d1
-    from the assembled bitmap and, for graphs, ord1 / ord2 with their presence arrays and the histogram text
+    about 2.4 bits per key) with, behind it, the DenseSelect blocks of "-d0" / "-d1" that lie wholly inside the rank's
+    share of the zeros / ones.  Only those and the few records of counts > 255 / the count histogram travel to
+    rank 0, which ORs the spans together (neighbours share their boundary words), builds the blocks that straddle two
+    ranks from the assembled bitmap, writes the header, master index and rank array of -d0 / -d1 and, for graphs, ord1 / ord2 with their presence arrays and the histogram text
     (goss_gpu_emit_assemble).  Returns {suffix: (size, device address)} of this rank's files."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    ctx.emit_part(first_index, total, estimate)
+    # where the ranges below this one end (the high part of their last key): which zeros of the bitmap are this range's,
+    # so that it builds its own blocks of "-d0" as well as of "-d1" (goss_gpu_emit_part_ranges) -- P numbers gathered
+    high, nonempty = ctx.emit_last_high(total, estimate)
+    mine_h = torch.tensor([high if high < (1 << 63) else high - (1 << 64), 1 if nonempty else 0], dtype=torch.int64, device=_exchange_device(device, group))
+    all_h = [torch.empty_like(mine_h) for _ in range(world)]
+    dist.all_gather(all_h, mine_h, group=group)
+    prev = 0
+    for r in range(rank):
+        h, ne = (int(x) for x in all_h[r].cpu().tolist())
+        if ne:
+            prev = h & ((1 << 64) - 1)
+    ctx.emit_part(first_index, total, estimate, prev_last_high=prev)
     files = {name: (size, ptr) for name, size, ptr in ctx.file_list()}
     size, ptr = files[".part.span"]
     xdev = _exchange_device(device, group)

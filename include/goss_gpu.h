@@ -346,8 +346,9 @@ int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, 
  *   "<base>.low-bits*"   this range's slice of every low-bits column file (base ".kmers" / "-edges"),
  *   "-counts.ord0"        (graph) this range's slice of the ord0 byte file,
  *   ".part.span"          this range's span of the high-bits bitmap (SparseArray.hh:87-118: one i of the whole array is
- *                         bit (key_i >> D) + i), built from its own keys: {u64 first word, u64 words}, then the words --
- *                         about 2.4 bits per key for the assembler (round 3 sent key >> D of every key: 4 or 8 bytes),
+ *                         bit (key_i >> D) + i), built from its own keys: a record {1, first word, words, bytes} + the words --
+ *                         about 2.4 bits per key for the assembler (round 3 sent key >> D of every key: 4 or 8 bytes) --
+ *                         followed by the range's DenseSelect blocks (below),
  *   ".part.big"           (graph) the entries with count > 255: {u64 global index, u32 count, u32 0},
  *   ".part.hist"          (graph) {u64 count, u64 frequency} pairs of this range, ascending.
  * first_index = number of result items in the ranges below this one, total = items in all ranges,
@@ -357,12 +358,29 @@ int goss_gpu_check_index(goss_gpu_ctx* ctx, const goss_gpu_sparse_files* files, 
  * goss_gpu_emit_assemble, on one context of the same (k, mode): from the concatenation (in range order)
  * of every ".part.span" on the device (span_bytes in all) and of the ".part.big" / ".part.hist" records in host
  * memory, builds the files that need all ranges: ".header", "<base>.header", "<base>.high-bits" (the spans ORed
- * together: neighbours share their boundary words), "<base>-d0", "<base>-d1" (DenseArray.cc:446-675, from the
- * positions of the assembled bitmap's ones)
+ * together: neighbours share their boundary words), "<base>-d0", "<base>-d1" (DenseArray.cc:446-675: the ranges' blocks
+ * where they sent them, the others from the positions of the assembled bitmap's ones / zeros)
  * and for graphs "-counts.ord1p.*", "-counts.ord1", "-counts.ord2p.*", "-counts.ord2", "-counts-hist.txt".
  * The files are appended to the context's list (a context may hold its own part and the assembly).
  */
 int goss_gpu_emit_part(goss_gpu_ctx* ctx, uint64_t first_index, uint64_t total, uint64_t estimate);
+/*
+ * DenseSelect blocks per range ("GPU p owns blocks fully inside its rank span and the host patches
+ * the straddling blocks"; the blocks are DenseSelect::Builder's, DenseArray.cc:446-647).  A block of "-d1" indexes 8192
+ * consecutive ones of the high-bits bitmap, a block of "-d0" 8192 consecutive zeros, and is a function of their positions
+ * alone: the owner of a range builds the blocks that lie wholly inside its ones [first_index, first_index + M) and -- told
+ * where the ranges below it end -- inside its zeros, and appends them to its ".part.span" file as records of their own
+ * ({kind, a, b, body bytes} + body: kind 1 the span {first word, words}, kind 2 blocks {sense, first block} with
+ * {blocks, body bytes}, bytes[], first positions[], types[], bodies); goss_gpu_emit_assemble takes the ranges' blocks as
+ * they are, builds the few that straddle two ranges from the assembled bitmap, and writes master index, rank array and
+ * header -- its work no longer grows with the number of keys.
+ *   goss_gpu_emit_last_high   the high part (key >> D) of the range's last key, *nonempty = 0 for a range without keys;
+ *                             the callers gather these (P numbers) and hand every range the last one below it.
+ *   goss_gpu_emit_part_ranges goss_gpu_emit_part with that number (prev_last_high: 0 for the first range): "-d0" blocks too
+ *                             (goss_gpu_emit_part, which does not know it, builds "-d1" blocks only).
+ */
+int goss_gpu_emit_last_high(goss_gpu_ctx* ctx, uint64_t total, uint64_t estimate, uint64_t* high, int* nonempty);
+int goss_gpu_emit_part_ranges(goss_gpu_ctx* ctx, uint64_t first_index, uint64_t total, uint64_t estimate, uint64_t prev_last_high);
 int goss_gpu_emit_assemble(goss_gpu_ctx* ctx, const void* d_spans, uint64_t span_bytes, uint64_t total,
                            uint64_t estimate, const void* h_big, uint64_t nbig, const uint64_t* h_hist, uint64_t nhist);
 

@@ -33,6 +33,11 @@ def _group_build(shards, k, mode):
         sizes = g.group_exchange(ctxs, sample_per_context=256)
         assert sizes == [c.result_ptrs()[2] for c in ctxs]
         g.group_emit(ctxs)
+        # DenseSelect blocks per range (round 5): the ranges built the blocks inside their own ones / zeros, the assembling
+        # context only those that straddle two ranges (at most one per range boundary and sense, and the arrays' last)
+        built, assembled = ctxs[0].stat("ds_blocks_from_ranges"), ctxs[0].stat("ds_blocks_assembled")
+        if sum(sizes) >= 8192 * 4 * len(ctxs):
+            assert built > 0 and assembled <= 2 * len(ctxs) + 2, (built, assembled, sizes)
         per_ctx = [c.files() for c in ctxs]
         for other in per_ctx[1:]:
             assert all(".low-bits" in n or n == "-counts.ord0" or n.startswith(".part.") for n in other), sorted(other)
