@@ -263,7 +263,7 @@ def multi_gpu_probe(ranks=8):
         try:
             d = json.loads(p.stdout.decode().strip().splitlines()[-1])
             out[name] = {"ms_per_step": d["ms_per_step"], "windows_per_step": d["value"] * 1e6 * d["ms_per_step"] * 1e-3,
-                         "device_ms_per_step": d["roofline"]["device_ms_per_step"]}
+                         "device_ms_per_step": d["roofline"]["device_ms_per_step"], "assemble_ms": d["roofline"].get("assemble_ms")}
         except (ValueError, IndexError, KeyError):
             out[name] = {"failed": p.stderr.decode(errors="replace")[-300:]}
     try:
@@ -275,13 +275,15 @@ def multi_gpu_probe(ranks=8):
         # first half of the records is counted while the second half travels: the wire runs beside device work unless
         # it is longer than half of the step; while it is busy RCCL's copy kernels hold about a tenth of the CUs
         exposed = max(0.0, wire_ms - 0.5 * rec["ms_per_step"]) + 0.1 * wire_ms + 10.0          # + the second exchange and merge
-        # emission: every rank builds its own slices and its span of the high-bits bitmap (inside the measured step: "emit");
-        # rank 0 then takes the spans (2.44 bits per distinct key of the whole build, ranks - 1 links at once), ORs them and
-        # builds -d0 / -d1 for ALL keys alone -- three quarters of a whole emit per rank's worth of keys, one after the other
-        emit_1 = rec["device_ms_per_step"].get("emit", 0.0)
+        # emission: every rank builds its own slices, its span of the high-bits bitmap and (round 5) the DenseSelect blocks
+        # inside its own ones and zeros -- all inside the measured step ("emit"); rank 0 then takes the spans and blocks
+        # (2.44 + ~0.3 bits per distinct key of the whole build, ranks - 1 links at once), ORs the spans, counts the ones per
+        # word and composes -d0 / -d1: the measured goss_gpu_emit_assemble of this rank's range (which it does for its own
+        # range inside the step already) once more for every OTHER rank's worth of keys
         distinct_all = ranks * 125e6
-        span_ms = distinct_all * 2.44 / 8 / 1e9 / ((ranks - 1) * 50.0) * 1e3
-        emission = span_ms + 0.75 * emit_1 * ranks
+        span_ms = distinct_all * 2.75 / 8 / 1e9 / ((ranks - 1) * 50.0) * 1e3
+        asm_1 = rec.get("assemble_ms") or 0.75 * rec["device_ms_per_step"].get("emit", 0.0)
+        emission = span_ms + asm_1 * (ranks - 1)
         step = rec["ms_per_step"] + exposed + emission
         out["projection"] = {"per_rank_step_ms": step, "ratio_to_one_rank": step / one["ms_per_step"],
                              "emission_ms": emission,
@@ -289,9 +291,10 @@ def multi_gpu_probe(ranks=8):
                              "assumed": "records on the wire %.1f GB per rank over %d links at 50 GB/s = %.0f ms, beside the routing of "
                                         "the later pieces and the counting of the first half of the records (exposed: what exceeds "
                                         "half of the step, here %.0f ms; a tenth of the wire time for RCCL's kernels on the CUs); "
-                                        "second exchange and merge 10 ms; emission on rank 0: spans of the bitmap in %.1f ms, "
-                                        "-d0 / -d1 of all %.0f M keys at 0.75 of this rank's emit per rank's worth of keys"
-                                        % (wire_gb, ranks - 1, wire_ms, max(0.0, wire_ms - 0.5 * rec["ms_per_step"]), span_ms, distinct_all / 1e6)}
+                                        "second exchange and merge 10 ms; emission on rank 0: spans and DenseSelect blocks of the other ranks in %.1f ms, "
+                                        "assembling them (bitmap ORed, ones counted, blocks that straddle two ranks built, index written) at "
+                                        "the %.2f ms this rank's own range took, per other rank, for all %.0f M keys"
+                                        % (wire_gb, ranks - 1, wire_ms, max(0.0, wire_ms - 0.5 * rec["ms_per_step"]), span_ms, asm_1, distinct_all / 1e6)}
     except KeyError:
         pass
     return out
@@ -598,7 +601,7 @@ def main():
                                                     "order": "canonical_map_kernel + radix passes over (key,count) pairs",
                                                     "hist": "radix_hist_kernel",
                                                     "scan": "scan_*_kernel", "scatter": "subpart32_kernel" if rem32 else "radix_onesweep_kernel",
-                                                    "reduce": "seg_hash_reduce32_kernel" if rem32 else "seg_hash_reduce_kernel"}.get(dom, dom),
+                                                    "reduce": "seg_hash_reduce32b_kernel" if rem32 else "seg_hash_reduce_kernel"}.get(dom, dom),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": tr["source"] if tr else None,
@@ -609,6 +612,8 @@ def main():
                                       "achieved": b_per_window * (windows / world) / (dt) / 1e9,
                                       "frac": b_per_window * (windows / world) / dt / 1e9 / HBM_PEAK_GBS},
                          "device_ms_per_step": {n: v["ms"] / args.steps for n, v in tim.items()},
+                         # (the multi-GPU path: what the assembling rank's goss_gpu_emit_assemble took in the last step, host clock)
+                         "assemble_ms": (ctx.stat("assemble_us") / 1e3) if use_dist else None,
                          "device_ms_total_per_step": dev_ms / args.steps},
         }
         # the other kernel classes against their own algorithmic bytes (same definitions)

@@ -157,6 +157,7 @@ struct goss_gpu_ctx {
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
+    uint64_t assemble_us = 0;           // host clock of the last goss_gpu_emit_assemble
     uint64_t ds_blocks_ranges = 0, ds_blocks_own = 0;      // DenseSelect blocks of the last assembly: taken from the ranges' records / built here from the bitmap
     uint32_t pk_fused_chunks = 0;       // chunks of a packed string the fused kernels read as they were
     uint32_t pk_unpacked_chunks = 0;    // ... and chunks (or samples) unpacked to bytes for the plain kernels
@@ -4054,8 +4055,10 @@ int goss_gpu_emit_assemble(goss_gpu_ctx* c, const void* d_spans, uint64_t span_b
             const uint64_t need = total * 12 + (256ULL << 20);
             if (c->arena.avail() < need) grow_arena(c, need);
         }
+        const auto t0 = std::chrono::steady_clock::now();
         emit_assemble(c, d_spans, span_bytes, total, estimate ? estimate : total, (const BigCount*)h_big, nbig, h_hist, nhist);
         HIP_TRY(hipStreamSynchronize(c->stream));
+        c->assemble_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     });
 }
 
@@ -5207,6 +5210,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
     else if (n == "packed_fused_chunks") *value = c->pk_fused_chunks;
     else if (n == "ds_blocks_from_ranges") *value = c->ds_blocks_ranges;
+    else if (n == "assemble_us") *value = c->assemble_us;
     else if (n == "ds_blocks_assembled") *value = c->ds_blocks_own;
     else if (n == "packed_unpacked_chunks") *value = c->pk_unpacked_chunks;
     else if (n == "rem32_bits") *value = c->rem32_bits_last;
