@@ -1863,7 +1863,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     if (n == 0) return kFusedDeclined;
     if (n > ka_slots || n > kb_slots) return decline("more keys than the buffers hold");
     uint64_t tiles = 0, sum = 0;
-    const uint64_t tile_keys = narrow ? (uint64_t)kSub32TileSlotsN : (msd && r32_slots) ? (uint64_t)kSub32Tile : msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
+    const uint64_t tile_keys = narrow ? (uint64_t)(r32_bits == 9 ? Sub32N<9>::kTileSlots : Sub32N<10>::kTileSlots) : (msd && r32_slots) ? (uint64_t)kSub32Tile : msd ? (uint64_t)SubCfg<K>::kTile : (uint64_t)kTile;      // of the pass that reads the regions
     for (int d = 0; d < 256; ++d)
     {
         // one-word keys: slots handed out in whole blocks, padding included (the next pass skips it)
@@ -1895,8 +1895,11 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         HIP_TRY(hipMemcpyAsync(dsub->start, hsub32_start.data(), (uint64_t)r32_regions * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(dsub->cap, hsub32_cap.data(), (uint64_t)r32_regions * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(cur2, 0, (uint64_t)r32_regions * 4, c->stream));
-        if (narrow)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32TileSlotsN>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+        if (narrow && r32_bits == 9)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<Sub32N<9>::kTileSlots>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
+                               (const GapTable*)dgt, tdesc, (uint32_t)tiles);
+        else if (narrow)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<Sub32N<10>::kTileSlots>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,
                                (const GapTable*)dgt, tdesc, (uint32_t)tiles);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(tiles32_kernel<kSub32Tile>), dim3(grid_for(tiles, 256)), dim3(256), 0, c->stream,

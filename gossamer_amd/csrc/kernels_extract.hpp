@@ -707,10 +707,11 @@ __host__ __device__ inline uint32_t rec_windows(uint32_t w2) { return (w2 >> 27)
 // vector instructions nothing waits for yet.  Stores first, ranking (and the next tile's byte encoder) last:
 // 36.9 -> 33.7 ms on C2.  Measured (bookkeeping, scatter, encoder, stores): (0,0,0,0) 36.3, (3,3,3,3) 35.5, (3,3,0,3) 34.9,
 // (0,3,0,3) 34.3, (0,0,0,3) 33.9, (1,2,0,3) 33.7, (3,0,0,0) 36.7.
+// (round 5, the narrow form: the encoder at 1 -- (1,2,1,3) 29.04 ms against (1,2,0,3) 29.26-29.41, (1,3,0,3) 30.23, (0,1,0,2) 29.77)
 #ifndef GOSS_E1_PRIO_C
 #define GOSS_E1_PRIO_C 1
 #define GOSS_E1_PRIO_S 2
-#define GOSS_E1_PRIO_E 0
+#define GOSS_E1_PRIO_E 1
 #define GOSS_E1_PRIO_D 3
 #endif
 // REPK (MODE 0): which strand of a k-mer is stored -- 0: strand_rep (even k), 1: the strand whose middle base has a clear

@@ -629,16 +629,21 @@ __global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restri
 // NARROW (round 5): the regions hold what extract1_part_kernel<.., NARROW> wrote -- 16-byte chunks {remainder, remainder,
 // remainder, D} with the three second-level digits at bits 0, 10, 20 of D and the number of keys the chunk holds at
 // bits 30-31: a lane takes a chunk with one 16-byte load, three keys, and has nothing to pack (5.33 bytes read per
-// key instead of 8).  A tile is 7 chunks per thread = 3 584 8-byte slots of the region.
-constexpr int kSub32ChunksN = 7;                         // chunks per thread of the narrow form
-constexpr int kSub32TileSlotsN = kTB * kSub32ChunksN * 2;   // ... in 8-byte slots of a region
+// key instead of 8).
+// Chunks per thread of the narrow form: 10 at nine digit bits (30 keys a thread, 7 680 a tile, 50 KB of LDS: three
+// workgroups per CU), 9 at ten bits (whose 1 024 counters and bases take 4 KB more).  Measured on C2 (round 5, tiles of
+// 5 / 6 / 7 / 8 / 9 / 10 chunks on 5 / 5 / 4 / 3 / 3 / 3 workgroups per CU): 30.9 / 28.8 / 25.8 / 25.1 / 24.1 / 23.6 ms --
+// longer runs per sub-region and fewer cursor atomics per key win over workgroups in flight.
+template <int B2> struct Sub32N { static constexpr int kChunks = B2 == 9 ? 10 : 9; static constexpr int kTileSlots = kTB * kChunks * 2; };
 template <bool SQ, int B2, bool NARROW = false>
-__global__ __launch_bounds__(kTB, GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(kTB, NARROW ? 3 : GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
                                                            uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
                                                            const Tile32* __restrict__ desc, uint32_t total_tiles,
                                                            const SubTable32* __restrict__ sub, LookbackCtl* __restrict__ ctl)
 {
+    constexpr int kSub32ChunksN = Sub32N<B2>::kChunks;
     constexpr int kItems = NARROW ? 3 * kSub32ChunksN : kSub32Items;
+    static_assert(kItems <= 32, "one bit of `have` per key");
     constexpr int kTile = kTB * kItems;
     constexpr uint32_t ND = 1u << B2;                        // second-level digits
     constexpr int DPT = ND / kTB;                            // digits a thread owns: 2, 4, 8 or 16 neighbours
