@@ -634,16 +634,20 @@ __global__ void tiles32_kernel(const GapTable* __restrict__ gt, Tile32* __restri
 // workgroups per CU), 9 at ten bits (whose 1 024 counters and bases take 4 KB more).  Measured on C2 (round 5, tiles of
 // 5 / 6 / 7 / 8 / 9 / 10 chunks on 5 / 5 / 4 / 3 / 3 / 3 workgroups per CU): 30.9 / 28.8 / 25.8 / 25.1 / 24.1 / 23.6 ms --
 // longer runs per sub-region and fewer cursor atomics per key win over workgroups in flight.
-template <int B2> struct Sub32N { static constexpr int kChunks = B2 == 9 ? 10 : 9; static constexpr int kTileSlots = kTB * kChunks * 2; };
+#ifndef GOSS_S32_CH
+#define GOSS_S32_CH 10
+#define GOSS_S32_OCCN 3
+#endif
+template <int B2> struct Sub32N { static constexpr int kChunks = B2 == 9 ? GOSS_S32_CH : GOSS_S32_CH - 1; static constexpr int kTileSlots = kTB * kChunks * 2; };
 template <bool SQ, int B2, bool NARROW = false>
-__global__ __launch_bounds__(kTB, NARROW ? 3 : GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(kTB, NARROW ? GOSS_S32_OCCN : GOSS_S32_OCC) void subpart32_kernel(const Key1* __restrict__ keys_in, uint32_t* __restrict__ out,
                                                            uint32_t rbits, uint32_t sqbit, unsigned long long* __restrict__ cursors,
                                                            const Tile32* __restrict__ desc, uint32_t total_tiles,
                                                            const SubTable32* __restrict__ sub, LookbackCtl* __restrict__ ctl)
 {
     constexpr int kSub32ChunksN = Sub32N<B2>::kChunks;
     constexpr int kItems = NARROW ? 3 * kSub32ChunksN : kSub32Items;
-    static_assert(kItems <= 32, "one bit of `have` per key");
+    static_assert(NARROW || kItems <= 32, "one bit of `have` per key");
     constexpr int kTile = kTB * kItems;
     constexpr uint32_t ND = 1u << B2;                        // second-level digits
     constexpr int DPT = ND / kTB;                            // digits a thread owns: 2, 4, 8 or 16 neighbours
@@ -693,11 +697,10 @@ __global__ __launch_bounds__(kTB, NARROW ? 3 : GOSS_S32_OCC) void subpart32_kern
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         // (a second loop: looking at a chunk inside the load loop would wait for every load in turn)
-#pragma unroll
-        for (int r = 0; r < kSub32ChunksN; ++r) have |= ((1u << (dw[r] >> 30)) - 1u) << (3 * r);
+        // (key r of the thread = field r % 3 of its chunk r / 3: a key iff the chunk holds more than r % 3 of them)
 #pragma unroll
         for (int r = 0; r < kItems; ++r)
-            if ((have >> r) & 1u) rank[r] = (uint16_t)atomicAdd(&hist[(dw[r / 3] >> (10 * (r % 3))) & (ND - 1u)], 1u);
+            if ((dw[r / 3] >> 30) > (uint32_t)(r % 3)) rank[r] = (uint16_t)atomicAdd(&hist[(dw[r / 3] >> (10 * (r % 3))) & (ND - 1u)], 1u);
     }
     else
     {
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(kTB, NARROW ? 3 : GOSS_S32_OCC) void subpart32_kern
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kItems; ++r)
-        if ((have >> r) & 1u)
+        if (NARROW ? (dw[NARROW ? r / 3 : 0] >> 30) > (uint32_t)(r % 3) : ((have >> (r & 31)) & 1u) != 0)
         {
             if constexpr (NARROW)
             {
