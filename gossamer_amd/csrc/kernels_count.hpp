@@ -940,6 +940,9 @@ __device__ __forceinline__ void r32b_pick4(uint32_t (&t)[4], const uint32_t (&of
 // Empty slots of bucket b hold a key that never looks at b in either of those two places (home b ^ 1, second b ^ 2), so
 // neither needs a look at the counts; the slow path's chain can reach b with that very key, and skips the bucket.
 // A slot is claimed by a 32-bit CAS on its key word (marker -> key); counts are only ever added to.
+#ifndef GOSS_R32B_VEC
+#define GOSS_R32B_VEC 4
+#endif
 template <int SLOTS, bool SQ>
 __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
                                                                 const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b
     auto home_of = [](uint32_t f) -> uint32_t { return f >> (32 - BB); };
     auto second_of = [](uint32_t f, uint32_t h) -> uint32_t { return h ^ (((f >> (32 - 2 * BB)) & (NB - 1u)) | 1u); };
 
-    constexpr int kVec = 4;                                  // 16-byte loads in flight per lane
+    constexpr int kVec = GOSS_R32B_VEC;                      // 16-byte loads in flight per lane
     const uint32_t head = (uint32_t)(b & 3ULL);
     const u32x4* const v4 = reinterpret_cast<const u32x4*>(rems + (b - head));
     const uint32_t n = (uint32_t)(e - b) + head;

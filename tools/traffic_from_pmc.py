@@ -15,7 +15,7 @@ src, units = sys.argv[1], float(sys.argv[2])
 text = open(src).read()
 blocks = re.split(r"\n(?=\S)", text)
 classes = {"extract": "extract1_part_kernel", "scatter": ("subpart32_kernel", "radix_onesweep_kernel<Key1, false, false, true, 22>"),
-           "reduce": ("seg_hash_reduce32_kernel", "seg_hash_reduce_kernel")}
+           "reduce": ("seg_hash_reduce32b_kernel", "seg_hash_reduce32_kernel", "seg_hash_reduce_kernel")}
 out = {"kernels_sha": bench.kernels_hash()}
 for cls, names in classes.items():
     names = (names,) if isinstance(names, str) else names
