@@ -888,9 +888,34 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
     const uint64_t nrec = navail;                            // (REC: the number of records travels in `navail`)
     uint64_t rc_next = 0, rc_end = 0;
     uint32_t ra0 = 0, ra1 = 0, ra2 = kSkPadWord2, rb0 = 0, rb1 = 0, rb2 = kSkPadWord2;      // the records the thread stages next (a pad: none)
-    uint32_t* rbuf = pk;                                     // [512][3] record words, then [513] prefix sums: phase A's share of `sorted`
-    uint32_t* rpre = pk + 512 * 3;
-    uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
+    // Staged records, 32 bytes each (phase A's share of `sorted`): words 0..2 the record's bases COMPLEMENTED (the reverse
+    // complement of window w is the field at bit 2 w), words 3..5 the bases in reverse order, base j at bit 2 (len + 14 - j)
+    // (the forward form of window w is the field at bit 30 - 2 w), word 6 the windows staged in front of the record, word 7
+    // twice its windows: a record is turned ONCE, by the thread that stages it, and every window is two funnel shifts
+    // of each image -- cut out of the bases and reversed window by window, phase B took 8 400 of a tile's 15 700 cycles.
+    uint32_t* rbuf = pk;                                     // [512][8]
+    uint32_t* rmark = pk + 512 * 8;                          // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
+    auto stage_rec = [&](uint32_t at, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t before) {
+        const uint32_t x2m = x2 & 0x0FFFFFFFu, nw = (x2 >> 28) + 1u;
+        if constexpr (!(MODE == 0 && REPK == 1))
+        {
+            // (the forms that read the bases only: see kTurned in phase B)
+            uint4* const q = reinterpret_cast<uint4*>(rbuf + 8u * at);
+            q[0] = make_uint4(~x0, ~x1, ~x2m, 0u);
+            q[1] = make_uint4(0u, 0u, before, 2u * nw);
+            return;
+        }
+        auto rev4 = [](uint32_t w) { const uint32_t r = __brev(w); return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1); };
+        // the 96 bits in reverse base order: base j at bit 2 (47 - j); moved down by 2 (33 - len) bits
+        uint32_t y0 = rev4(x2m), y1 = rev4(x1), y2 = rev4(x0);
+        uint32_t sh = 2u * (33u - len);
+        if (sh >= 32u) { y0 = y1; y1 = y2; y2 = 0u; sh -= 32u; }          // (uniform; twice for len = 1)
+        if (sh >= 32u) { y0 = y1; y1 = y2; y2 = 0u; sh -= 32u; }
+        const uint32_t v0 = __builtin_amdgcn_alignbit(y1, y0, sh), v1 = __builtin_amdgcn_alignbit(y2, y1, sh), v2 = y2 >> sh;
+        uint4* const q = reinterpret_cast<uint4*>(rbuf + 8u * at);
+        q[0] = make_uint4(~x0, ~x1, ~x2m, v0);
+        q[1] = make_uint4(v1, v2, before, 2u * nw);
+    };
     auto fetch_recs = [&](uint64_t base) {
         const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
         // (loads only: nothing here looks at what they return -- the window counts are taken where the records are
@@ -967,8 +992,8 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             const uint32_t sc = block_excl_scan_u32((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
             const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
             const uint32_t ea = ex + rna, eb = ea + rnb;          // ends of the thread's two records in the window sequence
-            if (pa) { rbuf[3 * ca] = ra0; rbuf[3 * ca + 1] = ra1; rbuf[3 * ca + 2] = ra2; rpre[ca] = ex; }
-            if (pb) { rbuf[3 * cb] = rb0; rbuf[3 * cb + 1] = rb1; rbuf[3 * cb + 2] = rb2; rpre[cb] = ea; }
+            if (pa) stage_rec(ca, ra0, ra1, ra2, ex);
+            if (pb) stage_rec(cb, rb0, rb1, rb2, ea);
             // the first record that does not fit ends the tile: records taken from the share, and their windows
             if (ex <= (uint32_t)T && eb > (uint32_t)T)
             {
@@ -1030,16 +1055,23 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
         {
             uint32_t m;
             uint64_t blo = 0, bhi = 0;
-            [[maybe_unused]] uint32_t r_at = 0, r_off = 0, r_nw = 0;          // (REC) record, window inside it, its windows
+            // (REC) the staged record the thread is at: its two images, twice the window inside it, twice its windows
+            [[maybe_unused]] uint32_t r_at = 0, r_s2 = 0, r_nw2 = 0, rc0 = 0, rc1 = 0, rc2 = 0, rv0 = 0, rv1 = 0, rv2 = 0;
+            [[maybe_unused]] uint32_t r_before = 0;
+            // (kTurned: the forms that cut their windows out of both images.  The others -- even lengths, the canonical form per
+            // window, graphs -- are within a few registers of what three workgroups per CU allow and spill 12 to 44 bytes
+            // with the six words of the images live in the loop: they take the bases back out of the complemented words)
+            constexpr bool kTurned = REC && MODE == 0 && REPK == 1;
             auto load_rec = [&]() {
-                blo = (uint64_t)rbuf[3 * r_at] | ((uint64_t)rbuf[3 * r_at + 1] << 32);
-                const uint32_t w2 = rbuf[3 * r_at + 2];
-                bhi = w2 & 0x0FFFFFFFu;
-                r_nw = (w2 >> 28) + 1;                             // (no pad is staged)
+                const uint4* const q = reinterpret_cast<const uint4*>(rbuf + 8u * r_at);
+                const uint4 a = q[0], b = q[1];
+                r_before = b.z; r_nw2 = b.w;
+                if constexpr (kTurned) { rc0 = a.x; rc1 = a.y; rc2 = a.z; rv0 = a.w; rv1 = b.x; rv2 = b.y; }
+                else { blo = ~((uint64_t)a.x | ((uint64_t)a.y << 32)); bhi = ~a.z & 0x0FFFFFFFu; }
             };
             // (a look-ahead -- the record behind the current one kept in registers, its LDS reads issued a record early --
             // changed nothing: 85.4 against 84.6 ms)
-            auto next_rec = [&]() { ++r_at; r_off = 0; load_rec(); };
+            auto next_rec = [&]() { ++r_at; r_s2 = 0; load_rec(); };
             if constexpr (REC)
             {
                 // windows P tid .. P tid + P - 1 of the tile's sequence, starting in record rmark[tid]
@@ -1047,8 +1079,8 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
                 const uint32_t left = wt > j0 ? wt - j0 : 0;
                 m = left >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << left) - 1u);
                 r_at = left ? rmark[tid] : 0u;                     // (marked by the record itself in phase A)
-                r_off = j0 - rpre[r_at];
                 load_rec();
+                r_s2 = 2u * (j0 - r_before);
             }
             else
             {
@@ -1104,22 +1136,44 @@ __global__ __launch_bounds__(kTB, GOSS_E1_OCC) void extract1_part_kernel(const u
             // [2 i, 2 i + bits) of the complemented buffer, its forward form the base-4 reverse of the same field.
             if constexpr (REC)
             {
-                // (a form that complements and base-4 reverses a record ONCE when it becomes the current one and cuts every window
-                // out of both by two funnel shifts -- 8 instructions per window where the reversal per window takes 14 and the
-                // cut by 64-bit shifts 9 -- needs six more live registers in this loop: 33 spilled to scratch, 137.8 against
-                // 85 ms.  Not kept; staging the reversed words in LDS beside the record would be the way.)
+                // (the record's images come from LDS, turned when the record was staged.  Turning it here, when it becomes the
+                // current one, needs six more live registers in this loop: 33 spilled to scratch, 137.8 against 85 ms)
+                const uint32_t kmlo = (uint32_t)kmask, kmhi = (uint32_t)(kmask >> 32);
+                if constexpr (!kTurned)
+                {
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+                    {
+                        // the window at bit r_s2 of record r_at, cut out of the record's bases and reversed
+                        const uint64_t x = (r_s2 ? ((blo >> r_s2) | (bhi << (64 - r_s2))) : blo) & kmask;
+                        emit(i, rev64(x) >> (64 - bits), (~x) & kmask);
+                        if (i + 1 < P)
+                        {
+                            r_s2 += 2u;
+                            if (r_s2 >= r_nw2 && r_at < 511) next_rec();
+                        }
+                    }
+                }
+                else
 #pragma unroll
                 for (int i = 0; i < P; ++i)
                 {
-                    // window r_off of record r_at, cut out of the record's bases; then on to the next window, which
-                    // may be the first of the next record
-                    const uint32_t s2 = 2 * r_off;
-                    const uint64_t x = (s2 ? ((blo >> s2) | (bhi << (64 - s2))) : blo) & kmask;
-                    emit(i, rev64(x) >> (64 - bits), (~x) & kmask);
+                    // the window at bit r_s2 of record r_at: two funnel shifts of each image (shifts of 0 .. 30 bits); then
+                    // on to the next window, which may be the first of the next record
+                    const uint32_t t2 = 30u - r_s2;
+                    const uint32_t rlo = __builtin_amdgcn_alignbit(rc1, rc0, r_s2) & kmlo, rhi = __builtin_amdgcn_alignbit(rc2, rc1, r_s2) & kmhi;
+                    const uint32_t flo = __builtin_amdgcn_alignbit(rv1, rv0, t2) & kmlo, fhi = __builtin_amdgcn_alignbit(rv2, rv1, t2) & kmhi;
+                    if (MODE == 0 && REPK == 1)
+                    {
+                        // (odd length: the low bit of the central base, bit len - 1 <= 30 of the forward form, picks the strand)
+                        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int32_t)flo, len - 1u, 1u);        // all ones: the reverse complement
+                        kreg[i].lo = ((uint64_t)bit_select(sel, rhi, fhi) << 32) | bit_select(sel, rlo, flo);
+                    }
+                    else emit(i, ((uint64_t)fhi << 32) | flo, ((uint64_t)rhi << 32) | rlo);
                     if (i + 1 < P)
                     {
-                        ++r_off;
-                        if (r_off >= r_nw && r_at < 511) next_rec();
+                        r_s2 += 2u;
+                        if (r_s2 >= r_nw2 && r_at < 511) next_rec();
                     }
                 }
             }

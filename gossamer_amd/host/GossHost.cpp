@@ -772,6 +772,13 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // (packed pushes give their buffers back from inside library calls of THIS thread: make them all happen before waiting)
     struct Drain { const PackedPush* p; ~Drain() { if (p && p->drain) { try { p->drain(); } catch (...) {} } } } drainLent{pushPacked};
 
+    // GOSS_PARSE_STATS=1: where the workers' time goes, summed over all of them (ns)
+    const bool wstats = std::getenv("GOSS_PARSE_STATS") != nullptr;
+    std::atomic<uint64_t> wBufNs{0}, wReadNs{0}, wParseNs{0}, wPackNs{0};
+    auto wnow = [] { return std::chrono::steady_clock::now(); };
+    auto wadd = [&](std::atomic<uint64_t>& a, std::chrono::steady_clock::time_point t) {
+        if (wstats) a.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(wnow() - t).count(), std::memory_order_relaxed);
+    };
     auto worker = [&]() {
         std::vector<char> raw;                  // the chunk's bytes as read from the file
         for (;;)
@@ -779,6 +786,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             ChunkResult r;
             size_t i;
             char* mybuf;
+            const auto tBuf = wnow();
             {
                 // buffer first, chunk number second (both under the lock): every outstanding chunk
                 // then owns a buffer and the in-order consumer can always make progress
@@ -789,6 +797,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 if (i >= nchunks) return;
                 mybuf = freeBufs.back(); freeBufs.pop_back();
             }
+            wadd(wBufNs, tBuf);
             const size_t begin = i * chunkBytes, limit = std::min(size, begin + chunkBytes);
             // The chunk's bytes are READ into a buffer of the worker's own (pread), with room behind `limit` for the
             // record that crosses it: 64 threads faulting the pages of one mapping in serialise on the address space's
@@ -800,6 +809,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 const size_t hi = std::min(size, limit + slack);
                 if (raw.size() < hi - lo) raw.resize(hi - lo);
                 size_t got = 0;
+                const auto tRead = wnow();
                 while (got < hi - lo)
                 {
                     const ssize_t k = pread(rfd, raw.data() + got, hi - lo - got, (off_t)(lo + got));
@@ -807,6 +817,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                     if (k == 0) break;
                     got += (size_t)k;
                 }
+                wadd(wReadNs, tRead);
+                const auto tParse = wnow();
+                struct ParseDone { decltype(wadd)& add; std::atomic<uint64_t>& a; std::chrono::steady_clock::time_point t;
+                                   ~ParseDone() { add(a, t); } } parseDone{wadd, wParseNs, tParse};
                 const char* lp = raw.data();
                 r = ChunkResult{};
                 r.buf = mybuf;
@@ -837,7 +851,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 // (flags right behind the codes: the library then moves both with one copy)
                 r.codes = (uint32_t*)(r.buf + packOff);
                 r.bad = (uint16_t*)(r.codes + (r.len + 15) / 16);
+                const auto tPack = wnow();
                 packBases(r.buf, r.len, r.codes, r.bad);
+                wadd(wPackNs, tPack);
             }
             r.done = true;
             {
@@ -863,6 +879,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                                                      n.c_str(), w, p, start, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)d); }
                     double start; }
         report{stats, waitSeconds, pushSeconds, drains, name, tEnter, std::chrono::duration<double>(std::chrono::steady_clock::now() - tEnter).count()};
+    struct WorkerReport { bool on; unsigned th; std::atomic<uint64_t>& b; std::atomic<uint64_t>& r; std::atomic<uint64_t>& p; std::atomic<uint64_t>& k;
+                          ~WorkerReport() { if (on) std::fprintf(stderr, "goss: parser workers (%u), seconds summed over them: waiting for a buffer %.3f, reading the file %.3f, framing %.3f, packing %.3f\n",
+                                                                 th, b.load() * 1e-9, r.load() * 1e-9, p.load() * 1e-9, k.load() * 1e-9); } }
+        workerReport{stats, threads, wBufNs, wReadNs, wParseNs, wPackNs};
     auto now = [] { return std::chrono::steady_clock::now(); };
     for (size_t i = 0; i < nchunks && !serialRest; ++i)
     {
