@@ -4932,6 +4932,14 @@ int goss_gpu_route_records_device(goss_gpu_ctx* c, const void* d_bases, uint64_t
         HIP_TRY(hipStreamSynchronize(c->stream));
         const RouteCounters* hr = (const RouteCounters*)h.data();
         for (uint32_t p = 0; p < nparts; ++p) { part_records[p] = hr->records[p]; if (part_windows) part_windows[p] = hr->windows[p]; }
+#if defined(GOSS_STAMPS)
+        if (nparts <= 128 && hr->records[128 + 7])
+        {
+            const double n = (double)hr->records[128 + 7];
+            std::fprintf(stderr, "libgossgpu: routing stamps per tile (ticks of wave 0): A %.0f  B %.0f  barrier %.0f  runs+scan %.0f  C %.0f  room %.0f  D %.0f   (%.0f tiles)\n",
+                         hr->records[128] / n, hr->records[129] / n, hr->records[130] / n, hr->records[131] / n, hr->records[132] / n, hr->records[133] / n, hr->records[134] / n, n);
+        }
+#endif
         if (hr->overflow) throw StatusError{GOSS_ERR_BUFFER, "a part's record buffer is too small (part_records holds what every part needs)"};
     });
 }

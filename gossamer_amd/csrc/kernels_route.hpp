@@ -111,9 +111,20 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
     const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     (void)maxwin;                                   // (records hold up to 16 windows in both modes)
 
+#if defined(GOSS_STAMPS)
+    // (timing build: cycles of wave 0 per phase, summed over its tiles, into the unused counters of parts 128..; with
+    // five workgroups per CU a phase's cycles say what all twenty waves of the CU issued meanwhile, not what it waited for)
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define GOSS_RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define GOSS_RSTAMP(i)
+#endif
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
         const uint64_t tb = tile * (uint64_t)T;
+#if defined(GOSS_STAMPS)
+        st_acc[7] += 1;
+#endif
         __builtin_amdgcn_s_setprio(3);              // (priorities by phase, as in extract1_part_kernel: loads first, stores next, the minimizers last)
         // ---- phase A: bytes of the tile -> codes + non-base flags ------------------------------------------
         for (uint32_t v = tid; v < (uint32_t)NVEC; v += kTB)
@@ -127,6 +138,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         if (tid < nparts) { cnt[tid] = 0; win[tid] = 0; }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
+        GOSS_RSTAMP(0);
 
         // ---- phase B: this thread's 16 windows: validity, minimizers, destinations, runs --------------------
         const uint32_t q0 = tid * P + mis;
@@ -229,7 +241,9 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         // its own).  Records never span tiles.
         lastd[tid] = last;
         vmask[tid] = (uint16_t)valid;
+        GOSS_RSTAMP(1);
         __syncthreads();
+        GOSS_RSTAMP(2);
         if (valid & 1u)
         {
             const uint32_t prev = tid ? lastd[tid - 1] : 0xFFFFFFFFu;
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
         uint32_t tot;
         const uint32_t at = block_excl_scan<uint32_t>(nrec, sh_scan, &tot);
         (void)tot;
+        GOSS_RSTAMP(3);
 
         // ---- phase C: every record of this thread takes a rank inside its part's share of the tile ----------------
         {
@@ -292,6 +307,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
                 ++r;
             }
         }
+        GOSS_RSTAMP(4);
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
         // ---- phase D: room in every part's buffer, then the records leave ------------------------------------------
@@ -328,6 +344,7 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             gbase[tid] = g0; gbase2[tid] = g1; grem[tid] = rem;
         }
         __syncthreads();
+        GOSS_RSTAMP(5);
         {
             const uint32_t b0 = (uint32_t)blo, b1 = (uint32_t)(blo >> 32), b2 = (uint32_t)bhi, b3 = (uint32_t)(bhi >> 32);
             for (uint32_t r = 0; r < nrec; ++r)
@@ -350,7 +367,13 @@ __global__ __launch_bounds__(kTB, GOSS_ROUTE_OCC) void route_records_kernel(cons
             }
         }
         __syncthreads();
+        GOSS_RSTAMP(6);
     }
+#if defined(GOSS_STAMPS)
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&rc->records[128 + i], st_acc[i]);
+#endif
+#undef GOSS_RSTAMP
     // what is left of the workgroup's blocks is filled with pads (records of no window), and the windows are told
     for (uint32_t p = 0; p < nparts; ++p)
     {
