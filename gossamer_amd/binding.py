@@ -20,7 +20,7 @@ SYMBOLS = [
     "goss_gpu_finish", "goss_gpu_result", "goss_gpu_result_copy", "goss_gpu_emit",
     "goss_gpu_file_count", "goss_gpu_file_info", "goss_gpu_file_read",
     "goss_gpu_emit_sparse_array", "goss_gpu_timing_get", "goss_gpu_timing_reset",
-    "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
+    "goss_gpu_synth_reads", "goss_synth_reads_host", "goss_gpu_reset", "goss_gpu_push_run_device", "goss_gpu_set_path", "goss_gpu_host_alloc", "goss_gpu_host_free", "goss_gpu_host_register", "goss_gpu_host_unregister", "goss_gpu_push_run_sparse", "goss_gpu_push_run_host", "goss_gpu_emit_estimate",
     "goss_gpu_select_counts", "goss_gpu_select_normal", "goss_gpu_emit_count_bits", "goss_gpu_emit_dump", "goss_gpu_lint", "goss_gpu_stat", "goss_gpu_check_index",
     "goss_gpu_set_budget_limit", "goss_gpu_emit_dump_range", "goss_gpu_prepare", "goss_gpu_emit_part", "goss_gpu_emit_assemble", "goss_gpu_emit_part_ranges", "goss_gpu_emit_last_high",
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",

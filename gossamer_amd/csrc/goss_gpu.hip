@@ -4719,6 +4719,19 @@ void goss_gpu_host_free(void* p)
     if (p) (void)hipHostFree(p);
 }
 
+int goss_gpu_host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return GOSS_ERR_INVALID_ARG;
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? GOSS_OK : GOSS_ERR_OOM;
+}
+
+void goss_gpu_host_unregister(void* p)
+{
+    if (p) { if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
+}
+
 int goss_gpu_set_path(goss_gpu_ctx* c, int path)
 {
     if (!c || path < 0 || path > 1) return GOSS_ERR_INVALID_ARG;

@@ -13,6 +13,7 @@
 
 #include <sys/mman.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -672,9 +673,18 @@ struct HostAlloc {                       // how the chunk buffers are obtained (
     // keep: buffers are not given back to the system when a file is done but kept for the next one (page-locked memory
     // costs ~0.3 s/GB to obtain and milliseconds per buffer to return: a build ends faster without the returns)
     bool keep = false;
+    // Two-step form (pin set): `alloc` is asked ONCE, for plain pages for the whole pool -- the workers parse into them
+    // while the device runtime is still starting -- and the pool is page-locked in place later, in one call, by the
+    // parser's allocator thread, once `ready` has returned true (it blocks until the runtime is up; false: it will not
+    // come up).  What is pushed before that is copied through the driver's own bounce buffers.
+    std::function<bool()> ready;
+    std::function<bool(void*, size_t)> pin;
+    std::function<void(void*)> unpin;
 };
 std::mutex gKeptMutex;
 std::map<size_t, std::vector<void*>> gKeptBuffers;          // by size
+struct KeptSlab { void* p; bool pinned; };
+std::map<size_t, std::vector<KeptSlab>> gKeptSlabs;         // two-step pools, by size
 
 // pushOwned (optional): the consumer keeps the buffer until it calls `release` -- several devices then copy
 // from several buffers at once; without it `push` returns when the bytes are on their way.
@@ -714,6 +724,8 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
 
     const size_t nchunks = (size + chunkBytes - 1) / chunkBytes;
     std::vector<ChunkResult> res(nchunks);
+    std::unique_ptr<std::atomic<uint8_t>[]> doneFlag(new std::atomic<uint8_t>[nchunks]);          // (what the consumer spins on before it sleeps)
+    for (size_t i = 0; i < nchunks; ++i) doneFlag[i].store(0, std::memory_order_relaxed);
     std::atomic<size_t> nextChunk{0};
     std::atomic<bool> abortAll{false};
     std::mutex m;
@@ -726,22 +738,71 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // pays for buffers it does not use and a long one does not wait for them up front.
     const size_t bufCap = chunkBytes / 2 + (1u << 16);
     // (packed pushes: codes and flags behind the bytes -- 6 bytes per 16 positions)
-    const size_t packOff = (bufCap + 63) & ~(size_t)63, codesBytes = (bufCap / 16 + 2) * 4;
-    const size_t bufBytes = pushPacked ? packOff + codesBytes + (bufCap / 16 + 2) * 2 + 64 : bufCap;
+    // Packed pushes: a pool buffer holds only what travels -- codes, then flags: 6 bytes per 16 positions -- and the
+    // bytes a chunk's bases are framed into before they are packed are the worker's own.  The same page-locked memory
+    // then makes four times as many buffers, and it takes many: the consumer takes the chunks in file order, a worker
+    // that is held up (the box is shared) holds up everything behind it, and the others need buffers to go on meanwhile
+    // (with 32 + 32 buffers of bytes + codes the workers waited for a buffer as long as they worked).
+    const size_t codesBytes = (bufCap / 16 + 2) * 4;
+    const size_t bufBytes = pushPacked ? codesBytes + (bufCap / 16 + 2) * 2 + 64 : bufCap;
     // (packed pushes keep their buffer until its copy has completed, and the consumer is away for ~25 ms whenever the
     // staging buffer is counted: more buffers than workers, so that the workers go on meanwhile)
-    size_t extraBufs = pushPacked ? 12 : 4;
+    size_t extraBufs = pushPacked ? 160 : 4;
     if (const char* e = std::getenv("GOSS_PARSE_POOL")) { const long v = atol(e); if (v >= 1) extraBufs = (size_t)v; }
     const size_t nbuf = std::min<size_t>((size_t)threads + extraBufs, nchunks + 1);
+    // Two condition variables on the one mutex: workers wait for a free buffer (cvFree, one of them woken per buffer that
+    // comes back), the in-order consumer for its next chunk (cvDone, woken by the worker that finishes a chunk).  With
+    // one for both every event woke all 33 threads, and the workers spent more time waiting than working.
+    std::condition_variable cvFree;
+    std::condition_variable& cvDone = cv;
+    auto wakeAll = [&]() { cvFree.notify_all(); cvDone.notify_all(); };
     std::vector<char*> freeBufs;
     std::vector<void*> allBufs;
+    KeptSlab slab{nullptr, false};
+    const size_t stride = (bufBytes + 4095) & ~(size_t)4095, slabBytes = stride * nbuf;
     std::atomic<bool> allocFailed{false};
-    struct FreeAll { std::vector<void*>& v; const HostAlloc& h; size_t bytes;
+    struct FreeAll { std::vector<void*>& v; const HostAlloc& h; size_t bytes; KeptSlab& slab; size_t slabBytes;
                      ~FreeAll() {
+                         if (slab.p)
+                         {
+                             if (h.keep) { std::lock_guard<std::mutex> lk(gKeptMutex); gKeptSlabs[slabBytes].push_back(slab); }
+                             else { if (slab.pinned) h.unpin(slab.p); h.release(slab.p); }
+                         }
                          if (h.keep) { std::lock_guard<std::mutex> lk(gKeptMutex); auto& k = gKeptBuffers[bytes]; k.insert(k.end(), v.begin(), v.end()); }
                          else for (void* b : v) h.release(b);
-                     } } freeAll{allBufs, ha, bufBytes};
+                     } } freeAll{allBufs, ha, bufBytes, slab, slabBytes};
     std::thread allocator([&]() {
+        auto fail = [&]() {
+            // (under the lock: a worker or the consumer between its predicate and its wait must not miss this)
+            { std::lock_guard<std::mutex> lk(m); allocFailed.store(true); abortAll.store(true); }
+            wakeAll();
+        };
+        if (ha.pin)
+        {
+            // two-step form: the whole pool at once, plain; page-locked when the device runtime is up
+            KeptSlab got{nullptr, false};
+            if (ha.keep)
+            {
+                std::lock_guard<std::mutex> lk(gKeptMutex);
+                auto it = gKeptSlabs.find(slabBytes);
+                if (it != gKeptSlabs.end() && !it->second.empty()) { got = it->second.back(); it->second.pop_back(); }
+            }
+            if (!got.p) got.p = ha.alloc(slabBytes);
+            if (!got.p) { fail(); return; }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                slab = got;
+                for (size_t i = 0; i < nbuf; ++i) freeBufs.push_back((char*)got.p + i * stride);
+            }
+            cvFree.notify_all();
+            if (!got.pinned && ha.ready && ha.ready() && !abortAll.load() && nextChunk.load() < nchunks)
+            {
+                const bool ok = ha.pin(got.p, slabBytes);
+                std::lock_guard<std::mutex> lk(m);
+                slab.pinned = ok;
+            }
+            return;
+        }
         for (size_t i = 0; i < nbuf && !abortAll.load() && nextChunk.load() < nchunks; ++i)
         {
             // (GOSS_TEST_FAIL_PARSER_ALLOC: fault injection for the test of this path -- the second buffer cannot be had)
@@ -753,22 +814,16 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 if (it != gKeptBuffers.end() && !it->second.empty()) { b = it->second.back(); it->second.pop_back(); }
             }
             if (!b) b = (i >= 1 && std::getenv("GOSS_TEST_FAIL_PARSER_ALLOC")) ? nullptr : ha.alloc(bufBytes);
-            if (!b)
-            {
-                // (under the lock: a worker or the consumer between its predicate and its wait must not miss this)
-                { std::lock_guard<std::mutex> lk(m); allocFailed.store(true); abortAll.store(true); }
-                cv.notify_all();
-                return;
-            }
+            if (!b) { fail(); return; }
             { std::lock_guard<std::mutex> lk(m); allBufs.push_back(b); freeBufs.push_back((char*)b); }
-            cv.notify_all();
+            cvFree.notify_one();
         }
     });
     struct JoinAlloc { std::thread& t; ~JoinAlloc() { if (t.joinable()) t.join(); } } joinAlloc{allocator};
     // buffers handed to pushOwned and not yet released: nothing here may be torn down before they are back
     size_t lent = 0;
     struct WaitLent { std::mutex& m; std::condition_variable& cv; size_t& lent;
-                      ~WaitLent() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return lent == 0; }); } } waitLent{m, cv, lent};
+                      ~WaitLent() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return lent == 0; }); } } waitLent{m, cvFree, lent};
     // (packed pushes give their buffers back from inside library calls of THIS thread: make them all happen before waiting)
     struct Drain { const PackedPush* p; ~Drain() { if (p && p->drain) { try { p->drain(); } catch (...) {} } } } drainLent{pushPacked};
 
@@ -781,6 +836,8 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     };
     auto worker = [&]() {
         std::vector<char> raw;                  // the chunk's bytes as read from the file
+        std::vector<char> bytes;                // (packed pushes) the chunk's bases before they are packed
+        if (pushPacked) bytes.resize(bufCap);
         for (;;)
         {
             ChunkResult r;
@@ -791,7 +848,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 // buffer first, chunk number second (both under the lock): every outstanding chunk
                 // then owns a buffer and the in-order consumer can always make progress
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return abortAll.load() || !freeBufs.empty(); });
+                cvFree.wait(lk, [&] { return abortAll.load() || !freeBufs.empty(); });
                 if (abortAll.load()) return;
                 i = nextChunk.fetch_add(1);
                 if (i >= nchunks) return;
@@ -835,9 +892,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 }
                 r.start = lo + s0;
                 MemLines src(lp, got, s0);
+                char* const to = pushPacked ? bytes.data() : r.buf;
                 auto sink = [&](const char* seq, size_t len) {
                     // a chunk's reads are shorter than the chunk's bytes (titles, '+', qualities)
-                    if (r.len + len + 1 <= bufCap) { memcpy(r.buf + r.len, seq, len); r.len += len; r.buf[r.len++] = '\n'; }
+                    if (r.len + len + 1 <= bufCap) { memcpy(to + r.len, seq, len); r.len += len; to[r.len++] = '\n'; }
                     else r.len = bufCap + 1;                 // cannot happen for a record-aligned chunk
                 };
                 r.ok = fastqLoop(src, limit - lo, sink, &r.reads, &r.lines, &r.fail);
@@ -849,10 +907,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             if (pushPacked && r.ok && r.start != (size_t)-1 && r.len && r.len <= bufCap)
             {
                 // (flags right behind the codes: the library then moves both with one copy)
-                r.codes = (uint32_t*)(r.buf + packOff);
+                r.codes = (uint32_t*)r.buf;
                 r.bad = (uint16_t*)(r.codes + (r.len + 15) / 16);
                 const auto tPack = wnow();
-                packBases(r.buf, r.len, r.codes, r.bad);
+                packBases(bytes.data(), r.len, r.codes, r.bad);
                 wadd(wPackNs, tPack);
             }
             r.done = true;
@@ -860,13 +918,15 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 std::lock_guard<std::mutex> lk(m);
                 res[i] = r;
             }
-            cv.notify_all();
+            doneFlag[i].store(1, std::memory_order_release);
+            cvDone.notify_one();
         }
     };
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
-    struct Join { std::vector<std::thread>& p; std::atomic<bool>& a; std::condition_variable& c;
-                  ~Join() { a.store(true); c.notify_all(); for (auto& t : p) if (t.joinable()) t.join(); } } join{pool, abortAll, cv};
+    struct Join { std::vector<std::thread>& p; std::atomic<bool>& a; std::condition_variable& c; std::condition_variable& c2; std::mutex& m;
+                  ~Join() { { std::lock_guard<std::mutex> lk(m); a.store(true); } c.notify_all(); c2.notify_all(); for (auto& t : p) if (t.joinable()) t.join(); } }
+        join{pool, abortAll, cv, cvFree, m};
 
     uint64_t reads = 0, baseLine = 1;
     size_t expected = 0;
@@ -889,13 +949,20 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         ChunkResult r;
         {
             const auto a = now();
+            // (a chunk that is about to be done is not worth a sleep: a look every few dozen nanoseconds for ~50 us first)
+            for (int spin = 0; spin < 1500 && !doneFlag[i].load(std::memory_order_acquire); ++spin)
+            {
+#if defined(__x86_64__)
+                _mm_pause();
+#endif
+            }
             std::unique_lock<std::mutex> lk(m);
             // Buffers lent to the library (packed pushes) come back only from inside a library call of THIS thread.  When
             // all of them are lent -- a burst of parsed chunks pushed back to back, their copies still queued -- the
             // workers wait for a buffer, chunk i is nobody's yet, and waiting here without calling the library would
             // wait for ever (one build in four hung that way once the device side had got faster): while buffers are
             // out and none is free, the wait is bounded and the library is asked to hand them back.
-            while (!cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return res[i].done || allocFailed.load(); }))
+            while (!cvDone.wait_for(lk, std::chrono::milliseconds(2), [&] { return res[i].done || allocFailed.load(); }))
             {
                 if (lent > 0 && freeBufs.empty() && pushPacked && pushPacked->drain)
                 {
@@ -915,7 +982,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         {
             // the chunk found no record start: fine only if the previous record ran past it
             { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
-            cv.notify_all();
+            cvFree.notify_one();
             if (expected < limit) serialRest = true;
             continue;
         }
@@ -923,7 +990,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             if (!r.buf) return;
             { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
             r.buf = nullptr;
-            cv.notify_all();
+            cvFree.notify_one();
         };
         if (r.start != expected || r.len > bufCap) { giveBack(); serialRest = true; break; }
         if (!r.ok) throw Error::Parse(name, r.fail.what + num(baseLine + r.fail.line - 1));
@@ -933,9 +1000,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             r.buf = nullptr;
             { std::lock_guard<std::mutex> lk(m); ++lent; }
             const auto a = now();
-            pushPacked->push(r.codes, r.bad, r.len, [&m, &cv, &freeBufs, &lent, b]() {
-                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); --lent; }
-                cv.notify_all();
+            pushPacked->push(r.codes, r.bad, r.len, [&m, &cvFree, &freeBufs, &lent, b]() {
+                bool last;
+                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); last = --lent == 0; }
+                if (last) cvFree.notify_all(); else cvFree.notify_one();          // (all: whoever waits for `lent` to reach zero is among them)
             });
             pushSeconds += std::chrono::duration<double>(now() - a).count();
         }
@@ -944,9 +1012,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             char* b = r.buf;
             r.buf = nullptr;
             { std::lock_guard<std::mutex> lk(m); ++lent; }
-            (*pushOwned)(b, r.len, [&m, &cv, &freeBufs, &lent, b]() {
-                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); --lent; }
-                cv.notify_all();
+            (*pushOwned)(b, r.len, [&m, &cvFree, &freeBufs, &lent, b]() {
+                bool last;
+                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); last = --lent == 0; }
+                if (last) cvFree.notify_all(); else cvFree.notify_one();
             });
         }
         else if (r.len)
@@ -966,8 +1035,8 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     {
         // a boundary guess did not line up (wrapped records, '@' starting quality lines, ...):
         // the rest of the file is framed serially from the last verified record boundary
-        abortAll.store(true);
-        cv.notify_all();
+        { std::lock_guard<std::mutex> lk(m); abortAll.store(true); }
+        wakeAll();
         std::vector<char> batch;
         batch.reserve(chunkBytes);
         MemLines src(p, size, expected);
@@ -1033,17 +1102,47 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     std::vector<int> devs = cxt.devices.empty() ? std::vector<int>{cxt.device} : cxt.devices;
     const size_t P = devs.size();
     std::vector<std::unique_ptr<GpuCtx>> gs;
-    for (size_t d = 0; d < P; ++d)
-    {
-        gs.emplace_back(new GpuCtx);
-        GpuCtx& g = *gs.back();
-        g.check(goss_gpu_create(&g.h, devs[d], (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
-        // a budget the user did not ask for is a starting size: inputs with little duplication (a
-        // genome in FASTA: every k-mer once) need room for runs that do not shrink
-        if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
-        // the arena is mapped while the first buffers are read and parsed
-        g.check(goss_gpu_prepare(g.h), "mapping HBM");
-    }
+    for (size_t d = 0; d < P; ++d) gs.emplace_back(new GpuCtx);
+    // The contexts are created by a thread of their own: loading the device runtime and its code takes 0.07 to 0.2 s, and
+    // with one device the parser's workers read and frame the first chunks meanwhile (into plain pages that are
+    // page-locked once the runtime is up: HostAlloc's two-step form).  Whoever needs a context waits for it (needCtx).
+    struct CtxState { std::mutex m; std::condition_variable cv; bool done = false; std::exception_ptr err; double readyAt = 0; } cs;
+    std::thread ctxThread([&]() {
+        std::exception_ptr err;
+        try
+        {
+            for (size_t d = 0; d < P; ++d)
+            {
+                GpuCtx& g = *gs[d];
+                g.check(goss_gpu_create(&g.h, devs[d], (uint32_t)K, mode, budget, nullptr), "creating the GPU context");
+                // a budget the user did not ask for is a starting size: inputs with little duplication (a
+                // genome in FASTA: every k-mer once) need room for runs that do not shrink
+                if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
+                // the arena is mapped while the first buffers are read and parsed
+                g.check(goss_gpu_prepare(g.h), "mapping HBM");
+            }
+        }
+        catch (...) { err = std::current_exception(); }
+        { std::lock_guard<std::mutex> lk(cs.m); cs.done = true; cs.err = err; cs.readyAt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+        cs.cv.notify_all();
+    });
+    struct JoinCtx { std::thread& t; ~JoinCtx() { if (t.joinable()) t.join(); } } joinCtx{ctxThread};          // (before `gs` goes)
+    std::atomic<bool> ctxSeen{false};
+    auto needCtx = [&]() {
+        if (ctxSeen.load(std::memory_order_acquire)) return;
+        std::unique_lock<std::mutex> lk(cs.m);
+        cs.cv.wait(lk, [&] { return cs.done; });
+        if (cs.err) std::rethrow_exception(cs.err);
+        ctxSeen.store(true, std::memory_order_release);
+    };
+    auto ctxUp = [&]() -> bool {              // (for the parser's allocator thread: blocks; false = no context will come)
+        std::unique_lock<std::mutex> lk(cs.m);
+        cs.cv.wait(lk, [&] { return cs.done; });
+        return !cs.err;
+    };
+    // (several devices: feeders, staging sizes and the exchange all start from the contexts)
+    const bool beside = P == 1 && !std::getenv("GOSS_CONTEXT_FIRST");
+    if (!beside) needCtx();
     GpuCtx& g = *gs[0];
     struct Feeder {
         struct Job { const char* p; size_t n; std::function<void()> done; };
@@ -1189,9 +1288,18 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     batch.reserve(cxt.batchBytes + (1u << 20));
     uint64_t reads = 0;
     HostAlloc pinned{[](size_t n) { void* p = nullptr; return goss_gpu_host_alloc(&p, n) == GOSS_OK ? p : nullptr; },
-                     [](void* p) { goss_gpu_host_free(p); }, true};
+                     [](void* p) { goss_gpu_host_free(p); }, true, nullptr, nullptr, nullptr};
+    if (beside)
+    {
+        pinned.alloc = [](size_t n) -> void* { void* p = nullptr; return posix_memalign(&p, 4096, (n + 4095) & ~(size_t)4095) == 0 ? p : nullptr; };
+        pinned.release = [](void* p) { std::free(p); };
+        pinned.ready = ctxUp;
+        pinned.pin = [](void* p, size_t n) { return goss_gpu_host_register(p, (n + 4095) & ~(size_t)4095) == GOSS_OK; };
+        pinned.unpin = [](void* p) { goss_gpu_host_unregister(p); };
+    }
     double pushSeconds = 0;
     auto timedPush = [&](const char* p, size_t n) {
+        needCtx();
         auto a = std::chrono::steady_clock::now();
         if (fed) feed(p, n, nullptr, true);
         else g.check(goss_gpu_push_bases_host(g.h, p, n), "counting k-mers");
@@ -1268,30 +1376,102 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     for (auto& f : fastqs)
     {
         if (gzFiles.size() > 1 && threads > 1 && compressed(f)) continue;      // done above
+        if (ctxSeen.load())
         { std::ostringstream o; o << "parsing sequences from " << f << " (contexts ready at "
             << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s)"; log(info, o.str()); }
+        else log(info, "parsing sequences from " + f + " (the context is created beside the parser)");
         flush();
         // one device: the workers pack their bases to 2 bits + a flag and the packed arrays are handed over without
         // waiting for the copy (GOSS_HOST_ASCII=1: the byte form, one synchronous push per chunk, as before)
+        // The library calls are made by a thread of their own, fed through a queue: a push costs 50 to 80 us of driver
+        // calls (two copies queued, an event, the buffers that have come back), 0.2 to 0.3 s for C2's 3 750 chunks -- on
+        // the consumer's own thread that time came on top of its waiting for the workers.  All calls on the context
+        // between here and the join below are this thread's, so the buffers are released on it.
         struct Cb { std::function<void()> fn; };
+        struct PushJob { const uint32_t* codes; const uint16_t* bad; size_t n; std::function<void()> release; bool flush; };
+        struct Pusher {
+            std::mutex m; std::condition_variable cv, cvIdle;
+            std::deque<PushJob> q; bool stop = false, busy = false; Error error; std::atomic<bool> failed{false};
+            double seconds = 0;
+            std::thread t;
+        } pu;
         PackedPush packed;
-        packed.push = [&](const uint32_t* codes, const uint16_t* bad, size_t n, std::function<void()> release) {
-            Cb* cb = new Cb{std::move(release)};
-            const int rc = goss_gpu_push_packed_host_async(g.h, codes, bad, n, [](void* u) { Cb* c = (Cb*)u; c->fn(); delete c; }, cb);
-            if (rc != GOSS_OK) { cb->fn(); delete cb; g.check(rc, "counting k-mers"); }
-        };
-        packed.drain = [&]() { g.check(goss_gpu_flush(g.h), "counting k-mers"); };
         const bool usePacked = !fed && !std::getenv("GOSS_HOST_ASCII");
+        auto pusherBody = [&]() {
+            try { needCtx(); }
+            catch (const Error& e) { std::lock_guard<std::mutex> lk(pu.m); pu.error = e; pu.failed.store(true); }
+            catch (...) { std::lock_guard<std::mutex> lk(pu.m); pu.error = Error::General("creating the GPU context failed\n"); pu.failed.store(true); }
+            for (;;)
+            {
+                PushJob j;
+                {
+                    std::unique_lock<std::mutex> lk(pu.m);
+                    pu.busy = false;
+                    if (pu.q.empty()) pu.cvIdle.notify_all();
+                    pu.cv.wait(lk, [&] { return pu.stop || !pu.q.empty(); });
+                    if (pu.q.empty()) return;
+                    j = std::move(pu.q.front()); pu.q.pop_front();
+                    pu.busy = true;
+                }
+                if (pu.failed.load()) { if (j.release) j.release(); continue; }          // (nothing is pushed any more: the buffers go back)
+                const auto a = std::chrono::steady_clock::now();
+                int rc;
+                if (j.flush) rc = goss_gpu_flush(g.h);
+                else
+                {
+                    Cb* cb = new Cb{std::move(j.release)};
+                    rc = goss_gpu_push_packed_host_async(g.h, j.codes, j.bad, j.n, [](void* u) { Cb* c = (Cb*)u; c->fn(); delete c; }, cb);
+                    if (rc != GOSS_OK) { cb->fn(); delete cb; }          // (a failed push: the buffer is ours again, goss_gpu.h)
+                }
+                pu.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+                if (rc != GOSS_OK)
+                {
+                    std::lock_guard<std::mutex> lk(pu.m);
+                    pu.error = Error::General(std::string("counting k-mers: ") + goss_gpu_strerror(rc) + " (" + goss_gpu_last_error(g.h) + ")\n");
+                    pu.failed.store(true);
+                }
+            }
+        };
+        auto pusherError = [&]() {
+            if (!pu.failed.load()) return;
+            std::lock_guard<std::mutex> lk(pu.m);
+            throw pu.error;
+        };
+        packed.push = [&](const uint32_t* codes, const uint16_t* bad, size_t n, std::function<void()> release) {
+            if (pu.failed.load()) { release(); pusherError(); }
+            { std::lock_guard<std::mutex> lk(pu.m); pu.q.push_back(PushJob{codes, bad, n, std::move(release), false}); }
+            pu.cv.notify_one();
+        };
+        // (every buffer handed over so far comes back before this returns)
+        packed.drain = [&]() {
+            {
+                std::unique_lock<std::mutex> lk(pu.m);
+                pu.q.push_back(PushJob{nullptr, nullptr, 0, nullptr, true});
+                pu.cv.notify_one();
+                pu.cvIdle.wait(lk, [&] { return pu.q.empty() && !pu.busy; });
+            }
+            pusherError();
+        };
+        if (usePacked) pu.t = std::thread(pusherBody);
+        struct StopPusher { Pusher& p; ~StopPusher() { { std::lock_guard<std::mutex> lk(p.m); p.stop = true; } p.cv.notify_all(); if (p.t.joinable()) p.t.join(); } } stopPusher{pu};
         // (at most 32 framing threads: measured on the bench's box -- 256 cores shared with other jobs -- the 31.5 GB of
         // C2 take 0.5 s with 32 and 1.2 to 3.5 s with 64, whose system time is four to ten times higher; the pushes'
         // driver calls slow down with them: 1.34 / 1.43 s for the build with -T 32 against 1.64 / 1.94 s with -T 64)
         uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, kMaxFramers), parseChunkBytes(), timedPush, pinned,
                                         fed ? &ownedPush : nullptr, usePacked ? &packed : nullptr);
+        // (the pusher is idle -- the parser has drained it -- and ends here: the calls that follow are this thread's again)
+        { std::lock_guard<std::mutex> lk(pu.m); pu.stop = true; }
+        pu.cv.notify_all();
+        if (pu.t.joinable()) pu.t.join();
+        pusherError();
+        pushSeconds += pu.seconds;
         if (r == ~0ULL) r = parseFastq(f, sink);
         reads += r;
     }
     if (reads == 0) throw Error::General("No valid reads.");                  // KmerizingAdapter.hh:70-78
     flush();
+    needCtx();
+    if (beside) { std::ostringstream o; o << "contexts ready at " << cs.readyAt << "s (beside the parser)"; log(info, o.str()); }
     if (fed) drainFeeders();
     auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (useRecords)
@@ -1816,7 +1996,7 @@ int gossMain(int argc, char* argv[])
                 for (auto& f : fastqs)
                 {
                     // -T > 1 exercises the parallel parser (same byte stream, file order)
-                    HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }, false};
+                    HostAlloc heap{[](size_t n) { return malloc(n); }, [](void* p) { free(p); }, false, nullptr, nullptr, nullptr};
                     // GOSS_DUMP_PACKED=1: the chunks go through the workers' 2-bit packer and are unpacked here the
                     // way the device unpacks them (a base letter in upper case, a newline for every non-base)
                     PackedPush viaPacked;

@@ -1,4 +1,20 @@
 // goss -- the `goss build-kmer-set` / `goss build-graph` executable (goss.cc:15-32).
 #include "GossHost.hpp"
 
-int main(int argc, char* argv[]) { return gosshost::gossMain(argc, argv); }
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+
+int main(int argc, char* argv[])
+{
+    const int rc = gosshost::gossMain(argc, argv);
+    // Every file the command wrote is closed by now.  What is left is tearing the device runtime down -- unmapping tens
+    // of GB of HBM, unlocking the parser's buffers, unloading the code: 0.05 to 0.1 s of a 1.3 s build that the kernel
+    // does anyway when the process ends.  GOSS_FULL_EXIT=1, or a tool that is loaded with the process and writes its
+    // results from an exit handler (rocprofv3, a sanitizer), keeps the orderly exit.
+    const char* full = std::getenv("GOSS_FULL_EXIT");
+    if ((full && *full == '1') || std::getenv("LD_PRELOAD") || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD"))
+        return rc;
+    std::fflush(nullptr);
+    _exit(rc);
+}

@@ -502,6 +502,15 @@ int goss_gpu_lint(goss_gpu_ctx* ctx, int asymmetric, goss_gpu_lint_report* out);
  */
 int goss_gpu_host_alloc(void** p, size_t bytes);
 void goss_gpu_host_free(void* p);
+/*
+ * The same for memory the caller already has (page-aligned, e.g. from mmap or posix_memalign): page-locks [p, p + bytes)
+ * in place.  A caller that wants to fill its buffers BEFORE the device runtime is up -- `goss` starts parsing while its
+ * context is created -- allocates them plainly, registers each once the context exists and while nothing is being
+ * copied from it, and unregisters it before freeing.  A buffer that is not (yet) registered may still be pushed: the
+ * copy is then synchronous inside the driver.  Returns GOSS_ERR_OOM when the pages cannot be locked.
+ */
+int goss_gpu_host_register(void* p, size_t bytes);
+void goss_gpu_host_unregister(void* p);
 
 /*
  * Counting strategy.  0 (default): partition on the top 16 key bits, then count every segment
