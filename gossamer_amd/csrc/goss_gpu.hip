@@ -4373,14 +4373,16 @@ bool rccl_load()
 // communicators of a device list (made once per list and process); nullptr = not to be had
 const std::vector<void*>* rccl_comms(const std::vector<int>& devs)
 {
+    // (a device twice -- several contexts on one GPU, what a one-GPU box can show -- has no communicators: decided before
+    // the library is loaded, which alone takes a second)
+    std::vector<int> sorted = devs;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return nullptr;
     std::lock_guard<std::mutex> lk(g_rccl.m);
     if (!rccl_load()) return nullptr;
     auto it = g_rccl.comms.find(devs);
     if (it != g_rccl.comms.end()) return it->second.empty() ? nullptr : &it->second;
-    std::vector<int> sorted = devs;
-    std::sort(sorted.begin(), sorted.end());
     std::vector<void*> cs;
-    if (std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end())          // (a device twice: no communicators)
     {
         cs.assign(devs.size(), nullptr);
         if (g_rccl.CommInitAll(cs.data(), (int)devs.size(), devs.data()) != 0) cs.clear();

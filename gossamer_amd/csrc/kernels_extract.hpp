@@ -1779,9 +1779,29 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
     const uint64_t nrec = navail;
     uint64_t rc_next = 0, rc_end = 0;
     uint32_t ra[5] = {0, 0, 0, 0, kSkPadWord2}, rb[5] = {0, 0, 0, 0, kSkPadWord2};      // (a pad: no window)
-    uint32_t* rbuf = pk;                                     // [512][5] record words, then [520] prefix sums, then the threads' marks: phase A's share of `sorted`
-    uint32_t* rpre = pk + 512 * 5;
-    uint32_t* rmark = rpre + 520;                            // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
+    // Staged records, 48 bytes each (phase A's share of `sorted`), turned ONCE by the thread that stages them (the one-word
+    // kernel's form): words 0..4 the record's bases complemented (the reverse complement of window w is the field at bit
+    // 2 w), words 5..9 the bases in reverse order, base j at bit 2 (len + 14 - j) (the forward form of window w is the
+    // field at bit 30 - 2 w), word 10 the windows staged in front of the record, word 11 twice its windows.
+    uint32_t* rbuf = pk;                                     // [512][12]
+    uint32_t* rmark = pk + 512 * 12;                         // [256] the staged record that holds thread g's first window; [256] = records taken, [257] = their windows
+    auto stage_rec = [&](uint32_t at, const uint32_t (&x)[5], uint32_t before) {
+        const uint32_t x4m = x[4] & 0x0FFFFFFFu, nw = (x[4] >> 28) + 1u;
+        auto rev4 = [](uint32_t w) { const uint32_t r = __brev(w); return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1); };
+        // the 160 bits in reverse base order: base j at bit 2 (79 - j); moved down by 2 (65 - len) bits (4 .. 66)
+        uint32_t y[6] = {rev4(x4m), rev4(x[3]), rev4(x[2]), rev4(x[1]), rev4(x[0]), 0u};
+        uint32_t sh = 2u * (65u - len);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd)
+            if (sh >= 32u) { y[0] = y[1]; y[1] = y[2]; y[2] = y[3]; y[3] = y[4]; y[4] = 0u; sh -= 32u; }          // (uniform)
+        uint32_t v[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[j] = __builtin_amdgcn_alignbit(y[j + 1], y[j], sh);
+        uint4* const q = reinterpret_cast<uint4*>(rbuf + 12u * at);
+        q[0] = make_uint4(~x[0], ~x[1], ~x[2], ~x[3]);
+        q[1] = make_uint4(~x4m, v[0], v[1], v[2]);
+        q[2] = make_uint4(v[3], v[4], before, 2u * nw);
+    };
     auto fetch_recs = [&](uint64_t base) {
         const uint64_t ia = base + 2 * (uint64_t)tid, ib = ia + 1;
         // (loads only: the window counts are taken where the records are staged -- extract1_part_kernel)
@@ -1843,16 +1863,8 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             const uint32_t sc = block_excl_scan_u32((rna + rnb) | ((pa + pb) << 16), sh_scan, &tot2);
             const uint32_t ex = sc & 0xFFFFu, ca = sc >> 16, cb = ca + pa;
             const uint32_t ea = ex + rna, eb = ea + rnb;
-            if (pa) {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) rbuf[5 * ca + j] = ra[j];
-                rpre[ca] = ex;
-            }
-            if (pb) {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) rbuf[5 * cb + j] = rb[j];
-                rpre[cb] = ea;
-            }
+            if (pa) stage_rec(ca, ra, ex);
+            if (pb) stage_rec(cb, rb, ea);
             if (ex <= (uint32_t)T && eb > (uint32_t)T)
             {
                 const uint32_t one = ea <= (uint32_t)T ? 1u : 0u;
@@ -1913,39 +1925,36 @@ __global__ __launch_bounds__(kTB, 2) void extract2_part_kernel(const uint8_t* __
             vm = left >= (uint32_t)P ? (uint32_t)((1ULL << P) - 1ULL) : ((1u << left) - 1u);
             nvalid += __popc(vm);
             uint32_t r_at = left ? rmark[tid] : 0u;
-            uint32_t r_off = j0 - rpre[r_at];
-            uint64_t w0 = 0, w1 = 0, w2 = 0;
-            uint32_t r_nw = 0;
+            uint32_t r_s2 = 0, r_nw2 = 0, r_before = 0;
+            uint32_t rc[5] = {0, 0, 0, 0, 0}, rv[5] = {0, 0, 0, 0, 0};
             auto load_rec = [&]() {
-                w0 = (uint64_t)rbuf[5 * r_at] | ((uint64_t)rbuf[5 * r_at + 1] << 32);
-                w1 = (uint64_t)rbuf[5 * r_at + 2] | ((uint64_t)rbuf[5 * r_at + 3] << 32);
-                const uint32_t x4 = rbuf[5 * r_at + 4];
-                w2 = x4 & 0x0FFFFFFFu;
-                r_nw = (x4 >> 28) + 1;                             // (no pad is staged)
+                const uint4* const q = reinterpret_cast<const uint4*>(rbuf + 12u * r_at);
+                const uint4 a = q[0], b = q[1], c = q[2];
+                rc[0] = a.x; rc[1] = a.y; rc[2] = a.z; rc[3] = a.w; rc[4] = b.x;
+                rv[0] = b.y; rv[1] = b.z; rv[2] = b.w; rv[3] = c.x; rv[4] = c.y;
+                r_before = c.z; r_nw2 = c.w;                       // (no pad is staged)
             };
-            auto next_rec = [&]() { ++r_at; r_off = 0; load_rec(); };
+            auto next_rec = [&]() { ++r_at; r_s2 = 0; load_rec(); };
             load_rec();
+            r_s2 = 2u * (j0 - r_before);
             const uint32_t spare = 256u + (tid & 31u);
             uint32_t bin[NK];
+            const uint32_t mh2 = (uint32_t)mask_hi, mh3 = (uint32_t)(mask_hi >> 32);
 #pragma unroll
             for (int i = 0; i < P; ++i)
             {
-                const uint32_t s2 = 2 * r_off;                     // <= 30
-                Key2 e;
-                e.lo = s2 ? ((w0 >> s2) | (w1 << (64 - s2))) : w0;
-                e.hi = (s2 ? ((w1 >> s2) | (w2 << (64 - s2))) : w1) & mask_hi;
-                Key2 f;
-                {
-                    const uint64_t rlo = rev64(e.hi), rhi = rev64(e.lo);
-                    const uint32_t sft = 128 - bits;
-                    if (sft == 64) { f.lo = rhi; f.hi = 0; }
-                    else { f.lo = (rlo >> sft) | (rhi << (64 - sft)); f.hi = rhi >> sft; }
-                }
-                const Key2 rck{~e.lo, (~e.hi) & mask_hi};
+                // the window at bit r_s2 of record r_at: four funnel shifts of each image (shifts of 0 .. 30 bits)
+                const uint32_t t2 = 30u - r_s2;
+                const uint32_t r0 = __builtin_amdgcn_alignbit(rc[1], rc[0], r_s2), r1 = __builtin_amdgcn_alignbit(rc[2], rc[1], r_s2);
+                const uint32_t r2 = __builtin_amdgcn_alignbit(rc[3], rc[2], r_s2) & mh2, r3 = __builtin_amdgcn_alignbit(rc[4], rc[3], r_s2) & mh3;
+                const uint32_t f0 = __builtin_amdgcn_alignbit(rv[1], rv[0], t2), f1 = __builtin_amdgcn_alignbit(rv[2], rv[1], t2);
+                const uint32_t f2 = __builtin_amdgcn_alignbit(rv[3], rv[2], t2) & mh2, f3 = __builtin_amdgcn_alignbit(rv[4], rv[3], t2) & mh3;
+                const Key2 f{(uint64_t)f0 | ((uint64_t)f1 << 32), (uint64_t)f2 | ((uint64_t)f3 << 32)};
+                const Key2 rck{(uint64_t)r0 | ((uint64_t)r1 << 32), (uint64_t)r2 | ((uint64_t)r3 << 32)};
                 if (i + 1 < P)
                 {
-                    ++r_off;
-                    if (r_off >= r_nw && r_at < 511) next_rec();
+                    r_s2 += 2u;
+                    if (r_s2 >= r_nw2 && r_at < 511) next_rec();
                 }
                 const bool ok = (vm >> i) & 1u;
                 Key2 k;
