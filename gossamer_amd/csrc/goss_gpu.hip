@@ -150,12 +150,13 @@ struct goss_gpu_ctx {
     bool fused_msd = true;              // GOSS_GPU_NO_MSD=1: never use the two-level (sub-region) form
     uint32_t fused_msd_chunks = 0;      // chunks counted by the two-level form
     bool rem32 = true;                  // GOSS_GPU_NO_REM32=1: never take the 32-bit-remainder form of the second level and the counting
-    int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096: counting table of that form (0 = by the distinct-key estimate)
+    int rem32_slots = 0;                // GOSS_GPU_REM32_SLOTS=2048|4096|8192|16384: counting table of that form (0 = by the distinct-key estimate)
     uint32_t narrow_capg = 656;         // GOSS_GPU_NARROW_CAPG (tests): granules a tile of the narrow form may lay out before it sends its carried granules off short
     bool ds_parts = true;               // GOSS_GPU_DS_PARTS=0: a range builds no DenseSelect blocks of its own (round 4: the assembler builds them all)
     bool narrow = true;                 // GOSS_GPU_NARROW=0: 8-byte keys between the two levels of the 32-bit-remainder form (rounds 3-4)
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
+    bool big_r32 = true;                // GOSS_GPU_R32_BIG=0: no 8 192- / 16 384-slot tables of remainders (a third partition level instead, as before)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
     uint64_t assemble_us = 0;           // host clock of the last goss_gpu_emit_assemble
     uint64_t ds_blocks_ranges = 0, ds_blocks_own = 0;      // DenseSelect blocks of the last assembly: taken from the ranges' records / built here from the bitmap
@@ -1074,12 +1075,15 @@ int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_
     hso.stage_cap = cap;
     HIP_TRY(hipMemcpyAsync(so, &hso, sizeof(SegOut), hipMemcpyHostToDevice, c->stream));
 #define GOSS_LAUNCH_R32(KERNEL, SLOTS, SQ)                                                                               \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<SLOTS, SQ>), unit_grid(nseg), dim3(kTB), 0, c->stream, rems, seg_beg, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<SLOTS, SQ>), unit_grid(nseg), dim3(SLOTS <= 4096 ? kTB : SLOTS / 4096 * kTB), 0, c->stream, rems, seg_beg, \
                        seg_end, so, seg_pos, seg_cnt, stage_keys, stage_counts, rbits, sqbit, split_bits)
-    // (round 5: buckets of four remainders, home bucket only in the fast path; GOSS_GPU_R32_FORM=0: the pair layout)
+    // (round 5: buckets of four remainders, home bucket only in the fast path; GOSS_GPU_R32_FORM=0: the pair layout, whose
+    // largest table has 4 096 slots)
     if (c->r32_form)
     {
         if (slots == 2048) { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 2048, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 2048, false); }
+        else if (slots == 8192) { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 8192, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 8192, false); }
+        else if (slots == 16384) { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 16384, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 16384, false); }
         else { if (squeeze) GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 4096, true); else GOSS_LAUNCH_R32(seg_hash_reduce32b_kernel, 4096, false); }
     }
     else
@@ -1534,10 +1538,15 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         // third level, and nine bits + a third level before ten + a third level.  The first pair whose remainder fits 32
         // bits and whose segments hold the estimated distinct keys in an LDS table (2048 slots at (9, 0) when they
         // do, else 4096 with a quarter to spare).
-        static const uint32_t order[][2] = {{9, 0}, {10, 0}, {9, 1}, {9, 2}, {9, 3}, {9, 4}, {10, 1}, {10, 2}, {10, 3}, {10, 4}};
+        // Reads with errors (round 5): where ten bits and the 4 096-slot table do not do, the tables of 8 192 and 16 384 slots
+        // (512 / 1 024 threads) come BEFORE a third level -- that level is a pass over all keys (~30 ms on C2's 12.6 G), the
+        // larger table the same counting on fewer, longer segments.  Third element: the largest table of the candidate.
+        static const uint32_t order[][3] = {{9, 0, 4096}, {10, 0, 4096}, {10, 0, 8192}, {10, 0, 16384}, {9, 1, 4096}, {9, 2, 4096}, {9, 3, 4096}, {9, 4, 4096},
+                                            {10, 1, 4096}, {10, 2, 4096}, {10, 3, 4096}, {10, 4, 4096}};
         for (const auto& cand : order)
         {
-            const uint32_t b2 = cand[0], b3 = cand[1];
+            const uint32_t b2 = cand[0], b3 = cand[1], table = cand[2];
+            if (table > 4096u && !(c->r32_form && c->big_r32 && !c->rem32_slots)) continue;
             if (b2 < c->rem32_bits_min || b3 < c->rem32_split_min) continue;
             if (keybits < 8 + b2 + 8) continue;
             const uint32_t rb = keybits - 8 - b2;
@@ -1549,7 +1558,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
             // (buckets of four: what is not at home costs a second look, and at a load of 0.37 that is 1.5 % of the keys, at
             // 0.19 a per-mille -- the small table only where it stays that empty)
             else if (per <= (c->r32_small_max ? c->r32_small_max : c->r32_form ? 400u : 2048u / 4 * 3 * 3 / 4) && b3 == 0 && b2 == (uint32_t)kSub32BitsMin) slots = 2048;
-            else if (per <= 4096 / 4 * 3 * 3 / 4) slots = 4096;
+            else if (per <= (uint64_t)table / 4 * 3 * 3 / 4) slots = (int)table;
             if (!slots) continue;
             r32_slots = slots; r32_bits = b2; rbits32 = rb; squeeze = sq; r32_split = b3;
             break;
@@ -1950,10 +1959,11 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         for (;;)
         {
             rc = segment_reduce32(c, rems, spare32, n, &r, seg_beg, seg_end, r32_slots, squeeze, rbits32, sqbit32, nseg32, r32_split);
-            if (rc != 1 || r32_slots == 4096 || c->rem32_slots) break;
-            // the remainders are still in their sub-regions: only the counting is redone, in the larger table
+            const int top_slots = c->r32_form && c->big_r32 ? 16384 : 4096;
+            if (rc != 1 || r32_slots >= top_slots || c->rem32_slots) break;
+            // the remainders are still in their sub-regions: only the counting is redone, in the next larger table
             c->segment_retries++;
-            r32_slots = 4096;
+            r32_slots = r32_slots < 4096 ? 4096 : 2 * r32_slots;
         }
         if (rc != 0)
         {
@@ -3408,12 +3418,13 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
     { const char* e = std::getenv("GOSS_GPU_REM32_BITS"); if (e && std::atoi(e) >= 9 && std::atoi(e) <= 10) c->rem32_bits_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SPLIT"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 4) c->rem32_split_min = (uint32_t)std::atoi(e); }
-    { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096)) c->rem32_slots = std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096 || std::atoi(e) == 8192 || std::atoi(e) == 16384)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_FORM"); if (e) c->r32_form = std::atoi(e) ? 1 : 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW"); if (e) c->narrow = std::atoi(e) != 0; }
     { const char* e = std::getenv("GOSS_GPU_DS_PARTS"); if (e) c->ds_parts = std::atoi(e) != 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW_CAPG"); if (e && std::atoi(e) > 0) c->narrow_capg = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_SMALL_MAX"); if (e) c->r32_small_max = (uint32_t)std::atoi(e); }
+    { const char* e = std::getenv("GOSS_GPU_R32_BIG"); if (e && *e == '0') c->big_r32 = false; }
     { const char* e = std::getenv("GOSS_GPU_NO_BIG_TABLE"); if (e && *e && *e != '0') c->big_table = false; }
     { const char* e = std::getenv("GOSS_GPU_HASH_MERGE_MIN"); if (e && *e) c->hash_merge_min = std::strtoull(e, nullptr, 10); }
     { const char* e = std::getenv("GOSS_GPU_BLK_LOG2"); if (e && *e) c->blk_log2_max = (uint32_t)std::atoi(e); }

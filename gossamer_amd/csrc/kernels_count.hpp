@@ -943,16 +943,21 @@ __device__ __forceinline__ void r32b_pick4(uint32_t (&t)[4], const uint32_t (&of
 #ifndef GOSS_R32B_VEC
 #define GOSS_R32B_VEC 4
 #endif
+// Tables of 8 192 and 16 384 slots (reads with errors: segments of up to 4 600 / 9 200 distinct keys counted without a
+// third partition level, which costs a pass over all keys) run with 512 / 1 024 threads, two / one workgroups per CU:
+// the same 16 waves per CU and the same 16 slots per thread in the ordering as the 4 096-slot table's.
+template <int SLOTS> struct R32bCfg { static constexpr int kThreads = SLOTS <= 4096 ? kTB : SLOTS == 8192 ? 2 * kTB : 4 * kTB;
+                                      static constexpr int kOcc = SLOTS == 2048 ? 5 : SLOTS == 4096 ? 4 : SLOTS == 8192 ? 2 : 1; };
 template <int SLOTS, bool SQ>
-__global__ __launch_bounds__(kTB, SLOTS == 2048 ? 5 : 4) void seg_hash_reduce32b_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
+__global__ __launch_bounds__(R32bCfg<SLOTS>::kThreads, R32bCfg<SLOTS>::kOcc) void seg_hash_reduce32b_kernel(const uint32_t* __restrict__ rems, const uint64_t* __restrict__ seg_off,
                                                                 const uint64_t* __restrict__ seg_end, SegOut* __restrict__ so,
                                                                 uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt,
                                                                 Key1* __restrict__ stage_keys, uint32_t* __restrict__ stage_counts,
                                                                 uint32_t rbits, uint32_t sqbit, uint32_t split_bits)
 {
-    constexpr int NT = kTB;
+    constexpr int NT = R32bCfg<SLOTS>::kThreads;
     constexpr int kLimit = SLOTS / 4 * 3;
-    constexpr int BB = SLOTS == 4096 ? 10 : SLOTS == 2048 ? 9 : -1;       // log2(buckets of four slots)
+    constexpr int BB = SLOTS == 16384 ? 12 : SLOTS == 8192 ? 11 : SLOTS == 4096 ? 10 : SLOTS == 2048 ? 9 : -1;       // log2(buckets of four slots)
     constexpr uint32_t NB = SLOTS / 4;
     constexpr uint32_t kCnt = 4u * SLOTS;                                 // byte offset of the count array
     static_assert(BB > 0, "table size");

@@ -71,8 +71,8 @@ def test_c2_full_size_properties():
 def test_c2_with_one_percent_errors_full_size_properties():
     """C2's reads with 1 % of the bases substituted at random (what sequencers produce: every error makes up to k new
     k-mers, 2.0e9 distinct 25-mers instead of 1.0e8).  The default pipeline then takes forms the clean reads never see --
-    the first level computes gossamer's canonical form itself, ten bits at the second level, a third level inside the
-    segments, 4096-slot tables of 32-bit remainders -- and must give, key for key and count for count, what the 8-byte
+    the first level computes gossamer's canonical form itself, ten bits at the second level, 16384-slot tables of 32-bit
+    remainders (round 5; a third level inside the segments and 4096-slot tables before) -- and must give, key for key and count for count, what the 8-byte
     forms behind a first level of strand representatives give (three partition digits, the canonical re-ordering of
     2e9 pairs): no kernel in common between the counting stages.  Counts add up to the windows, keys increase."""
     import torch
@@ -112,7 +112,7 @@ def test_c2_with_one_percent_errors_full_size_properties():
         ctx.push_device(buf.data_ptr(), buf.numel())
         c = ctx.finish()
         if not env:
-            assert ctx.stat("rem32_chunks") >= 1 and ctx.stat("canon_chunks") >= 1 and ctx.stat("rem32_split") >= 1, \
+            assert ctx.stat("rem32_chunks") >= 1 and ctx.stat("canon_chunks") >= 1 and ctx.stat("rem32_bits") == 10 and ctx.stat("rem32_split") == 0, \
                 {s: ctx.stat(s) for s in ("rem32_chunks", "canon_chunks", "rem32_split", "rem32_bits", "fused_chunks")}
         else:
             assert ctx.stat("rem32_chunks") == 0 and ctx.stat("canon_chunks") == 0

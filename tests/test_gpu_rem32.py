@@ -203,6 +203,50 @@ def test_rem32_wider_second_level_and_third_level(oracle, bits, split):
             assert got == exp, (k, mode, slots)
 
 
+def test_rem32_big_tables_before_a_third_level():
+    """Reads with many distinct k-mers (sequencing errors): where ten bits at the second level and the 4096-slot table do
+    not hold a segment's distinct keys, the tables of 8192 and 16384 slots (512 / 1024 threads a workgroup) are taken
+    before a third partition level (the sizing itself is what tests/test_gpu_fullsize.py's C2 with 1 % errors goes
+    through: 2e9 distinct keys, ten bits, no third level).  Here the kernels: 2.2e8 distinct 25-mers in 2^17 and 2^18
+    segments with either table forced, and the largest tables on small inputs of every shape; same keys and counts as
+    the 8-byte form, no retry."""
+    import torch
+    from gossamer_amd import dist as gd
+    n, L, G = 6_000_000, 150, 230_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    res = []
+    for e, want in (({"GOSS_GPU_NO_REM32": 1}, None), ({"GOSS_GPU_REM32_BITS": 10, "GOSS_GPU_REM32_SLOTS": 8192}, (10, 0)),
+                    ({"GOSS_GPU_REM32_SLOTS": 8192}, (9, 0)), ({"GOSS_GPU_REM32_BITS": 10, "GOSS_GPU_REM32_SLOTS": 16384}, (10, 0))):
+        with env(GOSS_GPU_CANON_L1=0, **e):
+            ctx = g.Context(25, g.MODE_KMER_SET, hbm_budget=24 << 30)
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=55)
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        if want:
+            assert (ctx.stat("rem32_chunks"), ctx.stat("rem32_bits"), ctx.stat("rem32_split"), ctx.stat("segment_retries")) == (1,) + want + (0,), e
+        kp, cp, m = ctx.result_ptrs()
+        res.append((gd.device_view(kp, m, torch.int64, "cuda").clone(), gd.device_view(cp, m, torch.int32, "cuda").clone(), c.windows))
+        ctx.close()
+    for other in res[1:]:
+        assert res[0][2] == other[2]
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+    del buf, res
+    for k, mode in ((25, 0), (21, 0), (24, 1)):
+        reads = g.synth_reads_host(200_000, 150, 1_000_000, seed=900 + k + mode)
+        want = None
+        for e in ({"GOSS_GPU_NO_REM32": 1}, {"GOSS_GPU_REM32_SLOTS": 8192}, {"GOSS_GPU_REM32_SLOTS": 16384}):
+            with env(GOSS_GPU_FUSED_MIN=0, **e):
+                with g.Context(k, mode, hbm_budget=8 << 30) as ctx:
+                    ctx.push_host(reads)
+                    ctx.finish()
+                    got = ctx.emit()
+                    assert ctx.stat("rem32_chunks") == (0 if "GOSS_GPU_NO_REM32" in e else 1), (k, mode, e)
+            want = want or got
+            assert got == want, (k, mode, e)
+
+
 def test_rem32_takes_a_third_level_when_the_tables_overflow():
     """2.2e8 distinct 25-mers with the estimate at a quarter and the small table forced: 420 per 17-bit segment expected,
     1 680 there -- the 2048-slot tables overflow and the chunk is redone with every segment split in two (840 each).  With
