@@ -375,15 +375,18 @@ def launch_ranks(n, argv):
     # (a rank that never ends -- a collective nobody answers -- must not hold the launcher for ever: after
     # GOSS_BENCH_RANK_TIMEOUT seconds, 1 800 by default, the ranks are ended and the launcher fails)
     deadline = time.time() + float(os.environ.get("GOSS_BENCH_RANK_TIMEOUT", "1800"))
+    first_term = None          # when the ranks were first told to end: ten seconds later whoever is left is killed
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
                 codes[r] = p.poll()
         if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+            if first_term is None:
+                first_term = time.time()
             for r, p in enumerate(procs):          # a rank failed: its peers would wait in a collective for ever
                 if codes[r] is None:
                     p.terminate()
-            if time.time() > deadline + 10:
+            if time.time() > first_term + 10:      # (a rank inside a collective does not see SIGTERM)
                 for r, p in enumerate(procs):
                     if codes[r] is None:
                         p.kill()

@@ -3662,7 +3662,12 @@ static void ensure_stage(goss_gpu_ctx* c)
         // (an arena that was given nearly all of the device leaves less than that beside it: smaller buffers then)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t room = free_b > (768ULL << 20) ? (free_b - (512ULL << 20)) / 2 : (64ULL << 20);
+        // (a deferred context -- a member of a group that exchanges records -- also keeps its routed records and its
+        // inbox beside the arena: 0.27 records per staged byte to send and a ninth more to receive, 12 or 20 bytes each --
+        // 3.2 + 3.6 staging buffers' worth for one-word keys, 5.3 + 6 for two-word keys; they are allocated at the first
+        // exchange and must still find room then)
+        const uint64_t units = !c->deferred ? 2u : c->words == 1 ? 9u : 14u;
+        const uint64_t room = free_b > (768ULL << 20) ? (free_b - (512ULL << 20)) / units : (128ULL << 20) / units;
         const uint64_t fits = room > (48ULL << 20) ? (room - (32ULL << 20)) : (1ULL << 20);
         if (c->stage_cap > fits) c->stage_cap = std::max<uint64_t>(fits, 1u << 20) & ~4095ULL;
     }

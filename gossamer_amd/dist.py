@@ -365,8 +365,10 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
     last_recs = None
     # (fault injection for the tests: this rank dies while piece GOSS_DIST_FAIL_PIECE is on its way -- its peers then
     # wait in a collective for ever, and whoever started the ranks must end the job: bench.py's launcher does)
-    fail_rank = int(os.environ.get("GOSS_DIST_FAIL_RANK", "-1"))
-    fail_piece = int(os.environ.get("GOSS_DIST_FAIL_PIECE", "0"))
+    # (only with GOSS_DIST_TEST_HOOKS=1 in the environment: a production run never looks at the two variables)
+    hooks = os.environ.get("GOSS_DIST_TEST_HOOKS") == "1"
+    fail_rank = int(os.environ.get("GOSS_DIST_FAIL_RANK", "-1")) if hooks else -1
+    fail_piece = int(os.environ.get("GOSS_DIST_FAIL_PIECE", "0")) if hooks else 0
     for i in range(pieces):
         if rank == fail_rank and i == min(fail_piece, pieces - 1):
             os._exit(7)

@@ -415,6 +415,9 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* contexts, uint32_t n, uint64_t esti
  *
  * goss_gpu_set_deferred(ctx, 1): host pushes of that context only stage their bases; a push that does not fit the
  * staging buffer returns GOSS_ERR_BUFFER (nothing of it was taken) instead of counting the buffer.
+ * Call it BEFORE the context's first push or goss_gpu_stage_room: the staging buffers are sized when they are first
+ * needed, and those of a deferred context leave room beside the arena for the records it will route and receive (0.27
+ * records per staged byte each way: 7 staging buffers' worth for one-word keys, 11 for two-word keys).
  * goss_gpu_stage_room: bytes the staging buffer still takes (a push of n bytes needs n + 1) and its capacity.
  * finish / emit / a device push on a deferred context count what is staged locally, as ever: the result of the
  * group is the same (goss_gpu_group_exchange merges equal keys), only the balance is lost.

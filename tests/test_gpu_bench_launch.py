@@ -60,7 +60,7 @@ def test_a_rank_that_dies_mid_exchange_ends_the_job():
     """Two ranks (fresh child processes of bench.py's launcher) exchange records in pieces; rank 1 dies while a piece is
     on its way (GOSS_DIST_FAIL_RANK: dist.py exits the process there).  Rank 0 then waits in a collective that will never
     complete: the launcher must notice the dead rank, end the other one and exit non-zero -- not hang."""
-    env = dict(os.environ, GOSS_DIST_FAIL_RANK="1", GOSS_DIST_FAIL_PIECE="1", GOSS_DIST_META_GROUP="1")
+    env = dict(os.environ, GOSS_DIST_TEST_HOOKS="1", GOSS_DIST_FAIL_RANK="1", GOSS_DIST_FAIL_PIECE="1", GOSS_DIST_META_GROUP="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange", "records",
                         "--reads", "2000000", "--genome", "3000000", "--steps", "1", "--warmup", "0", "--no-extra", "--e2e-reads", "0",
                         "--no-cpu-baseline", "--hbm-budget-gb", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
