@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <sstream>
 
 #include "../../include/goss_gpu.h"
@@ -641,6 +642,99 @@ void GossCmdRestoreGraph::operator()(const GossCmdContext& pCxt)
     }
 }
 
+// ---- `lint-graph --dump-properties`: Graph::stat().print(out, 1) (GossCmdLintGraph.cc:120-133) ----
+// The reference's containers describe themselves as a PropertyTree (Properties.hh:31-104: properties first, then the
+// sub-trees, both in the order of std::map<std::string,...>, one space of indentation per level, "name<TAB>value").
+// Everything in it comes from the headers and the sizes of the object's files:
+//   Graph::stat (Graph.hh:588-603), SparseArray::stat (SparseArray.cc:142-162), DenseSelect::stat
+//   (DenseArray.cc:94-132), WordyBitVector::stat (WordyBitVector.hh:265-270), IntegerArrayBasic / Stacked::stat
+//   (IntegerArray.cc:111-116, 182-187), VariableByteArray::stat (VariableByteArray.hh:249-266).
+// One figure cannot be restated: for low-bits widths of 56, 88, 104, 112 and 120 bits the reference's "storage" adds
+// sizeof() of a C++ ARRAY OBJECT (StackedArray<...> as the lower type, IntegerArray.cc:374-382) per element instead of
+// its bytes; here the bytes of the column files are counted for every width.
+struct PropTree {
+    std::map<std::string, std::string> props;
+    std::map<std::string, PropTree> kids;
+    void put(const std::string& k, uint64_t v) { props[k] = num(v); }
+    uint64_t get(const std::string& k) const { auto i = props.find(k); return i == props.end() ? 0 : std::strtoull(i->second.c_str(), nullptr, 10); }
+    void print(std::vector<std::string>& out, size_t ind) const
+    {
+        for (auto& kv : props) out.push_back(std::string(ind, ' ') + kv.first + "\t" + kv.second);
+        for (auto& kv : kids) { out.push_back(std::string(ind, ' ') + kv.first); kv.second.print(out, ind + 1); }
+    }
+};
+
+std::string decimal128(uint64_t lo, uint64_t hi)          // BigIntegerBase::writeDecimal (BigInteger.cc:41-110)
+{
+    unsigned __int128 v = ((unsigned __int128)hi << 64) | lo;
+    if (v == 0) return "0";
+    std::string r;
+    while (v) { r.push_back((char)('0' + (int)(v % 10))); v /= 10; }
+    std::reverse(r.begin(), r.end());
+    return r;
+}
+
+uint64_t fileBytes(const std::string& name)
+{
+    struct stat st;
+    if (::stat(name.c_str(), &st) != 0) throw Error::Errno(name, errno);
+    return (uint64_t)st.st_size;
+}
+
+PropTree denseSelectStat(const std::string& name)
+{
+    Mapped f; f.open(name);
+    if (f.n < 128) throw Error::General("\tfile '" + name + "' is too short to be a DenseSelect index\n");
+    uint64_t h[16]; memcpy(h, f.p, 128);
+    PropTree t;
+    t.put("storage", 128 + (uint64_t)f.n);
+    t.put("invertSense", h[1] & 1);
+    PropTree index, small, inter, large;
+    index.put("entries", h[8]); index.put("size", h[9]);
+    small.put("entries", h[10]); small.put("size", h[11]);
+    inter.put("entries", h[12]); inter.put("size", h[13]);
+    large.put("entries", h[14]); large.put("size", h[15]);
+    t.kids["index"] = index; t.kids["smallBlocks"] = small; t.kids["intermediateBlocks"] = inter; t.kids["largeBlocks"] = large;
+    return t;
+}
+
+PropTree sparseStat(const std::string& base)
+{
+    Mapped hdr; hdr.open(base + ".header");
+    if (hdr.n < 64) throw Error::General("\tfile '" + base + ".header' is too short to be a SparseArray header\n");
+    uint64_t h[8]; memcpy(h, hdr.p, 64);
+    PropTree t, hb, lb;
+    hb.put("storage", fileBytes(base + ".high-bits") / 8 * 8);
+    std::vector<Col> cols;
+    if (!layout((uint32_t)h[2], "", 0, cols)) throw Error::General("IntegerArray::create: unsupported integer width " + num(h[2]));
+    uint64_t low = 0;
+    for (auto& c : cols) low += fileBytes(base + ".low-bits" + c.suffix) / c.bytes * c.bytes;
+    lb.put("storage", low);
+    t.kids["high-bits"] = hb; t.kids["low-bits"] = lb;
+    t.kids["D0"] = denseSelectStat(base + "-d0");
+    t.kids["D1"] = denseSelectStat(base + "-d1");
+    t.props["size"] = decimal128(h[5], h[6]);
+    t.put("count", h[7]);
+    t.put("storage", 64 + hb.get("storage") + lb.get("storage") + t.kids["D0"].get("storage") + t.kids["D1"].get("storage"));
+    return t;
+}
+
+PropTree graphStat(const std::string& name, uint64_t K)
+{
+    PropTree t, counts;
+    t.kids["edges"] = sparseStat(name + "-edges");
+    counts.kids["ord1-pred"] = sparseStat(name + "-counts.ord1p");
+    counts.kids["ord2-pred"] = sparseStat(name + "-counts.ord2p");
+    const uint64_t o0 = fileBytes(name + "-counts.ord0"), o1 = fileBytes(name + "-counts.ord1"), o2 = fileBytes(name + "-counts.ord2") / 2;
+    counts.put("size", o0);
+    counts.put("storage", o0 + counts.kids["ord1-pred"].get("storage") + o1 + counts.kids["ord2-pred"].get("storage") + 2 * o2);
+    t.kids["counts"] = counts;
+    t.put("count", t.kids["edges"].get("count"));
+    t.put("K", K);
+    t.put("storage", 24 + t.kids["edges"].get("storage") + counts.get("storage"));
+    return t;
+}
+
 // GossCmdLintGraph::operator() (GossCmdLintGraph.cc:110-275).  Pass 1 runs on the device over the
 // decoded edge list; pass 2 (iterator against select / rank) becomes the strict-ordering check of
 // the same list.  At most 32 offending edges are printed, in edge order.
@@ -653,10 +747,12 @@ void GossCmdLintGraph::operator()(const GossCmdContext& pCxt)
     g.check(goss_gpu_result(g.h, nullptr, nullptr, &m), "counting");
     if (mDumpProperties)
     {
+        // (the reference prints the tree into a string and logs it line by line until eof: one empty line at the end)
+        std::vector<std::string> lines;
+        graphStat(mIn, o.K).print(lines, 1);
         log(info, "Graph properties:");
-        log(info, " K " + num(o.K));
-        log(info, " count " + num(m));
-        log(info, " asymmetric " + num(o.asymmetric ? 1 : 0));
+        for (auto& l : lines) log(info, l);
+        log(info, "");
     }
     log(info, "Pass 1: Checking counts are sane.");
     goss_gpu_lint_report rep;

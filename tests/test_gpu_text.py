@@ -19,6 +19,49 @@ def disk(tmp_path, base):
     return {n: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith(base + ".") or n.startswith(base + "-")}
 
 
+def property_lines(files, base, k):
+    """Graph::stat().print(out, 1) of the reference (Graph.hh:588-603, SparseArray.cc:142-162, DenseArray.cc:94-132,
+    WordyBitVector.hh:265-270, IntegerArray.cc:111-116 / 182-187, VariableByteArray.hh:249-266, Properties.hh:72-85) from
+    the object's files: properties, then sub-trees, both in map order; one space per level."""
+    import struct
+
+    def u64s(b, n):
+        return struct.unpack("<%dQ" % n, b[:8 * n])
+
+    def dense(name):
+        f = files[name]
+        h = u64s(f, 16)
+        return {"storage": 128 + len(f), "invertSense": h[1] & 1,
+                "index": {"entries": h[8], "size": h[9]}, "smallBlocks": {"entries": h[10], "size": h[11]},
+                "intermediateBlocks": {"entries": h[12], "size": h[13]}, "largeBlocks": {"entries": h[14], "size": h[15]}}
+
+    def sparse(b):
+        h = u64s(files[b + ".header"], 8)
+        hb = len(files[b + ".high-bits"]) // 8 * 8
+        lb = sum(len(v) for n, v in files.items() if n.startswith(b + ".low-bits"))
+        t = {"high-bits": {"storage": hb}, "low-bits": {"storage": lb}, "D0": dense(b + "-d0"), "D1": dense(b + "-d1"),
+             "size": h[5] | (h[6] << 64), "count": h[7]}
+        t["storage"] = 64 + hb + lb + t["D0"]["storage"] + t["D1"]["storage"]
+        return t
+
+    o0, o1, o2 = (len(files[base + "-counts.ord%d" % i]) for i in range(3))
+    counts = {"ord1-pred": sparse(base + "-counts.ord1p"), "ord2-pred": sparse(base + "-counts.ord2p"), "size": o0}
+    counts["storage"] = o0 + counts["ord1-pred"]["storage"] + o1 + counts["ord2-pred"]["storage"] + o2
+    g = {"edges": sparse(base + "-edges"), "counts": counts, "K": k}
+    g["count"] = g["edges"]["count"]
+    g["storage"] = 24 + g["edges"]["storage"] + counts["storage"]
+    out = []
+
+    def emit(t, ind):
+        for key in sorted(x for x in t if not isinstance(t[x], dict)):
+            out.append(" " * ind + key + "\t" + str(t[key]))
+        for key in sorted(x for x in t if isinstance(t[x], dict)):
+            out.append(" " * ind + key)
+            emit(t[key], ind + 1)
+    emit(g, 1)
+    return out
+
+
 def test_dump_restore_lint(oracle, tmp_path):
     rng = random.Random(47)
     genome = "".join(rng.choice("ACGT") for _ in range(20000))
@@ -64,6 +107,15 @@ def test_dump_restore_lint(oracle, tmp_path):
         err = p.stderr.decode()
         assert "Pass 1: Checking counts are sane." in err and "Pass 2: Checking traversal is sane." in err
         assert "warning" not in err
+        # --dump-properties: the reference's PropertyTree of the graph, line for line (one empty line behind it)
+        p = run(["lint-graph", "-G", str(tmp_path / gr), "--dump-properties", "-v"])
+        assert p.returncode == 0, p.stderr.decode()
+        msgs = [ln.split("\tinfo\t", 1)[1] if "\tinfo\t" in ln else None for ln in p.stderr.decode().split("\n")]
+        at = msgs.index("Graph properties:")
+        want = property_lines(disk(tmp_path, gr), gr, k)
+        got = [m if m is not None else "" for m in msgs[at + 1:at + 2 + len(want)]]
+        assert got == want + [""], "\n".join(got)
+        assert msgs[at + 2 + len(want)] == "Pass 1: Checking counts are sane."
         # damage the select index of a copy (the second block of -edges-d1 starts one position late):
         # pass 2 evaluates the object's own select / rank on the device and must notice
         import shutil
