@@ -593,10 +593,14 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     metas = torch.stack(metas).cpu().tolist()
-    # high parts -> rank 0 (an all-to-all in which only rank 0 receives)
-    recv = [int(r[0]) for r in metas] if rank == 0 else [0] * world
-    send = [size] + [0] * (world - 1)
-    allhigh = torch.empty(max(1, sum(recv)), dtype=torch.uint8, device=xdev)
+    # span + small records -> rank 0: ONE all-to-all in which only rank 0 receives (every rank's bytes = its span, its
+    # counts above 255 and its histogram, back to back; rank 0 knows the three sizes of every rank from `metas`)
+    rec = torch.frombuffer(bytearray(small + hist), dtype=torch.uint8).to(xdev) if small or hist else torch.empty(0, dtype=torch.uint8, device=xdev)
+    both = torch.cat([mine, rec]) if rec.numel() else mine
+    per = [int(r[0] + r[1] + r[2]) for r in metas]
+    recv = per if rank == 0 else [0] * world
+    send = [int(both.numel())] + [0] * (world - 1)
+    allb = torch.empty(max(1, sum(recv)), dtype=torch.uint8, device=xdev)
 
     def cut(t, sizes):
         out, at = [], 0
@@ -604,24 +608,22 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
             out.append(t[at:at + n])
             at += n
         return out
-    all_to_all_views(cut(allhigh, recv), cut(mine, send), max(int(r[0]) for r in metas), group)
-    # the small records: padded to the longest, gathered through the same kind of collective
-    rec = torch.frombuffer(bytearray(small + hist), dtype=torch.uint8).to(xdev) if small or hist else torch.empty(0, dtype=torch.uint8, device=xdev)
-    recv2 = [int(r[1] + r[2]) for r in metas] if rank == 0 else [0] * world
-    send2 = [int(rec.numel())] + [0] * (world - 1)
-    allrec = torch.empty(max(1, sum(recv2)), dtype=torch.uint8, device=xdev)
-    all_to_all_views(cut(allrec, recv2), cut(rec, send2), max(int(r[1] + r[2]) for r in metas), group)
+    all_to_all_views(cut(allb, recv), cut(both, send), max(per), group)
     _sync(device)
     if rank == 0:
-        big, hst = b"", b""
-        raw = bytes(allrec[:sum(recv2)].cpu().numpy().tobytes())
-        at = 0
+        spans, big, hst, at = [], b"", b"", 0
         for r in metas:
-            big += raw[at:at + int(r[1])]
-            hst += raw[at + int(r[1]):at + int(r[1]) + int(r[2])]
-            at += int(r[1]) + int(r[2])
+            n0, n1, n2 = int(r[0]), int(r[1]), int(r[2])
+            spans.append(allb[at:at + n0])
+            if n1 or n2:
+                raw = bytes(allb[at + n0:at + n0 + n1 + n2].cpu().numpy().tobytes())
+                big += raw[:n1]
+                hst += raw[n1:]
+            at += n0 + n1 + n2
+        # (the spans side by side, as the assembler takes them; with one rank, or no records between them, they already are)
+        allhigh = spans[0] if world == 1 else torch.cat(spans)
         hp = allhigh.to(device) if allhigh.device.type != "cuda" else allhigh
-        ctx.emit_assemble(hp.data_ptr(), sum(recv), total, estimate, big, hst)
+        ctx.emit_assemble(hp.data_ptr(), sum(int(r[0]) for r in metas), total, estimate, big, hst)
         del hp
     return {name: (size, ptr) for name, size, ptr in ctx.file_list()}
 
