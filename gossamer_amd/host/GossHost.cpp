@@ -734,8 +734,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // bounds the memory in flight and keeps the pages warm / pinned for the copy to the device
     // (the bases are at most half of a FASTQ chunk's bytes: as many quality values as bases, plus
     // titles and separators).  Page-locking memory costs ~0.3 s/GB, so the pool is filled by a thread
-    // of its own, one buffer after the other, while the workers already parse: a short file never
-    // pays for buffers it does not use and a long one does not wait for them up front.
+    // of its own while the workers already parse: one buffer after the other (one-step allocators: a
+    // short file never pays for buffers it does not use), or as ONE slab of plain pages that is handed
+    // out at once and page-locked in place when the device runtime is up (two-step allocators).
     const size_t bufCap = chunkBytes / 2 + (1u << 16);
     // (packed pushes: codes and flags behind the bytes -- 6 bytes per 16 positions)
     // Packed pushes: a pool buffer holds only what travels -- codes, then flags: 6 bytes per 16 positions -- and the
@@ -1155,7 +1156,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     };
     std::vector<std::unique_ptr<Feeder>> feeders;
     std::atomic<bool> feedFailed{false};
-    const bool fed = P > 1;           // (one device: the consumer pushes itself -- a feeder thread was measured and gave nothing, the pushes are the bound)
+    const bool fed = P > 1;           // (one device: no feeders -- the parallel parser's packed chunks go through a pusher thread of their own, see below)
     if (fed)
         for (size_t d = 0; d < P; ++d)
         {
