@@ -126,7 +126,11 @@ struct goss_gpu_ctx {
     uint32_t rep_chunks = 0;            // chunks counted in strand-representative space and mapped to canonical order afterwards
     bool ef_by_words = false;           // GOSS_GPU_EF_BY_WORDS=1: the high-bits bitmap by a binary search per word (round 1's kernel)
     bool graph_rep = true;              // GOSS_GPU_NO_GRAPH_REP=1: the fused path of a graph build counts both strands of every window (round 3's form)
-    int canon_l1 = 1;                   // GOSS_GPU_CANON_L1=0|1|2: the fused first level computes gossamer's canonical form itself never / from 10 % distinct keys on / always
+    int canon_l1 = 1;                   // GOSS_GPU_CANON_L1=0|1|2: the fused first level computes gossamer's canonical form itself never / from canon_l1_at distinct keys per window on / always
+    // (0.05: re-ordering M distinct pairs into the canonical order costs 53 ms per 10^9 of them, two FNV hashes per window
+    // 34 ms per 12.6 G windows -- even at M = 0.051 x windows, and the counting of canonical keys is the faster above that
+    // (C2 with 0.3 % / 0.5 % errors: 160 -> 148 / 216 -> 170 ms); 0.10 until the end of round 5)
+    double canon_l1_at = 0.05;          // GOSS_GPU_CANON_L1_AT=<fraction>
     uint32_t canon_chunks = 0;          // chunks counted that way
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
@@ -1481,9 +1485,9 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // One-word k-mer sets are counted as strand representatives and mapped to gossamer's canonical form afterwards -- a
     // re-ordering of the DISTINCT keys (0.06 ms per million), cheap beside two FNV hashes per WINDOW in the first level
     // (+ ~2.4 ms per 10^9 windows) while distinct keys are few.  Reads with many errors turn that round (2e9 distinct
-    // 25-mers of 12.6e9 windows: 116 ms of re-ordering against ~30 ms of hashing): from 10 % distinct keys on the first
-    // level computes the canonical form itself and the run needs no re-ordering.
-    const bool canon_l1 = rep_kmer && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > 0.10 * (double)n_exp));
+    // 25-mers of 12.6e9 windows: 116 ms of re-ordering against ~30 ms of hashing): from 5 % distinct keys per window on
+    // (canon_l1_at) the first level computes the canonical form itself and the run needs no re-ordering.
+    const bool canon_l1 = rep_kmer && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > c->canon_l1_at * (double)n_exp));
     if (canon_l1)
     {
         // (the regions are sized from the sample: it must be in the key space the first level writes)
@@ -3415,6 +3419,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_EF_BY_WORDS"); if (e && *e && *e != '0') c->ef_by_words = true; }
     { const char* e = std::getenv("GOSS_GPU_NO_GRAPH_REP"); if (e && *e && *e != '0') c->graph_rep = false; }
     { const char* e = std::getenv("GOSS_GPU_CANON_L1"); if (e && *e >= '0' && *e <= '2') c->canon_l1 = *e - '0'; }
+    { const char* e = std::getenv("GOSS_GPU_CANON_L1_AT"); if (e && std::atof(e) > 0) c->canon_l1_at = std::atof(e); }
     { const char* e = std::getenv("GOSS_GPU_NO_REM32"); if (e && *e && *e != '0') c->rem32 = false; }
     { const char* e = std::getenv("GOSS_GPU_REM32_BITS"); if (e && std::atoi(e) >= 9 && std::atoi(e) <= 10) c->rem32_bits_min = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_REM32_SPLIT"); if (e && std::atoi(e) >= 0 && std::atoi(e) <= 4) c->rem32_split_min = (uint32_t)std::atoi(e); }
