@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 #include <zlib.h>
 #if defined(__x86_64__)
@@ -830,6 +831,22 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
 
     // GOSS_PARSE_STATS=1: where the workers' time goes, summed over all of them (ns)
     const bool wstats = std::getenv("GOSS_PARSE_STATS") != nullptr;
+    // How a worker gets at its chunk's bytes.  Reads (pread into a buffer of its own) are the faster way through pages
+    // that have been read before: 55-63 GB/s for the 32 workers against 40 through page faults on the mapping.  A tmpfs
+    // file that was JUST WRITTEN is another matter: the kernel's read path hands out its new pages at 13-15 GB/s
+    // whatever the number of readers (43 s of system time for 31.5 GB), page faults on the mapping at 34-40 GB/s
+    // (profiles/r05/cold_threads.txt, cold_mmap.txt: first pass 2.8 s against 0.8-0.9).  So the chunks are read, every
+    // worker says how fast its reads went (not its first), and as soon as three of four of sixteen reads in a row ran
+    // below 1.5 GB/s on a tmpfs file the rest of the file is framed where it is mapped.  (Files on disks stay with reads: page faults there mean
+    // many small requests.)  GOSS_PARSE_MMAP=1 / 0: the mapping / reads whatever the file.
+    std::atomic<int> readMode{0};            // 0: reads, undecided; 1: the mapping; 2: reads, decided
+    std::atomic<uint32_t> slowReads{0}, timedReads{0}, slowSeen{0};
+    {
+        struct statfs sfs;
+        const bool tmpfs = fstatfs(rfd, &sfs) == 0 && (unsigned long)sfs.f_type == 0x01021994UL;          // TMPFS_MAGIC
+        if (!tmpfs) readMode.store(2);
+        if (const char* e = std::getenv("GOSS_PARSE_MMAP")) readMode.store(*e == '1' ? 1 : 2);
+    }
     std::atomic<uint64_t> wBufNs{0}, wReadNs{0}, wParseNs{0}, wPackNs{0};
     auto wnow = [] { return std::chrono::steady_clock::now(); };
     auto wadd = [&](std::atomic<uint64_t>& a, std::chrono::steady_clock::time_point t) {
@@ -839,6 +856,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         std::vector<char> raw;                  // the chunk's bytes as read from the file
         std::vector<char> bytes;                // (packed pushes) the chunk's bases before they are packed
         if (pushPacked) bytes.resize(bufCap);
+        bool firstRead = true;
         for (;;)
         {
             ChunkResult r;
@@ -865,21 +883,46 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             for (size_t slack = parseSlackBytes();; slack *= 8)
             {
                 const size_t hi = std::min(size, limit + slack);
-                if (raw.size() < hi - lo) raw.resize(hi - lo);
+
                 size_t got = 0;
                 const auto tRead = wnow();
-                while (got < hi - lo)
+                const int mode = readMode.load(std::memory_order_relaxed);
+                const bool fromMapping = mode == 1;
+                if (fromMapping) got = hi - lo;          // (the chunk is framed where the file is mapped)
+                else
                 {
-                    const ssize_t k = pread(rfd, raw.data() + got, hi - lo - got, (off_t)(lo + got));
-                    if (k < 0) { if (errno == EINTR) continue; break; }
-                    if (k == 0) break;
-                    got += (size_t)k;
+                    if (raw.size() < hi - lo) raw.resize(hi - lo);
+                    while (got < hi - lo)
+                    {
+                        const ssize_t k = pread(rfd, raw.data() + got, hi - lo - got, (off_t)(lo + got));
+                        if (k < 0) { if (errno == EINTR) continue; break; }
+                        if (k == 0) break;
+                        got += (size_t)k;
+                    }
+                    // (a worker's first read also faults in the pages of its buffer: its later ones are timed)
+                    const bool timeIt = mode == 0 && !firstRead && slack == parseSlackBytes() && got >= (1u << 20);
+                    firstRead = false;
+                    if (timeIt)
+                    {
+                        // (every sixteen timed reads: twelve or more below 1.5 GB/s -> the mapping from here on.  The reads
+                        // are watched to the end of the file: pages that were last touched through a mapping read fast
+                        // for a few dozen chunks and then as slowly as new ones)
+                        const double secs = std::chrono::duration<double>(wnow() - tRead).count();
+                        if ((double)got < 1.5e9 * secs) slowReads.fetch_add(1);
+                        const uint32_t n = timedReads.fetch_add(1) + 1;
+                        if (n % 16 == 0)
+                        {
+                            const uint32_t slow = slowReads.exchange(0);
+                            slowSeen.fetch_add(slow);
+                            if (slow >= 12) { int expect = 0; readMode.compare_exchange_strong(expect, 1); }
+                        }
+                    }
                 }
                 wadd(wReadNs, tRead);
                 const auto tParse = wnow();
                 struct ParseDone { decltype(wadd)& add; std::atomic<uint64_t>& a; std::chrono::steady_clock::time_point t;
                                    ~ParseDone() { add(a, t); } } parseDone{wadd, wParseNs, tParse};
-                const char* lp = raw.data();
+                const char* lp = fromMapping ? p + lo : raw.data();
                 r = ChunkResult{};
                 r.buf = mybuf;
                 if (got != hi - lo) { r.start = begin; r.len = bufCap + 1; r.ok = true; break; }      // (a short read: the serial path reports it)
@@ -914,6 +957,13 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                 packBases(bytes.data(), r.len, r.codes, r.bad);
                 wadd(wPackNs, tPack);
             }
+            // (a chunk framed from the mapping: its page-table entries go now, by this worker -- left to the munmap at
+            // the end, one thread takes a quarter of a second for 31.5 GB of them)
+            if (readMode.load(std::memory_order_relaxed) == 1 && limit > begin + 2 * 4096)
+            {
+                const size_t a = (begin + 4095) & ~(size_t)4095, e = limit & ~(size_t)4095;
+                if (e > a) madvise((void*)(p + a), e - a, MADV_DONTNEED);
+            }
             r.done = true;
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -944,6 +994,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
                           ~WorkerReport() { if (on) std::fprintf(stderr, "goss: parser workers (%u), seconds summed over them: waiting for a buffer %.3f, reading the file %.3f, framing %.3f, packing %.3f\n",
                                                                  th, b.load() * 1e-9, r.load() * 1e-9, p.load() * 1e-9, k.load() * 1e-9); } }
         workerReport{stats, threads, wBufNs, wReadNs, wParseNs, wPackNs};
+    struct ModeReport { bool on; std::atomic<int>& m; std::atomic<uint32_t>& slow; std::atomic<uint32_t>& timed;
+                        ~ModeReport() { if (on) std::fprintf(stderr, "goss: parser: chunks %s (%u of %u timed reads below 1.5 GB/s)\n",
+                                                             m.load() == 1 ? "framed where the file is mapped at the end" : "read into the workers' buffers", slow.load(), timed.load()); } }
+        modeReport{stats, readMode, slowSeen, timedReads};
     auto now = [] { return std::chrono::steady_clock::now(); };
     for (size_t i = 0; i < nchunks && !serialRest; ++i)
     {

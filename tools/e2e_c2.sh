@@ -16,7 +16,7 @@ for e in "$@"; do
   [[ -n "$SLEEP" ]] && sleep $SLEEP
   echo "== -T 64, env: [$e]"
   time env $e GOSS_PARSE_STATS=1 ./gossamer_amd/goss build-kmer-set -k 25 -T 64 -i $D/reads.fq -O $D/ks -v 2> $D/log.txt
-  grep -E "staging buffer|consumer|total build|parsed and|arena|contexts ready|merged at|written at|parallel parser|parser workers|beside" $D/log.txt | sed 's/^.*info//'
+  grep -E "staging buffer|consumer|total build|parsed and|arena|contexts ready|merged at|written at|parallel parser|parser workers|beside|parser: chunks" $D/log.txt | sed 's/^.*info//'
 done
 echo "== parser alone"
 for i in 1 2; do time GOSS_PARSE_STATS=1 ./gossamer_amd/goss dump-bases -T 64 -i $D/reads.fq 2> $D/log.txt > /dev/null; grep -E "consumer|parser workers" $D/log.txt; done
