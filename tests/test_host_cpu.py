@@ -229,6 +229,14 @@ def test_parallel_fastq_parser_matches_serial(tmp_path):
                              env=dict(env, GOSS_PARSE_SLACK="7"))
         assert par.returncode == 0, par.stderr
         assert par.stdout == serial.stdout, (name, "slack")
+        # the chunks framed where the file is mapped (what the workers go over to when the reads of a tmpfs file run
+        # slowly: pages nobody has read yet) and by reads only, whatever the file system says
+        for mode in ("1", "0"):
+            for extra in ({}, {"GOSS_PARSE_SLACK": "7"}):
+                par = subprocess.run([GOSS, "dump-bases", "-T", "4", "-i", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                     env=dict(env, GOSS_PARSE_MMAP=mode, **extra))
+                assert par.returncode == 0, par.stderr
+                assert par.stdout == serial.stdout, (name, "mapping" if mode == "1" else "reads", extra)
     # an error deep in the file: same message, same line number
     bad = files["plain.fq"].split("\n")
     bad[4 * 4000 + 2] = "-"             # the '+' line of record 4000
