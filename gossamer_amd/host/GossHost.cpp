@@ -654,7 +654,12 @@ size_t parseChunkBytes()
     return 8u << 20;      // small enough that page-locking the buffer pool (threads + 4 buffers of half this size) takes ~0.1 s
 }
 
-constexpr uint64_t kMaxFramers = 32;      // worker threads of the parallel FASTQ parser, whatever -T says beyond it
+// worker threads of the parallel FASTQ parser, whatever -T says beyond it (GOSS_PARSE_MAX_THREADS overrides: experiments)
+uint64_t maxFramers()
+{
+    static const uint64_t n = [] { const char* e = std::getenv("GOSS_PARSE_MAX_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 ? (uint64_t)v : (uint64_t)32; }();
+    return n;
+}
 
 // Bytes read behind a chunk for the record that crosses its end (GOSS_PARSE_SLACK overrides: the tests make it tiny so
 // that the re-reads with a larger window happen).
@@ -1512,7 +1517,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         // (at most 32 framing threads: measured on the bench's box -- 256 cores shared with other jobs -- the 31.5 GB of
         // C2 take 0.5 s with 32 and 1.2 to 3.5 s with 64, whose system time is four to ten times higher; the pushes'
         // driver calls slow down with them: 1.34 / 1.43 s for the build with -T 32 against 1.64 / 1.94 s with -T 64)
-        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, kMaxFramers), parseChunkBytes(), timedPush, pinned,
+        uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(threads, maxFramers()), parseChunkBytes(), timedPush, pinned,
                                         fed ? &ownedPush : nullptr, usePacked ? &packed : nullptr);
         // (the pusher is idle -- the parser has drained it -- and ends here: the calls that follow are this thread's again)
         { std::lock_guard<std::mutex> lk(pu.m); pu.stop = true; }
@@ -2062,7 +2067,7 @@ int gossMain(int argc, char* argv[])
                         fwrite(out.data(), 1, n, stdout);
                         release();
                     };
-                    uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(T, kMaxFramers), parseChunkBytes(),
+                    uint64_t r = parseFastqParallel(f, (unsigned)std::min<uint64_t>(T, maxFramers()), parseChunkBytes(),
                                                     [&](const char* p, size_t n) { fwrite(p, 1, n, stdout); }, heap, nullptr,
                                                     std::getenv("GOSS_DUMP_PACKED") ? &viaPacked : nullptr);
                     if (r == ~0ULL) r = parseFastq(f, sink);
