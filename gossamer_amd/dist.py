@@ -98,12 +98,22 @@ def sampled_splitters(sorted_keys, parts, group=None, per_rank=1024):
     mine = torch.cat([torch.tensor([n], dtype=torch.int64), sample.reshape(-1)]).to(xdev)
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine, group=group)
+    allc = torch.stack(allv).cpu()          # (one copy for all ranks' samples)
+    if not two:
+        # one-word keys are below 2^62: the signed order of the int64 words is theirs (no trip through python ints:
+        # 8 x 1 024 of them took 5 ms of a step)
+        rows = [allc[r, 1:1 + int(allc[r, 0])] for r in range(world)]
+        vals = torch.cat(rows).sort().values if rows else torch.empty(0, dtype=torch.int64)
+        n_all = int(vals.numel())
+        if not n_all:
+            return torch.zeros(parts - 1, dtype=torch.int64, device=sorted_keys.device)
+        at = torch.tensor([min(n_all - 1, (n_all * p) // parts) for p in range(1, parts)], dtype=torch.int64)
+        return vals.index_select(0, at).to(sorted_keys.device).reshape(parts - 1)
     vals = []
-    for v in allv:
-        v = v.cpu()
+    for r in range(world):
+        v = allc[r]
         c = int(v[0].item())
-        rows = v[1:].reshape(per_rank, width)[:c]
-        vals += _key_ints(rows if two else rows.reshape(-1))
+        vals += _key_ints(v[1:].reshape(per_rank, width)[:c])
     vals.sort()
     if not vals:
         cuts = [0] * (parts - 1)
@@ -503,6 +513,26 @@ def _add_big_counts(ctx, allbig, splitters, words, rank):
             exact -= piece
 
 
+_T = {"on": None, "t": 0.0, "acc": {}}
+
+
+def _tick(name, device=None):
+    """GOSS_DIST_TIMING=1: host wall clock between the named points of a distributed step (the device waited for at each),
+    printed by rank 0 at the end of emit_distributed -- where a step's time outside the kernels goes."""
+    import os
+    import time
+    if _T["on"] is None:
+        _T["on"] = os.environ.get("GOSS_DIST_TIMING") == "1"
+    if not _T["on"]:
+        return
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    now = time.perf_counter()
+    if name is not None:
+        _T["acc"][name] = _T["acc"].get(name, 0.0) + (now - _T["t"]) * 1e3
+    _T["t"] = now
+
+
 def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters="sampled", exchange="counted", record_pieces=0):
     """count -> range-partition -> merge of the received runs: this rank's range of the global result stays in the
     Context.  Returns (this rank's windows, key words, the splitters used).
@@ -512,14 +542,17 @@ def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters=
     same places)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    _tick(None, device)
     ctx.reset()
     if exchange == "records" and key_bits <= 126:
         windows = route_and_exchange_records(ctx, bases_ptr, nbytes, device, group, record_pieces)
+        _tick("route + exchange + pushes", device)
         c = ctx.finish()
     else:
         ctx.push_device(bases_ptr, nbytes)
         c = ctx.finish()
         windows = c.windows
+    _tick("finish (first)", device)
     words = c.key_words
     if (key_bits > 62) != (words == 2):
         raise ValueError("key_bits = %d does not match the context's %d-word keys (2*len: len = k, or k+1 for graphs)" % (key_bits, words))
@@ -528,16 +561,20 @@ def count_range(ctx, bases_ptr, nbytes, key_bits, device, group=None, splitters=
     if xdev.type == "cpu":
         keys, counts = keys.cpu(), counts.cpu()
     counts, allbig = _carry_big_counts(ctx, keys, counts, words, group)
+    _tick("big counts", device)
     if isinstance(splitters, str):
         splitters = sampled_splitters(keys, world, group) if splitters == "sampled" else uniform_splitters(key_bits, world, device=keys.device)
+    _tick("splitters", device)
     rk, rc, recv = exchange_runs(keys, counts, splitters, group)
     _sync(device)          # the library runs on its own stream: finish the collectives first
+    _tick("exchange of the counted ranges", device)
     del keys, counts
     # merge the received runs: they replace the local result
     ctx.reset()
     _push_received(ctx, rk, rc, recv, words)
     _add_big_counts(ctx, allbig, splitters, words, rank)
     ctx.finish()
+    _tick("received runs pushed and merged", device)
     del rk, rc             # the runs were copied into the library's arena
     return windows, words, splitters
 
@@ -570,6 +607,7 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
     rank = dist.get_rank(group)
     # where the ranges below this one end (the high part of their last key): which zeros of the bitmap are this range's,
     # so that it builds its own blocks of "-d0" as well as of "-d1" (goss_gpu_emit_part_ranges) -- P numbers gathered
+    _tick("sizes gathered", device)
     high, nonempty = ctx.emit_last_high(total, estimate)
     mine_h = torch.tensor([high if high < (1 << 63) else high - (1 << 64), 1 if nonempty else 0], dtype=torch.int64, device=_exchange_device(device, group))
     all_h = [torch.empty_like(mine_h) for _ in range(world)]
@@ -579,7 +617,9 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
         h, ne = (int(x) for x in all_h[r].cpu().tolist())
         if ne:
             prev = h & ((1 << 64) - 1)
+    _tick("last high parts gathered", device)
     ctx.emit_part(first_index, total, estimate, prev_last_high=prev)
+    _tick("own part emitted", device)
     files = {name: (size, ptr) for name, size, ptr in ctx.file_list()}
     size, ptr = files[".part.span"]
     xdev = _exchange_device(device, group)
@@ -610,6 +650,7 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
         return out
     all_to_all_views(cut(allb, recv), cut(both, send), max(per), group)
     _sync(device)
+    _tick("spans to rank 0", device)
     if rank == 0:
         spans, big, hst, at = [], b"", b"", 0
         for r in metas:
@@ -625,6 +666,10 @@ def emit_distributed(ctx, device, first_index, total, group=None, estimate=0):
         hp = allhigh.to(device) if allhigh.device.type != "cuda" else allhigh
         ctx.emit_assemble(hp.data_ptr(), sum(int(r[0]) for r in metas), total, estimate, big, hst)
         del hp
+    _tick("assembled", device)
+    if _T["on"] and rank == 0:
+        import sys
+        sys.stderr.write("dist timing (ms, summed over the steps so far): " + ", ".join("%s %.2f" % kv for kv in _T["acc"].items()) + "\n")
     return {name: (size, ptr) for name, size, ptr in ctx.file_list()}
 
 
