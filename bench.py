@@ -466,6 +466,13 @@ def main():
         raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, %d visible (use --backend gloo to share GPUs)" % (world, world, ndev))
     dev_index = local_rank % ndev
     sharing = (world + ndev - 1) // ndev          # ranks per GPU (1 except under gloo on a small box)
+    # (the pool's boxes end a run with more than six processes on one card: refused here, before any rank has opened
+    # the GPU -- counting devices does not -- so that every rank exits and the launcher reports it)
+    max_sharing = int(os.environ.get("GOSS_BENCH_MAX_RANKS_PER_GPU", "4"))
+    if sharing > max_sharing:
+        raise SystemExit("bench.py: %d ranks on %d GPU(s) = %d processes per card, at most %d are allowed (--backend gloo shares "
+                         "GPUs for tests: use --gpus %d or fewer here; GOSS_BENCH_MAX_RANKS_PER_GPU raises the bound)"
+                         % (world, ndev, sharing, max_sharing, max_sharing * ndev))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
@@ -540,6 +547,7 @@ def main():
     tim = ctx.timing().as_dict()
     w_local = windows
     fused = ctx.stat("fused_chunks") > 0
+    narrow = ctx.stat("narrow_chunks") > 0        # ... and reads remainder + digit (5.33 bytes a key) from the first level
     rem32 = ctx.stat("rem32_chunks") > 0          # second level writes / counting reads 4-byte remainders
 
     if world > 1:
@@ -569,9 +577,10 @@ def main():
                 per_unit = L / (L - klen + 1) * 3.0 / 8.0 + kbytes * keys_per_window
                 units = w_local / args.steps / max(1, d["launches"] / args.steps)
             elif rem32:
-                # the 32-bit-remainder form: the second level reads an 8-byte key and writes a 4-byte remainder, the
-                # counting kernel reads the remainder
-                per_unit = 4.0 if name == "reduce" else 12.0
+                # the 32-bit-remainder form: the counting kernel reads a 4-byte remainder; the second level reads what
+                # the first level wrote for it -- remainder + digit, twelve keys to a 64-byte granule = 5.33 bytes, in
+                # the narrow form that has been the default since round 5, an 8-byte key before -- and writes the remainder
+                per_unit = 4.0 if name == "reduce" else ((16.0 / 3.0 if narrow else 8.0) + 4.0)
                 units = d["units"] / launches
             else:
                 per_unit = (1.0 if name == "reduce" else 2.0) * kbytes

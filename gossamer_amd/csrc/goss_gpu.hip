@@ -162,6 +162,7 @@ struct goss_gpu_ctx {
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     bool big_r32 = true;                // GOSS_GPU_R32_BIG=0: no 8 192- / 16 384-slot tables of remainders (a third partition level instead, as before)
     uint32_t rem32_chunks = 0;          // chunks counted in that form
+    uint32_t narrow_chunks = 0;         // ... of them with remainder + digit (5.33 bytes a key) between the two levels
     uint64_t assemble_us = 0;           // host clock of the last goss_gpu_emit_assemble
     uint64_t ds_blocks_ranges = 0, ds_blocks_own = 0;      // DenseSelect blocks of the last assembly: taken from the ranges' records / built here from the bitmap
     uint32_t pk_fused_chunks = 0;       // chunks of a packed string the fused kernels read as they were
@@ -1984,6 +1985,7 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         }
         c->fused_msd_chunks++;
         c->rem32_chunks++;
+        if (narrow) c->narrow_chunks++;
         c->rem32_bits_last = r32_bits;
         c->rem32_split_last = r32_split;
     }
@@ -3095,7 +3097,10 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
         const uint64_t tmark = c->arena.mark();
         // whole blocks of ones [first_index, first_index + m) -- the array's last, partial block is the last range's --
         // and of zeros [prev_high, last_high) (the last range: up to the array's nd + 2 zeros)
-        const bool last_range = first_index + m == total;
+        // (the LAST NON-EMPTY range owns the tails: an empty range behind it -- first_index == total, m == 0 -- would satisfy
+        // first_index + m == total as well and build the same tail blocks a second time; an empty range builds no block,
+        // and when every range is empty the assembler builds them all from the bitmap)
+        const bool last_range = m > 0 && first_index + m == total;
         const uint64_t count1 = total, count0 = nd + 2;
         DsPlan p1, p0;
         const DsSrc<K> src1{keys, m, D, 0, first_index, nullptr, 0}, src0{keys, m, D, 1, first_index, nullptr, 0};
@@ -3105,7 +3110,7 @@ void emit_part(goss_gpu_ctx* c, uint64_t first_index, uint64_t total, uint64_t e
             const uint64_t e = last_range ? (count1 + 8191) >> 13 : (first_index + m) >> 13;
             if (e > b0) p1 = ds_plan<K>(c, src1, count1, b0, e - b0);
         }
-        if (have_prev && c->ds_parts && (m || last_range))
+        if (have_prev && c->ds_parts && m)
         {
             const uint64_t z0 = prev_high, z1 = last_range ? count0 : last_high;
             const uint64_t b0 = (z0 + 8191) >> 13;
@@ -4274,11 +4279,21 @@ int goss_gpu_group_emit(goss_gpu_ctx* const* ctxs, uint32_t n, uint64_t estimate
     }
     // every context's own span and blocks, side by side
     {
+        // (a thread that cannot be started -- std::system_error out of std::thread's constructor -- must neither cross the
+        // C boundary nor leave joinable threads behind: that member's part is then built on the caller's thread, the parts
+        // being independent of one another)
         std::vector<int> status(n, GOSS_OK);
         std::vector<std::thread> pool;
+        pool.reserve(n);
         for (uint32_t i = 0; i < n; ++i)
-            pool.emplace_back([&, i]() { status[i] = goss_gpu_emit_part_ranges(ctxs[i], first[i], total, estimate, prev[i]); });
-        for (auto& t : pool) t.join();
+        {
+            auto work = [&status, ctxs, &first, total, estimate, &prev, i]() {
+                status[i] = goss_gpu_emit_part_ranges(ctxs[i], first[i], total, estimate, prev[i]);
+            };
+            try { pool.emplace_back(work); }
+            catch (const std::system_error&) { work(); }
+        }
+        for (auto& t : pool) if (t.joinable()) t.join();
         for (uint32_t i = 0; i < n; ++i)
             if (status[i] != GOSS_OK) { if (i) c0->last_error = ctxs[i]->last_error; return status[i]; }
     }
@@ -5255,6 +5270,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_overflows") *value = c->fused_overflows;
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
+    else if (n == "narrow_chunks") *value = c->narrow_chunks;
     else if (n == "packed_fused_chunks") *value = c->pk_fused_chunks;
     else if (n == "ds_blocks_from_ranges") *value = c->ds_blocks_ranges;
     else if (n == "assemble_us") *value = c->assemble_us;

@@ -24,6 +24,25 @@ def pytest_sessionstart(session):
                        stderr=subprocess.DEVNULL, timeout=1800, check=False)
 
 
+# Collection order (the driver runs the suite with -x): the parity tests proper first -- C1, the keys / counts / files
+# against the oracle, the full-size properties, the fused and 32-bit-remainder forms -- then everything that runs in the
+# pytest process or starts one `goss`, and the tests that start rank processes or a second python on the GPU LAST: a
+# problem with a launcher must never again keep the parity tests from running.
+_FIRST = ("test_golden", "test_gpu_parity", "test_gpu_c1", "test_gpu_fullsize", "test_gpu_fused", "test_gpu_rem32")
+_LAST = ("test_gpu_fuzz", "test_gpu_multirank", "test_gpu_bench_launch")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _FIRST:
+            return _FIRST.index(mod)
+        if mod in _LAST:
+            return 1000 + _LAST.index(mod)
+        return 100
+    items.sort(key=rank)          # (stable: the order inside a module stays)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

@@ -126,7 +126,9 @@ def _record_group_build(shards, k, mode, rounds=2, transport=0, stage_cap=None):
 
 
 @pytest.mark.parametrize("kind,k,parts", [("kmer", 25, 4), ("graph", 27, 4), ("kmer", 21, 3), ("graph", 30, 2), ("kmer", 31, 8),
-                                          ("kmer", 45, 4), ("graph", 55, 4), ("graph", 31, 3), ("kmer", 63, 2)])
+                                          ("kmer", 45, 4), ("graph", 55, 4), ("graph", 31, 3), ("kmer", 63, 2),
+                                          # BASELINE's eight-way shapes (C3: k = 25; C4's key width over eight members) in one process
+                                          ("kmer", 25, 8), ("graph", 55, 8)])
 def test_group_route_exchange_builds_the_oracles_object(oracle, kind, k, parts):
     """goss_gpu_group_route_exchange (what `goss --devices` with four and more devices drives): the members' reads cut
     into records routed by minimizer, part p counted by member p -- here all on cuda:0, so the parts travel by peer
@@ -138,6 +140,170 @@ def test_group_route_exchange_builds_the_oracles_object(oracle, kind, k, parts):
     got, sizes, windows, stats, _ = _record_group_build(_split_reads(reads, parts), k, g.MODE_GRAPH if kind == "graph" else g.MODE_KMER_SET)
     assert windows == nwin == sum(st["windows"] for st in stats)
     assert all(st["transport"] == 2 and st["records"] > 0 for st in stats), stats          # (one device several times: no communicators)
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
+@pytest.mark.parametrize("k", [25, 45])
+def test_set_algebra_over_eight_members(oracle, k):
+    """BASELINE config C5's eight-way split in ONE process (eight rank processes on one card are more than a box of the
+    pool allows): both read sets go through goss_gpu_group_route_exchange over the same eight members -- a key's member
+    is a function of its minimizer, so member p holds class p of set A and class p of set B and combines them alone
+    (weighted runs + goss_gpu_select_counts, as the single-GPU commands and set_algebra_distributed do) -- then the
+    range exchange of the results and the distributed emission.  Files equal to the oracle's intersect-kmer-sets /
+    subtract-kmer-set (GossCmdIntersectKmerSets.cc:29-128, GossCmdSubtractKmerSet.cc:32-85)."""
+    import torch
+    parts = 8
+    texts = [g.synth_reads_host(6000, 150, 400000, seed=71, first_read=f) for f in (0, 3000)]
+    files, names = {}, []
+    for i, t in enumerate(texts):
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "reads", t)], k, out="s%d" % i)
+        files.update(f)
+        names.append("s%d" % i)
+    words = 2 if 2 * k > 62 else 1
+    classes = []          # classes[set][member] = the member's sorted keys of that set (a tensor on the device)
+    for t in texts:
+        ctxs = [g.Context(k, g.MODE_KMER_SET, hbm_budget=512 << 20) for _ in range(parts)]
+        try:
+            for c in ctxs:
+                c.set_deferred(True)
+            for c, s in zip(ctxs, _split_reads(t, parts)):
+                c.push_host(s)
+            g.group_route_exchange(ctxs)
+            mine = []
+            for c in ctxs:
+                c.finish()
+                kp, _, m = c.result_ptrs()
+                mine.append(gd.key_view(kp, m, words, "cuda").clone())
+            classes.append(mine)
+        finally:
+            for c in ctxs:
+                c.close()
+    assert sum(x.shape[0] for x in classes[0]) == struct.unpack("<QQQ", files["s0.header"])[2]
+    for sel, op in (((0, 1), "intersect"), ((0, 1), "subtract"), ((1, 0), "subtract")):
+        if op == "intersect":
+            exp = oracle.intersect_kmer_sets(files, [names[j] for j in sel], "out")
+            weights, keep = (1, 1), 2
+        else:
+            exp = oracle.subtract_kmer_set(files, names[sel[0]], names[sel[1]], "out")
+            weights, keep = (1, 2), 1
+        exp = _suffix_map(exp, "out")
+        ctxs = [g.Context(k, g.MODE_KMER_SET, hbm_budget=512 << 20) for _ in range(parts)]
+        try:
+            for p, c in enumerate(ctxs):
+                held = []
+                for j, w in zip(sel, weights):
+                    keys = classes[j][p]
+                    if keys.shape[0]:
+                        held.append((keys, torch.full((keys.shape[0],), w, dtype=torch.int32, device="cuda")))
+                torch.cuda.synchronize()
+                for keys, w in held:
+                    c.push_run(keys.data_ptr(), w.data_ptr(), keys.shape[0])
+                c.finish()
+                c.select_counts(keep, keep)
+            sizes = g.group_exchange(ctxs, sample_per_context=256)
+            g.group_emit(ctxs)
+            got = gd.assemble_files([c.files() for c in ctxs])
+        finally:
+            for c in ctxs:
+                c.close()
+        assert sum(sizes) == struct.unpack("<QQQ", exp[".header"])[2] > 0, (sel, op)
+        assert sorted(got) == sorted(exp), (sel, op)
+        for name in exp:
+            assert got[name] == exp[name], (sel, op, name)
+
+
+@pytest.mark.parametrize("kind,k", [("kmer", 25), ("kmer", 45), ("graph", 27)])
+def test_group_emit_with_empty_ranges(oracle, kind, k):
+    """Ranges that are EMPTY when the object is emitted (a set operation whose result has nothing in a range, splitters
+    that leave the ranges behind the last key without one): an empty range builds no DenseSelect block and the tail of
+    "-d0" -- the zeros behind the last key, thousands of them -- belongs to the last NON-empty range alone (round 5
+    let every empty range behind it build that tail again: "a block built twice").  And an object with no key at all
+    over several members: every block comes from the assembler."""
+    reads = g.synth_reads_host(9000, 150, 60000, seed=41)
+    graph = kind == "graph"
+    exp, _ = (oracle.build_graph if graph else oracle.build_kmer_set)([(oracle.LINE, "reads", reads)], k, out="ob")
+    exp = _suffix_map(exp, "ob")
+    mode = g.MODE_GRAPH if graph else g.MODE_KMER_SET
+    for layout in ("full,empty,empty", "empty,full,empty", "empty,empty,full,empty"):
+        ctxs = [g.Context(k, mode, hbm_budget=512 << 20) for _ in layout.split(",")]
+        try:
+            for c, what in zip(ctxs, layout.split(",")):
+                if what == "full":
+                    c.push_host(reads)
+                c.finish()
+            g.group_emit(ctxs)
+            got = gd.assemble_files([c.files() for c in ctxs])
+        finally:
+            for c in ctxs:
+                c.close()
+        assert sorted(got) == sorted(exp), layout
+        for name in exp:
+            assert got[name] == exp[name], (layout, name)
+
+
+def test_group_emit_of_an_empty_object(oracle):
+    """intersect of two disjoint k-mer sets over several members: no member holds a key, total = 0 -- the oracle's
+    empty KmerSet files (every DenseSelect block built by the assembling member; round 5: every member built block 0)."""
+    a = g.synth_reads_host(300, 150, 20000, seed=3)
+    b = g.synth_reads_host(300, 150, 20000, seed=4)
+    files = {}
+    for name, t in (("a", a), ("b", b)):
+        f, _ = oracle.build_kmer_set([(oracle.LINE, "reads", t)], 25, out=name)
+        files.update(f)
+    exp = _suffix_map(oracle.intersect_kmer_sets(files, ["a", "b"], "out"), "out")
+    assert struct.unpack("<QQQ", exp[".header"])[2] == 0
+    for members in (1, 2, 5):
+        ctxs = [g.Context(25, g.MODE_KMER_SET, hbm_budget=256 << 20) for _ in range(members)]
+        try:
+            for c in ctxs:
+                c.finish()
+            g.group_emit(ctxs)
+            got = gd.assemble_files([c.files() for c in ctxs])
+        finally:
+            for c in ctxs:
+                c.close()
+        assert sorted(got) == sorted(exp), members
+        for name in exp:
+            assert got[name] == exp[name], (members, name)
+
+
+def test_group_emit_without_threads_to_be_had(oracle, tmp_path):
+    """goss_gpu_group_emit starts a host thread per member; when none can be started (RLIMIT_NPROC reached: std::thread's
+    constructor throws std::system_error) nothing may cross the C boundary or be left joinable -- the members' parts are
+    built on the caller's thread, same files.  In a child process, the limit lowered after the contexts were made.  (A
+    privileged user is not bound by the limit: the call then simply runs with its threads.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reads = g.synth_reads_host(6000, 150, 50000, seed=43)
+    exp, _ = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ob")
+    exp = _suffix_map(exp, "ob")
+    (tmp_path / "reads.txt").write_bytes(reads)
+    script = """
+import os, resource, sys
+sys.path.insert(0, %r)
+import gossamer_amd as g
+from gossamer_amd import dist as gd
+reads = open(%r, "rb").read()
+lines = reads.split(b"\n")[:-1]
+ctxs = [g.Context(25, g.MODE_KMER_SET, hbm_budget=256 << 20) for _ in range(3)]
+for i, c in enumerate(ctxs):
+    c.push_host(b"".join(l + b"\n" for l in lines[i::3]))
+    c.finish()
+g.group_exchange(ctxs, sample_per_context=256)
+soft, hard = resource.getrlimit(resource.RLIMIT_NPROC)
+resource.setrlimit(resource.RLIMIT_NPROC, (1, hard))
+g.group_emit(ctxs)
+resource.setrlimit(resource.RLIMIT_NPROC, (soft, hard))
+for name, data in gd.assemble_files([c.files() for c in ctxs]).items():
+    open(os.path.join(%r, "out" + name), "wb").write(data)
+""" % (root, str(tmp_path / "reads.txt"), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    got = {n[3:]: (tmp_path / n).read_bytes() for n in os.listdir(tmp_path) if n.startswith("out")}
     assert sorted(got) == sorted(exp)
     for name in exp:
         assert got[name] == exp[name], name

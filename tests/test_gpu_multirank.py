@@ -1,6 +1,6 @@
 """The multi-GPU path with more than one rank and libgossgpu.so doing the work of every rank.
 
-One MI355X is enough: N processes (2 and 4) each create a Context on cuda:0 with a small
+One MI355X is enough: N processes (2 and 4: tests/gpu_procs.py has the bound) each create a Context on cuda:0 with a small
 budget, count their shard of the reads with the HIP kernels, exchange (key,count) runs over a
 gloo group (keys staged through host memory, the code path of gossamer_amd.dist is otherwise
 the one RCCL runs), merge their range on the device, and the object is assembled and emitted.
@@ -17,6 +17,7 @@ import sys
 import pytest
 
 import gossamer_amd as g
+import gpu_procs
 
 pytestmark = pytest.mark.gpu
 
@@ -95,6 +96,7 @@ def _split_reads(text, world):
 
 def _run(world, cases):
     import torch.multiprocessing as mp
+    gpu_procs.check(world)          # (before anything is started: the pool ends a run with more than six holders of the card)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + random.randrange(2000)
@@ -145,10 +147,12 @@ def test_hip_path_with_several_ranks(oracle, world):
     _run(world, _build_cases(oracle, world))
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 4])
 def test_set_algebra_with_several_ranks(oracle, world):
-    """C5 at test scale over 2 and 8 ranks (BASELINE's split): two k-mer sets counted and range-partitioned with common
-    splitters, intersected / subtracted range by range, assembled on rank 0."""
+    """C5 at test scale over 2 and 4 rank processes: two k-mer sets counted and range-partitioned with common
+    splitters, intersected / subtracted range by range, assembled on rank 0.  (BASELINE's eight-way split: the same
+    range logic over eight gloo ranks on the CPU, tests/test_dist_gloo.py, and eight contexts in one process,
+    tests/test_gpu_group.py -- eight rank processes on one card are more than a box of the pool allows.)"""
     texts = [g.synth_reads_host(6000, 150, 400000, seed=71, first_read=f) for f in (0, 3000)]
     cases = []
     for k in (25, 45):

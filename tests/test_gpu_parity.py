@@ -395,6 +395,34 @@ def test_record_exchange_world1(oracle, nccl_world1, k, graph):
         assert got[name] == exp[name], name
 
 
+@pytest.mark.parametrize("k,graph", [(25, False), (27, True), (55, True)])
+def test_one_rank_takes_the_load_of_an_eight_rank_build(oracle, nccl_world1, k, graph):
+    """C3's eight-way cut with one process: GOSS_DIST_ROUTE_PARTS=8 makes the rank cut its reads into records for
+    EIGHT destinations (the routing kernel's eight-part form: minimizer -> part, a buffer per part) and count all
+    eight parts itself -- every window once, whatever part it went to -- then the range exchange and the distributed
+    emission as in a build over ranks.  Files equal to the oracle's build of the reads."""
+    import os
+    import torch
+    from gossamer_amd import dist as gd
+    reads = g.synth_reads_host(20000, 150, 100000, seed=13)
+    exp, nwin = (oracle.build_graph if graph else oracle.build_kmer_set)([(oracle.LINE, "reads", reads)], k, out="ob")
+    exp = _suffix_map(exp, "ob")
+    buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
+    os.environ["GOSS_DIST_ROUTE_PARTS"] = "8"
+    try:
+        with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
+            r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), exchange="records")
+            got = gd.assemble_files([ctx.files()])
+            sizes = gd._ROUTE_SIZES[(buf.data_ptr(), buf.numel(), 8)]
+    finally:
+        os.environ.pop("GOSS_DIST_ROUTE_PARTS", None)
+    assert len(sizes) == 8 and all(n > 0 for n in sizes), sizes          # (eight parts were cut, none of them empty)
+    assert r["windows"] == nwin
+    assert sorted(got) == sorted(exp)
+    for name in exp:
+        assert got[name] == exp[name], name
+
+
 def test_all_to_all_segments_above_one_gib(nccl_world1):
     """RCCL 2.26 drops the second half of an all-to-all segment above 1 GiB without an error (found on this box: one rank
     sending to itself).  gossamer_amd.dist moves every segment in rounds of 512 MiB: 1.5 GiB must arrive whole."""
