@@ -26,7 +26,7 @@ SYMBOLS = [
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
     "goss_gpu_set_deferred", "goss_gpu_stage_room", "goss_gpu_group_route_exchange",
-    "goss_gpu_push_keys_host", "goss_gpu_push_keys_device",
+    "goss_gpu_push_keys_host", "goss_gpu_push_keys_device", "goss_gpu_push_packed_device", "goss_gpu_pack_bases_device",
     "goss_gpu_route_records_device", "goss_gpu_push_records_device",
     "goss_gpu_push_bases_host_async", "goss_gpu_push_packed_host", "goss_gpu_push_packed_host_async", "goss_gpu_flush",
 ]
@@ -281,6 +281,18 @@ class Context:
     def push_device(self, ptr, nbytes):
         _torch_ready()
         self._check(self._L.goss_gpu_push_bases_device(self._h, C.c_void_p(ptr), nbytes))
+
+    def push_packed_device(self, codes_ptr, nonbase_ptr, nbases):
+        """goss_gpu_push_packed_device: packed bases resident in HBM (u32 of codes + u16 of flags per 16 positions)."""
+        _torch_ready()
+        self._L.goss_gpu_push_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_push_packed_device(self._h, C.c_void_p(codes_ptr), C.c_void_p(nonbase_ptr), nbases))
+
+    def pack_bases_device(self, bases_ptr, nbytes, codes_ptr, nonbase_ptr):
+        """goss_gpu_pack_bases_device: bytes in HBM -> the packed form in the caller's arrays (ceil(nbytes / 16) each)."""
+        _torch_ready()
+        self._L.goss_gpu_pack_bases_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        self._check(self._L.goss_gpu_pack_bases_device(self._h, C.c_void_p(bases_ptr), nbytes, C.c_void_p(codes_ptr), C.c_void_p(nonbase_ptr)))
 
     def push_run(self, keys_ptr, counts_ptr, m):
         _torch_ready()

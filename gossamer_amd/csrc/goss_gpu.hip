@@ -3610,6 +3610,42 @@ int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nb
     });
 }
 
+// Packed bases that are already resident in HBM: counted where they lie, like goss_gpu_push_bases_device's bytes -- the
+// context's packed string (ctx.pk) is the caller's two arrays for the length of the call.
+int goss_gpu_push_packed_device(goss_gpu_ctx* c, const uint32_t* d_codes, const uint16_t* d_nonbase, uint64_t nbases)
+{
+    if (!c || (nbases && (!d_codes || !d_nonbase))) return GOSS_ERR_INVALID_ARG;
+    if (((uintptr_t)d_codes & 3u) || ((uintptr_t)d_nonbase & 1u)) { c->last_error = "packed arrays must be aligned to their elements"; return GOSS_ERR_INVALID_ARG; }
+    if (c->finished) { c->last_error = "push after finish"; return GOSS_ERR_STATE; }
+    if (c->broken) { c->last_error = kBrokenMsg; return GOSS_ERR_STATE; }
+    if (c->deferred) { c->last_error = "a deferred context takes host pushes only (its staging buffer is what the group routes)"; return GOSS_ERR_STATE; }
+    return guarded(c, [&]() {
+        flush_staging(c);
+        struct PkOff { goss_gpu_ctx* c; ~PkOff() { c->pk.on = false; } } pkOff{c};
+        c->pk.on = true; c->pk.codes = d_codes; c->pk.bad = d_nonbase;
+        if (c->words == 1) push_device<Key1>(c, (const uint8_t*)kPkFake, nbases);
+        else push_device<Key2>(c, (const uint8_t*)kPkFake, nbases);
+    });
+}
+
+// The byte form of a base string in HBM -> the packed form in the caller's two arrays (ceil(nbytes / 16) elements
+// each), on the context's stream; returns when the arrays are written.
+int goss_gpu_pack_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nbytes, uint32_t* d_codes, uint16_t* d_nonbase)
+{
+    if (!c || (nbytes && (!d_bases || !d_codes || !d_nonbase))) return GOSS_ERR_INVALID_ARG;
+    if (((uintptr_t)d_codes & 3u) || ((uintptr_t)d_nonbase & 1u)) { c->last_error = "packed arrays must be aligned to their elements"; return GOSS_ERR_INVALID_ARG; }
+    return guarded(c, [&]() {
+        if (!nbytes) return;
+        const uintptr_t addr = (uintptr_t)d_bases;
+        const uint32_t mis = (uint32_t)(addr & 15u);
+        const uint64_t groups = (nbytes + 15) / 16;
+        hipLaunchKernelGGL(pack_bases_kernel, dim3(grid_for(groups, kTB)), dim3(kTB), 0, c->stream, (const uint8_t*)(addr - mis), mis, nbytes,
+                           d_codes, d_nonbase, groups);
+        check_launch("a kernel launch was refused");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    });
+}
+
 // Buffers of asynchronous pushes whose copies have completed go back to the caller (from the caller's own
 // thread, inside this call); wait = all of them.
 static void release_pending(goss_gpu_ctx* c, bool wait)
@@ -3811,16 +3847,17 @@ static void push_packed_host(goss_gpu_ctx* c, const uint32_t* codes, const uint1
         HIP_TRY(hipMemcpyAsync(dbad, hb, groups * 2, hipMemcpyHostToDevice, c->copy_stream));
         // positions behind the piece's last in its last group are no bases (the caller's flags need not say so), and the
         // positions of a continued push whose windows were counted with the buffer before are none any more: the two
-        // flag words concerned are sent once more, corrected (from pageable memory: staged by the call itself)
+        // flag words concerned are set once more, corrected -- by a 16-bit memset behind the copies on their stream: the
+        // value travels in the command, no host memory has to outlive the call
         if ((n & 15ULL) && (uint16_t)(hb[groups - 1] | (ones << (n & 15ULL))) != hb[groups - 1])
         {
             const uint16_t w = (uint16_t)(hb[groups - 1] | (ones << (n & 15ULL)));
-            HIP_TRY(hipMemcpyAsync(dbad + (groups - 1), &w, 2, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)(dbad + (groups - 1)), w, 1, c->copy_stream));
         }
         if (kill)
         {
             const uint16_t w = (uint16_t)(hb[0] | ((1u << kill) - 1u) | ((groups == 1 && (n & 15ULL)) ? (ones << (n & 15ULL)) : 0u));
-            HIP_TRY(hipMemcpyAsync(dbad, &w, 2, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)dbad, w, 1, c->copy_stream));
             kill = 0;
         }
         // (the group behind the piece is a group of separators as it stands: a buffer fills from its start, nothing has

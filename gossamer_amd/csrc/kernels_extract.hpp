@@ -109,6 +109,64 @@ __global__ __launch_bounds__(kTB) void unpack_bases_kernel(const uint32_t* __res
     reinterpret_cast<uint4*>(out)[g] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// The byte form of a base string -> the packed form (goss_gpu_pack_bases_device): group g = positions 16 g .. 16 g + 15
+// of the string that starts `mis` bytes into a 16-byte aligned address; one u32 of codes and one u16 of flags per
+// group, positions at or beyond npos flagged.  GossReadBaseString's per-base encoder (GossReadBaseString.hh:133-188) as
+// a kernel of its own: what the fused kernels do with every 16-byte vector they fetch, for a caller that wants the
+// reads resident in 3 bits per base.  1 byte read, 3/8 byte written per position.
+__global__ __launch_bounds__(kTB) void pack_bases_kernel(const uint8_t* __restrict__ aligned, uint32_t mis, uint64_t npos,
+                                                         uint32_t* __restrict__ codes, uint16_t* __restrict__ nonbase, uint64_t ngroups)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint64_t limit = (uint64_t)mis + npos;                 // bytes of the aligned string that exist
+    // the two aligned vectors the group's 16 bytes lie in (one when the string itself is aligned)
+    uint32_t w[8];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+    {
+        const uint64_t byte0 = (g + v) * 16;
+        uint32_t x[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        if (v == 0 || mis)
+        {
+            if (byte0 + 16 <= limit)
+            {
+                const uint4 q = *reinterpret_cast<const uint4*>(aligned + byte0);
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+            }
+            else if (byte0 < limit)
+                for (int j = 0; j < 16; ++j)
+                {
+                    const uint64_t b = byte0 + j;
+                    const uint32_t c = b < limit ? aligned[b] : 0x0Au;
+                    x[j >> 2] = (x[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[4 * v + i] = x[i];
+    }
+    // bytes mis .. mis + 15 of the 32: a byte funnel over neighbouring words (mis = 4 a + b)
+    const uint32_t a = mis >> 2, b = mis & 3u;
+    uint32_t c = 0, bads = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        uint32_t lo = w[i], hi = w[i + 1];
+        if (a == 1) { lo = w[i + 1]; hi = w[i + 2]; }
+        else if (a == 2) { lo = w[i + 2]; hi = w[i + 3]; }
+        else if (a == 3) { lo = w[i + 3]; hi = w[i + 4]; }
+        const uint32_t word = __builtin_amdgcn_alignbyte(hi, lo, b);
+        uint32_t bad;
+        const uint32_t x = base_codes(word, bad);
+        c |= pack_codes(x) << (8 * i);
+        bads |= pack_flags(bad) << (4 * i);
+    }
+    const uint64_t left = npos - g * 16;                         // (>= 1: g < ngroups)
+    if (left < 16) bads = (bads | (0xFFFFu << (uint32_t)left)) & 0xFFFFu;
+    codes[g] = c;
+    nonbase[g] = (uint16_t)bads;
+}
+
 // Strand representative of a k-mer for COUNTING: of {x, rc(x)} the one whose bits, rotated left
 // by len (the central bases first), are smaller.  It is a function of the unordered pair, so both
 // strands of a k-mer count as one key; the rotation makes the choice depend on the central bases,

@@ -294,7 +294,7 @@ def _push_received(ctx, rk, rc, recv, words):
         off += n
 
 
-_ROUTE_SIZES = {}          # (bases_ptr, nbytes, parts) -> records per part of the last routing of that input (the probe below)
+_ROUTE_SIZES = {}          # (bases_ptr, nbytes, parts, k, mode) -> records per part of the last routing of that input (the probe below)
 
 
 def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, pieces=0):
@@ -314,15 +314,21 @@ def route_and_exchange_records(ctx, bases_ptr, nbytes, device, group=None, piece
         # one rank's load of a `probe`-rank build, measured on one GPU (tools/scale_probe.sh): the records are cut as
         # they would be for that many destinations and the rank takes all its own parts -- the number of windows one
         # rank of the real build receives from everybody
-        need = _ROUTE_SIZES.get((bases_ptr, nbytes, probe), [1] * probe)          # (exact after the first call on this input)
-        for attempt in range(2):
+        # (the parts must lie back to back for the ONE push below: sizes that merely suffice -- remembered from another
+        # input at the same address, say -- leave gaps between the parts, so the routing is redone until every part takes
+        # exactly what it was given; the slots a part takes do not depend on the room it finds)
+        memo = (bases_ptr, nbytes, probe, ctx.k, ctx.mode)
+        need = _ROUTE_SIZES.get(memo, [1] * probe)          # (exact after the first call on this input)
+        for attempt in range(3):
             first = [sum(need[:p]) for p in range(probe)]
-            sbuf = torch.empty(sum(need) * RB, dtype=torch.uint8, device=dev)
+            sbuf = torch.empty(max(1, sum(need)) * RB, dtype=torch.uint8, device=dev)
             recs, wins, ok = ctx.route_records(bases_ptr, nbytes, probe, sbuf.data_ptr(), first, need)
-            if ok:
+            if ok and recs == need:
                 break
             need = recs
-        _ROUTE_SIZES[(bases_ptr, nbytes, probe)] = recs
+        else:
+            raise RuntimeError("routing did not settle on the sizes it asked for")
+        _ROUTE_SIZES[memo] = recs
         ctx.push_records(sbuf.data_ptr(), sum(recs), sum(wins))
         return sum(wins)
     # The reads are cut into pieces (window starts [s_i, s_i+1): piece i = bytes [s_i, s_i+1 + len - 1), so no window is

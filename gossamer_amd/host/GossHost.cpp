@@ -692,6 +692,25 @@ std::map<size_t, std::vector<void*>> gKeptBuffers;          // by size
 struct KeptSlab { void* p; bool pinned; };
 std::map<size_t, std::vector<KeptSlab>> gKeptSlabs;         // two-step pools, by size
 
+}  // namespace
+
+// What the parser parked between files (HostAlloc::keep: only the page-locked allocator of the build commands parks
+// anything -- its one-step buffers come from goss_gpu_host_alloc, its two-step slabs are plain pages registered in
+// place) is given back on an orderly exit: registered pages unregistered before they are freed.  `goss` ends with
+// _exit once its files are closed and never gets here; GOSS_FULL_EXIT=1 and runs under a profiler do.
+void releaseKeptBuffers()
+{
+    std::lock_guard<std::mutex> lk(gKeptMutex);
+    for (auto& kv : gKeptSlabs)
+        for (KeptSlab& s : kv.second) { if (s.pinned) goss_gpu_host_unregister(s.p); std::free(s.p); }
+    gKeptSlabs.clear();
+    for (auto& kv : gKeptBuffers)
+        for (void* b : kv.second) goss_gpu_host_free(b);
+    gKeptBuffers.clear();
+}
+
+namespace {
+
 // pushOwned (optional): the consumer keeps the buffer until it calls `release` -- several devices then copy
 // from several buffers at once; without it `push` returns when the bytes are on their way.
 typedef std::function<void(const char*, size_t, std::function<void()>)> OwnedPush;
@@ -1657,6 +1676,19 @@ const OptDef kGpuSpecific[] = {
     {"hbm-budget", "", kU64, "HBM budget in GB for keys and sort workspace (default: 80% of free HBM)"},
 };
 
+// --tmp-dir: the last one given, which must be a directory (the reference fails when it first creates a temporary file
+// there: "PhysicalFileFactory::tmpName"; here the check comes first, with the name in the message)
+std::string tmpDirOption(const std::map<std::string, std::vector<std::string>>& vals)
+{
+    auto it = vals.find("tmp-dir");
+    if (it == vals.end() || it->second.empty()) return std::string();
+    const std::string& d = it->second.back();
+    struct stat st;
+    if (::stat(d.c_str(), &st) != 0) throw Error::Errno(d, errno);
+    if (!S_ISDIR(st.st_mode)) throw Error::General("--tmp-dir: " + d + " is not a directory\n");
+    return d;
+}
+
 struct Parsed {
     std::map<std::string, std::vector<std::string>> vals;
     size_t count(const std::string& k) const { auto i = vals.find(k); return i == vals.end() ? 0 : i->second.size(); }
@@ -1981,6 +2013,7 @@ int gossMain(int argc, char* argv[])
             uint64_t dev = 0, budgetGb = 0;
             if (chk.optionalU64("device", dev)) cxt.device = (int)dev;
             if (chk.optionalU64("hbm-budget", budgetGb)) cxt.hbmBudget = budgetGb << 30;
+            cxt.tmpDir = tmpDirOption(opts.vals);
             try
             {
                 if (cmdName == "merge-kmer-sets") { GossCmdMergeKmerSets cmd(ins, maxMerge, outName); cmd(cxt); }
@@ -2147,6 +2180,9 @@ int gossMain(int argc, char* argv[])
         uint64_t dev = 0, budgetGb = 0;
         if (chk.optionalU64("device", dev)) cxt.device = (int)dev;
         if (chk.optionalU64("hbm-budget", budgetGb)) cxt.hbmBudget = budgetGb << 30;
+        cxt.tmpDir = tmpDirOption(opts.vals);
+        if (!cxt.tmpDir.empty())
+            (*logger)(info, "--tmp-dir " + cxt.tmpDir + ": not needed by this build (the runs of its chunks are held in HBM and merged there; no temporary file is written)");
         if (opts.count("devices"))
         {
             // "0,1,2,3": one context per listed device (an ordinal may appear twice: two contexts share that GPU)

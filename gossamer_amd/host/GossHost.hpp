@@ -118,6 +118,11 @@ struct GossCmdContext {
     std::vector<int> devices = {};  // --devices a,b,..: the build commands count on all of them (one context each)
     uint64_t hbmBudget = 0;         // bytes; 0 = library default (80% of free HBM)
     size_t batchBytes = 256u << 20; // bases handed to the device per push
+    // --tmp-dir (App.cc:233-240, PhysicalFileFactory::tmpName): where temporary files go.  Given: the partial results of a
+    // merge with more inputs than --max-merge are written there as runs and removed by the command (the reference's
+    // temporary objects, GossCmdMerge.tcc:176-208); not given: they stay in host memory.  The build commands need no
+    // temporary file: the runs of their chunks are held in HBM.
+    std::string tmpDir = {};
 };
 
 typedef std::vector<std::string> strings;
@@ -261,5 +266,9 @@ void writeObjectFiles(const std::vector<goss_gpu_ctx*>& hs, const std::string& o
 
 // App::main for the commands of this build (App.cc:176-417).
 int gossMain(int argc, char* argv[]);
+
+// Gives back what the parser parked between files (page-locked buffers; registered slabs are unregistered first): the
+// orderly exit's share of the tear-down (`goss` itself ends with _exit once its files are closed).
+void releaseKeptBuffers();
 
 }  // namespace gosshost

@@ -191,7 +191,26 @@ void pushObject(GpuCtx& g, const std::string& name, bool graph, uint32_t weight 
 
 struct HostRun { std::vector<uint64_t> keys; std::vector<uint32_t> counts; uint64_t m = 0; };
 
-struct Item { std::string name; bool temp = false; HostRun run; uint64_t count = 0; };
+struct Item { std::string name; bool temp = false; HostRun run; uint64_t count = 0; std::string spill; };
+
+// A partial merge as a temporary file under --tmp-dir (the role of the reference's temporary objects, GossCmdMerge.tcc:
+// 176-208 with PhysicalFileFactory::tmpName): `m` keys of `words` 64-bit words, then `m` 32-bit counts.  Written once,
+// mapped once when its group is merged, removed by the command -- also when the command fails in between.
+struct SpillFiles {
+    std::vector<std::string> names;
+    ~SpillFiles() { for (auto& n : names) ::unlink(n.c_str()); }
+};
+std::string writeSpill(const std::string& dir, uint64_t serial, const HostRun& run, size_t words)
+{
+    const std::string name = dir + "/goss-merge-" + std::to_string((long long)::getpid()) + "-" + std::to_string(serial) + ".run";
+    FILE* fp = std::fopen(name.c_str(), "wb");
+    if (!fp) throw Error::Errno(name, errno);
+    const size_t nk = run.m * words;
+    const bool ok = (nk == 0 || std::fwrite(run.keys.data(), 8, nk, fp) == nk) && (run.m == 0 || std::fwrite(run.counts.data(), 4, run.m, fp) == run.m);
+    const int werr = errno;
+    if (std::fclose(fp) != 0 || !ok) { ::unlink(name.c_str()); throw Error::Errno(name, ok ? errno : werr); }
+    return name;
+}
 
 void writeOut(GpuCtx& g, const std::string& out)
 {
@@ -251,7 +270,24 @@ void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_
         g.check(goss_gpu_reset(g.h), "resetting the GPU context");
         for (auto& it : group)
         {
-            if (it.temp) g.check(goss_gpu_push_run_host(g.h, it.run.keys.data(), it.run.counts.data(), it.run.m), "re-reading a partial merge");
+            if (it.temp && !it.spill.empty())
+            {
+                // a partial merge that was written under --tmp-dir: mapped, handed over, unmapped (the file goes when the command ends)
+                if (it.run.m)
+                {
+                    const size_t bytes = (size_t)it.run.m * (words * 8 + 4);
+                    const int fd = ::open(it.spill.c_str(), O_RDONLY);
+                    if (fd < 0) throw Error::Errno(it.spill, errno);
+                    void* mp = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+                    const int merr = errno;
+                    ::close(fd);
+                    if (mp == MAP_FAILED) throw Error::Errno(it.spill, merr);
+                    const int rc = goss_gpu_push_run_host(g.h, (const uint64_t*)mp, (const uint32_t*)((const char*)mp + (size_t)it.run.m * words * 8), it.run.m);
+                    munmap(mp, bytes);
+                    g.check(rc, "re-reading a partial merge");
+                }
+            }
+            else if (it.temp) g.check(goss_gpu_push_run_host(g.h, it.run.keys.data(), it.run.counts.data(), it.run.m), "re-reading a partial merge");
             else pushObject(g, it.name, graph);
         }
         log(info, "starting graph merge");
@@ -261,6 +297,7 @@ void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_
     };
 
     uint64_t serial = 0;
+    SpillFiles spills;
     while (todo.size() > maxMerge)
     {
         std::vector<Item> group; std::vector<ObjectInfo> ginfo;
@@ -277,6 +314,15 @@ void runMerge(const GossCmdContext& cxt, bool graph, const strings& ins, uint64_
         t.run.m = m; t.run.keys.resize(m * words); t.run.counts.resize(m);
         g.check(goss_gpu_result_copy(g.h, 0, m, t.run.keys.data(), t.run.counts.data()), "reading a partial merge");
         t.count = m;
+        if (!cxt.tmpDir.empty())
+        {
+            // --tmp-dir given: the partial result leaves host memory as well
+            t.spill = writeSpill(cxt.tmpDir, serial, t.run, words);
+            spills.names.push_back(t.spill);
+            log(info, "partial merge " + t.name + " written to " + t.spill);
+            std::vector<uint64_t>().swap(t.run.keys);
+            std::vector<uint32_t>().swap(t.run.counts);
+        }
         ObjectInfo ti = ginfo[0]; ti.count = m;
         todo.push_back(std::move(t)); tinfo.push_back(ti);
         log(info, "finishing graph merge");

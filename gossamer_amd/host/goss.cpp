@@ -14,7 +14,10 @@ int main(int argc, char* argv[])
     // results from an exit handler (rocprofv3, a sanitizer), keeps the orderly exit.
     const char* full = std::getenv("GOSS_FULL_EXIT");
     if ((full && *full == '1') || std::getenv("LD_PRELOAD") || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD"))
+    {
+        gosshost::releaseKeptBuffers();
         return rc;
+    }
     std::fflush(nullptr);
     _exit(rc);
 }

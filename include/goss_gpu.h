@@ -137,6 +137,19 @@ int goss_gpu_push_bases_host_async(goss_gpu_ctx* ctx, const char* bases, uint64_
 int goss_gpu_push_packed_host(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases);
 int goss_gpu_push_packed_host_async(goss_gpu_ctx* ctx, const uint32_t* codes, const uint16_t* nonbase, uint64_t nbases,
                                     goss_gpu_release_fn release, void* user);
+/*
+ * Packed bases already resident in HBM on the context's device (not modified; ceil(nbases / 16) elements per array,
+ * positions at or beyond nbases in the last group are ignored): counted where they lie, as goss_gpu_push_bases_device
+ * counts bytes -- the same kernels, fetching 3 bits per base instead of 8 and encoding nothing.  Whatever produced the
+ * arrays must have completed before the call.  288 GB of HBM hold 2.7 x the reads in this form; bench.py reports the
+ * headline workload in both forms.  Same role as goss_gpu_push_bases_device (GossRead::Iterator + the insert loop,
+ * GossRead.hh:57-114, GossCmdBuildKmerSet.tcc:246-256).
+ * goss_gpu_pack_bases_device: the byte form (any byte that is not ACGTacgt a non-base) -> the packed form in the
+ * caller's two arrays, on the context's stream; returns when they are written.  GossReadBaseString's per-base encoder
+ * (GossReadBaseString.hh:133-188) as an entry point of its own.
+ */
+int goss_gpu_push_packed_device(goss_gpu_ctx* ctx, const uint32_t* d_codes, const uint16_t* d_nonbase, uint64_t nbases);
+int goss_gpu_pack_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t* d_codes, uint16_t* d_nonbase);
 /* Wait for every queued copy and hand all buffers of asynchronous pushes back (release is called for each). */
 int goss_gpu_flush(goss_gpu_ctx* ctx);
 

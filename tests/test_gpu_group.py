@@ -288,10 +288,10 @@ sys.path.insert(0, %r)
 import gossamer_amd as g
 from gossamer_amd import dist as gd
 reads = open(%r, "rb").read()
-lines = reads.split(b"\n")[:-1]
+lines = reads.split(b"\\n")[:-1]
 ctxs = [g.Context(25, g.MODE_KMER_SET, hbm_budget=256 << 20) for _ in range(3)]
 for i, c in enumerate(ctxs):
-    c.push_host(b"".join(l + b"\n" for l in lines[i::3]))
+    c.push_host(b"".join(l + b"\\n" for l in lines[i::3]))
     c.finish()
 g.group_exchange(ctxs, sample_per_context=256)
 soft, hard = resource.getrlimit(resource.RLIMIT_NPROC)

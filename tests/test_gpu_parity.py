@@ -413,7 +413,7 @@ def test_one_rank_takes_the_load_of_an_eight_rank_build(oracle, nccl_world1, k, 
         with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=1 << 30) as ctx:
             r = gd.count_distributed(ctx, buf.data_ptr(), buf.numel(), 2 * (k + 1 if graph else k), torch.device("cuda", 0), exchange="records")
             got = gd.assemble_files([ctx.files()])
-            sizes = gd._ROUTE_SIZES[(buf.data_ptr(), buf.numel(), 8)]
+            sizes = gd._ROUTE_SIZES[(buf.data_ptr(), buf.numel(), 8, ctx.k, ctx.mode)]
     finally:
         os.environ.pop("GOSS_DIST_ROUTE_PARTS", None)
     assert len(sizes) == 8 and all(n > 0 for n in sizes), sizes          # (eight parts were cut, none of them empty)
@@ -526,6 +526,17 @@ def test_goss_merge_commands(oracle, tmp_path):
             assert sorted(got) == sorted(exp), (cmd_m, k, mm)
             for name in exp:
                 assert got[name] == exp[name], (cmd_m, k, mm, name)
+            if mm == 2:
+                # --tmp-dir given: the partial merges are written there as runs, read back and removed by the command
+                # (GossCmdMerge.tcc:176-208's temporary objects) -- same files, nothing left behind
+                tdir = tmp_path / ("tmp_" + tag)
+                tdir.mkdir()
+                for n in got:
+                    os.remove(tmp_path / n)
+                p = run(args + ["--tmp-dir", str(tdir)])
+                assert p.returncode == 0, p.stderr.decode()
+                assert p.stderr.decode().count("written to " + str(tdir)) == 2, p.stderr.decode()
+                assert disk(out) == got and os.listdir(tdir) == []
     # a single input is a re-encode with M = its own count
     exp = oracle.merge(files, names[:1], 1, "one")
     p = run(["merge-graphs", "-G", str(tmp_path / names[0]), "-O", str(tmp_path / "one")])

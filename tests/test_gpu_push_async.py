@@ -99,3 +99,65 @@ def test_packed_pushes_are_read_as_they_are_by_the_fused_kernels(oracle, k, mode
     assert c.windows == nwin
     assert st["packed_fused_chunks"] >= 1 and st["packed_unpacked_chunks"] == 0 and st["fused_chunks"] == st["packed_fused_chunks"], st
     assert got == exp
+
+
+@pytest.mark.parametrize("mis", [0, 1, 5, 15])
+def test_pack_bases_device_is_the_host_packer(mis):
+    """goss_gpu_pack_bases_device (the per-base encoder of GossReadBaseString.hh:133-188 as a kernel): codes and flags of
+    a byte string that starts anywhere equal the numpy restatement of the host parser's packer -- lower case, N, line
+    ends and arbitrary bytes flagged, the positions behind the string's end in its last group flagged."""
+    import numpy as np
+    import torch
+    rng = random.Random(17 + mis)
+    for n in (1, 15, 16, 17, 4096 + 3, 100_001):
+        text = bytes(rng.choice(b"ACGTacgtNn\n\r-\x00\xff" if rng.random() < 0.2 else b"ACGT") for _ in range(n))
+        codes, bad = g.pack_bases(text)
+        buf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        buf[mis:mis + n] = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        groups = (n + 15) // 16
+        dc = torch.full((groups + 1,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        db = torch.full((groups + 1,), 0x5A5A, dtype=torch.int16, device="cuda")
+        with g.Context(25, 0, hbm_budget=64 * MB) as ctx:
+            ctx.pack_bases_device(buf.data_ptr() + mis, n, dc.data_ptr(), db.data_ptr())
+        gc = dc.cpu().numpy().view(np.uint32)
+        gb = db.cpu().numpy().view(np.uint16)
+        assert gc[groups] == 0x5A5A5A5A and gb[groups] == 0x5A5A          # (nothing written behind the last group)
+        # (codes of flagged positions are not specified: compared where the position is a base)
+        mask = np.zeros(groups, dtype=np.uint32)
+        for j in range(16):
+            mask |= ((~bad.astype(np.uint32) >> j) & 1) * (3 << (2 * j))
+        assert np.array_equal(gb[:groups], bad), (n, mis)
+        assert np.array_equal(gc[:groups] & mask, codes & mask), (n, mis)
+
+
+@pytest.mark.parametrize("k,mode,nreads", [(25, 0, 4000), (27, 1, 4000), (55, 1, 4000), (25, 0, 300_000), (31, 1, 300_000), (45, 0, 300_000)])
+def test_packed_bases_resident_in_hbm(oracle, k, mode, nreads):
+    """goss_gpu_push_packed_device: packed bases that already lie in HBM -- packed there by goss_gpu_pack_bases_device
+    -- are counted where they lie; files equal to the oracle's build of the bytes.  Small inputs take the plain kernels
+    (the chunk is unpacked for them), 300 000 reads the fused path, whose kernels read the groups as they are; two pushes,
+    the second from arrays that start in the middle of the first's allocation."""
+    import torch
+    reads = g.synth_reads_host(nreads, 150, 5 * nreads, seed=77 + k)
+    exp, nwin = (oracle.build_graph if mode else oracle.build_kmer_set)([(oracle.LINE, "reads", reads)], k, out="o")
+    exp = {n[1:]: d for n, d in exp.items()}
+    lines = reads.split(b"\n")[:-1]
+    cut = len(lines) // 3
+    parts = [b"".join(l + b"\n" for l in lines[:cut]), b"".join(l + b"\n" for l in lines[cut:])]
+    with g.Context(k, mode, hbm_budget=24 << 30) as ctx:
+        held = []
+        for text in parts:
+            buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+            groups = (len(text) + 15) // 16
+            dc = torch.empty(groups, dtype=torch.int32, device="cuda")
+            db = torch.empty(groups, dtype=torch.int16, device="cuda")
+            ctx.pack_bases_device(buf.data_ptr(), len(text), dc.data_ptr(), db.data_ptr())
+            del buf
+            ctx.push_packed_device(dc.data_ptr(), db.data_ptr(), len(text))
+            held.append((dc, db))
+        c = ctx.finish()
+        got = ctx.emit()
+        st = {n: ctx.stat(n) for n in ("packed_fused_chunks", "packed_unpacked_chunks", "fused_chunks")}
+    assert c.windows == nwin
+    if nreads >= 300_000:
+        assert st["packed_fused_chunks"] >= 1 and st["packed_unpacked_chunks"] == 0, st
+    assert got == exp

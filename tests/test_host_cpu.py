@@ -356,3 +356,16 @@ def test_bench_children_have_time_limits():
     assert p is None and "timed out" in err and time.time() - t0 < 10
     p, err = bench.run_bounded(["true"], 5)
     assert err is None and p.returncode == 0
+
+
+def test_tmp_dir_must_be_a_directory(tmp_path):
+    """--tmp-dir (App.cc:233-240): checked before anything else is done -- a name that does not exist or is not a
+    directory ends the command with the name in the message (no GPU is touched before that: runs here)."""
+    (tmp_path / "file").write_text("x")
+    (tmp_path / "r.txt").write_text("ACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    for cmd in (["build-kmer-set", "-k", "25", "--line-in", str(tmp_path / "r.txt"), "-O", str(tmp_path / "o")],
+                ["merge-kmer-sets", "-G", str(tmp_path / "a"), "-G", str(tmp_path / "b"), "-O", str(tmp_path / "o")]):
+        rc, out, err = run_goss(*cmd, "--tmp-dir", str(tmp_path / "file"))
+        assert rc == 1 and "is not a directory" in err and str(tmp_path / "file") in err, err
+        rc, out, err = run_goss(*cmd, "--tmp-dir", str(tmp_path / "nowhere"))
+        assert rc == 1 and str(tmp_path / "nowhere") in err, err
