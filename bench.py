@@ -322,9 +322,11 @@ def c4_record(g, torch, device, local_rank):
         ctx.synth_reads(bases.data_ptr(), n, L, G, seed=1)
         torch.cuda.synchronize(device)
         ms, c = [], None
+        chunks_before = 0
         for it in range(2):
             ctx.reset()
             ctx.timing(reset=True)
+            chunks_before = ctx.stat("fused_chunks")          # (the counter runs on over a reset: the timed build's share is the difference)
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             ctx.push_device(bases.data_ptr(), bases.numel())
@@ -342,7 +344,7 @@ def c4_record(g, torch, device, local_rank):
                             "achieved": b * c.windows / (ms[-1] * 1e-3) / 1e9,
                             "frac": b * c.windows / (ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "device_ms": {nm: v["ms"] for nm, v in tim.items()}},
-               "chunks": ctx.stat("fused_chunks")}
+               "chunks": ctx.stat("fused_chunks") - chunks_before}
         ctx.close()
         return rec
     except Exception as e:          # the headline line must not be lost to the side record
@@ -427,6 +429,7 @@ def main():
                     "process of the default run's cpu_baseline")
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end CLI record: C2's 100 M by default, "
                     "fewer when the scratch file system has no room (0 = skip)")
+    ap.add_argument("--no-packed", action="store_true", help="skip the side record of the same workload with the reads resident in HBM in the packed form")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed-by-the-headline C4 record (build-graph k=55, 200 M reads)")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
@@ -649,6 +652,50 @@ def main():
                             "algorithmic_bytes_per_unit_per_launch": o["per_unit"], "achieved": o["achieved"],
                             "frac": o["achieved"] / HBM_PEAK_GBS}
         out["roofline"]["other_kernels"] = others
+        # Beside the headline, never `value`: the same workload with the reads resident in HBM in the PACKED form (3 bits per
+        # base: what the `goss` parser's threads hand over and SURVEY.md section 8(d)'s read term counts) -- packed on the
+        # device by goss_gpu_pack_bases_device outside the timed region, counted by goss_gpu_push_packed_device: the same
+        # kernels fetching 0.45 instead of 1.2 bytes per window and encoding nothing.
+        if world == 1 and not use_dist and not args.graph and not args.no_packed:
+            try:
+                groups = (nbytes + 15) // 16
+                dcodes = torch.empty(groups, dtype=torch.int32, device=device)
+                dflags = torch.empty(groups, dtype=torch.int16, device=device)
+                ctx.pack_bases_device(bases.data_ptr(), nbytes, dcodes.data_ptr(), dflags.data_ptr())
+
+                def packed_step():
+                    ctx.reset()
+                    ctx.push_packed_device(dcodes.data_ptr(), dflags.data_ptr(), nbytes)
+                    c = ctx.finish()
+                    ctx.emit_device()
+                    return c.windows, c.distinct
+
+                for _ in range(max(1, args.warmup)):
+                    packed_step()
+                ctx.timing(reset=True)
+                barrier()
+                tp = time.perf_counter()
+                pw = pd = 0
+                for _ in range(args.steps):
+                    w, pd = packed_step()
+                    pw += w
+                barrier()
+                pdt = time.perf_counter() - tp
+                ptim = ctx.timing().as_dict()
+                e_ms = ptim["extract"]["ms"] / max(1, ptim["extract"]["launches"])
+                e_bytes = (L / (L - klen + 1) * 3.0 / 8.0 + kbytes) * (pw / args.steps) / max(1.0, ptim["extract"]["launches"] / args.steps)
+                out["packed_input"] = {"value": pw / pdt / 1e6, "unit": out["unit"], "ms_per_step": pdt / args.steps * 1e3,
+                                       "distinct_kmers": pd, "same_result_as_headline": bool(pd == distinct and pw == windows),
+                                       "device_ms_per_step": {n: v["ms"] / args.steps for n, v in ptim.items()},
+                                       "first_level": {"launch_avg_ms": e_ms, "achieved": e_bytes / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0,
+                                                       "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if e_ms > 0 else 0.0},
+                                       "pipeline_frac": b_per_window * pw / pdt / 1e9 / HBM_PEAK_GBS,
+                                       "packed_fused_chunks": ctx.stat("packed_fused_chunks"),
+                                       "note": "reads resident in HBM as 2-bit codes + non-base flags (packed by goss_gpu_pack_bases_device "
+                                               "before the timed region); `value` above is the byte form, which encodes inside the timed region"}
+                del dcodes, dflags
+            except Exception as e:          # the headline line must not be lost to the side record
+                out["packed_input"] = {"failed": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             note("headline done: %.1f ms per step; CPU baseline (child process, <= 420 s)" % (dt / args.steps * 1e3))
             out["cpu_baseline"] = cpu_baseline_child(k, L, genome_len, args.seed, args.cpu_sample_reads)

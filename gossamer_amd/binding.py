@@ -26,7 +26,7 @@ SYMBOLS = [
     "goss_gpu_file_device", "goss_gpu_big_counts", "goss_gpu_push_run_graph",
     "goss_gpu_group_exchange", "goss_gpu_group_emit",
     "goss_gpu_set_deferred", "goss_gpu_stage_room", "goss_gpu_group_route_exchange",
-    "goss_gpu_push_keys_host", "goss_gpu_push_keys_device", "goss_gpu_push_packed_device", "goss_gpu_pack_bases_device",
+    "goss_gpu_push_keys_host", "goss_gpu_push_keys_device", "goss_gpu_push_packed_device", "goss_gpu_pack_bases_device", "goss_gpu_expect_bases",
     "goss_gpu_route_records_device", "goss_gpu_push_records_device",
     "goss_gpu_push_bases_host_async", "goss_gpu_push_packed_host", "goss_gpu_push_packed_host_async", "goss_gpu_flush",
 ]
@@ -281,6 +281,11 @@ class Context:
     def push_device(self, ptr, nbytes):
         _torch_ready()
         self._check(self._L.goss_gpu_push_bases_device(self._h, C.c_void_p(ptr), nbytes))
+
+    def expect_bases(self, total_bases):
+        """goss_gpu_expect_bases: a hint -- how many bases will be pushed in all before finish (0: unknown)."""
+        self._L.goss_gpu_expect_bases.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(self._L.goss_gpu_expect_bases(self._h, total_bases))
 
     def push_packed_device(self, codes_ptr, nonbase_ptr, nbases):
         """goss_gpu_push_packed_device: packed bases resident in HBM (u32 of codes + u16 of flags per 16 positions)."""

@@ -131,6 +131,15 @@ struct goss_gpu_ctx {
     // 34 ms per 12.6 G windows -- even at M = 0.051 x windows, and the counting of canonical keys is the faster above that
     // (C2 with 0.3 % / 0.5 % errors: 160 -> 148 / 216 -> 170 ms); 0.10 until the end of round 5)
     double canon_l1_at = 0.05;          // GOSS_GPU_CANON_L1_AT=<fraction>
+    // more of the same input is known to follow the chunk being counted (a staging buffer that filled up while the caller
+    // keeps pushing; a chunk of a device push that is not its last): its run will be merged with the runs of the others
+    // in representative space and the re-ordering into canonical order paid ONCE, on the merged run -- the chunk's own
+    // share of distinct keys then says little about what that costs (C2 from FASTQ: thirteen chunks of 0.8 G windows
+    // that each see all 10^8 k-mers of the genome, 12 %, took the canonical form per window -- 67 ms of first level
+    // where the representatives take 31, ten second-level bits, and a re-ordering per run)
+    bool more_follows = false;
+    uint64_t expect_bases = 0;          // goss_gpu_expect_bases: bases the caller means to push in all (0: not said)
+    int space_choice = -1;              // the key space the build's fused chunks count in once one has chosen: 0 representatives, 1 canonical forms (-1: none yet)
     uint32_t canon_chunks = 0;          // chunks counted that way
     bool extract_v1 = false;            // GOSS_GPU_EXTRACT_V1=1: per-base LDS extraction kernel for one-word keys
     bool fused = true;                  // GOSS_GPU_NO_FUSED=1: never fuse the first partition pass into the extraction
@@ -909,8 +918,11 @@ inline uint64_t birthday_estimate(uint64_t s, uint64_t d)
 // f2 and f3 (lambda = 3 f3 / f2, G = 2 f2 e^lambda / lambda^2), the singletons it does not explain are
 // population keys of multiplicity ~1 seen with probability p each.  Never less than the plain estimate.
 template <class K>
-uint64_t spectrum_estimate(goss_gpu_ctx* c, const K* keys, uint64_t avail, double population)
+uint64_t spectrum_estimate(goss_gpu_ctx* c, const K* keys, uint64_t avail, double population, uint64_t* rare_out = nullptr)
 {
+    // *rare_out: of the estimate, the keys of multiplicity ~1 in the population (more of the same input brings more
+    // of THEM; the frequent keys it mostly brings again); the whole estimate where the spectrum could not be fitted
+    if (rare_out) *rare_out = avail;
     if (avail < 2) return avail;
     const uint64_t scan = std::min<uint64_t>(avail, 1ULL << 30);
     uint32_t q = 1;
@@ -945,8 +957,8 @@ uint64_t spectrum_estimate(goss_gpu_ctx* c, const K* keys, uint64_t avail, doubl
         const double scale_q = (double)q;
         // plain estimate on the slice (equally frequent keys), scaled to the key space
         const uint64_t plain = scan >= (uint64_t)population ? (uint64_t)(d * scale_q) : (uint64_t)((double)birthday_estimate(sf, (uint64_t)d) * scale_q);
-        double model = 0;
-        if (p >= 1.0) model = d;                                  // the whole population was looked at
+        double model = 0, rare_keys = -1.0;
+        if (p >= 1.0) { model = d; rare_keys = f1; }              // the whole population was looked at
         else if (f2 >= 256.0 && f3 >= 64.0)
         {
             const double lambda = 3.0 * f3 / f2;
@@ -954,10 +966,12 @@ uint64_t spectrum_estimate(goss_gpu_ctx* c, const K* keys, uint64_t avail, doubl
             const double rare = std::max(0.0, f1 - G * lambda * std::exp(-lambda)) / p;
             // (seen but fitted by neither: the keys seen four times and more are part of G already)
             model = G + rare;
+            rare_keys = rare;
         }
         est = std::max<uint64_t>(plain, (uint64_t)(model * scale_q));
         est = std::max<uint64_t>(est, (uint64_t)(d * scale_q));
         if (plain == 0 && model == 0) est = 0;                    // no repeated key at all: unknown
+        if (rare_out) *rare_out = rare_keys < 0 ? est : std::min<uint64_t>(est, (uint64_t)(rare_keys * scale_q));
         if (c->debug)
             std::fprintf(stderr, "libgossgpu: spectrum of 1/%u of the key space over %llu keys (p = %.4f): d %.0f f1 %.0f f2 %.0f f3 %.0f -> plain %llu, fitted %.0f, estimate %llu\n",
                          q, (unsigned long long)scan, p, d, f1, f2, f3, (unsigned long long)plain, model * scale_q, (unsigned long long)est);
@@ -1479,8 +1493,10 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     const bool exact = nslices == 1;                                   // the sample is the chunk
     const double scale = (double)nstarts / (double)(nslices * slice_starts);
     const uint64_t n_exp = (uint64_t)((double)ns * scale);          // expected number of keys
-    uint64_t m_est = spectrum_estimate<K>(c, ka, ns, (double)n_exp);
+    uint64_t m_rare = 0;
+    uint64_t m_est = spectrum_estimate<K>(c, ka, ns, (double)n_exp, &m_rare);
     if (c->est_scale != 1.0) m_est = (uint64_t)((double)m_est * c->est_scale);      // tests: a wrong estimate on purpose
+    m_rare = std::min(m_rare, m_est);
     lap("distinct keys estimated");
     if (m_est == 0 || m_est > n_exp / 3) return decline("too little duplication for the segment path");
     // One-word k-mer sets are counted as strand representatives and mapped to gossamer's canonical form afterwards -- a
@@ -1488,7 +1504,32 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
     // (+ ~2.4 ms per 10^9 windows) while distinct keys are few.  Reads with many errors turn that round (2e9 distinct
     // 25-mers of 12.6e9 windows: 116 ms of re-ordering against ~30 ms of hashing): from 5 % distinct keys per window on
     // (canon_l1_at) the first level computes the canonical form itself and the run needs no re-ordering.
-    const bool canon_l1 = rep_kmer && (c->canon_l1 == 2 || (c->canon_l1 == 1 && (double)m_est > c->canon_l1_at * (double)n_exp));
+    // A chunk that is ONE OF SEVERAL shares the re-ordering with the others -- the runs are merged in representative
+    // space and re-ordered once -- so what counts is the whole build: its windows W (what the caller said it will push,
+    // goss_gpu_expect_bases; else what has been counted plus this chunk, times four when more is known to follow) and
+    // its distinct keys D = the chunk's frequent keys (more of the same input mostly brings THEM again) + its keys of
+    // multiplicity ~1 scaled to W (every chunk brings its own).  C2 from FASTQ: thirteen chunks of 0.8 G windows each
+    // see all 10^8 k-mers of the genome (12 % of their windows) -- per chunk that read "canonical", 67 ms of first
+    // level where representatives take 31, ten second-level bits, a re-ordering per run; of the build's 12.6 G windows
+    // they are 0.8 %.  Once a chunk has chosen, the chunks that follow count in the same space while its run waits:
+    // a run in canonical space among runs of representatives sends every one of those through a re-ordering of its own.
+    bool canon_auto = (double)m_est > c->canon_l1_at * (double)n_exp;
+    if (rep_kmer && c->canon_l1 == 1)
+    {
+        if (c->space_choice >= 0 && !c->runs.empty()) canon_auto = c->space_choice == 1;
+        else
+        {
+            const double w_c = (double)n_exp;
+            double w_all = (double)c->windows + w_c * (c->more_follows ? 4.0 : 1.0);
+            if (c->expect_bases) w_all = std::max(w_all, (double)c->expect_bases * std::min(1.0, c->valid_frac));
+            const double d_all = (double)(m_est - m_rare) + (double)m_rare * (w_all / w_c);
+            canon_auto = d_all > c->canon_l1_at * w_all;
+            if (c->debug) std::fprintf(stderr, "libgossgpu: fused path: %.0f distinct keys (%.0f of multiplicity ~1) of %.0f windows here, %.0f of %.0f in all: %s\n",
+                                       (double)m_est, (double)m_rare, w_c, d_all, w_all, canon_auto ? "canonical forms in the first level" : "strand representatives");
+        }
+    }
+    const bool canon_l1 = rep_kmer && (c->canon_l1 == 2 || (c->canon_l1 == 1 && canon_auto));
+    if (rep_kmer && c->canon_l1 == 1) c->space_choice = canon_l1 ? 1 : 0;
     if (canon_l1)
     {
         // (the regions are sized from the sample: it must be in the key space the first level writes)
@@ -2132,7 +2173,10 @@ void process_chunk(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstarts, ui
         // number of keys -- bucket regions with 6 % of slack, sub-regions with 13 %
         if (c->valid_frac < 0.97 && nstarts > kValidSizingMin)
         {
-            ka_slots = std::min<uint64_t>(cap, (uint64_t)((double)capf * c->valid_frac * kValidSlackA) + (1u << 20));
+            // (+ the blocks the first level's workgroups hold in every region -- 256 regions x 768 workgroups x two blocks
+            // of up to 256 slots: an eighth of a chunk of 0.8 G windows, which the slack alone did not cover -- every
+            // staged chunk of a FASTQ build was sampled twice, 2 x 2 ms of joint histogram among it)
+            ka_slots = std::min<uint64_t>(cap, (uint64_t)((double)capf * c->valid_frac * kValidSlackA) + (1u << 20) + std::min<uint64_t>(capf / 8, 104u << 20));
             kb_slots = std::min<uint64_t>(cap, (uint64_t)((double)capf * c->valid_frac * kValidSlackB) + (8u << 20));
             reduced = ka_slots < cap || kb_slots < cap;
         }
@@ -2475,6 +2519,8 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         uint64_t navail = std::min(nbytes - done, ns + c->len - 1);
         const uint64_t lo0 = c->arena.lo, hi0 = c->arena.hi;
         const size_t runs0 = c->runs.size();
+        struct MoreOff { goss_gpu_ctx* c; bool was; ~MoreOff() { c->more_follows = was; } } moreOff{c, c->more_follows};
+        c->more_follows = moreOff.was || done + ns < nstarts_total;
         try
         {
             process_chunk<K>(c, d + done, ns, navail);
@@ -3580,6 +3626,9 @@ static void flush_staging_background(goss_gpu_ctx* c)
         {
             HIP_TRY(hipSetDevice(c->device));
             (void)hipGetLastError();
+            // (the buffer filled up under a caller that goes on pushing: this chunk is one of several)
+            struct MoreOff { goss_gpu_ctx* c; ~MoreOff() { c->more_follows = false; } } moreOff{c};
+            c->more_follows = true;
             count_staged(c, buf, n, packed);
             check_launch("a kernel launch was refused");
         }
@@ -3608,6 +3657,15 @@ int goss_gpu_push_bases_device(goss_gpu_ctx* c, const void* d_bases, uint64_t nb
         if (c->words == 1) push_device<Key1>(c, (const uint8_t*)d_bases, nbytes);
         else push_device<Key2>(c, (const uint8_t*)d_bases, nbytes);
     });
+}
+
+// What the caller means to push in all (the `goss` commands know their files' sizes): lets the first chunks of a build
+// of many choose the key space they count in for the whole build rather than for themselves.
+int goss_gpu_expect_bases(goss_gpu_ctx* c, uint64_t total_bases)
+{
+    if (!c) return GOSS_ERR_INVALID_ARG;
+    c->expect_bases = total_bases;
+    return GOSS_OK;
 }
 
 // Packed bases that are already resident in HBM: counted where they lie, like goss_gpu_push_bases_device's bytes -- the
@@ -4826,6 +4884,8 @@ int goss_gpu_reset(goss_gpu_ctx* c)
         c->res_big.clear();
         c->files.clear();
         c->windows = c->keys_total = 0;
+        c->space_choice = -1;
+        c->expect_bases = 0;
         c->finished = c->emitted = false;
         c->broken = false;
         c->res_keys = nullptr; c->res_counts = nullptr; c->M = 0;

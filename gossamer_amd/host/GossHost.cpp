@@ -1144,7 +1144,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
     // the caller gave no budget: ~1 base per FASTQ byte/2 (FASTA, lines: per byte), two key
     // buffers + tables per key, compressed input expands ~4x
     uint64_t budget = cxt.hbmBudget;
-    if (budget == 0)
+    uint64_t inputBases = 0;          // bases of all inputs, estimated from the files' sizes (0: unknown) -- goss_gpu_expect_bases
     {
         uint64_t bases = 0; bool unknown = false;
         auto add = [&](const std::string& f, double basesPerByte) {
@@ -1158,7 +1158,8 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         for (auto& f : lines) add(f, 1.0);
         for (auto& f : fastas) add(f, 1.0);
         for (auto& f : fastqs) add(f, 0.5);
-        if (!unknown)
+        if (!unknown) inputBases = bases;
+        if (!unknown && budget == 0)
         {
             const uint64_t keyBytes = (2 * (K + (mode == GOSS_MODE_GRAPH ? 1 : 0)) <= 62) ? 8 : 16;
             const uint64_t perBase = (mode == GOSS_MODE_GRAPH ? 2 : 1) * (2 * keyBytes + 2) + 1;
@@ -1174,7 +1175,7 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
         // against 0.77 s -- and cost half as much on used ones; 12 GB is slower: 2.8 s, the chunks get too small)
         uint64_t kDefaultCap = (wide ? 48ULL : 24ULL) << 30;
         if (const char* e = std::getenv("GOSS_ARENA_START_GB")) { const long v = atol(e); if (v >= 1) kDefaultCap = (uint64_t)v << 30; }
-        if (budget == 0 || budget > kDefaultCap) budget = kDefaultCap;
+        if (cxt.hbmBudget == 0 && (budget == 0 || budget > kDefaultCap)) budget = kDefaultCap;
     }
     // One context per device.  With several (--devices) every context has a feeder thread with a short queue:
     // batches go round the devices, each device copies and counts its own while the others do the same.
@@ -1197,6 +1198,9 @@ void runBuild(const GossCmdContext& cxt, uint64_t K, int mode, const std::string
                 // a budget the user did not ask for is a starting size: inputs with little duplication (a
                 // genome in FASTA: every k-mer once) need room for runs that do not shrink
                 if (cxt.hbmBudget == 0) g.check(goss_gpu_set_budget_limit(g.h, ~0ULL), "setting the HBM limit");
+                // what the build will push in all (every context its share): the first chunks of a build of many then
+                // choose the key space they count in for the whole build (goss_gpu_expect_bases)
+                if (inputBases) g.check(goss_gpu_expect_bases(g.h, inputBases / P), "announcing the input's size");
                 // the arena is mapped while the first buffers are read and parsed
                 g.check(goss_gpu_prepare(g.h), "mapping HBM");
             }

@@ -150,6 +150,15 @@ int goss_gpu_push_packed_host_async(goss_gpu_ctx* ctx, const uint32_t* codes, co
  */
 int goss_gpu_push_packed_device(goss_gpu_ctx* ctx, const uint32_t* d_codes, const uint16_t* d_nonbase, uint64_t nbases);
 int goss_gpu_pack_bases_device(goss_gpu_ctx* ctx, const void* d_bases, uint64_t nbytes, uint32_t* d_codes, uint16_t* d_nonbase);
+/*
+ * How many bases the caller means to push in all before goss_gpu_finish (0 = unknown; forgotten by goss_gpu_reset).
+ * A hint, never needed for the result: a build that is counted in several chunks merges their runs before it re-orders
+ * them into the reference's canonical order, and which key space the chunks count in (strand representatives, or the
+ * FNV-ordered form per window: DESIGN.md section 3) is then a question of the WHOLE build's distinct keys per window,
+ * which its first chunk cannot see (thirteen chunks of C2 each hold all 10^8 k-mers of the genome).  The reference
+ * sizes its hash table from -B / -S the same way (GossCmdBuildKmerSet.cc:151-215): from what the caller says.
+ */
+int goss_gpu_expect_bases(goss_gpu_ctx* ctx, uint64_t total_bases);
 /* Wait for every queued copy and hand all buffers of asynchronous pushes back (release is called for each). */
 int goss_gpu_flush(goss_gpu_ctx* ctx);
 

@@ -109,6 +109,47 @@ def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
                     os.environ[n] = v
 
 
+@pytest.mark.parametrize("hint", [False, True])
+def test_chunks_of_one_build_choose_their_key_space_for_the_build(oracle, hint):
+    """A build counted in several chunks merges their runs before it re-orders them, so the key space its chunks count in
+    is chosen for the WHOLE build: every chunk of these reads holds all 1.5 M k-mers of the genome -- a tenth of its own
+    windows, which alone would read "canonical forms in the first level" -- and a thirtieth of the build's.  With the
+    caller's word on the input's size (goss_gpu_expect_bases) and without it (more input is known to follow the first
+    chunks): all chunks in representative space, one re-ordering at finish, files the oracle's.  And the other way
+    round: reads whose k-mers occur once stay in canonical space whatever follows."""
+    reads = g.synth_reads_host(300000, 150, 1500000, seed=23)          # 45 M window starts, 1.5 M distinct 25-mers
+    exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", reads)], 25, out="ks")
+    exp = _suffix_map(exp, "ks")
+    old = os.environ.get("GOSS_GPU_FUSED_MIN")
+    os.environ["GOSS_GPU_FUSED_MIN"] = "0"
+    try:
+        with g.Context(25, g.MODE_KMER_SET, hbm_budget=400 << 20) as ctx:
+            if hint:
+                ctx.expect_bases(len(reads))
+            ctx.push_host(reads)
+            c = ctx.finish()
+            st = {n: ctx.stat(n) for n in ("rep_chunks", "canon_chunks", "fused_chunks")}
+            assert st["rep_chunks"] >= 3 and st["fused_chunks"] == st["rep_chunks"] and st["canon_chunks"] == 0, st
+            assert c.windows == nwin
+            _same(ctx.emit(), exp)
+        # a genome read once (every k-mer of multiplicity one): canonical forms, with or without more to follow
+        unique = g.synth_reads_host(60000, 150, 40_000_000, seed=29)
+        exp1, nwin1 = oracle.build_kmer_set([(oracle.LINE, "reads", unique)], 25, out="ks")
+        with g.Context(25, g.MODE_KMER_SET, hbm_budget=400 << 20) as ctx:
+            if hint:
+                ctx.expect_bases(len(unique))
+            ctx.push_host(unique)
+            c = ctx.finish()
+            assert ctx.stat("rep_chunks") == 0, {n: ctx.stat(n) for n in ("rep_chunks", "canon_chunks", "fused_chunks")}
+            assert c.windows == nwin1
+            _same(ctx.emit(), _suffix_map(exp1, "ks"))
+    finally:
+        if old is None:
+            os.environ.pop("GOSS_GPU_FUSED_MIN", None)
+        else:
+            os.environ["GOSS_GPU_FUSED_MIN"] = old
+
+
 def test_reads_with_sequencing_errors_need_no_retry(oracle):
     """Reads with 1 % substituted bases: the k-mers of the genome occur ~30 times, the ~25 k-mers around every
     error once -- 5 times more distinct keys than the genome has.  An estimate that takes all keys for equally

@@ -111,7 +111,7 @@ def test_pack_bases_device_is_the_host_packer(mis):
     rng = random.Random(17 + mis)
     for n in (1, 15, 16, 17, 4096 + 3, 100_001):
         text = bytes(rng.choice(b"ACGTacgtNn\n\r-\x00\xff" if rng.random() < 0.2 else b"ACGT") for _ in range(n))
-        codes, bad = g.pack_bases(text)
+        codes, bad = g.binding.pack_bases(text)
         buf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
         buf[mis:mis + n] = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
         groups = (n + 15) // 16
@@ -130,18 +130,18 @@ def test_pack_bases_device_is_the_host_packer(mis):
         assert np.array_equal(gc[:groups] & mask, codes & mask), (n, mis)
 
 
-@pytest.mark.parametrize("k,mode,nreads", [(25, 0, 4000), (27, 1, 4000), (55, 1, 4000), (25, 0, 300_000), (31, 1, 300_000), (45, 0, 300_000)])
+@pytest.mark.parametrize("k,mode,nreads", [(25, 0, 4000), (27, 1, 4000), (55, 1, 4000), (25, 0, 400_000), (31, 1, 400_000), (45, 0, 400_000)])
 def test_packed_bases_resident_in_hbm(oracle, k, mode, nreads):
     """goss_gpu_push_packed_device: packed bases that already lie in HBM -- packed there by goss_gpu_pack_bases_device
     -- are counted where they lie; files equal to the oracle's build of the bytes.  Small inputs take the plain kernels
-    (the chunk is unpacked for them), 300 000 reads the fused path, whose kernels read the groups as they are; two pushes,
-    the second from arrays that start in the middle of the first's allocation."""
+    (the chunk is unpacked for them); of 400 000 reads in two pushes the second -- 300 000 reads, 45 M window starts -- is a
+    chunk the fused path takes, whose kernels read the groups as they are."""
     import torch
     reads = g.synth_reads_host(nreads, 150, 5 * nreads, seed=77 + k)
     exp, nwin = (oracle.build_graph if mode else oracle.build_kmer_set)([(oracle.LINE, "reads", reads)], k, out="o")
     exp = {n[1:]: d for n, d in exp.items()}
     lines = reads.split(b"\n")[:-1]
-    cut = len(lines) // 3
+    cut = len(lines) // 4
     parts = [b"".join(l + b"\n" for l in lines[:cut]), b"".join(l + b"\n" for l in lines[cut:])]
     with g.Context(k, mode, hbm_budget=24 << 30) as ctx:
         held = []
@@ -158,6 +158,6 @@ def test_packed_bases_resident_in_hbm(oracle, k, mode, nreads):
         got = ctx.emit()
         st = {n: ctx.stat(n) for n in ("packed_fused_chunks", "packed_unpacked_chunks", "fused_chunks")}
     assert c.windows == nwin
-    if nreads >= 300_000:
-        assert st["packed_fused_chunks"] >= 1 and st["packed_unpacked_chunks"] == 0, st
+    if nreads >= 400_000:
+        assert st["packed_fused_chunks"] >= 1 and st["fused_chunks"] == st["packed_fused_chunks"], st
     assert got == exp
