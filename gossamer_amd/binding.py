@@ -459,9 +459,9 @@ class Context:
         keys = keys[: m * w]
         cnts = cnts[:m]
         if w == 1:
-            ks = [int(x) for x in keys]
+            ks = keys.tolist()
         else:
-            ks = [int(keys[2 * i]) | (int(keys[2 * i + 1]) << 64) for i in range(m)]
+            ks = [l | (h << 64) for l, h in zip(keys[0::2].tolist(), keys[1::2].tolist())]
         return ks, cnts
 
     def big_counts(self):

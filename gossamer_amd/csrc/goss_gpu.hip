@@ -131,13 +131,14 @@ struct goss_gpu_ctx {
     // 34 ms per 12.6 G windows -- even at M = 0.051 x windows, and the counting of canonical keys is the faster above that
     // (C2 with 0.3 % / 0.5 % errors: 160 -> 148 / 216 -> 170 ms); 0.10 until the end of round 5)
     double canon_l1_at = 0.05;          // GOSS_GPU_CANON_L1_AT=<fraction>
-    // more of the same input is known to follow the chunk being counted (a staging buffer that filled up while the caller
-    // keeps pushing; a chunk of a device push that is not its last): its run will be merged with the runs of the others
+    // more of the same input is known to follow the push being counted (a staging buffer that filled up while the caller
+    // keeps pushing): its runs will be merged with the runs of the others
     // in representative space and the re-ordering into canonical order paid ONCE, on the merged run -- the chunk's own
     // share of distinct keys then says little about what that costs (C2 from FASTQ: thirteen chunks of 0.8 G windows
     // that each see all 10^8 k-mers of the genome, 12 %, took the canonical form per window -- 67 ms of first level
     // where the representatives take 31, ten second-level bits, and a re-ordering per run)
     bool more_follows = false;
+    uint64_t more_starts = 0;           // ... and how many window starts of the push being counted lie behind this chunk (a device push knows)
     uint64_t expect_bases = 0;          // goss_gpu_expect_bases: bases the caller means to push in all (0: not said)
     int space_choice = -1;              // the key space the build's fused chunks count in once one has chosen: 0 representatives, 1 canonical forms (-1: none yet)
     uint32_t canon_chunks = 0;          // chunks counted that way
@@ -1520,7 +1521,10 @@ int process_chunk_fused(goss_gpu_ctx* c, const uint8_t* d_bases, uint64_t nstart
         else
         {
             const double w_c = (double)n_exp;
-            double w_all = (double)c->windows + w_c * (c->more_follows ? 4.0 : 1.0);
+            // (what follows: known for the rest of the push being counted; a guess -- three times as much again -- when
+            // that push is a staging buffer that filled up under a caller who goes on pushing)
+            const double w_push = w_c + (double)c->more_starts * std::min(1.0, c->valid_frac);          // this push, from this chunk on
+            double w_all = (double)c->windows + w_push * (c->more_follows ? 4.0 : 1.0);
             if (c->expect_bases) w_all = std::max(w_all, (double)c->expect_bases * std::min(1.0, c->valid_frac));
             const double d_all = (double)(m_est - m_rare) + (double)m_rare * (w_all / w_c);
             canon_auto = d_all > c->canon_l1_at * w_all;
@@ -2519,8 +2523,9 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
         uint64_t navail = std::min(nbytes - done, ns + c->len - 1);
         const uint64_t lo0 = c->arena.lo, hi0 = c->arena.hi;
         const size_t runs0 = c->runs.size();
-        struct MoreOff { goss_gpu_ctx* c; bool was; ~MoreOff() { c->more_follows = was; } } moreOff{c, c->more_follows};
-        c->more_follows = moreOff.was || done + ns < nstarts_total;
+        // (behind this chunk: the rest of this push and what the push's own caller has said lies behind IT)
+        struct MoreOff { goss_gpu_ctx* c; uint64_t was; ~MoreOff() { c->more_starts = was; } } moreOff{c, c->more_starts};
+        c->more_starts = moreOff.was + (nstarts_total - done - ns);
         try
         {
             process_chunk<K>(c, d + done, ns, navail);
@@ -3814,6 +3819,8 @@ static void push_bases_host(goss_gpu_ctx* c, const char* bases, uint64_t nbytes,
             c->stage_pk[c->stage_cur] = false;
             HIP_TRY(hipMemcpyAsync(c->stage, bases + done, nb, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            struct MoreOff { goss_gpu_ctx* c; ~MoreOff() { c->more_starts = 0; } } moreOff{c};
+            c->more_starts = nstarts_total - done - ns;          // (the pieces behind this one: the chunks choose their key space for all of them)
             count_staged(c, c->stage, nb);
             HIP_TRY(hipStreamSynchronize(c->stream));
             done += ns;

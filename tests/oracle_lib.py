@@ -181,6 +181,33 @@ def collect(inputs, length, mode):
     return out, nreads, nwin
 
 
+def count(inputs, length, mode):
+    """(sorted distinct keys, their counts, reads, windows) of the reference's key stream: go_collect + go_sort_count,
+    the keys converted through numpy -- what the tests used to do with a Python dict over every window's key, which
+    took most of the GPU suite's time."""
+    import numpy as np
+    arr, keep = _inputs(inputs)
+    ks = Keys()
+    err = C.create_string_buffer(512)
+    rc = lib().go_collect(arr, len(inputs), length, mode, C.byref(ks), err, 512)
+    if rc:
+        lib().go_keys_free(C.byref(ks))
+        raise OracleError(err.value.decode())
+    n = ks.n
+    nreads, nwin = ks.nreads, ks.nwindows
+    if n == 0:
+        lib().go_keys_free(C.byref(ks))
+        return [], [], nreads, nwin
+    counts = (C.c_uint64 * n)()
+    m = lib().go_sort_count(ks.keys, n, counts)
+    raw = np.ctypeslib.as_array(C.cast(ks.keys, C.POINTER(C.c_uint64)), shape=(n, 2))[:m].copy()
+    cnt = np.ctypeslib.as_array(counts)[:m].copy()
+    lib().go_keys_free(C.byref(ks))
+    lo, hi = raw[:, 0].tolist(), raw[:, 1].tolist()
+    keys = lo if not any(hi) else [(h << 64) | l for l, h in zip(lo, hi)]
+    return keys, cnt.tolist(), nreads, nwin
+
+
 class FileSet:
     """In-memory output file set (role of the reference's StringFileFactory)."""
 

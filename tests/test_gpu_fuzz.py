@@ -14,18 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_random_configurations_against_the_oracle():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "40", "11", "groups"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "28", "11", "groups"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-4000:]
-    assert "40 cases, 0 failed" in out
+    assert "28 cases, 0 failed" in out
 
 
 def test_large_random_configurations_against_the_oracle():
     """The "large" mode: 0.4 to 1 M reads per case -- several chunks per build, the fused path taken without
-    forcing, arenas of 0.5 to 8 GB."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "12", "23", "large"],
+    forcing, arenas of 0.5 to 8 GB.  (Six cases here, twenty-eight of the small kind above: the suite has 600 of the
+    driver's 900 seconds; outside the suite the same script has run thousands.)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "6", "23", "large"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=2400)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-4000:]
-    assert "12 cases, 0 failed" in out
+    assert "6 cases, 0 failed" in out

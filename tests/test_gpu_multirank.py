@@ -155,6 +155,8 @@ def test_set_algebra_with_several_ranks(oracle, world):
     tests/test_gpu_group.py -- eight rank processes on one card are more than a box of the pool allows.)"""
     texts = [g.synth_reads_host(6000, 150, 400000, seed=71, first_read=f) for f in (0, 3000)]
     cases = []
+    # (four rank processes: one-word keys with both exchanges, two-word keys once -- every case costs a round of four
+    # processes' pushes, exchanges and emissions, and the suite has 600 of the driver's 900 seconds; two ranks: all)
     for k in (25, 45):
         files, names, sizes = {}, [], []
         for i, t in enumerate(texts):
@@ -164,6 +166,8 @@ def test_set_algebra_with_several_ranks(oracle, world):
             sizes.append(struct.unpack("<QQQ", f["s%d.header" % i])[2])
         shards = [_split_reads(t, world) for t in texts]
         for sel, op in (((0, 1), "intersect"), ((0, 1), "subtract"), ((1, 0), "subtract")):
+            if world > 2 and ((k == 45 and op != "subtract") or (k == 25 and sel == (1, 0))):
+                continue
             if op == "intersect":
                 exp = oracle.intersect_kmer_sets(files, [names[j] for j in sel], "out")
             else:

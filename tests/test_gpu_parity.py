@@ -29,12 +29,8 @@ def make_reads(rng, nreads, read_len, genome_len, n_rate=0.02, lower=False):
 
 
 def oracle_counts(oracle, reads, length, mode):
-    keys, nreads, nwin = oracle.collect([(oracle.LINE, "r", "\n".join(reads) + "\n")], length, mode)
-    d = {}
-    for k in keys:
-        d[k] = d.get(k, 0) + 1
-    ks = sorted(d)
-    return ks, [d[k] for k in ks], nwin
+    ks, cs, nreads, nwin = oracle.count([(oracle.LINE, "r", "\n".join(reads) + "\n")], length, mode)
+    return ks, cs, nwin
 
 
 def gpu_counts(reads, k, mode, budget=256 * MB, pushes=1, path=0):
