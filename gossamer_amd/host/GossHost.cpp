@@ -514,6 +514,16 @@ struct GpuCtx {
 // Every file of the emitted object to "<out><suffix>".  The calling thread (the context's) copies
 // 32 MB pieces from the device into a ring of page-locked buffers; a pool of writer threads pwrites
 // them, so the copies into the page cache run on several cores while the next pieces arrive.
+namespace {
+// What the parallel parser parks between files (HostAlloc::keep): page-locked buffers by size, and the slabs of its
+// two-step pools -- plain pages locked in place.  A parked slab is idle while the object's files are written: the
+// writer below borrows one for its output buffers instead of page-locking 192 MB of its own (0.3 s/GB).
+std::mutex gKeptMutex;
+std::map<size_t, std::vector<void*>> gKeptBuffers;          // by size
+struct KeptSlab { void* p; bool pinned; };
+std::map<size_t, std::vector<KeptSlab>> gKeptSlabs;         // two-step pools, by size
+}  // namespace
+
 void writeObjectFiles(goss_gpu_ctx* h, const std::string& out)
 {
     writeObjectFiles(std::vector<goss_gpu_ctx*>{h}, out);
@@ -542,9 +552,20 @@ void writeObjectFiles(const std::vector<goss_gpu_ctx*>& hs, const std::string& o
     std::deque<Job> jobs;
     std::vector<int> freeBufs;
     bool done = false, failed = false;
+    // (a page-locked slab the parser has parked, when there is one that is large enough: borrowed, parked again at the end)
+    KeptSlab borrowed{nullptr, false};
+    size_t borrowedBytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(gKeptMutex);
+        for (auto& kv : gKeptSlabs)
+            if (kv.first >= (size_t)kBuffers * kPiece)
+                for (size_t q = 0; q < kv.second.size() && !borrowed.p; ++q)
+                    if (kv.second[q].pinned) { borrowed = kv.second[q]; borrowedBytes = kv.first; kv.second.erase(kv.second.begin() + (long)q); }
+    }
     for (int i = 0; i < kBuffers; ++i)
     {
-        if (goss_gpu_host_alloc(&bufs[i], kPiece) == GOSS_OK) pinned[i] = true;
+        if (borrowed.p) bufs[i] = (char*)borrowed.p + (size_t)i * kPiece;
+        else if (goss_gpu_host_alloc(&bufs[i], kPiece) == GOSS_OK) pinned[i] = true;
         else bufs[i] = malloc(kPiece);
         if (!bufs[i]) throw Error::General("out of host memory for the output buffers\n");
         freeBufs.push_back(i);
@@ -578,7 +599,8 @@ void writeObjectFiles(const std::vector<goss_gpu_ctx*>& hs, const std::string& o
         cvJob.notify_all();
         for (auto& t : pool) t.join();
         for (int fd : fds) if (::close(fd) != 0) failed = true;
-        for (int i = 0; i < kBuffers; ++i) { if (pinned[i]) goss_gpu_host_free(bufs[i]); else free(bufs[i]); }
+        if (borrowed.p) { std::lock_guard<std::mutex> lk(gKeptMutex); gKeptSlabs[borrowedBytes].push_back(borrowed); }
+        else for (int i = 0; i < kBuffers; ++i) { if (pinned[i]) goss_gpu_host_free(bufs[i]); else free(bufs[i]); }
     };
     try
     {
@@ -687,10 +709,6 @@ struct HostAlloc {                       // how the chunk buffers are obtained (
     std::function<bool(void*, size_t)> pin;
     std::function<void(void*)> unpin;
 };
-std::mutex gKeptMutex;
-std::map<size_t, std::vector<void*>> gKeptBuffers;          // by size
-struct KeptSlab { void* p; bool pinned; };
-std::map<size_t, std::vector<KeptSlab>> gKeptSlabs;         // two-step pools, by size
 
 }  // namespace
 

@@ -175,7 +175,7 @@ def test_rem32_skewed_low_bits(oracle):
         assert got == exp
 
 
-@pytest.mark.parametrize("bits,split", [(10, 0), (9, 1), (9, 3), (10, 2), (9, 4), (10, 4)])
+@pytest.mark.parametrize("bits,split", [(10, 0), (9, 1), (9, 4), (10, 4)])          # (two and three third-level bits: tests/fuzz_parity.py draws them)
 def test_rem32_wider_second_level_and_third_level(oracle, bits, split):
     """Ten bits at the second level, and a third level inside the segments (1 .. 4 bits: what reads with many distinct
     k-mers get by themselves), forced on the same reads: k = 25 (squeezed at 9 bits, 32-bit remainders at 10), k = 21,
