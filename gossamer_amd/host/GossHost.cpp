@@ -258,7 +258,10 @@ bool fastqLoop(Src& src, uint64_t limit, Sink&& sink, uint64_t* reads, uint64_t*
         const char* l; size_t n;
         cur(l, n);
         if (!(n > 0 && l[0] == '@')) return bad("expected '@' at beginning of line ");
-        label.assign(l + 1, n - 1);
+        // (the title is only ever compared with a repeated one on the '+' line: a source whose lines stay where they are
+        // -- a chunk of the parallel parser -- keeps a pointer; copying 100 M titles was a sixth of the framer's time)
+        const char* lab = l + 1; size_t labn = n - 1;
+        if (!Src::kStableLines) { label.assign(l + 1, n - 1); lab = label.data(); }
         // the common record has its sequence on one line: no copy then
         const char* seq1 = nullptr; size_t seq1n = 0;
         bool multi = false;
@@ -278,7 +281,7 @@ bool fastqLoop(Src& src, uint64_t limit, Sink&& sink, uint64_t* reads, uint64_t*
             }
         }
         if (!(n > 0 && l[0] == '+')) return bad("expected '+' at beginning of line ");
-        if (n > 1 && !(n - 1 == label.size() && memcmp(l + 1, label.data(), n - 1) == 0))
+        if (n > 1 && !(n - 1 == labn && memcmp(l + 1, lab, n - 1) == 0))
             return bad("quality title does not match sequence title at line ");
         const char* sp = multi ? seq.data() : seq1;
         const size_t sn = multi ? seq.size() : seq1n;
@@ -793,6 +796,10 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     // staging buffer is counted: more buffers than workers, so that the workers go on meanwhile)
     size_t extraBufs = pushPacked ? 160 : 4;
     if (const char* e = std::getenv("GOSS_PARSE_POOL")) { const long v = atol(e); if (v >= 1) extraBufs = (size_t)v; }
+    // (Tried in round 6 and not kept: "run-ahead" buffers behind the locked ones, never page-locked, for the workers to parse
+    // into while the device runtime is still starting -- the pageable copies out of them held the pusher thread 0.55 s
+    // instead of 0.22 and their first-touch page faults doubled the packing time: 0.62-0.68 s became 0.77-0.83,
+    // profiles/r06/e2e_steps.txt.)
     const size_t nbuf = std::min<size_t>((size_t)threads + extraBufs, nchunks + 1);
     // Two condition variables on the one mutex: workers wait for a free buffer (cvFree, one of them woken per buffer that
     // comes back), the in-order consumer for its next chunk (cvDone, woken by the worker that finishes a chunk).  With
@@ -804,6 +811,7 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
     std::vector<void*> allBufs;
     KeptSlab slab{nullptr, false};
     const size_t stride = (bufBytes + 4095) & ~(size_t)4095, slabBytes = stride * nbuf;
+    auto putFree = [&](char* b) { freeBufs.push_back(b); };          // (under `m`)
     std::atomic<bool> allocFailed{false};
     struct FreeAll { std::vector<void*>& v; const HostAlloc& h; size_t bytes; KeptSlab& slab; size_t slabBytes;
                      ~FreeAll() {
@@ -1078,14 +1086,14 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
         if (r.start == (size_t)-1)
         {
             // the chunk found no record start: fine only if the previous record ran past it
-            { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
+            { std::lock_guard<std::mutex> lk(m); putFree(r.buf); }
             cvFree.notify_one();
             if (expected < limit) serialRest = true;
             continue;
         }
         auto giveBack = [&]() {
             if (!r.buf) return;
-            { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(r.buf); }
+            { std::lock_guard<std::mutex> lk(m); putFree(r.buf); }
             r.buf = nullptr;
             cvFree.notify_one();
         };
@@ -1097,9 +1105,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             r.buf = nullptr;
             { std::lock_guard<std::mutex> lk(m); ++lent; }
             const auto a = now();
-            pushPacked->push(r.codes, r.bad, r.len, [&m, &cvFree, &freeBufs, &lent, b]() {
+            pushPacked->push(r.codes, r.bad, r.len, [&m, &cvFree, &putFree, &lent, b]() {
                 bool last;
-                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); last = --lent == 0; }
+                { std::lock_guard<std::mutex> lk(m); putFree(b); last = --lent == 0; }
                 if (last) cvFree.notify_all(); else cvFree.notify_one();          // (all: whoever waits for `lent` to reach zero is among them)
             });
             pushSeconds += std::chrono::duration<double>(now() - a).count();
@@ -1109,9 +1117,9 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             char* b = r.buf;
             r.buf = nullptr;
             { std::lock_guard<std::mutex> lk(m); ++lent; }
-            (*pushOwned)(b, r.len, [&m, &cvFree, &freeBufs, &lent, b]() {
+            (*pushOwned)(b, r.len, [&m, &cvFree, &putFree, &lent, b]() {
                 bool last;
-                { std::lock_guard<std::mutex> lk(m); freeBufs.push_back(b); last = --lent == 0; }
+                { std::lock_guard<std::mutex> lk(m); putFree(b); last = --lent == 0; }
                 if (last) cvFree.notify_all(); else cvFree.notify_one();
             });
         }
