@@ -151,11 +151,39 @@ def main():
                         stats = {"records": sum(recs), "parts": nparts, "rec_chunks": ctx.stat("rec_chunks"), "fused_chunks": ctx.stat("fused_chunks")}
                 elif parts == 1:
                     with g.Context(k, g.MODE_GRAPH if graph else g.MODE_KMER_SET, hbm_budget=budget) as ctx:
-                        ctx.push_host(reads)
+                        # (round 6) what the caller says it will push -- nothing, the truth, far too little, far too much: a
+                        # hint for the key space the chunks count in, never for the result; and how the bases arrive: one
+                        # host push, several, packed on the host, or packed on the device and counted where they lie
+                        hint = rng.choice([None, None, 1.0, 0.05, 30.0])
+                        if hint is not None:
+                            ctx.expect_bases(int(len(reads) * hint))
+                        how = rng.choice(["host", "host", "pieces", "packed-host", "packed-device"])
+                        if how == "host":
+                            ctx.push_host(reads)
+                        elif how == "packed-device":
+                            import torch
+                            buf = torch.frombuffer(bytearray(reads), dtype=torch.uint8).cuda()
+                            groups = (len(reads) + 15) // 16
+                            dc = torch.empty(groups, dtype=torch.int32, device="cuda")
+                            db = torch.empty(groups, dtype=torch.int16, device="cuda")
+                            ctx.pack_bases_device(buf.data_ptr(), len(reads), dc.data_ptr(), db.data_ptr())
+                            del buf
+                            ctx.push_packed_device(dc.data_ptr(), db.data_ptr(), len(reads))
+                        else:
+                            lines = reads.split(b"\n")[:-1]
+                            npieces = rng.choice([2, 3, 7])
+                            per = (len(lines) + npieces - 1) // npieces
+                            for i in range(0, len(lines), per):
+                                piece = b"".join(x + b"\n" for x in lines[i:i + per])
+                                if how == "packed-host":
+                                    ctx.push_packed_host(piece, async_=rng.random() < 0.5)
+                                else:
+                                    ctx.push_host(piece)
                         c = ctx.finish()
                         got = ctx.emit()
                         windows = c.windows
-                        stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "runs")}
+                        stats = {s: ctx.stat(s) for s in ("fused_chunks", "fused_msd_chunks", "big_table_chunks", "segment_retries", "rep_chunks", "canon_chunks", "runs")}
+                        stats.update(hint=hint, how=how)
                 else:
                     # several contexts of this process, each counting a share of the reads (goss_gpu_group_exchange / _emit);
                     # half of these cases exchange BEFORE counting: deferred contexts, the shards pushed in 1 .. 3 portions
