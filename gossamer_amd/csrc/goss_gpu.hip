@@ -1302,7 +1302,12 @@ void expand_graph_run(goss_gpu_ctx* c, size_t ri)
                        c->runs[ri].counts, m, c->len, bk, bc, dbig, kMaxBig, npal);
     const bool mute = c->mute_timing;
     c->mute_timing = true;                  // the sort's passes belong to this phase
-    const bool in_b = radix_sort<K, true>(c, bk, tk, bc, tc, m, key_digits(c));
+    // (the pads -- all ones, in the slots of the palindromes -- must end up BEHIND every key: where the key's 2 len bits
+    // fill whole digits (len a multiple of four: 12, 16, .. 28, 32, ..) the edge T..T has every digit a pad has, a stable
+    // sort on those digits alone leaves the two kinds in input order, and the cut below dropped T..T for a pad whenever a
+    // palindrome stood in front of it: one digit more -- zeros for a key, ones for a pad -- tells them apart)
+    const uint32_t nd = key_digits(c) + ((2 * c->len) % 8 == 0 ? 1u : 0u);
+    const bool in_b = radix_sort<K, true>(c, bk, tk, bc, tc, m, nd);
     c->mute_timing = mute;
     std::vector<unsigned long long> hb(2 + 3 * kMaxBig);
     HIP_TRY(hipMemcpyAsync(hb.data(), dbig, hb.size() * 8, hipMemcpyDeviceToHost, c->stream));

@@ -232,6 +232,15 @@ def main():
                 else:
                     os.environ[n] = v
         bad += 0 if ok else 1
+        if not ok and os.environ.get("FUZZ_DUMP_DIR"):
+            # (a failing case's input and settings, for a replay outside the random sequence: tools/dbg/fuzz_replay.py)
+            import json
+            dd = os.environ["FUZZ_DUMP_DIR"]
+            os.makedirs(dd, exist_ok=True)
+            with open(os.path.join(dd, "case%d.reads" % case), "wb") as f:
+                f.write(reads)
+            with open(os.path.join(dd, "case%d.json" % case), "w") as f:
+                json.dump({"graph": graph, "k": k, "budget": budget, "env": env, "stats": {a: (b if isinstance(b, (int, float, str, type(None))) else str(b)) for a, b in stats.items()}, "why": why}, f)
         print("%s case %d: %s k=%d reads=%d len=%d..%d genome=%d err=%g n=%g budget=%dM env=%s windows=%d %s %.1fs %s"
               % ("ok  " if ok else "FAIL", case, "graph" if graph else "kmer", k, nreads, lmin, lmax, genome_len, err, nrate, budget >> 20,
                  {a: b for a, b in env.items() if a != "GOSS_GPU_FUSED_MIN"}, nwin, stats, time.time() - t0, why), flush=True)

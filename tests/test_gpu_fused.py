@@ -2,6 +2,7 @@
 as the oracle when it runs, when a bucket region overflows and the chunk is redone unfused, and
 when it declines the input."""
 import os
+import random
 
 import pytest
 
@@ -107,6 +108,48 @@ def test_chunk_runs_stay_in_representative_space_until_they_must_not(oracle):
                     os.environ.pop(n, None)
                 else:
                     os.environ[n] = v
+
+
+@pytest.mark.parametrize("k", [11, 15, 19, 23, 27, 31, 35, 47, 13, 26])
+def test_graph_strand_pairs_keep_the_all_t_edge_beside_palindromes(oracle, k):
+    """Graph builds count one strand of every edge and write the other afterwards (graph_expand_kernel); a palindromic
+    edge has no other strand and leaves a pad in its slot, and the pads are sorted behind the keys and cut off.  Where
+    the edge's 2 (k + 1) bits fill whole bytes -- k + 1 = 12, 16, 20, 24, 28, 32, 36, 48 -- the edge T..T has every digit a pad
+    has: a sort on the key's digits alone left them in input order and the cut dropped T..T for a pad whenever a
+    palindrome stood in front of it (found by tests/fuzz_parity.py in round 6: reads of a real genome hold poly-A
+    everywhere).  Reads with poly-A, poly-T and palindromic stretches through the fused path; files against the oracle
+    (ReverseComplementAdapter.hh:20-93: both strands of every edge)."""
+    rng = random.Random(7 * k)
+    L = k + 1
+    genome = "".join(rng.choice("ACGT") for _ in range(30000))
+    half = "".join(rng.choice("ACGT") for _ in range(L // 2))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    pal = half + "".join(comp[c] for c in reversed(half))          # (even L: its own reverse complement)
+    special = ["A" * (L + 20), "T" * (L + 7), "ACGT" * 40, pal + "ACGTTGCA", "AT" * 60, "C" * (L + 3), "G" * (L + 1)]
+    reads = []
+    for i in range(30000):
+        n = rng.randint(max(40, L), 150)
+        p = rng.randint(0, len(genome) - n)
+        reads.append(genome[p:p + n])
+        if i % 600 == 0:
+            reads.extend(rng.sample(special, 3))
+    txt = ("\n".join(reads) + "\n").encode()
+    exp, nwin = oracle.build_graph([(oracle.LINE, "r", txt)], k, out="gr")
+    exp = _suffix_map(exp, "gr")
+    old = os.environ.get("GOSS_GPU_FUSED_MIN")
+    os.environ["GOSS_GPU_FUSED_MIN"] = "0"
+    try:
+        with g.Context(k, g.MODE_GRAPH, hbm_budget=2 << 30) as ctx:
+            ctx.push_host(txt)
+            c = ctx.finish()
+            assert ctx.stat("fused_chunks") >= 1 and ctx.stat("rep_chunks") >= 1, k          # (the strand-pair form was taken)
+            assert c.windows == nwin
+            _same(ctx.emit(), exp)
+    finally:
+        if old is None:
+            os.environ.pop("GOSS_GPU_FUSED_MIN", None)
+        else:
+            os.environ["GOSS_GPU_FUSED_MIN"] = old
 
 
 @pytest.mark.parametrize("hint", [False, True])
