@@ -18,6 +18,29 @@ import oracle_lib as oracle  # noqa: E402
 
 def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
     genome = "".join(rng.choice("ACGT") for _ in range(genome_len))
+    # (round 6) what a random genome almost never holds and a real one holds everywhere: homopolymers, short repeats and
+    # reverse-complement palindromes, planted into the genome -- the edge T..T beside palindromes is how this script
+    # found the strand-pair expansion's pad bug
+    if rng.random() < 0.6:
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        g2 = list(genome)
+        for _ in range(rng.choice([3, 20, 200])):
+            n = rng.randint(8, min(140, max(9, genome_len // 4)))
+            kind = rng.randrange(5)
+            if kind == 0:
+                piece = rng.choice("ACGT") * n
+            elif kind == 1:
+                piece = (rng.choice(["AT", "CG", "AC", "ACGT", "TTAGGG"]) * n)[:n]
+            elif kind == 2:
+                half = "".join(rng.choice("ACGT") for _ in range(n // 2))
+                piece = half + "".join(comp[c] for c in reversed(half))
+            elif kind == 3:
+                piece = "A" * (n // 2) + "T" * (n - n // 2)
+            else:
+                piece = "T" * (n // 2) + "A" * (n - n // 2)
+            at = rng.randint(0, max(0, genome_len - len(piece)))
+            g2[at:at + len(piece)] = piece
+        genome = "".join(g2)[:genome_len]
     out = []
     for _ in range(nreads):
         L = rng.randint(lmin, lmax)
