@@ -1859,7 +1859,13 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
         if (sh < 64) return (uint32_t)((lo >> sh) | ((uint64_t)v.z << (64 - sh)));
         return sh >= 96 ? 0u : (v.z >> (sh - 64));
     };
-    auto rem_less = [](const uint4& a, const uint4& b2) { return a.z < b2.z || (a.z == b2.z && (a.y < b2.y || (a.y == b2.y && a.x < b2.x))); };
+    // (ties: only between a slot whose 96 remainder bits are all ones -- a key that ends in 48 T's -- and the pads of the
+    // bitonic branch below, which carry the same words and the count 0: the key goes first.  Without that the network
+    // left them in any order and the cut at `d` entries could hand out a pad -- the key with the count 0 -- in the key's
+    // place: found by tests/fuzz_parity.py in round 6 on reads with poly-A stretches)
+    auto rem_less = [](const uint4& a, const uint4& b2) {
+        return a.z < b2.z || (a.z == b2.z && (a.y < b2.y || (a.y == b2.y && (a.x < b2.x || (a.x == b2.x && a.w != 0u && b2.w == 0u)))));
+    };
     uint32_t rnk[kPer], bin[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
