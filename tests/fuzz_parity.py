@@ -244,8 +244,10 @@ def main():
                 ok = windows == nwin and sorted(got) == sorted(exp) and all(got[n] == exp[n] for n in exp)
                 why = "" if ok else "windows %d/%d, files differ: %s" % (windows, nwin, [n for n in exp if got.get(n) != exp[n]][:4])
             except g.GossGpuError as e:
-                # a budget too small for the input is a legitimate refusal, anything else is not
-                ok = e.status == -3
+                # a budget too small for the input is a legitimate refusal -- and so is a deferred context's "this push does
+                # not fit the staging buffer" (-9: the caller of goss_gpu_group_route_exchange cuts its pushes by
+                # goss_gpu_stage_room; this script pushes whole shards) -- anything else is not
+                ok = e.status == -3 or (e.status == -9 and "deferred" in str(e))
                 why = "refused: %s" % e
                 stats = {}
         finally:
