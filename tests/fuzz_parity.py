@@ -137,6 +137,9 @@ def main():
                         p = subprocess.run([os.path.join(ROOT, "gossamer_amd", "goss"), "build-graph" if graph else "build-kmer-set", "-k", str(k),
                                             "--line-in", os.path.join(d, "r.txt"), "-O", os.path.join(d, "o"), "--hbm-budget", "1", "-T", "4", "-v",
                                             "--devices", ",".join(["0"] * ndev)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=e2)
+                        if p.returncode != 0 and b"out of memory (HBM budget)" in p.stderr:
+                            # (--hbm-budget 1: a legitimate refusal, as for the library's own -3 below)
+                            raise g.GossGpuError(-3, "out of memory (HBM budget)", "goss --devices")
                         if p.returncode != 0:
                             raise RuntimeError("goss --devices failed: " + p.stderr.decode(errors="replace")[-400:])
                         got = {n[1:]: open(os.path.join(d, n), "rb").read() for n in os.listdir(d) if n.startswith("o.") or n.startswith("o-")}
