@@ -235,3 +235,90 @@ def test_c5_full_size_properties():
         rep = ctx.check_index({k[len(".kmers"):]: v for k, v in files.items() if k.startswith(".kmers")})
         assert rep["select"] == 0 and rep["rank"] == 0 and rep["access"] == 0 and rep["failures"] == 0, rep
 
+
+
+@pytest.mark.parametrize("k,mode,n", [(25, 0, 20_000_000), (55, 1, 15_000_000), (27, 1, 20_000_000)])
+def test_reads_with_homopolymer_tails_at_scale(k, mode, n):
+    """What a random genome never holds and real reads hold everywhere: poly-A / poly-T stretches (tails of 30 to 80
+    bases on a sixth of the reads, planted on the device).  Their keys are the all-zeros and all-ones patterns that pads
+    and empty-slot markers are made of -- round 6's fuzz runs found two places where a key of all ones was taken for a
+    pad (the strand-pair expansion's sort, the two-word counting table's ordering).  At a size the fused kernels take by
+    themselves: the default pipeline and the unfused one (look-back partition passes, no kernel in common before the
+    counting stage; for graphs both strands extracted instead of strand pairs) must agree key for key and count for
+    count, counts add up to the adapter's key stream, and the keys of the stretches are there: A..A and T..T with equal
+    counts (graph: an edge and its reverse complement; k-mer set: one canonical form of the two)."""
+    import torch
+    from gossamer_amd import dist as gd
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if total_b < 250 * (1 << 30):
+        pytest.skip("needs the 288 GB of an MI355X")
+    L, G = 150, 20_000_000
+    buf = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda")
+    budget = min(int((free_b - buf.numel()) * 0.9), 160 << 30)
+    res = []
+    length = k + 1 if mode else k
+    for env in ({}, {"GOSS_GPU_NO_FUSED": "1"}):
+        old = {a: os.environ.get(a) for a in env}
+        os.environ.update(env)
+        try:
+            ctx = g.Context(k, mode, hbm_budget=budget)
+        finally:
+            for a, v in old.items():
+                if v is None:
+                    del os.environ[a]
+                else:
+                    os.environ[a] = v
+        if not res:
+            ctx.synth_reads(buf.data_ptr(), n, L, G, seed=3)
+            torch.cuda.synchronize()
+            # tails: read r (every sixth) ends in t(r) = 30 .. 80 copies of 'A' (even r / 6) or 'T' (odd)
+            rows = buf.view(n, L + 1)
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(11)
+            step = 6_000_000
+            col = torch.arange(L, device="cuda")
+            for at in range(0, n, step):
+                part = rows[at:at + step:6]
+                m = part.shape[0]
+                tlen = torch.randint(30, 81, (m, 1), device="cuda", generator=gen)
+                letter = torch.where((torch.arange(m, device="cuda") % 2 == 0).view(m, 1), torch.tensor(65, device="cuda"), torch.tensor(84, device="cuda")).to(torch.uint8)
+                mask = col.view(1, L) >= (L - tlen)
+                body = part[:, :L]
+                body[mask] = letter.expand(m, L)[mask]
+                del tlen, letter, mask, body
+            torch.cuda.synchronize()
+        ctx.push_device(buf.data_ptr(), buf.numel())
+        c = ctx.finish()
+        if not env:
+            assert ctx.stat("fused_chunks") >= 1
+        else:
+            assert ctx.stat("fused_chunks") == 0
+        kp, cp, m = ctx.result_ptrs()
+        words = c.key_words
+        keys = gd.key_view(kp, m, words, "cuda").clone()
+        counts = gd.device_view(cp, m, torch.int32, "cuda").clone()
+        assert m == c.distinct
+        if not res:
+            assert int(counts.to(torch.int64).sum().item()) == c.keys == c.windows * (2 if mode else 1)
+            # the stretches' own keys: A..A = 0 is the first key, T..T = all ones of 2 * length bits the last
+            first = keys[0]
+            last = keys[-1]
+            bits = 2 * length
+            if words == 1:
+                a_key, t_key = int(first.item()), int(last.item()) & ((1 << 64) - 1)
+            else:
+                lo0, hi0 = (int(x) & ((1 << 64) - 1) for x in first.tolist())
+                lo1, hi1 = (int(x) & ((1 << 64) - 1) for x in last.tolist())
+                a_key, t_key = lo0 | (hi0 << 64), lo1 | (hi1 << 64)
+            has_a, has_t = a_key == 0, t_key == (1 << bits) - 1
+            if mode:
+                assert has_a and has_t, (hex(a_key), hex(t_key))
+                assert int(counts[0].item()) == int(counts[-1].item()) > 1_000_000
+            else:
+                # one canonical form of the pair (A..A, T..T) -- whichever the FNV order picks -- holds both strands' windows
+                assert has_a != has_t, (hex(a_key), hex(t_key))
+                assert int((counts[0] if has_a else counts[-1]).item()) > 1_000_000
+        res.append((keys, counts, c.windows))
+        ctx.close()
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
