@@ -171,6 +171,8 @@ struct goss_gpu_ctx {
     int r32_form = 1;                   // GOSS_GPU_R32_FORM=0: the pair layout of rounds 3-4 (seg_hash_reduce32_kernel), 1: buckets of four (round 5)
     uint32_t r32_small_max = 0;         // distinct keys per segment up to which the 2048-slot table is taken (GOSS_GPU_R32_SMALL_MAX; 0 = the form's default)
     bool big_r32 = true;                // GOSS_GPU_R32_BIG=0: no 8 192- / 16 384-slot tables of remainders (a third partition level instead, as before)
+    bool overflow_by_sort = true;       // GOSS_GPU_OVERFLOW_BY_SORT=0: a table that overflows sends the whole chunk up the ladder of forms (rounds 1-5)
+    uint64_t overflow_units = 0;        // segments counted by sort because their table overflowed
     uint32_t rem32_chunks = 0;          // chunks counted in that form
     uint32_t narrow_chunks = 0;         // ... of them with remainder + digit (5.33 bytes a key) between the two levels
     uint64_t assemble_us = 0;           // host clock of the last goss_gpu_emit_assemble
@@ -1018,6 +1020,85 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
     return segment_reduce<K>(c, part, spare, n, segbits, out);
 }
 
+// Units (segments) whose counting table overflowed are counted one by one, by sort, into the staging area the kernel
+// filled for the others (round 6).  A FEW giant segments are what skew looks like -- reads with homopolymer stretches:
+// every window that begins with nine T's lies in one 17-bit segment, tens of millions of distinct keys where a table
+// holds thousands -- and the ladder of "the whole chunk again with more bits" neither splits them (the bits below the
+// prefix are all T as well) nor ends before the full sort of the chunk: 3.8 s for 2.5 G windows that now take 0.1 s.
+// `expand(unit, first, n, dst)` queues the unit's n keys as full keys at dst.  Returns 0 (all counted: *h updated, the
+// device's seg_pos / seg_cnt patched), or the code the caller hands on: 1 -- too many such units, no room for their
+// sort, a count beyond 32 bits: the old ladder takes over -- or 2, the staging area is full.
+constexpr size_t kMaxOverflowUnits = 4096;
+template <class K, class Expand, class UnitLow>
+int count_overflowed_units(goss_gpu_ctx* c, uint32_t nunit, const uint64_t* d_beg, const uint64_t* d_end, uint64_t* d_pos, uint64_t* d_cnt,
+                           SegOut* h, K* stage_keys, uint32_t* stage_counts, Expand expand, UnitLow unit_low)
+{
+    // (`unit_low(u)`: the smallest key a key of unit u can be -- the units are ranges of the key space in unit order)
+    std::vector<uint64_t> cnt(nunit), beg(nunit), end(nunit);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nunit * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(beg.data(), d_beg, (size_t)nunit * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(end.data(), d_end, (size_t)nunit * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> units;
+    uint64_t total = 0;
+    for (uint32_t u = 0; u < nunit; ++u)
+        if (cnt[u] == kSegOverflowed) { units.push_back(u); total += end[u] - beg[u]; if (units.size() > kMaxOverflowUnits) return 1; }
+    if (units.empty() || total == 0) return 1;          // (the flag without a marked unit: not this function's case)
+    // ALL of them in one sort (their keys are full keys: the units stay apart) -- one by one, a few hundred small sorts
+    // cost half a millisecond of launches and waits each
+    const uint64_t need = total * (3 * sizeof(K) + 16) + units.size() * (2 * sizeof(K) + 16) + (64ULL << 20);
+    if (c->arena.avail() < need) return 1;
+    const uint64_t mark = c->arena.mark(), lo0 = c->arena.lo;
+    const size_t maps0 = c->big_maps.size();
+    K* a = (K*)c->arena.temp(total * sizeof(K));
+    K* b = (K*)c->arena.temp(total * sizeof(K));
+    {
+        uint64_t at = 0;
+        for (uint32_t u : units) { expand(u, beg[u], end[u] - beg[u], a + at); at += end[u] - beg[u]; }
+    }
+    const bool mute = c->mute_timing;
+    c->mute_timing = true;          // (the sort's passes belong to the counting phase that is being timed)
+    const bool moved = radix_sort<K, false>(c, a, b, nullptr, nullptr, total, key_digits(c));
+    Run r = reduce_runs<K>(c, moved ? b : a, nullptr, total, moved ? a : b);
+    c->mute_timing = mute;
+    int rc = 0;
+    if (r.big >= 0 || c->big_maps.size() != maps0) { c->big_maps.resize(maps0); rc = 1; }          // (a count of 2^32 - 1 or more: the general way keeps those)
+    else if (h->cursor + r.m > h->stage_cap) rc = 2;
+    else
+    {
+        const uint32_t nu = (uint32_t)units.size();
+        std::vector<K> lows(nu), highs(nu);
+        std::vector<uint8_t> last(nu);
+        for (uint32_t i = 0; i < nu; ++i)
+        {
+            lows[i] = unit_low(units[i]);
+            last[i] = units[i] + 1 == nunit ? 1 : 0;
+            highs[i] = last[i] ? lows[i] : unit_low(units[i] + 1);
+        }
+        K* d_lows = (K*)c->arena.temp(nu * sizeof(K));
+        K* d_highs = (K*)c->arena.temp(nu * sizeof(K));
+        uint32_t* d_units = (uint32_t*)c->arena.temp(nu * 4 + 16);
+        uint8_t* d_last = (uint8_t*)c->arena.temp(nu + 16);
+        HIP_TRY(hipMemcpyAsync(d_lows, lows.data(), nu * sizeof(K), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_highs, highs.data(), nu * sizeof(K), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_units, units.data(), nu * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_last, last.data(), nu, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(stage_keys + h->cursor, r.keys, r.m * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(stage_counts + h->cursor, r.counts, r.m * 4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(unit_bounds_kernel<K>), dim3(grid_for(nu, kTB)), dim3(kTB), 0, c->stream, (const K*)r.keys, r.m, (const K*)d_lows,
+                           (const K*)d_highs, (const uint8_t*)d_last, (const uint32_t*)d_units, nu, (unsigned long long)h->cursor, d_pos, d_cnt);
+        HIP_TRY(hipStreamSynchronize(c->stream));          // (the host vectors go)
+        h->cursor += r.m;
+        h->overflow = 0;
+        c->overflow_units += nu;
+        if (c->debug) std::fprintf(stderr, "libgossgpu: %u segment(s) with more distinct keys than a table holds counted by sort (%llu keys, %llu distinct)\n",
+                                   nu, (unsigned long long)total, (unsigned long long)r.m);
+    }
+    c->arena.lo = lo0;               // (the run's storage: it lives on in the staging area)
+    c->arena.release(mark);
+    return rc;
+}
+
 // Count every segment of the partitioned keys `part` in LDS; `spare` (n keys) is the staging area.
 // Segment s is part[seg_beg[s], seg_end[s]) when the bounds are given (sub-region layout), else
 // the bounds are found by binary search in the dense, partitioned array.
@@ -1054,6 +1135,35 @@ int segment_reduce(goss_gpu_ctx* c, K* part, K* spare, uint64_t n, uint32_t segb
     SegOut* h = (SegOut*)c->h_pinned;
     HIP_TRY(hipMemcpyAsync(h, so, sizeof(SegOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h->overflow == 1u && big <= 1 && c->overflow_by_sort)
+    {
+        // (tables that overflowed, nothing else: those segments by sort -- not the forms in which several workgroups
+        // share a segment, whose units are not ranges of `part`)
+        SegOut hs = *h;
+        const int rc = count_overflowed_units<K>(c, nunit, seg_beg, seg_end, seg_pos, seg_cnt, &hs, stage_keys, stage_counts,
+            [&](uint32_t u, uint64_t first, uint64_t cnt_u, K* dst) {
+                if constexpr (std::is_same<K, Key2>::value)
+                {
+                    if (big == -3)          // (12-byte records of the remainders: the second level's packed form)
+                    {
+                        hipLaunchKernelGGL(expand_rem96_kernel, dim3(grid_for(cnt_u, kTB)), dim3(kTB), 0, c->stream,
+                                           reinterpret_cast<const Rem96*>(part) + first, cnt_u, (uint64_t)u, shift, dst);
+                        return;
+                    }
+                }
+                HIP_TRY(hipMemcpyAsync(dst, part + first, cnt_u * sizeof(K), hipMemcpyDeviceToDevice, c->stream));
+            },
+            [&](uint32_t u) -> K {
+                if constexpr (std::is_same<K, Key2>::value)
+                {
+                    const unsigned __int128 v = (unsigned __int128)u << shift;
+                    return Key2{(uint64_t)v, (uint64_t)(v >> 64)};
+                }
+                else return Key1{(uint64_t)u << shift};
+            });
+        *h = hs;
+        if (rc == 2) h->overflow = 2u;
+    }
     if (h->overflow)
     {
         const int why = (h->overflow & 1u) ? 1 : 2;
@@ -1122,6 +1232,27 @@ int segment_reduce32(goss_gpu_ctx* c, const uint32_t* rems, Key1* spare, uint64_
                      (double)h->stamps[0] / h->stamps[7], (double)h->stamps[1] / h->stamps[7], (double)h->stamps[2] / h->stamps[7], (double)h->stamps[3] / h->stamps[7],
                      (double)h->stamps[4] / h->stamps[7], (double)h->stamps[5] / h->stamps[7], (double)h->stamps[6] / h->stamps[7], (unsigned long long)h->stamps[7]);
 #endif
+    if (h->overflow == 1u && c->overflow_by_sort)
+    {
+        SegOut hs = *h;
+        const int rc = count_overflowed_units<Key1>(c, nseg, seg_beg, seg_end, seg_pos, seg_cnt, &hs, stage_keys, stage_counts,
+            [&](uint32_t u, uint64_t first, uint64_t cnt_u, Key1* dst) {
+                const uint64_t prefix = (uint64_t)(u >> split_bits) << rbits;          // (as the counting kernel's write-out)
+                if (squeeze)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(expand_rem32_kernel<true>), dim3(grid_for(cnt_u, kTB)), dim3(kTB), 0, c->stream, rems + first, cnt_u, prefix, sqbit, dst);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(expand_rem32_kernel<false>), dim3(grid_for(cnt_u, kTB)), dim3(kTB), 0, c->stream, rems + first, cnt_u, prefix, sqbit, dst);
+            },
+            [&](uint32_t u) -> Key1 {
+                // the unit's smallest key: its segment's prefix, and the unit's number in the top split_bits of the remainder
+                const uint32_t rem_bits = rbits - (squeeze ? 1u : 0u);
+                const uint32_t sub = split_bits ? (u & ((1u << split_bits) - 1u)) << (rem_bits - split_bits) : 0u;
+                const uint64_t low = squeeze ? rem32_unpack<true>(sub, sqbit) : rem32_unpack<false>(sub, sqbit);
+                return Key1{((uint64_t)(u >> split_bits) << rbits) | low};
+            });
+        *h = hs;
+        if (rc == 2) h->overflow = 2u;
+    }
     if (h->overflow)
     {
         const int why = (h->overflow & 1u) ? 1 : 2;
@@ -3487,6 +3618,7 @@ int goss_gpu_create(goss_gpu_ctx** out, int device, uint32_t k, int mode, uint64
     { const char* e = std::getenv("GOSS_GPU_REM32_SLOTS"); if (e && (std::atoi(e) == 2048 || std::atoi(e) == 4096 || std::atoi(e) == 8192 || std::atoi(e) == 16384)) c->rem32_slots = std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_FORM"); if (e) c->r32_form = std::atoi(e) ? 1 : 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW"); if (e) c->narrow = std::atoi(e) != 0; }
+    { const char* e = std::getenv("GOSS_GPU_OVERFLOW_BY_SORT"); if (e) c->overflow_by_sort = std::atoi(e) != 0; }
     { const char* e = std::getenv("GOSS_GPU_DS_PARTS"); if (e) c->ds_parts = std::atoi(e) != 0; }
     { const char* e = std::getenv("GOSS_GPU_NARROW_CAPG"); if (e && std::atoi(e) > 0) c->narrow_capg = (uint32_t)std::atoi(e); }
     { const char* e = std::getenv("GOSS_GPU_R32_SMALL_MAX"); if (e) c->r32_small_max = (uint32_t)std::atoi(e); }
@@ -5380,6 +5512,7 @@ int goss_gpu_stat(goss_gpu_ctx* c, const char* name, uint64_t* value)
     else if (n == "fused_msd_chunks") *value = c->fused_msd_chunks;
     else if (n == "rem32_chunks") *value = c->rem32_chunks;
     else if (n == "narrow_chunks") *value = c->narrow_chunks;
+    else if (n == "overflow_units") *value = c->overflow_units;
     else if (n == "packed_fused_chunks") *value = c->pk_fused_chunks;
     else if (n == "ds_blocks_from_ranges") *value = c->ds_blocks_ranges;
     else if (n == "assemble_us") *value = c->assemble_us;

@@ -57,6 +57,49 @@ struct SegOut {
 #endif
 };
 
+// seg_cnt of a unit whose table overflowed (round 6): the unit is then counted by itself, by sort (count_overflowed_units in
+// goss_gpu.hip) -- a few giant segments are what homopolymer stretches make of a real read set (every window that begins
+// with nine T's lies in ONE 17-bit segment), and redoing the whole chunk with more bits does not split them.
+constexpr unsigned long long kSegOverflowed = ~0ULL;
+
+// the keys of an overflowed unit as full keys: 32-bit remainders (subpart32_kernel's output) / 12-byte records
+template <bool SQ>
+__global__ __launch_bounds__(kTB) void expand_rem32_kernel(const uint32_t* __restrict__ rems, uint64_t n, uint64_t prefix, uint32_t sqbit,
+                                                           Key1* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) out[i].lo = prefix | rem32_unpack<SQ>(rems[i], sqbit);
+}
+__global__ __launch_bounds__(kTB) void expand_rem96_kernel(const Rem96* __restrict__ recs, uint64_t n, uint64_t seg, uint32_t rem_bits,
+                                                           Key2* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const Rem96 r = recs[i];
+    const unsigned __int128 full = ((unsigned __int128)seg << rem_bits) | ((unsigned __int128)r.r2 << 64) | ((uint64_t)r.r0 | ((uint64_t)r.r1 << 32));
+    out[i] = Key2{(uint64_t)full, (uint64_t)(full >> 64)};
+}
+
+// Where the overflowed units' keys lie in the sorted distinct keys of all of them: unit i = keys in [low_i, high_i)
+// (last[i]: no upper bound) -> its place in the staging area and its number of distinct keys
+template <class K>
+__global__ __launch_bounds__(kTB) void unit_bounds_kernel(const K* __restrict__ keys, uint64_t m, const K* __restrict__ lows, const K* __restrict__ highs,
+                                                          const uint8_t* __restrict__ last, const uint32_t* __restrict__ units, uint32_t nunits,
+                                                          unsigned long long cursor, uint64_t* __restrict__ seg_pos, uint64_t* __restrict__ seg_cnt)
+{
+    const uint32_t i = blockIdx.x * kTB + threadIdx.x;
+    if (i >= nunits) return;
+    auto lower = [&](const K& x) {
+        uint64_t lo = 0, hi = m;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < x) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const uint64_t p0 = lower(lows[i]);
+    const uint64_t p1 = last[i] ? m : lower(highs[i]);
+    seg_pos[units[i]] = cursor + p0;
+    seg_cnt[units[i]] = p1 - p0;
+}
+
 // NT threads per workgroup, a table of SLOTS slots (a power of two) taking SLOTS * 3 / 4 distinct keys.
 template <int NT, int SLOTS, bool FILTER = false>
 __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ keys, const uint64_t* __restrict__ seg_off,
@@ -396,7 +439,7 @@ __device__ __forceinline__ void seg_hash_reduce_body(const Key1* __restrict__ ke
     __syncthreads();
     if (ovf)
     {
-        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
         return;
     }
 
@@ -794,7 +837,7 @@ __global__ __launch_bounds__(kTB, SLOTS == 2048 ? GOSS_R32_OCC : 4) void seg_has
     __syncthreads();
     if (ovf)
     {
-        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
         return;
     }
 
@@ -1176,7 +1219,7 @@ __global__ __launch_bounds__(R32bCfg<SLOTS>::kThreads, R32bCfg<SLOTS>::kOcc) voi
     GOSS_STAMP(4);
     if (ovf)
     {
-        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
         return;
     }
 
@@ -1468,7 +1511,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
     __syncthreads();
     if (ovf)
     {
-        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
         return;
     }
     // Order the occupied slots as the one-word kernel does: every thread takes its slots into
@@ -1550,7 +1593,7 @@ __device__ __forceinline__ void seg_hash_reduce2_body(const Key2* __restrict__ k
         {
             // (6144-slot table only) more entries than the largest network the arrays hold: the host retries
             // with more partition bits
-            if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+            if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
             return;
         }
         for (uint32_t i = tot_occ + tid; i < nsort; i += NT) { thi[i] = ~0ULL; tlo[i] = ~0ULL; st[i] = 0; }
@@ -1835,7 +1878,7 @@ __device__ __forceinline__ void seg_hash_reduce96_body(const Key2* __restrict__ 
     __syncthreads();
     if (ovf)
     {
-        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = 0; }
+        if (tid == 0) { atomicOr(&so->overflow, 1u); seg_pos[s] = 0; seg_cnt[s] = kSegOverflowed; }
         return;
     }
     // order the occupied slots by remainder (= by key: the prefix is common): registers, bucket sort on

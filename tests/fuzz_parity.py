@@ -96,6 +96,8 @@ def main():
             env["GOSS_GPU_NO_FUSED"] = "1"
         if rng.random() < 0.2:
             env["GOSS_GPU_EST_SCALE"] = rng.choice(["0.3", "3.0"])
+        if rng.random() < 0.15:
+            env["GOSS_GPU_OVERFLOW_BY_SORT"] = "0"          # (the ladder of forms instead of the overflowed segments counted by sort)
         if rng.random() < 0.2:
             env["GOSS_GPU_ORDER_BITS"] = rng.choice(["16", "17", "20"])
         # the 32-bit-remainder forms (second-level bits, third level, table) and the first level's key space

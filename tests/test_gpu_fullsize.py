@@ -237,7 +237,7 @@ def test_c5_full_size_properties():
 
 
 
-@pytest.mark.parametrize("k,mode,n", [(25, 0, 20_000_000), (55, 1, 15_000_000), (27, 1, 20_000_000)])
+@pytest.mark.parametrize("k,mode,n", [(25, 0, 20_000_000), (55, 1, 15_000_000)])
 def test_reads_with_homopolymer_tails_at_scale(k, mode, n):
     """What a random genome never holds and real reads hold everywhere: poly-A / poly-T stretches (tails of 30 to 80
     bases on a sixth of the reads, planted on the device).  Their keys are the all-zeros and all-ones patterns that pads
@@ -290,7 +290,9 @@ def test_reads_with_homopolymer_tails_at_scale(k, mode, n):
         ctx.push_device(buf.data_ptr(), buf.numel())
         c = ctx.finish()
         if not env:
-            assert ctx.stat("fused_chunks") >= 1
+            # (the fused path took the chunk, and the few segments that hold the stretches' families -- more distinct keys
+            # than a table takes -- were counted by sort instead of sending the whole chunk up the ladder of forms)
+            assert ctx.stat("fused_chunks") >= 1 and ctx.stat("overflow_units") >= 1, {a: ctx.stat(a) for a in ("fused_chunks", "overflow_units", "segment_retries")}
         else:
             assert ctx.stat("fused_chunks") == 0
         kp, cp, m = ctx.result_ptrs()

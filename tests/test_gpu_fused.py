@@ -26,7 +26,7 @@ def _build(reads, k, env=None, budget=8 << 30, mode=None):
             c = ctx.finish()
             files = ctx.emit()
             stats = {n: ctx.stat(n) for n in ("fused_chunks", "fused_msd_chunks", "fused_overflows", "segment_retries",
-                                              "lookback_failures")}
+                                              "lookback_failures", "overflow_units")}
         return c, files, stats
     finally:
         for name, val in old.items():
@@ -642,28 +642,35 @@ def test_segment_sort_skewed_low_bits(oracle):
     _same(got, _suffix_map(exp, "gr"))
 
 
-def test_one_segment_with_more_keys_than_any_table(oracle):
+@pytest.mark.parametrize("by_sort", [True, False])
+def test_one_segment_with_more_keys_than_any_table(oracle, by_sort):
     """One fixed prefix, 9 random bases behind it: ~2x 20 000 distinct keys of which half share
-    their top 32 bits -- the 4096-slot table overflows with 16, 20 and 24 segment bits (2^24
-    workgroups: the launch HIP used to refuse), and the full radix sort must take over.  One- and
-    two-word keys, k-mer set and graph."""
+    their top 32 bits -- the 4096-slot table overflows with 16, 20 and 24 segment bits.  Since round 6 the segment
+    whose table overflowed is counted by itself, by sort, and the others keep what their tables counted (skew: a few
+    giant segments are what homopolymer stretches make of real reads); GOSS_GPU_OVERFLOW_BY_SORT=0: the ladder of
+    rounds 1-5 -- the whole chunk again with more segment bits (2^24 workgroups: the launch HIP used to refuse),
+    then the full radix sort -- which still stands behind the new way.  One- and two-word keys, k-mer set and graph."""
     import random
     rng = random.Random(12)
+    env = {} if by_sort else {"GOSS_GPU_OVERFLOW_BY_SORT": "0"}
     for k, prefix in ((25, "ACGTTGCAAGCTTAGG"), (45, "ACGTTGCAAGCTTAGGCATTGACCGTAAGCTTGACA")):
         reads = [prefix + "".join(rng.choice("ACGT") for _ in range(9)) for _ in range(20000)]
         reads += [rng.choice(reads) for _ in range(10000)]
         txt = "\n".join(reads) + "\n"
         exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", txt)], k, out="ks")
-        c, got, st = _build(txt.encode(), k)
+        c, got, st = _build(txt.encode(), k, env=env)
         assert c.windows == nwin == 30000
-        assert st["segment_retries"] >= 3
+        if by_sort:
+            assert st["overflow_units"] >= 1 and st["segment_retries"] == 0, st
+        else:
+            assert st["segment_retries"] >= 3 and st["overflow_units"] == 0, st
         _same(got, _suffix_map(exp, "ks"))
         exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], k - 1, out="gr")
-        with g.Context(k - 1, g.MODE_GRAPH, hbm_budget=2 << 30) as ctx:
-            ctx.push_host(txt.encode())
-            c = ctx.finish()
-            assert ctx.stat("segment_retries") >= 3
-            got = ctx.emit()
+        c, got, st = _build(txt.encode(), k - 1, env=env, budget=2 << 30, mode=g.MODE_GRAPH)
+        if by_sort:
+            assert st["overflow_units"] >= 1 and st["segment_retries"] == 0, st
+        else:
+            assert st["segment_retries"] >= 3, st
         assert c.windows == nwin
         _same(got, _suffix_map(exp, "gr"))
 
@@ -730,13 +737,28 @@ def test_segments_of_24_bits_succeed_after_16_and_20_overflow(oracle):
     txt = "\n".join(reads) + "\n"
     exp, nwin = oracle.build_graph([(oracle.LINE, "reads", txt)], 27, out="gr")
     assert nwin == len(reads) == 192000
+    # (the ladder itself: since round 6 a segment whose table overflows is counted by sort first -- switched off here)
+    old = os.environ.get("GOSS_GPU_OVERFLOW_BY_SORT")
+    os.environ["GOSS_GPU_OVERFLOW_BY_SORT"] = "0"
+    try:
+        with g.Context(27, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
+            ctx.push_host(txt.encode())
+            c = ctx.finish()
+            assert c.windows == nwin and c.distinct == 2 * 48000
+            assert ctx.stat("segment_retries") == 2, ctx.stat("segment_retries")
+            got = ctx.emit()
+    finally:
+        if old is None:
+            os.environ.pop("GOSS_GPU_OVERFLOW_BY_SORT", None)
+        else:
+            os.environ["GOSS_GPU_OVERFLOW_BY_SORT"] = old
+    _same(got, _suffix_map(exp, "gr"))
     with g.Context(27, g.MODE_GRAPH, hbm_budget=1 << 30) as ctx:
         ctx.push_host(txt.encode())
         c = ctx.finish()
         assert c.windows == nwin and c.distinct == 2 * 48000
-        assert ctx.stat("segment_retries") == 2, ctx.stat("segment_retries")
-        got = ctx.emit()
-    _same(got, _suffix_map(exp, "gr"))
+        assert ctx.stat("segment_retries") == 0 and ctx.stat("overflow_units") >= 1
+        _same(ctx.emit(), _suffix_map(exp, "gr"))
 
 
 def test_fused_path_declines_unique_input(oracle):

@@ -142,18 +142,25 @@ def test_rem32_tables_overflow_in_turn():
 def test_rem32_gives_way_to_the_8_byte_form(oracle):
     """Reads = one fixed 16-base prefix + 9 random bases, 1.2 M of them (the fused path wants a million keys): every
     forward 25-mer lies under ONE 17-bit prefix and is its own strand representative (262 144 distinct ones) -- both
-    32-bit tables overflow, the chunk is redone in the 8-byte form, whose own ladder ends in the full sort.  Files
-    against the oracle."""
+    32-bit tables overflow, the chunk is redone in the 8-byte form, whose own ladder ends in the full sort (the way of
+    rounds 1-5, still there behind the new one); by default the one segment is counted by sort and the chunk keeps its
+    form.  Files against the oracle."""
     rng = random.Random(12)
     prefix = "ACGTTGCAAGCTGAGG"          # (base 12, the middle of the 25-mer, is a G: the forward strand is the representative)
     reads = [prefix + "".join(rng.choice("ACGT") for _ in range(9)) for _ in range(1_200_000)]
     txt = ("\n".join(reads) + "\n").encode()
     exp, nwin = oracle.build_kmer_set([(oracle.LINE, "reads", txt)], 25, out="o")
     exp = {n[1:]: d for n, d in exp.items()}
-    with env(GOSS_GPU_FUSED_MIN=0, GOSS_GPU_EST_SCALE=0.05):
+    # (the ladder of rounds 1-5: GOSS_GPU_OVERFLOW_BY_SORT=0 -- it still stands behind round 6's way, below)
+    with env(GOSS_GPU_FUSED_MIN=0, GOSS_GPU_EST_SCALE=0.05, GOSS_GPU_OVERFLOW_BY_SORT=0):
         c, got, st = build(txt, 25, 0, budget=2 << 30)
     assert c.windows == nwin == 1_200_000
     assert st["rem32_chunks"] == 0 and st["segment_retries"] >= 2, st
+    assert got == exp
+    # round 6: the one segment whose table overflowed is counted by sort, the chunk stays in the 32-bit form
+    with env(GOSS_GPU_FUSED_MIN=0, GOSS_GPU_EST_SCALE=0.05):
+        c, got, st = build(txt, 25, 0, budget=2 << 30)
+    assert c.windows == nwin and st["rem32_chunks"] == 1 and st["segment_retries"] == 0, st
     assert got == exp
 
 
