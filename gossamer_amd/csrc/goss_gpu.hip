@@ -1020,8 +1020,8 @@ int segment_count(goss_gpu_ctx* c, K* ka, K* kb, uint64_t n, uint32_t segbits, b
     return segment_reduce<K>(c, part, spare, n, segbits, out);
 }
 
-// Units (segments) whose counting table overflowed are counted one by one, by sort, into the staging area the kernel
-// filled for the others (round 6).  A FEW giant segments are what skew looks like -- reads with homopolymer stretches:
+// Units (segments) whose counting table overflowed are counted by themselves -- all of them in one sort -- into the staging
+// area the kernel filled for the others (round 6).  A FEW giant segments are what skew looks like -- reads with homopolymer stretches:
 // every window that begins with nine T's lies in one 17-bit segment, tens of millions of distinct keys where a table
 // holds thousands -- and the ladder of "the whole chunk again with more bits" neither splits them (the bits below the
 // prefix are all T as well) nor ends before the full sort of the chunk: 3.8 s for 2.5 G windows that now take 0.1 s.
@@ -1056,11 +1056,14 @@ int count_overflowed_units(goss_gpu_ctx* c, uint32_t nunit, const uint64_t* d_be
         uint64_t at = 0;
         for (uint32_t u : units) { expand(u, beg[u], end[u] - beg[u], a + at); at += end[u] - beg[u]; }
     }
-    const bool mute = c->mute_timing;
-    c->mute_timing = true;          // (the sort's passes belong to the counting phase that is being timed)
-    const bool moved = radix_sort<K, false>(c, a, b, nullptr, nullptr, total, key_digits(c));
-    Run r = reduce_runs<K>(c, moved ? b : a, nullptr, total, moved ? a : b);
-    c->mute_timing = mute;
+    Run r{nullptr, nullptr, 0};
+    {
+        // (the sort's passes belong to the counting phase that is being timed; put back also when the sort gives up)
+        struct Mute { goss_gpu_ctx* c; bool was; ~Mute() { c->mute_timing = was; } } muted{c, c->mute_timing};
+        c->mute_timing = true;
+        const bool moved = radix_sort<K, false>(c, a, b, nullptr, nullptr, total, key_digits(c));
+        r = reduce_runs<K>(c, moved ? b : a, nullptr, total, moved ? a : b);
+    }
     int rc = 0;
     if (r.big >= 0 || c->big_maps.size() != maps0) { c->big_maps.resize(maps0); rc = 1; }          // (a count of 2^32 - 1 or more: the general way keeps those)
     else if (h->cursor + r.m > h->stage_cap) rc = 2;
@@ -2673,6 +2676,7 @@ void push_device(goss_gpu_ctx* c, const uint8_t* d, uint64_t nbytes)
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->arena.lo = lo0; c->arena.hi = hi0;
             c->runs.resize(runs0);
+            c->mute_timing = false;             // (a phase that gave up part-way may have left it set)
             if (grow_arena(c, 0)) continue;
             limit = (ns / 2) & ~4095ULL;
             continue;
@@ -2738,6 +2742,7 @@ void push_records(goss_gpu_ctx* c, const uint8_t* d, uint64_t nrecs, uint64_t nw
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->arena.lo = lo0; c->arena.hi = hi0;
             c->runs.resize(runs0);
+            c->mute_timing = false;             // (a phase that gave up part-way may have left it set)
             if (grow_arena(c, 0)) continue;
             limit = (ns / 2) & ~4095ULL;
             continue;
