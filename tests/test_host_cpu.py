@@ -6,6 +6,7 @@ import os
 import random
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -369,3 +370,13 @@ def test_tmp_dir_must_be_a_directory(tmp_path):
         assert rc == 1 and "is not a directory" in err and str(tmp_path / "file") in err, err
         rc, out, err = run_goss(*cmd, "--tmp-dir", str(tmp_path / "nowhere"))
         assert rc == 1 and str(tmp_path / "nowhere") in err, err
+
+
+def test_random_files_through_serial_parallel_and_oracle_framing():
+    """tools/dbg/parser_fuzz.py: random FASTQ / FASTA files (wrapped records, '@' / '+' at the start of quality lines,
+    \\r\\n, empty reads, cut-off tails, planted defects) framed serially, by the parallel framer under random thread counts /
+    chunk sizes / slack / mapping, and by the oracle's restatement of FastqParser.hh:78-176 / FastaParser.hh: the same
+    bases in the same order, or the same message with the same line number."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "parser_fuzz.py"), "120", "23"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
