@@ -16,7 +16,7 @@ import gossamer_amd as g  # noqa: E402
 import oracle_lib as oracle  # noqa: E402
 
 
-def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
+def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower, read_rng=None):
     genome = "".join(rng.choice("ACGT") for _ in range(genome_len))
     # (round 6) what a random genome almost never holds and a real one holds everywhere: homopolymers, short repeats and
     # reverse-complement palindromes, planted into the genome -- the edge T..T beside palindromes is how this script
@@ -41,6 +41,8 @@ def make_reads(rng, nreads, genome_len, lmin, lmax, err, nrate, lower):
             at = rng.randint(0, max(0, genome_len - len(piece)))
             g2[at:at + len(piece)] = piece
         genome = "".join(g2)[:genome_len]
+    if read_rng is not None:          # (fuzz_setops.py: several read sets over ONE genome)
+        rng = read_rng
     out = []
     for _ in range(nreads):
         L = rng.randint(lmin, lmax)
