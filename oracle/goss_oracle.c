@@ -1883,17 +1883,23 @@ static int merge_load(const go_fs* fs, const char* name, int kind, uint64_t* K, 
         snprintf(base, sizeof base, "%s-counts-hist.txt", name);
         int fi = go_fs_find(fs, base);
         if (fi < 0) { snprintf(err, errcap, "missing file %s", base); return -1; }
+        /* (the file's bytes are not NUL-terminated: the numbers are read within [p, e) -- strtoull on the last
+         *  line's '\n' would skip it and go on reading whatever lies behind the buffer) */
         uint64_t tot = 0;
         const char* p = (const char*)fs->files[fi].data; const char* e = p + fs->files[fi].size;
-        while (p < e)
+        for (;;)
         {
-            char* q; unsigned long long m = strtoull(p, &q, 10);
-            if (q == p) break;
-            p = q;
-            unsigned long long c = strtoull(p, &q, 10);
-            if (q == p) break;
-            p = q; (void)m;
-            tot += c;
+            uint64_t v[2]; int got = 0;
+            for (; got < 2; ++got)
+            {
+                while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+                if (p >= e || *p < '0' || *p > '9') break;
+                uint64_t x2 = 0;
+                while (p < e && *p >= '0' && *p <= '9') x2 = x2 * 10 + (uint64_t)(*p++ - '0');
+                v[got] = x2;
+            }
+            if (got < 2) break;
+            tot += v[1];
         }
         *cnt = tot;
     }

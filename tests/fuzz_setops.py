@@ -30,7 +30,11 @@ def disk(d, base):
     return {n: open(os.path.join(d, n), "rb").read() for n in os.listdir(d) if n.startswith(base + ".") or n.startswith(base + "-")}
 
 
+LAST = {}          # the two file sets of the last comparison (kept beside the inputs when a case fails)
+
+
 def differs(got, exp):
+    LAST["got"], LAST["exp"] = got, exp
     if sorted(got) != sorted(exp):
         return "file names: %s / %s" % (sorted(set(got) - set(exp))[:4], sorted(set(exp) - set(got))[:4])
     bad = [n for n in exp if got[n] != exp[n]]
@@ -216,6 +220,10 @@ def main():
                 for n in os.listdir(d):
                     if n.startswith("p") and n.endswith(".txt"):
                         shutil.copy(os.path.join(d, n), os.path.join(keep, "setops%d_%s" % (case, n)))
+                for side in ("got", "exp"):
+                    for n, v in LAST.get(side, {}).items():
+                        with open(os.path.join(keep, "setops%d_%s_%s" % (case, side, n)), "wb") as f:
+                            f.write(v)
         shutil.rmtree(d, ignore_errors=True)
     print("setops fuzz: seed %d, %d cases, %d failed, %.0f s" % (seed, cases, bad, time.time() - t00))
     sys.exit(1 if bad else 0)
