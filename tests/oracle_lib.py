@@ -34,6 +34,8 @@ class Keys(C.Structure):
 
 
 def build():
+    if os.environ.get("GOSS_ORACLE_SO"):          # (a sanitizer build of the oracle, say: tools/oracle_asan.sh)
+        return os.environ["GOSS_ORACLE_SO"]
     src = os.path.join(_ROOT, "oracle", "goss_oracle.c")
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
