@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as oracle  # noqa: E402  (the checker)
 
-GOSS = os.path.join(ROOT, "gossamer_amd", "goss")
+GOSS = os.environ.get("GOSS_BIN") or os.path.join(ROOT, "gossamer_amd", "goss")          # (GOSS_BIN: a sanitizer build of the host)
 
 
 def make_fastq(rng):
