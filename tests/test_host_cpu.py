@@ -13,7 +13,7 @@ import pytest
 import gossamer_amd as g
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOSS = os.path.join(ROOT, "gossamer_amd", "goss")
+GOSS = os.environ.get("GOSS_BIN") or os.path.join(ROOT, "gossamer_amd", "goss")          # (GOSS_BIN: a sanitizer build, tools/host_asan.sh)
 
 
 @pytest.fixture(scope="module", autouse=True)
