@@ -1067,7 +1067,20 @@ uint64_t parseFastqParallel(const std::string& name, unsigned threads, size_t ch
             // workers wait for a buffer, chunk i is nobody's yet, and waiting here without calling the library would
             // wait for ever (one build in four hung that way once the device side had got faster): while buffers are
             // out and none is free, the wait is bounded and the library is asked to hand them back.
+#ifdef GOSS_TSAN_BUILD
+            // (tools/host_tsan.sh: gcc 11's ThreadSanitizer does not know pthread_cond_clockwait -- behind a wait_for its
+            //  picture of the mutex is wrong and every later report with it; the same wait by sleeping)
+            auto waitDone = [&] {
+                if (res[i].done || allocFailed.load()) return true;
+                lk.unlock();
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+                lk.lock();
+                return res[i].done || allocFailed.load();
+            };
+            while (!waitDone())
+#else
             while (!cvDone.wait_for(lk, std::chrono::milliseconds(2), [&] { return res[i].done || allocFailed.load(); }))
+#endif
             {
                 if (lent > 0 && freeBufs.empty() && pushPacked && pushPacked->drain)
                 {
